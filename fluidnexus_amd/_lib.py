@@ -1,0 +1,121 @@
+"""ctypes binding of libfnx_raster.so (the C ABI in include/fnx_raster.h).
+
+There is deliberately no CPU or PyTorch fallback: if the HIP library is missing or cannot be
+loaded, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_RASTER = None
+
+c_void_p, c_int, c_float, c_int64, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+FNX_OK = 0
+FNX_ERR_INVALID_ARG = 1
+FNX_ERR_NON_RGB_NEEDS_COLORS = 2
+FNX_ERR_HIP = 3
+FNX_ERR_CAPACITY = 4
+
+
+class GeomLayout(C.Structure):
+    _fields_ = [(n, c_size_t) for n in
+                ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "total")]
+
+
+class ImageLayout(C.Structure):
+    _fields_ = [(n, c_size_t) for n in
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "tile_cursor", "total")]
+
+
+class BinningLayout(C.Structure):
+    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "total")]
+
+
+ALLOC_FN = C.CFUNCTYPE(c_void_p, c_size_t, c_void_p)
+
+# every symbol include/fnx_raster.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "fnx_abi_version", "fnx_last_error", "fnx_geom_bytes", "fnx_image_bytes", "fnx_binning_bytes",
+    "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",
+    "fnx_rasterize_backward", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
+)
+
+
+def raster_path() -> str:
+    return os.path.join(_HERE, "libfnx_raster.so")
+
+
+def raster():
+    """Load libfnx_raster.so; raises RuntimeError when it has not been built."""
+    global _RASTER
+    if _RASTER is not None:
+        return _RASTER
+    path = raster_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
+            "fluidnexus_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    p, i, f = c_void_p, c_int, c_float
+    lib.fnx_abi_version.restype = i
+    lib.fnx_last_error.restype = C.c_char_p
+    lib.fnx_geom_bytes.restype = c_size_t
+    lib.fnx_geom_bytes.argtypes = [i]
+    lib.fnx_image_bytes.restype = c_size_t
+    lib.fnx_image_bytes.argtypes = [i, i]
+    lib.fnx_binning_bytes.restype = c_size_t
+    lib.fnx_binning_bytes.argtypes = [c_int64]
+    lib.fnx_forward_stage1.restype = i
+    lib.fnx_forward_stage1.argtypes = [i, p, p, i, i, i, i, i, p, p, p, p, p, f, p, p, p, p, p, f, f, i, p, p]
+    lib.fnx_read_num_rendered.restype = i
+    lib.fnx_read_num_rendered.argtypes = [p, i, i, p, C.POINTER(i)]
+    lib.fnx_read_status.restype = i
+    lib.fnx_read_status.argtypes = [p, i, i, p]
+    lib.fnx_forward_stage2.restype = i
+    lib.fnx_forward_stage2.argtypes = [i, p, p, c_int64, p, i, i, i, p, p, p, p, p, p]
+    lib.fnx_rasterize_forward.restype = i
+    lib.fnx_rasterize_forward.argtypes = [i, ALLOC_FN, p, ALLOC_FN, p, ALLOC_FN, p, i, i, i, p, i, i, p, p, p, p, p, f,
+                                          p, p, p, p, p, f, f, i, p, p, p, p, C.POINTER(i)]
+    lib.fnx_rasterize_backward.restype = i
+    lib.fnx_rasterize_backward.argtypes = [i, i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, f, f, p, p, p, p, p,
+                                           p, p, p, p, p, p, p, p, p, p]
+    lib.fnx_mark_visible.restype = i
+    lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
+    lib.fnx_geom_layout.argtypes = [i, C.POINTER(GeomLayout)]
+    lib.fnx_image_layout.argtypes = [i, i, C.POINTER(ImageLayout)]
+    lib.fnx_binning_layout.argtypes = [c_int64, C.POINTER(BinningLayout)]
+    _RASTER = lib
+    return lib
+
+
+class FnxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+def check(rc: int):
+    if rc != FNX_OK:
+        msg = raster().fnx_last_error().decode("utf-8", "replace")
+        raise FnxError(rc, msg)
+
+
+def geom_layout(P: int) -> GeomLayout:
+    L = GeomLayout()
+    raster().fnx_geom_layout(P, C.byref(L))
+    return L
+
+
+def image_layout(W: int, H: int) -> ImageLayout:
+    L = ImageLayout()
+    raster().fnx_image_layout(W, H, C.byref(L))
+    return L
+
+
+def binning_layout(R: int) -> BinningLayout:
+    L = BinningLayout()
+    raster().fnx_binning_layout(R, C.byref(L))
+    return L

@@ -1,0 +1,56 @@
+"""Builds the gfx950 shared libraries in-tree with hipcc (no JIT cache, no torch headers).
+
+`python -m fluidnexus_amd.build` or `fluidnexus_amd.build.build_all()`; called by
+__graft_entry__.build().  hipcc cross-compiles for gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+
+# library name -> sources.  -ffp-contract=off is part of the numerics contract.
+LIBS = {
+    "libfnx_raster.so": ["raster_forward.hip", "raster_backward.hip", "raster_api.hip"],
+}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(out: str, srcs: list[str]) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = list(srcs) + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(_HERE, "..", "include", "fnx_raster.h"))
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_all(force: bool = False, verbose: bool = False) -> list[str]:
+    built = []
+    for name, files in LIBS.items():
+        out = os.path.join(_HERE, name)
+        srcs = [os.path.join(_CSRC, f) for f in files]
+        if force or _stale(out, srcs):
+            cmd = [hipcc()] + FLAGS + ["-o", out] + srcs
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        built.append(out)
+    return built
+
+
+if __name__ == "__main__":
+    for p in build_all(force="--force" in sys.argv, verbose=True):
+        print(p)

@@ -1,0 +1,100 @@
+// Device-side helpers shared by the gfx950 rasteriser kernels.
+//
+// Numerics contract (DESIGN.md "Numerics"): this library is compiled with -ffp-contract=off, so
+// every fp32 expression below is evaluated exactly as written (IEEE add/mul/div/sqrt); fused
+// multiply-adds appear only where spelled __builtin_fmaf.  That makes the per-Gaussian stage and
+// the forward blend bit-reproducible against a scalar CPU evaluation of the same expressions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FNX_TILE_X 16  // ch3/cuda_rasterizer/config.h:16
+#define FNX_TILE_Y 16  // ch3/cuda_rasterizer/config.h:17
+#define FNX_TILE_PIX (FNX_TILE_X * FNX_TILE_Y)
+
+namespace fnx {
+
+// 3x3 matrix stored as columns (c0,c1,c2), element m[c][r]; the product keeps the k = 0,1,2
+// left-to-right summation order of the maths library the reference uses (glm mat3 operator*).
+struct M3 {
+    float m[3][3];
+};
+__device__ __forceinline__ M3 m3_mul(const M3 &A, const M3 &B) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3 &A) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+    return R;
+}
+__device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1,
+                                      float c2) {
+    M3 R;
+    R.m[0][0] = a0; R.m[0][1] = a1; R.m[0][2] = a2;
+    R.m[1][0] = b0; R.m[1][1] = b1; R.m[1][2] = b2;
+    R.m[2][0] = c0; R.m[2][1] = c1; R.m[2][2] = c2;
+    return R;
+}
+
+// Row-vector 4x4 transforms (matrices arrive transposed: SURVEY A.1; ch3 auxiliary.h:54-71).
+__device__ __forceinline__ float3 xform4x3(const float3 p, const float *m) {
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(const float3 p, const float *m) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+// NDC -> pixel centre, evaluated in fp64 then rounded (ch3 auxiliary.h:41-43 uses double literals).
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// Tile rectangle of a splat (ch3 auxiliary.h:45-52): float divide, truncation toward zero, clamp.
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int &x0, int &y0, int &x1,
+                                          int &y1) {
+    x0 = min(gx, max(0, (int)((px - radius) / FNX_TILE_X)));
+    y0 = min(gy, max(0, (int)((py - radius) / FNX_TILE_Y)));
+    x1 = min(gx, max(0, (int)((px + radius + FNX_TILE_X - 1) / FNX_TILE_X)));
+    y1 = min(gy, max(0, (int)((py + radius + FNX_TILE_Y - 1) / FNX_TILE_Y)));
+}
+
+// exp() with a fixed instruction sequence (Cody-Waite reduction + degree-6 polynomial, <= 1 ulp on
+// [-87, 0]) so the blend is reproducible on any IEEE machine; the parity oracle evaluates the same
+// sequence on the CPU.  v_rndne_f32 + 8 v_fma_f32 + a few VALU ops.
+__device__ __forceinline__ float exp_fixed(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float t = x * 1.44269504088896341f;
+    const float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    const int ni = (int)n;
+    return y * __uint_as_float((uint32_t)(ni + 127) << 23);
+}
+
+// Real-SH basis constants (ch3 auxiliary.h:22-39).
+__device__ static const float kSH0 = 0.28209479177387814f;
+__device__ static const float kSH1 = 0.4886025119029199f;
+__device__ static const float kSH2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                         -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float kSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                         0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                         -0.5900435899266435f};
+
+}  // namespace fnx

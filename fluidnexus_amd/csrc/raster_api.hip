@@ -1,0 +1,309 @@
+// C ABI of the rasteriser (include/fnx_raster.h): argument checks, scratch-blob carving and the
+// launch sequence.  No torch types, no allocation, no host synchronisation except where the
+// header says so.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "fnx_state.h"
+
+namespace fnx {
+// launchers defined in raster_forward.hip / raster_backward.hip
+void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
+                       float scale_modifier, const float *rotations, const float *opacities, const float *shs,
+                       uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
+                       const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
+                       float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
+                       uint32_t *tiles_touched, uint32_t *tile_count, int prefiltered);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *tile_cursor,
+                      uint32_t *header);
+void launch_scatter(hipStream_t s, int P, const float2 *means2D, const float *depths, const int *radii, int W, int H,
+                    const uint32_t *ranges, uint32_t *tile_cursor, uint64_t *pairs, uint32_t *header,
+                    uint32_t capacity);
+void launch_tile_sort(hipStream_t s, int T, const uint32_t *ranges, uint64_t *pairs, uint32_t *point_list,
+                      const uint32_t *header, uint32_t capacity);
+void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
+                          const float2 *means2D, const float *features, const float4 *conic_opacity,
+                          const float *depths, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
+                          float *out_depth, const uint32_t *header, uint32_t capacity);
+void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
+void launch_blend_backward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
+                           const float *bg, const float2 *means2D, const float4 *conic_opacity, const float *colors,
+                           const float *final_Ts, const uint32_t *n_contrib, const float *dL_dpixels,
+                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                           const uint32_t *header, uint32_t capacity);
+void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
+                          const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
+                          float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
+                          float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
+                          const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
+                          float *dL_dscale, float *dL_drot);
+}  // namespace fnx
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return FNX_OK;
+}
+
+char *aligned(char *p) { return (char *)(((uintptr_t)p + fnx::kAlign - 1) / fnx::kAlign * fnx::kAlign); }
+const char *aligned(const char *p) { return aligned(const_cast<char *>(p)); }
+
+struct Geom {
+    float *depths;
+    uint8_t *clamped;
+    int *radii;
+    float2 *means2D;
+    float *cov3D;
+    float4 *conic_opacity;
+    float *rgb;
+    uint32_t *tiles_touched;
+};
+Geom carve_geom(char *blob, int P) {
+    fnx_geom_layout_t L;
+    fnx::geom_layout(P, &L);
+    char *b = aligned(blob);
+    Geom g;
+    g.depths = (float *)(b + L.depths);
+    g.clamped = (uint8_t *)(b + L.clamped);
+    g.radii = (int *)(b + L.radii);
+    g.means2D = (float2 *)(b + L.means2D);
+    g.cov3D = (float *)(b + L.cov3D);
+    g.conic_opacity = (float4 *)(b + L.conic_opacity);
+    g.rgb = (float *)(b + L.rgb);
+    g.tiles_touched = (uint32_t *)(b + L.tiles_touched);
+    return g;
+}
+struct Img {
+    uint32_t *header;
+    float *final_T;
+    uint32_t *n_contrib;
+    uint32_t *ranges;
+    uint32_t *tile_count;
+    uint32_t *tile_cursor;
+};
+Img carve_img(char *blob, int W, int H) {
+    fnx_image_layout_t L;
+    fnx::image_layout(W, H, &L);
+    char *b = aligned(blob);
+    Img i;
+    i.header = (uint32_t *)(b + L.header);
+    i.final_T = (float *)(b + L.final_T);
+    i.n_contrib = (uint32_t *)(b + L.n_contrib);
+    i.ranges = (uint32_t *)(b + L.ranges);
+    i.tile_count = (uint32_t *)(b + L.tile_count);
+    i.tile_cursor = (uint32_t *)(b + L.tile_cursor);
+    return i;
+}
+struct Bin {
+    uint32_t *point_list;
+    uint64_t *pairs;
+};
+Bin carve_bin(char *blob, int64_t R) {
+    fnx_binning_layout_t L;
+    fnx::binning_layout(R, &L);
+    char *b = aligned(blob);
+    Bin o;
+    o.point_list = (uint32_t *)(b + L.point_list);
+    o.pairs = (uint64_t *)(b + L.pairs);
+    return o;
+}
+
+bool channels_ok(int c) { return c == 1 || c == 3; }
+
+}  // namespace
+
+extern "C" {
+
+int fnx_abi_version(void) { return 1; }
+const char *fnx_last_error(void) { return g_err; }
+
+size_t fnx_geom_bytes(int P) {
+    fnx_geom_layout_t L;
+    fnx::geom_layout(P, &L);
+    return L.total;
+}
+size_t fnx_image_bytes(int W, int H) {
+    fnx_image_layout_t L;
+    fnx::image_layout(W, H, &L);
+    return L.total;
+}
+size_t fnx_binning_bytes(int64_t R) {
+    fnx_binning_layout_t L;
+    fnx::binning_layout(R, &L);
+    return L.total;
+}
+void fnx_geom_layout(int P, fnx_geom_layout_t *out) { fnx::geom_layout(P, out); }
+void fnx_image_layout(int W, int H, fnx_image_layout_t *out) { fnx::image_layout(W, H, out); }
+void fnx_binning_layout(int64_t R, fnx_binning_layout_t *out) { fnx::binning_layout(R, out); }
+
+int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
+                       const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                       const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                       const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, int *radii, fnx_stream_t stream) {
+    if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
+    if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
+    if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    Img img = carve_img(image_buffer, width, height);
+    const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
+    // header + tile_count must start from zero (header first: it is tiny and separate)
+    hipMemsetAsync(img.header, 0, 32, s);
+    hipMemsetAsync(img.tile_count, 0, (size_t)T * 4, s);
+    if (P == 0) {
+        hipMemsetAsync(img.ranges, 0, (size_t)T * 8, s);
+        return hip_check("stage1(P=0)");
+    }
+    if (!geom_buffer || !means3D || !opacities || !viewmatrix || !projmatrix)
+        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (channels != 3 && colors_precomp == nullptr)  // rasterizer_impl.cu:226-228
+        return fail(FNX_ERR_NON_RGB_NEEDS_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
+    if (colors_precomp == nullptr && (shs == nullptr || cam_pos == nullptr))
+        return fail(FNX_ERR_INVALID_ARG, "neither colors_precomp nor shs+cam_pos given");
+    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail(FNX_ERR_INVALID_ARG, "neither cov3D_precomp nor scales+rotations given");
+    Geom g = carve_geom(geom_buffer, P);
+    int *rad = radii ? radii : g.radii;  // rasterizer_impl.cu:214-216
+    fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
+                           cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
+                           tan_fovy, rad, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched,
+                           img.tile_count, prefiltered);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.tile_cursor, img.header);
+    return hip_check("stage1");
+}
+
+int fnx_read_num_rendered(const char *image_buffer, int width, int height, fnx_stream_t stream, int *num_rendered) {
+    if (!image_buffer || !num_rendered) return fail(FNX_ERR_INVALID_ARG, "NULL argument");
+    Img img = carve_img(const_cast<char *>(image_buffer), width, height);
+    uint32_t v = 0;
+    hipError_t e = hipMemcpyAsync(&v, img.header + fnx::HDR_NUM_RENDERED, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "read_num_rendered: %s", hipGetErrorString(e));
+    *num_rendered = (int)v;
+    return FNX_OK;
+}
+
+int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_t stream) {
+    if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "NULL argument");
+    Img img = carve_img(const_cast<char *>(image_buffer), width, height);
+    uint32_t h[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyAsync(h, img.header, 12, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "read_status: %s", hipGetErrorString(e));
+    if (h[fnx::HDR_STATUS] == FNX_ERR_CAPACITY)
+        return fail(FNX_ERR_CAPACITY, "binning capacity %u < num_rendered %u", h[fnx::HDR_CAPACITY],
+                    h[fnx::HDR_NUM_RENDERED]);
+    return FNX_OK;
+}
+
+int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
+                       char *image_buffer, int P, int width, int height, const float *background,
+                       const float *colors_precomp, const int *radii, float *out_color, float *out_depth,
+                       fnx_stream_t stream) {
+    if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
+    if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
+    if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
+        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
+    if (binning_capacity > 0 && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = carve_geom(geom_buffer, P);
+    Img img = carve_img(image_buffer, width, height);
+    Bin bin = carve_bin(binning_buffer, binning_capacity);
+    const int *rad = radii ? radii : g.radii;
+    const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
+    const uint32_t cap = (uint32_t)binning_capacity;
+    fnx::launch_scatter(s, P, g.means2D, g.depths, rad, width, height, img.ranges, img.tile_cursor, bin.pairs,
+                        img.header, cap);
+    fnx::launch_tile_sort(s, T, img.ranges, bin.pairs, bin.point_list, img.header, cap);
+    const float *features = colors_precomp ? colors_precomp : g.rgb;  // rasterizer_impl.cu:299
+    fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.means2D, features,
+                              g.conic_opacity, g.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
+                              img.header, cap);
+    return hip_check("stage2");
+}
+
+int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_user, fnx_alloc_fn binningBuffer,
+                          void *binning_user, fnx_alloc_fn imageBuffer, void *image_user, int P, int D, int M,
+                          const float *background, int width, int height, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                          const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                          float tan_fovy, int prefiltered, float *out_color, float *out_depth, int *radii,
+                          fnx_stream_t stream, int *num_rendered) {
+    if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail(FNX_ERR_INVALID_ARG, "NULL allocator");
+    if (num_rendered) *num_rendered = 0;
+    char *geom = geometryBuffer(fnx_geom_bytes(P), geom_user);
+    char *img = imageBuffer(fnx_image_bytes(width, height), image_user);
+    int rc = fnx_forward_stage1(channels, geom, img, P, D, M, width, height, means3D, shs, colors_precomp, opacities,
+                                scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                                tan_fovx, tan_fovy, prefiltered, radii, stream);
+    if (rc != FNX_OK) return rc;
+    int R = 0;
+    rc = fnx_read_num_rendered(img, width, height, stream, &R);  // the reference's blocking D2H copy
+    if (rc != FNX_OK) return rc;
+    if (num_rendered) *num_rendered = R;
+    char *bin = binningBuffer(fnx_binning_bytes(R), binning_user);
+    return fnx_forward_stage2(channels, geom, bin, R, img, P, width, height, background, colors_precomp, radii,
+                              out_color, out_depth, stream);
+}
+
+int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,
+                           const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                           float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                           char *image_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                           float *dL_dscale, float *dL_drot, fnx_stream_t stream) {
+    (void)R;
+    if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
+    if (P == 0) return FNX_OK;  // rasterize_points.cu:160
+    if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix ||
+        !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
+    if (scales && (!rotations || !dL_dscale || !dL_drot))
+        return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = carve_geom(geom_buffer, P);
+    Img img = carve_img(image_buffer, width, height);
+    // the capacity this blob was filled with is irrelevant here: point_list sits at offset 0
+    Bin bin = carve_bin(binning_buffer, 0);
+    const int *rad = radii ? radii : g.radii;
+    const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;      // rasterizer_impl.cu:367
+    const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
+    fnx::launch_blend_backward(channels, s, width, height, img.ranges, bin.point_list, background, g.means2D,
+                               g.conic_opacity, color_ptr, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic,
+                               dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu);
+    fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
+                              cov3D_ptr, viewmatrix, projmatrix, width, height, tan_fovx, tan_fovy, campos, dL_dmean2D,
+                              dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    return hip_check("backward");
+}
+
+int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                     fnx_stream_t stream) {
+    (void)projmatrix;
+    if (P == 0) return FNX_OK;
+    if (P < 0 || !means3D || !viewmatrix || !present) return fail(FNX_ERR_INVALID_ARG, "bad argument");
+    fnx::launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+    return hip_check("mark_visible");
+}
+
+}  // extern "C"

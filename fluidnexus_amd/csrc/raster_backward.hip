@@ -1,0 +1,471 @@
+// Backward pass of the gfx950 Gaussian rasteriser.
+//
+//   blend_backward : per tile, back-to-front, pixel gradients -> per-splat screen-space gradients
+//                    (ch3 backward.cu:384-536)
+//   geom_backward  : per splat, screen-space gradients -> means / cov3D / scale / rotation / SH
+//                    (ch3 backward.cu:137-263 computeCov2DCUDA fused with :332-381 preprocessCUDA;
+//                    same arithmetic, same order of the three mean-gradient terms)
+//
+// The reference issues 6+C global fp32 atomics per contributing (pixel, splat) pair.  Here each
+// pair's contribution is first summed across the 64 lanes of its wave with DPP row operations,
+// then across the tile's 4 waves in LDS, and one set of atomics per (tile, splat) reaches HBM:
+// ~256x fewer device-scope atomics, same sums up to fp32 association order.
+#include "fnx_device.h"
+#include "fnx_state.h"
+
+namespace fnx {
+
+// Sum over the 64 lanes of a wave; the total lands in lane 63.  DPP steps: quad swaps, row
+// shifts by 4 and 8, then row broadcasts 15 and 31 (gfx9 DPP encodings).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+__device__ __forceinline__ int xcd_tile_b(int bid, int T) {
+    const int q = T >> 3, r = T & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
+                      int H, const float *__restrict__ bg, const float2 *__restrict__ means2D,
+                      const float4 *__restrict__ conic_opacity, const float *__restrict__ colors,
+                      const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
+                      const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
+                      float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
+                      const uint32_t *__restrict__ header, uint32_t capacity) {
+    constexpr int NV = 6 + C;  // mean2D.xy | conic.xyw | opacity | colour[C]
+    __shared__ uint32_t s_id[256];
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float s_col[C][256];
+    __shared__ float s_acc[NV][256];
+    __shared__ uint32_t s_max[4];
+    if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] != 0u) return;
+    const int tile = xcd_tile_b(blockIdx.x, T);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tx * FNX_TILE_X + (tid & 15), py = ty * FNX_TILE_Y + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    if (r1 == r0) return;
+
+    const float T_final = inside ? final_Ts[pix_id] : 0.f;
+    float Tr = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+    float accum_rec[C], dL_dpixel[C], last_color[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+        accum_rec[ch] = 0.f;
+        last_color[ch] = 0.f;
+        dL_dpixel[ch] = inside ? dL_dpixels[(size_t)ch * H * W + pix_id] : 0.f;
+    }
+    float last_alpha = 0.f;
+    float bg_dot_dpixel = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
+
+    // No pixel of this tile looks past list position max(n_contrib): start there (positions are
+    // 0-based from the front; entry q is used by a pixel iff q < its n_contrib, backward.cu:467-469).
+    uint32_t m = last_contributor;
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    const uint32_t qmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    for (uint32_t top = qmax; top > 0;) {
+        const uint32_t cnt = min(256u, top);
+        // stage entries q = top-1 ... top-cnt (slot j <-> q = top-1-j), zero the slot accumulators
+        __syncthreads();
+        if ((uint32_t)tid < cnt) {
+            const uint32_t id = point_list[r0 + top - 1 - tid];
+            s_id[tid] = id;
+            s_xy[tid] = means2D[id];
+            s_co[tid] = conic_opacity[id];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) s_col[ch][tid] = colors[(size_t)id * C + ch];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
+        __syncthreads();
+
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t q = top - 1 - j;
+            float val[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) val[v] = 0.f;
+            bool active = q < last_contributor;
+            if (active) {
+                const float2 xy = s_xy[j];
+                const float dx = xy.x - pxf, dy = xy.y - pyf;
+                const float4 co = s_co[j];
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                active = !(power > 0.0f);
+                if (active) {
+                    const float G = exp_fixed(power);
+                    const float alpha = fminf(0.99f, co.w * G);
+                    active = !(alpha < 1.0f / 255.0f);
+                    if (active) {
+                        Tr = Tr / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * Tr;
+                        float dL_dalpha = 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) {
+                            const float c = s_col[ch][j];
+                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            last_color[ch] = c;
+                            const float dL_dchannel = dL_dpixel[ch];
+                            dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+                            val[6 + ch] = dchannel_dcolor * dL_dchannel;
+                        }
+                        dL_dalpha *= Tr;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                        const float dL_dG = co.w * dL_dalpha;
+                        const float gdx = G * dx;
+                        const float gdy = G * dy;
+                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        val[0] = dL_dG * dG_ddelx * ddelx_dx;
+                        val[1] = dL_dG * dG_ddely * ddely_dy;
+                        val[2] = -0.5f * gdx * dx * dL_dG;
+                        val[3] = -0.5f * gdx * dy * dL_dG;
+                        val[4] = -0.5f * gdy * dy * dL_dG;
+                        val[5] = G * dL_dalpha;
+                    }
+                }
+            }
+            if (__ballot(active) != 0ull) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float s = wave_sum_to_lane63(val[v]);
+                    if (lane == 63) atomicAdd(&s_acc[v][j], s);
+                }
+            }
+        }
+        __syncthreads();
+        if ((uint32_t)tid < cnt) {
+            const uint32_t id = s_id[tid];
+            float a[NV];
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                a[v] = s_acc[v][tid];
+                any |= (a[v] != 0.f);
+            }
+            if (any) {
+                unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], a[0]);
+                unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], a[1]);
+                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], a[2]);
+                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], a[3]);
+                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 3], a[4]);
+                unsafeAtomicAdd(&dL_dopacity[id], a[5]);
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) unsafeAtomicAdd(&dL_dcolors[(size_t)id * C + ch], a[6 + ch]);
+            }
+        }
+        top -= cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SH colour backward (ch3 backward.cu:20-132)
+__device__ inline void sh_backward(int idx, int deg, int M, const float *means, const float *campos, const float *shs,
+                                   const uint8_t *clamped, const float *dL_dcolor, float *dL_dmeans, float *dL_dshs) {
+    const float ox = means[3 * idx] - campos[0], oy = means[3 * idx + 1] - campos[1], oz = means[3 * idx + 2] - campos[2];
+    const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    const float *sh = shs + (size_t)idx * M * 3;
+    float *dL_dsh = dL_dshs + (size_t)idx * M * 3;
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? 0.0f : 1.0f);
+    float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};
+#define SH(k, c) sh[(k) * 3 + (c)]
+#define DSH(k, c) dL_dsh[(k) * 3 + (c)]
+#pragma unroll
+    for (int c = 0; c < 3; c++) DSH(0, c) = kSH0 * g[c];
+    if (deg > 0) {
+        const float d1 = -kSH1 * y, d2 = kSH1 * z, d3 = -kSH1 * x;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            DSH(1, c) = d1 * g[c];
+            DSH(2, c) = d2 * g[c];
+            DSH(3, c) = d3 * g[c];
+            ddx[c] = -kSH1 * SH(3, c);
+            ddy[c] = -kSH1 * SH(1, c);
+            ddz[c] = kSH1 * SH(2, c);
+        }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            const float d4 = kSH2[0] * xy, d5 = kSH2[1] * yz, d6 = kSH2[2] * (2.f * zz - xx - yy), d7 = kSH2[3] * xz,
+                        d8 = kSH2[4] * (xx - yy);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                DSH(4, c) = d4 * g[c];
+                DSH(5, c) = d5 * g[c];
+                DSH(6, c) = d6 * g[c];
+                DSH(7, c) = d7 * g[c];
+                DSH(8, c) = d8 * g[c];
+                ddx[c] += kSH2[0] * y * SH(4, c) + kSH2[2] * 2.f * -x * SH(6, c) + kSH2[3] * z * SH(7, c) +
+                          kSH2[4] * 2.f * x * SH(8, c);
+                ddy[c] += kSH2[0] * x * SH(4, c) + kSH2[1] * z * SH(5, c) + kSH2[2] * 2.f * -y * SH(6, c) +
+                          kSH2[4] * 2.f * -y * SH(8, c);
+                ddz[c] += kSH2[1] * y * SH(5, c) + kSH2[2] * 2.f * 2.f * z * SH(6, c) + kSH2[3] * x * SH(7, c);
+            }
+            if (deg > 2) {
+                const float d9 = kSH3[0] * y * (3.f * xx - yy), d10 = kSH3[1] * xy * z,
+                            d11 = kSH3[2] * y * (4.f * zz - xx - yy),
+                            d12 = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy),
+                            d13 = kSH3[4] * x * (4.f * zz - xx - yy), d14 = kSH3[5] * z * (xx - yy),
+                            d15 = kSH3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    DSH(9, c) = d9 * g[c];
+                    DSH(10, c) = d10 * g[c];
+                    DSH(11, c) = d11 * g[c];
+                    DSH(12, c) = d12 * g[c];
+                    DSH(13, c) = d13 * g[c];
+                    DSH(14, c) = d14 * g[c];
+                    DSH(15, c) = d15 * g[c];
+                    ddx[c] += (kSH3[0] * SH(9, c) * 3.f * 2.f * xy + kSH3[1] * SH(10, c) * yz +
+                               kSH3[2] * SH(11, c) * -2.f * xy + kSH3[3] * SH(12, c) * -3.f * 2.f * xz +
+                               kSH3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy) + kSH3[5] * SH(14, c) * 2.f * xz +
+                               kSH3[6] * SH(15, c) * 3.f * (xx - yy));
+                    ddy[c] += (kSH3[0] * SH(9, c) * 3.f * (xx - yy) + kSH3[1] * SH(10, c) * xz +
+                               kSH3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) +
+                               kSH3[3] * SH(12, c) * -3.f * 2.f * yz + kSH3[4] * SH(13, c) * -2.f * xy +
+                               kSH3[5] * SH(14, c) * -2.f * yz + kSH3[6] * SH(15, c) * -3.f * 2.f * xy);
+                    ddz[c] += (kSH3[1] * SH(10, c) * xy + kSH3[2] * SH(11, c) * 4.f * 2.f * yz +
+                               kSH3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) +
+                               kSH3[4] * SH(13, c) * 4.f * 2.f * xz + kSH3[5] * SH(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    const float vx = ddx[0] * g[0] + ddx[1] * g[1] + ddx[2] * g[2];
+    const float vy = ddy[0] * g[0] + ddy[1] * g[1] + ddy[2] * g[2];
+    const float vz = ddz[0] * g[0] + ddz[1] * g[1] + ddz[2] * g[2];
+    // gradient through the direction normalisation (ch3 auxiliary.h:95-105)
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    const float o0 = ((+sum2 - ox * ox) * vx - oy * ox * vy - oz * ox * vz) * invsum32;
+    const float o1 = (-ox * oy * vx + (sum2 - oy * oy) * vy - oz * oy * vz) * invsum32;
+    const float o2 = (-ox * oz * vx - oy * oz * vy + (sum2 - oz * oz) * vz) * invsum32;
+    dL_dmeans[3 * idx + 0] += o0;
+    dL_dmeans[3 * idx + 1] += o1;
+    dL_dmeans[3 * idx + 2] += o2;
+}
+
+__device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// scale/rotation backward (ch3 backward.cu:267-327; raw-quaternion gradient, :326)
+__device__ inline void cov3d_backward(int idx, const float *scale, float mod, const float *rot,
+                                      const float *dL_dcov3Ds, float *dL_dscales, float *dL_drots) {
+    const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    const M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                         2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                         2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    M3 S = m3_cols(1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f);
+    const float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    S.m[0][0] = s[0];
+    S.m[1][1] = s[1];
+    S.m[2][2] = s[2];
+    const M3 Mm = m3_mul(S, R);
+    const float *d = dL_dcov3Ds + 6 * (size_t)idx;
+    const M3 dSigma = m3_cols(d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2],
+                              0.5f * d[4], d[5]);
+    M3 M2;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = 2.0f * Mm.m[c][rr];
+    const M3 dM = m3_mul(M2, dSigma);
+    const M3 Rt = m3_t(R);
+    M3 dMt = m3_t(dM);
+    dL_dscales[3 * (size_t)idx + 0] = dot3(Rt.m[0], dMt.m[0]);
+    dL_dscales[3 * (size_t)idx + 1] = dot3(Rt.m[1], dMt.m[1]);
+    dL_dscales[3 * (size_t)idx + 2] = dot3(Rt.m[2], dMt.m[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dMt.m[0][k] *= s[0];
+        dMt.m[1][k] *= s[1];
+        dMt.m[2][k] *= s[2];
+    }
+#define D(i, j) dMt.m[i][j]
+    const float qx = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+    const float qy = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) -
+                     4 * x * (D(2, 2) + D(1, 1));
+    const float qz = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) -
+                     4 * y * (D(2, 2) + D(0, 0));
+    const float qw = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) -
+                     4 * z * (D(1, 1) + D(0, 0));
+#undef D
+    dL_drots[4 * (size_t)idx + 0] = qx;
+    dL_drots[4 * (size_t)idx + 1] = qy;
+    dL_drots[4 * (size_t)idx + 2] = qz;
+    dL_drots[4 * (size_t)idx + 3] = qw;
+}
+
+// One thread per visible splat: conic gradient -> cov2D -> cov3D and mean (EWA Jacobian, clamp
+// masks), then projection Jacobian of the 2D mean, then SH and scale/rotation.
+template <int C>
+__global__ void __launch_bounds__(256)
+geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, const int *__restrict__ radii,
+                     const float *__restrict__ shs, const uint8_t *__restrict__ clamped,
+                     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
+                     const float *__restrict__ cov3Ds, const float *__restrict__ view, const float *__restrict__ proj,
+                     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ campos,
+                     const float *__restrict__ dL_dmean2D, const float *__restrict__ dL_dconics,
+                     float *__restrict__ dL_dmeans, float *__restrict__ dL_dcolor, float *__restrict__ dL_dcov,
+                     float *__restrict__ dL_dsh, float *__restrict__ dL_dscale, float *__restrict__ dL_drot) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const float *cov3D = cov3Ds + 6 * (size_t)idx;
+    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float gc0 = dL_dconics[4 * (size_t)idx], gc1 = dL_dconics[4 * (size_t)idx + 1],
+                gc2 = dL_dconics[4 * (size_t)idx + 3];
+    float3 t = xform4x3(mean, view);
+    const float limx = 1.3f * tan_fovx;
+    const float limy = 1.3f * tan_fovy;
+    const float txtz = t.x / t.z;
+    const float tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float x_grad_mul = txtz < -limx || txtz > limx ? 0 : 1;
+    const float y_grad_mul = tytz < -limy || tytz > limy ? 0 : 1;
+    const M3 J = m3_cols(h_x / t.z, 0.0f, -(h_x * t.x) / (t.z * t.z), 0.0f, h_y / t.z, -(h_y * t.y) / (t.z * t.z), 0.f,
+                         0.f, 0.f);
+    const M3 Wm = m3_cols(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    const M3 Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    const M3 Tm_ = m3_mul(Wm, J);
+    M3 cov2D = m3_mul(m3_mul(m3_t(Tm_), m3_t(Vrk)), Tm_);
+    const float a = cov2D.m[0][0] += 0.3f;
+    const float b = cov2D.m[0][1];
+    const float c = cov2D.m[1][1] += 0.3f;
+    const float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define Tm(i, j) Tm_.m[i][j]
+#define Vm(i, j) Vrk.m[i][j]
+    float *dcv = dL_dcov + 6 * (size_t)idx;
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * gc0 + 2 * b * c * gc1 + (denom - a * c) * gc2);
+        dL_dc = denom2inv * (-a * a * gc2 + 2 * a * b * gc1 + (denom - a * c) * gc0);
+        dL_db = denom2inv * 2 * (b * c * gc0 - (denom + 2 * b * b) * gc1 + a * b * gc2);
+        dcv[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
+        dcv[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
+        dcv[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
+        dcv[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db +
+                 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
+        dcv[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db +
+                 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
+        dcv[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db +
+                 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dcv[i] = 0;
+    }
+    const float dL_dT00 = 2 * (Tm(0, 0) * Vm(0, 0) + Tm(0, 1) * Vm(0, 1) + Tm(0, 2) * Vm(0, 2)) * dL_da +
+                          (Tm(1, 0) * Vm(0, 0) + Tm(1, 1) * Vm(0, 1) + Tm(1, 2) * Vm(0, 2)) * dL_db;
+    const float dL_dT01 = 2 * (Tm(0, 0) * Vm(1, 0) + Tm(0, 1) * Vm(1, 1) + Tm(0, 2) * Vm(1, 2)) * dL_da +
+                          (Tm(1, 0) * Vm(1, 0) + Tm(1, 1) * Vm(1, 1) + Tm(1, 2) * Vm(1, 2)) * dL_db;
+    const float dL_dT02 = 2 * (Tm(0, 0) * Vm(2, 0) + Tm(0, 1) * Vm(2, 1) + Tm(0, 2) * Vm(2, 2)) * dL_da +
+                          (Tm(1, 0) * Vm(2, 0) + Tm(1, 1) * Vm(2, 1) + Tm(1, 2) * Vm(2, 2)) * dL_db;
+    const float dL_dT10 = 2 * (Tm(1, 0) * Vm(0, 0) + Tm(1, 1) * Vm(0, 1) + Tm(1, 2) * Vm(0, 2)) * dL_dc +
+                          (Tm(0, 0) * Vm(0, 0) + Tm(0, 1) * Vm(0, 1) + Tm(0, 2) * Vm(0, 2)) * dL_db;
+    const float dL_dT11 = 2 * (Tm(1, 0) * Vm(1, 0) + Tm(1, 1) * Vm(1, 1) + Tm(1, 2) * Vm(1, 2)) * dL_dc +
+                          (Tm(0, 0) * Vm(1, 0) + Tm(0, 1) * Vm(1, 1) + Tm(0, 2) * Vm(1, 2)) * dL_db;
+    const float dL_dT12 = 2 * (Tm(1, 0) * Vm(2, 0) + Tm(1, 1) * Vm(2, 1) + Tm(1, 2) * Vm(2, 2)) * dL_dc +
+                          (Tm(0, 0) * Vm(2, 0) + Tm(0, 1) * Vm(2, 1) + Tm(0, 2) * Vm(2, 2)) * dL_db;
+#undef Tm
+#undef Vm
+    const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+    const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+    const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+    const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+    const float tz = 1.f / t.z;
+    const float tz2 = tz * tz;
+    const float tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 +
+                         (2 * h_y * t.y) * tz3 * dL_dJ12;
+    // term 1 of the mean gradient: through the covariance (assigned, ch3 backward.cu:262)
+    float gm0 = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
+    float gm1 = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+    float gm2 = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+
+    // term 2: through the projected 2D mean (ch3 backward.cu:358-372)
+    const float4 m_hom = xform4x4(mean, proj);
+    const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+    const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+    const float g0 = dL_dmean2D[3 * (size_t)idx], g1 = dL_dmean2D[3 * (size_t)idx + 1];
+    const float dmx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
+    const float dmy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
+    const float dmz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
+    gm0 += dmx;
+    gm1 += dmy;
+    gm2 += dmz;
+    dL_dmeans[3 * (size_t)idx + 0] = gm0;
+    dL_dmeans[3 * (size_t)idx + 1] = gm1;
+    dL_dmeans[3 * (size_t)idx + 2] = gm2;
+    // term 3: view-dependent colour
+    if (shs) sh_backward(idx, D, M, means3D, campos, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
+    if (scales) cov3d_backward(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov, dL_dscale, dL_drot);
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_blend_backward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
+                           const float *bg, const float2 *means2D, const float4 *conic_opacity, const float *colors,
+                           const float *final_Ts, const uint32_t *n_contrib, const float *dL_dpixels,
+                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                           const uint32_t *header, uint32_t capacity) {
+    const int gx = tiles_x(W), T = gx * tiles_y(H);
+    if (C == 3)
+        hipLaunchKernelGGL((blend_backward_kernel<3>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg,
+                           means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolors, header, capacity);
+    else
+        hipLaunchKernelGGL((blend_backward_kernel<1>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg,
+                           means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolors, header, capacity);
+}
+
+void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
+                          const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
+                          float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
+                          float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
+                          const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
+                          float *dL_dscale, float *dL_drot) {
+    const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:360-361
+    const float focal_x = W / (2.0f * tan_fovx);
+    if (C == 3)
+        hipLaunchKernelGGL((geom_backward_kernel<3>), dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
+                           shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
+                           tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
+                           dL_dscale, dL_drot);
+    else
+        hipLaunchKernelGGL((geom_backward_kernel<1>), dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
+                           shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
+                           tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
+                           dL_dscale, dL_drot);
+}
+
+}  // namespace fnx

@@ -1,0 +1,229 @@
+"""Autograd boundary of the MI355X-native Gaussian rasteriser.
+
+Mirrors, name for name, the Python interface of the reference's two rasteriser packages
+  FluidDynamics/submodules/gaussian_rasterization_ch3/diff_gaussian_rasterization_ch3/__init__.py
+  (rasterize_gaussians :9-30, _RasterizeGaussians :33-140, GaussianRasterizationSettings :143-154,
+  GaussianRasterizer :157-215) and its ch1 twin (NUM_CHANNELS = 1),
+on top of the C ABI in include/fnx_raster.h (loaded with ctypes; no torch C++ glue).
+
+Differences from the reference that callers can observe:
+  * one implementation parameterised by `channels`; the ch3 / ch1 packages are thin aliases;
+  * work is enqueued on torch's current HIP stream (reference: legacy default stream);
+  * `set_host_sync(False)` removes the per-forward device->host read of num_rendered
+    (rasterizer_impl.cu:264) by sizing the binning scratch from a running high-water mark; an
+    overflow is reported by `check_status()` / the next forward.
+There is no CPU path: tensors must live on a HIP device and the HIP library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_HOST_SYNC = True          # True = reference behaviour (exact-size binning buffer, one sync per forward)
+_CAP_SLACK = 1.3           # head-room over the high-water mark when host sync is off
+_capacity_hwm: dict = {}   # (device, W, H, channels) -> capacity in instances
+_pending_status: list = []  # image blobs whose overflow status has not been read yet
+
+
+def set_host_sync(enabled: bool, initial_capacity: int | None = None):
+    """enabled=False: never read num_rendered back inside forward (see module docstring)."""
+    global _HOST_SYNC
+    _HOST_SYNC = bool(enabled)
+    if initial_capacity is not None:
+        _capacity_hwm["default"] = int(initial_capacity)
+
+
+def check_status():
+    """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity."""
+    lib = _lib.raster()
+    stream = torch.cuda.current_stream().cuda_stream
+    while _pending_status:
+        img, W, H, key = _pending_status.pop()
+        n = C.c_int(0)
+        _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
+        _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n.value * _CAP_SLACK) + 1024)
+        _lib.check(lib.fnx_read_status(img.data_ptr(), W, H, stream))
+
+
+def _ptr(t: torch.Tensor):
+    """0-element tensor == 'not provided' == NULL (rasterize_points.cu:95-101)."""
+    return t.data_ptr() if t.numel() else None
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings, channels=3):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings, channels)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings, channels):
+        lib = _lib.raster()
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:56-58
+        if not means3D.is_cuda:
+            raise RuntimeError("fluidnexus_amd rasteriser: tensors must be on a HIP device (no CPU path)")
+        dev = means3D.device
+        rs = raster_settings
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        Cn = int(channels)
+        means3D = _f32c(means3D)
+        sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
+        scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
+        bg, view, proj, campos = _f32c(rs.bg), _f32c(rs.view_matrix), _f32c(rs.proj_matrix), _f32c(rs.campos)
+        M = sh.shape[1] if sh.numel() else 0
+        stream = torch.cuda.current_stream().cuda_stream
+        u8 = dict(dtype=torch.uint8, device=dev)
+        geom = torch.empty(lib.fnx_geom_bytes(P), **u8)
+        img = torch.empty(lib.fnx_image_bytes(W, H), **u8)
+        if P == 0:  # rasterize_points.cu:81: zeros, no kernels
+            color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+            depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+            radii = torch.zeros(0, dtype=torch.int32, device=dev)
+            binning = torch.empty(0, **u8)
+            num_rendered = 0
+        else:
+            color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)
+            _lib.check(lib.fnx_forward_stage1(
+                Cn, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
+                _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(cov3Ds_precomp), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), float(rs.tan_fov_x),
+                float(rs.tan_fov_y), int(bool(rs.prefiltered)), radii.data_ptr(), stream))
+            if _HOST_SYNC:
+                n = C.c_int(0)
+                _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
+                num_rendered = cap = int(n.value)
+            else:
+                key = (dev.index, W, H, Cn, P)
+                cap = _capacity_hwm.get(key) or _capacity_hwm.get("default") or max(4 * P, 1 << 20)
+                _capacity_hwm[key] = cap
+                num_rendered = -1
+                _pending_status.append((img, W, H, key))
+                if len(_pending_status) > 64:
+                    del _pending_status[0]
+            binning = torch.empty(lib.fnx_binning_bytes(cap), **u8)
+            _lib.check(lib.fnx_forward_stage2(Cn, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H,
+                                              bg.data_ptr(), _ptr(colors_precomp), radii.data_ptr(),
+                                              color.data_ptr(), depth.data_ptr(), stream))
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.channels = Cn
+        ctx.aux = (bg, view, proj, campos)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii, depth)  # the reference ignores their grads (__init__.py:83)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        lib = _lib.raster()
+        rs = ctx.raster_settings
+        Cn = ctx.channels
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        bg, view, proj, campos = ctx.aux
+        dev = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = sh.shape[1] if sh.numel() else 0
+        # one zero-filled slab for all nine gradient arrays (torch::zeros x9, rasterize_points.cu:150-158)
+        widths = (3, 3, Cn, 4, 1, 6, 3 * M, 3, 4)
+        flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)
+        parts, off = [], 0
+        for w in widths:
+            parts.append(flat[off:off + P * w])
+            off += P * w
+        g_means3D, g_means2D, g_colors, g_conic, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
+        if P != 0:
+            dL = _f32c(grad_out_color)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.fnx_rasterize_backward(
+                Cn, P, int(rs.sh_degree), M, max(ctx.num_rendered, 0), bg.data_ptr(), W, H, means3D.data_ptr(),
+                _ptr(sh), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(cov3Ds_precomp), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), float(rs.tan_fov_x),
+                float(rs.tan_fov_y), radii.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr(), dL.data_ptr(),
+                g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity.data_ptr(), g_colors.data_ptr(),
+                g_means3D.data_ptr(), g_cov3D.data_ptr(), g_sh.data_ptr() if M else None, g_scales.data_ptr(),
+                g_rot.data_ptr(), stream))
+        # same order and shapes as ch3 __init__.py:128-138 / rasterize_points.cu:150-158
+        return (g_means3D.view(P, 3), g_means2D.view(P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Field names as in ch3 __init__.py:143-154 (not upstream 3DGS's tanfovx/viewmatrix/...)."""
+    image_height: int
+    image_width: int
+    tan_fov_x: float
+    tan_fov_y: float
+    bg: torch.Tensor
+    scale_modifier: float
+    view_matrix: torch.Tensor
+    proj_matrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+class GaussianRasterizer(nn.Module):
+    """ch3 __init__.py:157-215.  `channels` selects the ch3 (3) or ch1 (1) behaviour."""
+
+    channels = 3
+
+    def __init__(self, raster_settings, channels=None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        if channels is not None:
+            self.channels = int(channels)
+
+    def mark_visible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            lib = _lib.raster()
+            if not positions.is_cuda:
+                raise RuntimeError("fluidnexus_amd rasteriser: tensors must be on a HIP device (no CPU path)")
+            pos = _f32c(positions)
+            P = pos.shape[0]
+            present = torch.zeros(P, dtype=torch.bool, device=pos.device)
+            _lib.check(lib.fnx_mark_visible(P, _ptr(pos), _f32c(rs.view_matrix).data_ptr(),
+                                            _f32c(rs.proj_matrix).data_ptr(), _ptr(present),
+                                            torch.cuda.current_stream().cuda_stream))
+        return present
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if self.channels != 3 and colors_precomp is None:
+            raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")  # rasterizer_impl.cu:226-228
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings, self.channels)

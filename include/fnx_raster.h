@@ -1,0 +1,145 @@
+/*
+ * fnx_raster.h -- C ABI of the MI355X-native (gfx950) differentiable 3D-Gaussian rasteriser.
+ *
+ * Drop-in boundary for the torch-free C++ API the reference binds through pybind11:
+ *   CudaRasterizer::Rasterizer::{forward, backward, markVisible}
+ *   FluidDynamics/submodules/gaussian_rasterization_ch3/cuda_rasterizer/rasterizer.h:18-84
+ *   (identical in gaussian_rasterization_ch1; the two differ only in NUM_CHANNELS, config.h:15,
+ *   which is the `channels` argument here).
+ *
+ * Conventions (reference behaviour in brackets):
+ *  - every pointer is a DEVICE pointer to contiguous fp32/int32 data unless stated otherwise;
+ *    NULL means "not provided" [0-element tensors surface as nullptr, rasterize_points.cu:95-101].
+ *  - all work is enqueued on `stream` (a hipStream_t) [reference: legacy default stream].
+ *  - outputs and scratch are caller-allocated.  The three scratch blobs (geometry, binning,
+ *    image) are opaque, produced by forward and consumed by backward [__init__.py:77-79];
+ *    their sizes come from fnx_*_bytes() [reference: std::function<char*(size_t)> resize
+ *    callbacks, rasterizer.h:31-33; fnx_rasterize_forward keeps that callback form].
+ *  - gradient outputs must be zero-filled by the caller [torch::zeros, rasterize_points.cu:150-158].
+ *  - every entry point returns FNX_OK or an error code; fnx_last_error() gives the text
+ *    [reference: AT_ERROR / std::runtime_error, no CUDA error checks].
+ *  - P == 0 is a no-op that leaves the (zero-filled) outputs untouched [rasterize_points.cu:81,160].
+ */
+#ifndef FNX_RASTER_H
+#define FNX_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNX_OK 0
+#define FNX_ERR_INVALID_ARG 1
+#define FNX_ERR_NON_RGB_NEEDS_COLORS 2 /* rasterizer_impl.cu:226-228 */
+#define FNX_ERR_HIP 3
+#define FNX_ERR_CAPACITY 4 /* binning buffer smaller than num_rendered */
+#define FNX_ERR_UNSUPPORTED 5
+
+typedef void *fnx_stream_t; /* hipStream_t */
+
+/* Resizable-buffer callback: must return a device pointer to at least `bytes` bytes
+ * [std::function<char*(size_t)>, rasterizer.h:31-33 / resizeFunctional, rasterize_points.cu:27-33]. */
+typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
+
+int fnx_abi_version(void);
+const char *fnx_last_error(void);
+
+/* Scratch sizes [required<GeometryState>(P), required<ImageState>(W*H), required<BinningState>(R),
+ * rasterizer_impl.cu:210,222,266]. */
+size_t fnx_geom_bytes(int P);
+size_t fnx_image_bytes(int width, int height);
+size_t fnx_binning_bytes(int64_t num_rendered);
+
+/*
+ * Rasterizer::forward, one call, callback allocation (rasterizer.h:30-54).  Synchronises `stream`
+ * once to read num_rendered (the reference's blocking cudaMemcpy, rasterizer_impl.cu:264).
+ * Returns the error code; *num_rendered receives the reference's return value.
+ */
+int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_user, fnx_alloc_fn binningBuffer,
+                          void *binning_user, fnx_alloc_fn imageBuffer, void *image_user, int P, int D, int M,
+                          const float *background, int width, int height, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                          const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                          float tan_fovy, int prefiltered, float *out_color, float *out_depth, int *radii,
+                          fnx_stream_t stream, int *num_rendered);
+
+/*
+ * The same forward split at the reference's host sync so that a caller can avoid it:
+ *   stage 1 = per-Gaussian preprocess + per-tile instance counts + tile ranges (num_rendered stays
+ *             on the device, inside image_buffer);
+ *   fnx_read_num_rendered = the optional blocking read-back;
+ *   stage 2 = instance emission, per-tile depth sort, alpha blending, with a caller-chosen
+ *             binning capacity.  If num_rendered > capacity nothing is rendered and
+ *             fnx_read_status reports FNX_ERR_CAPACITY.
+ */
+int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
+                       const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                       const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                       const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, int *radii, fnx_stream_t stream);
+int fnx_read_num_rendered(const char *image_buffer, int width, int height, fnx_stream_t stream, int *num_rendered);
+int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
+                       char *image_buffer, int P, int width, int height, const float *background,
+                       const float *colors_precomp, const int *radii, float *out_color, float *out_depth,
+                       fnx_stream_t stream);
+/* Blocking: FNX_OK or FNX_ERR_CAPACITY for the last forward that used image_buffer. */
+int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_t stream);
+
+/*
+ * Rasterizer::backward (rasterizer.h:56-83).  R is accepted for signature parity and ignored
+ * (the instance count lives in image_buffer).  dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
+ * dL_dcolor [P,C], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
+ */
+int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,
+                           const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                           float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                           char *image_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                           float *dL_dscale, float *dL_drot, fnx_stream_t stream);
+
+/* Rasterizer::markVisible (rasterizer.h:20-25): present[i] = view-space z > 0.2 (auxiliary.h:138). */
+int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                     fnx_stream_t stream);
+
+/*
+ * Byte offsets of the named arrays inside the opaque scratch blobs, for parity tests and tools
+ * (the reference re-derives the same pointers with fromChunk, rasterizer_impl.cu:144-180).
+ */
+typedef struct {
+    size_t depths;        /* f32[P]   view-space z                                  */
+    size_t clamped;       /* u8[3P]   SH clamp flags                                */
+    size_t radii;         /* i32[P]   internal radii (used when radii == NULL)      */
+    size_t means2D;       /* f32[2P]  pixel-space centres                           */
+    size_t cov3D;         /* f32[6P]                                                */
+    size_t conic_opacity; /* f32[4P]                                                */
+    size_t rgb;           /* f32[3P]  SH colours                                    */
+    size_t tiles_touched; /* u32[P]                                                 */
+    size_t total;
+} fnx_geom_layout_t;
+typedef struct {
+    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen  */
+    size_t final_T;     /* f32[H*W]                                                 */
+    size_t n_contrib;   /* u32[H*W]                                                 */
+    size_t ranges;      /* u32[2T] per-tile [start,end)                             */
+    size_t tile_count;  /* u32[T]                                                   */
+    size_t tile_cursor; /* u32[T]                                                   */
+    size_t total;
+} fnx_image_layout_t;
+typedef struct {
+    size_t point_list; /* u32[R] Gaussian ids sorted by (tile, depth bits, id)      */
+    size_t pairs;      /* u64[R] (depth bits << 32 | id), grouped by tile, unsorted */
+    size_t total;
+} fnx_binning_layout_t;
+void fnx_geom_layout(int P, fnx_geom_layout_t *out);
+void fnx_image_layout(int width, int height, fnx_image_layout_t *out);
+void fnx_binning_layout(int64_t num_rendered, fnx_binning_layout_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNX_RASTER_H */
