@@ -1,0 +1,171 @@
+"""-m gpu: HIP rasteriser (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (DESIGN.md "Parity"): every forward quantity BIT-EXACT (integers: radii, tiles_touched,
+ranges, point_list, n_contrib; floats: means2D, depths, conic, cov3D, colour, depth, final_T);
+gradients within fp32 summation-order tolerance of the oracle's double-accumulated sums."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from fluidnexus_amd import synthetic as S  # noqa: E402
+
+
+def _run_pair(oracle, g, cam, W, H, bg, channels=3, shs=None, sh_degree=0, cov=False, fov=0.8):
+    from tests.hip_harness import HipRun, scene_kwargs
+    kw = scene_kwargs(g, cam, W, H, fov)
+    extra = {}
+    if shs is not None:
+        extra.update(shs=shs, sh_degree=sh_degree)
+    else:
+        extra.update(colors_precomp=g["colors"])
+    if cov is not False:
+        extra.update(cov3D_precomp=cov)
+    else:
+        extra.update(scales=g["scales"], rotations=g["rotations"])
+    f = oracle.forward(kw["means3D"], kw["opacities"], bg, kw["view"], kw["proj"], kw["campos"], W, H, kw["tanx"],
+                       kw["tany"], channels=channels, **extra)
+    h = HipRun(bg=bg, channels=channels, **kw, **extra)
+    return f, h
+
+
+def _assert_forward_exact(f, h):
+    it = h.intermediates()
+    assert h.R == f["num_rendered"]
+    for k in ("radii", "tiles_touched", "ranges", "point_list", "n_contrib"):
+        a, b = it[k].astype(np.int64), f[k].astype(np.int64)
+        assert a.shape == b.shape and (a == b).all(), f"{k}: {np.sum(a != b)} mismatches"
+    vis = f["radii"] > 0
+    for k in ("means2D", "depths", "conic_opacity", "cov3D"):
+        a, b = it[k][vis], f[k][vis]
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), f"{k} not bit-exact: max |d| {np.abs(a - b).max()}"
+    for k in ("color", "depth", "final_T"):
+        a, b = it[k], f[k]
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), f"{k} not bit-exact: max |d| {np.abs(a - b).max()}"
+    return it
+
+
+def _assert_grads_close(go, gh, rtol=2e-4):
+    for k, ref in go.items():
+        if ref.size == 0:
+            continue
+        got = gh[k].reshape(ref.shape)
+        scale = np.abs(ref).max() + 1e-20
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / scale
+        assert err < rtol, f"{k}: rel-to-max error {err:.3e}"
+
+
+@pytest.mark.parametrize("P,W,H,seed", [(64, 32, 32, 0), (1000, 64, 48, 1), (10000, 256, 256, 2), (3000, 100, 70, 3)])
+def test_forward_backward_ch3_precomp(oracle, P, W, H, seed):
+    g = S.random_gaussians(P, seed=seed, box=0.5, log_scale=(-5.0, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.array([0.1, 0.4, 0.9], np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg)
+    _assert_forward_exact(f, h)
+    dL = np.random.RandomState(seed).normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+def test_ch1_grey(oracle):
+    P, W, H = 5000, 128, 96
+    g = S.random_gaussians(P, seed=5, channels=1, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.array([0.3, 0.0, 0.0], np.float32)  # ch1 reads bg[0] only (forward.cu:370 with C = 1)
+    f, h = _run_pair(oracle, g, cam, W, H, bg, channels=1)
+    _assert_forward_exact(f, h)
+    dL = np.random.RandomState(7).normal(size=(1, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colours(oracle, deg):
+    P, W, H = 2000, 64, 64
+    g = S.random_gaussians(P, seed=11 + deg, log_scale=(-4.5, -2.5))
+    shs = (np.random.RandomState(deg).normal(size=(P, 16, 3)) * 0.4).astype(np.float32)
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.zeros(3, np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg, shs=shs, sh_degree=deg)
+    it = _assert_forward_exact(f, h)
+    vis = f["radii"] > 0
+    assert (it["rgb"][vis].view(np.uint32) == f["rgb"][vis].view(np.uint32)).all()
+    assert (it["clamped"][vis] == f["clamped"][vis]).all()
+    dL = np.random.RandomState(3).normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+def test_cov3d_precomp(oracle):
+    P, W, H = 1500, 64, 64
+    g = S.random_gaussians(P, seed=21, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.ones(3, np.float32)
+    f0, _ = _run_pair(oracle, g, cam, W, H, bg)
+    f, h = _run_pair(oracle, g, cam, W, H, bg, cov=f0["cov3D"].copy())
+    _assert_forward_exact(f, h)
+    dL = np.random.RandomState(4).normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+def test_edge_cases(oracle):
+    """behind-camera and off-screen splats, opaque stacks that saturate T, a tile list longer
+    than one 256-entry staging round, an LDS-overflowing tile (global-memory sort fallback)."""
+    W, H = 48, 48
+    rng = np.random.RandomState(0)
+    n_stack = 6000  # > 4096 pairs in the central tiles -> global sort path; >256 -> multi-round
+    xyz = np.concatenate([
+        rng.uniform(-0.02, 0.02, size=(n_stack, 3)),            # dense stack at the centre
+        rng.uniform(-0.5, 0.5, size=(200, 3)) + [0, 0, 3.0],    # behind the camera (z_view <= 0.2)
+        rng.uniform(-0.5, 0.5, size=(200, 3)) + [5.0, 0, 0],    # far off-screen
+    ]).astype(np.float32)
+    P = xyz.shape[0]
+    g = dict(means3D=xyz, scales=np.exp(rng.uniform(-4.5, -3.5, size=(P, 3))).astype(np.float32),
+             rotations=np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1)),
+             opacities=rng.uniform(0.0, 1.0, size=(P, 1)).astype(np.float32),
+             colors=rng.uniform(0, 1, size=(P, 3)).astype(np.float32))
+    g["opacities"][:50] = 1.0  # hits the 0.99 cap
+    g["opacities"][50:60] = 0.0
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.array([0.5, 0.5, 0.5], np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg)
+    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 4096
+    assert f["final_T"].min() < 2e-4  # saturating stack reached the T < 1e-4 stop
+    _assert_forward_exact(f, h)
+    dL = rng.normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL), rtol=5e-4)
+
+
+def test_empty_and_capacity(oracle):
+    from tests.hip_harness import HipRun, scene_kwargs
+    from fluidnexus_amd import _lib
+    W, H = 32, 32
+    cam = S.front_camera(W, H, device="cpu")
+    g = S.random_gaussians(500, seed=9, log_scale=(-4.0, -2.5))
+    kw = scene_kwargs(g, cam, W, H)
+    bg = np.zeros(3, np.float32)
+    # too-small binning capacity: nothing rendered, status says so
+    h = HipRun(bg=bg, colors_precomp=g["colors"], scales=g["scales"], rotations=g["rotations"], capacity=16, **kw)
+    assert h.R > 16
+    assert h.status() == _lib.FNX_ERR_CAPACITY
+    # all splats culled: image == background, R == 0
+    g2 = dict(g)
+    g2["means3D"] = g["means3D"] + np.array([0, 0, 10.0], np.float32)
+    kw2 = scene_kwargs(g2, cam, W, H)
+    bg2 = np.array([0.25, 0.5, 0.75], np.float32)
+    h2 = HipRun(bg=bg2, colors_precomp=g["colors"], scales=g["scales"], rotations=g["rotations"], **kw2)
+    assert h2.R == 0 and h2.status() == 0
+    col = h2.color.cpu().numpy()
+    assert (col == bg2[:, None, None]).all()
+    assert (h2.depth.cpu().numpy() == 15.0).all()
+
+
+def test_mark_visible(oracle):
+    import torch
+    from diff_gaussian_rasterization_ch3 import GaussianRasterizationSettings, GaussianRasterizer
+    cam = S.front_camera(64, 64, device="cuda")
+    g = S.random_gaussians(4000, seed=2, box=2.5)
+    rs = GaussianRasterizationSettings(64, 64, 0.4, 0.4, torch.zeros(3, device="cuda"), 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 0, cam.camera_center, False)
+    vis = GaussianRasterizer(rs).mark_visible(torch.from_numpy(g["means3D"]).cuda()).cpu().numpy()
+    ref = oracle.mark_visible(g["means3D"], cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy())
+    assert (vis == ref).all() and 0 < vis.sum() < vis.size
