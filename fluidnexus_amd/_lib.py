@@ -22,16 +22,17 @@ FNX_ERR_CAPACITY = 4
 
 class GeomLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "total")]
+                ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "sort_key0",
+                 "sort_key1", "sort_val0", "sort_val1", "rank_of", "sort_hist", "blk_hist", "blk_rel", "total")]
 
 
 class ImageLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("header", "final_T", "n_contrib", "ranges", "tile_count", "tile_cursor", "total")]
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "total")]
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "total")]
+    _fields_ = [(n, c_size_t) for n in ("point_list", "bins", "total")]
 
 
 ALLOC_FN = C.CFUNCTYPE(c_void_p, c_size_t, c_void_p)
@@ -63,7 +64,7 @@ def raster():
     lib.fnx_abi_version.restype = i
     lib.fnx_last_error.restype = C.c_char_p
     lib.fnx_geom_bytes.restype = c_size_t
-    lib.fnx_geom_bytes.argtypes = [i]
+    lib.fnx_geom_bytes.argtypes = [i, i, i]
     lib.fnx_image_bytes.restype = c_size_t
     lib.fnx_image_bytes.argtypes = [i, i]
     lib.fnx_binning_bytes.restype = c_size_t
@@ -84,7 +85,7 @@ def raster():
                                            p, p, p, p, p, p, p, p, p, p]
     lib.fnx_mark_visible.restype = i
     lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
-    lib.fnx_geom_layout.argtypes = [i, C.POINTER(GeomLayout)]
+    lib.fnx_geom_layout.argtypes = [i, i, i, C.POINTER(GeomLayout)]
     lib.fnx_image_layout.argtypes = [i, i, C.POINTER(ImageLayout)]
     lib.fnx_binning_layout.argtypes = [c_int64, C.POINTER(BinningLayout)]
     _RASTER = lib
@@ -103,9 +104,9 @@ def check(rc: int):
         raise FnxError(rc, msg)
 
 
-def geom_layout(P: int) -> GeomLayout:
+def geom_layout(P: int, W: int, H: int) -> GeomLayout:
     L = GeomLayout()
-    raster().fnx_geom_layout(P, C.byref(L))
+    raster().fnx_geom_layout(P, W, H, C.byref(L))
     return L
 
 

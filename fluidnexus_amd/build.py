@@ -15,7 +15,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 # library name -> sources.  -ffp-contract=off is part of the numerics contract.
 LIBS = {
-    "libfnx_raster.so": ["raster_forward.hip", "raster_backward.hip", "raster_api.hip"],
+    "libfnx_raster.so": ["raster_forward.hip", "raster_binning.hip", "raster_backward.hip", "raster_api.hip"],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-value"]

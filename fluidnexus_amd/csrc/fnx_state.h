@@ -14,9 +14,19 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 inline int tiles_x(int W) { return (W + 15) / 16; }
 inline int tiles_y(int H) { return (H + 15) / 16; }
 
-inline void geom_layout(int P, fnx_geom_layout_t *o) {
+// Splats are processed in blocks of kSplatBlock consecutive ids (preprocess, instance emission);
+// the depth sort works on chunks of kSortChunk keys per workgroup.
+constexpr int kSplatBlock = 1024;
+constexpr int kSortChunk = 1024;
+constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB
+inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
+inline int sort_blocks(int P) { return (P + kSortChunk - 1) / kSortChunk; }
+
+inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     size_t off = 0;
     size_t p = (size_t)(P > 0 ? P : 0);
+    size_t t = (size_t)tiles_x(W) * tiles_y(H);
+    size_t nb = (size_t)splat_blocks(P > 0 ? P : 0), nsb = (size_t)sort_blocks(P > 0 ? P : 0);
     o->depths = off;        off = align_up(off + p * 4);
     o->clamped = off;       off = align_up(off + p * 3);
     o->radii = off;         off = align_up(off + p * 4);
@@ -25,6 +35,14 @@ inline void geom_layout(int P, fnx_geom_layout_t *o) {
     o->conic_opacity = off; off = align_up(off + p * 16);
     o->rgb = off;           off = align_up(off + p * 12);
     o->tiles_touched = off; off = align_up(off + p * 4);
+    o->sort_key0 = off;     off = align_up(off + p * 4);
+    o->sort_key1 = off;     off = align_up(off + p * 4);
+    o->sort_val0 = off;     off = align_up(off + p * 4);
+    o->sort_val1 = off;     off = align_up(off + p * 4);
+    o->rank_of = off;       off = align_up(off + p * 4);
+    o->sort_hist = off;     off = align_up(off + (2 * 256 * nsb + 256) * 4);
+    o->blk_hist = off;      off = align_up(off + nb * t * 2);
+    o->blk_rel = off;       off = align_up(off + nb * t * 4);
     o->total = off + kAlign;
 }
 
@@ -36,7 +54,6 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     o->n_contrib = off;   off = align_up(off + n * 4);
     o->ranges = off;      off = align_up(off + t * 8);
     o->tile_count = off;  off = align_up(off + t * 4);
-    o->tile_cursor = off; off = align_up(off + t * 4);
     o->total = off + kAlign;
 }
 
@@ -44,7 +61,7 @@ inline void binning_layout(int64_t R, fnx_binning_layout_t *o) {
     size_t r = (size_t)(R > 0 ? R : 0);
     size_t off = 0;
     o->point_list = off; off = align_up(off + r * 4);
-    o->pairs = off;      off = align_up(off + r * 8);
+    o->bins = off;       off = align_up(off + r * 4);
     o->total = off + kAlign;
 }
 

@@ -16,14 +16,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint32_t *tile_count, int prefiltered);
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *tile_cursor,
-                      uint32_t *header);
-void launch_scatter(hipStream_t s, int P, const float2 *means2D, const float *depths, const int *radii, int W, int H,
-                    const uint32_t *ranges, uint32_t *tile_cursor, uint64_t *pairs, uint32_t *header,
-                    uint32_t capacity);
-void launch_tile_sort(hipStream_t s, int T, const uint32_t *ranges, uint64_t *pairs, uint32_t *point_list,
-                      const uint32_t *header, uint32_t capacity);
+                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, int prefiltered);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header);
+void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
+                         uint32_t *tile_count);
+void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of);
+void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, const int *radii, const uint32_t *ranges,
+                 const uint32_t *blk_rel, const uint32_t *rank_of, uint32_t *bins, uint32_t *header,
+                 uint32_t capacity);
+void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
+                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float2 *means2D, const float *features, const float4 *conic_opacity,
                           const float *depths, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
@@ -72,10 +75,13 @@ struct Geom {
     float4 *conic_opacity;
     float *rgb;
     uint32_t *tiles_touched;
+    uint32_t *sort_key0, *sort_key1, *sort_val0, *sort_val1, *rank_of, *sort_hist;
+    uint16_t *blk_hist;
+    uint32_t *blk_rel;
 };
-Geom carve_geom(char *blob, int P) {
+Geom carve_geom(char *blob, int P, int W, int H) {
     fnx_geom_layout_t L;
-    fnx::geom_layout(P, &L);
+    fnx::geom_layout(P, W, H, &L);
     char *b = aligned(blob);
     Geom g;
     g.depths = (float *)(b + L.depths);
@@ -86,6 +92,14 @@ Geom carve_geom(char *blob, int P) {
     g.conic_opacity = (float4 *)(b + L.conic_opacity);
     g.rgb = (float *)(b + L.rgb);
     g.tiles_touched = (uint32_t *)(b + L.tiles_touched);
+    g.sort_key0 = (uint32_t *)(b + L.sort_key0);
+    g.sort_key1 = (uint32_t *)(b + L.sort_key1);
+    g.sort_val0 = (uint32_t *)(b + L.sort_val0);
+    g.sort_val1 = (uint32_t *)(b + L.sort_val1);
+    g.rank_of = (uint32_t *)(b + L.rank_of);
+    g.sort_hist = (uint32_t *)(b + L.sort_hist);
+    g.blk_hist = (uint16_t *)(b + L.blk_hist);
+    g.blk_rel = (uint32_t *)(b + L.blk_rel);
     return g;
 }
 struct Img {
@@ -94,7 +108,6 @@ struct Img {
     uint32_t *n_contrib;
     uint32_t *ranges;
     uint32_t *tile_count;
-    uint32_t *tile_cursor;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -106,12 +119,11 @@ Img carve_img(char *blob, int W, int H) {
     i.n_contrib = (uint32_t *)(b + L.n_contrib);
     i.ranges = (uint32_t *)(b + L.ranges);
     i.tile_count = (uint32_t *)(b + L.tile_count);
-    i.tile_cursor = (uint32_t *)(b + L.tile_cursor);
     return i;
 }
 struct Bin {
     uint32_t *point_list;
-    uint64_t *pairs;
+    uint32_t *bins;
 };
 Bin carve_bin(char *blob, int64_t R) {
     fnx_binning_layout_t L;
@@ -119,7 +131,7 @@ Bin carve_bin(char *blob, int64_t R) {
     char *b = aligned(blob);
     Bin o;
     o.point_list = (uint32_t *)(b + L.point_list);
-    o.pairs = (uint64_t *)(b + L.pairs);
+    o.bins = (uint32_t *)(b + L.bins);
     return o;
 }
 
@@ -132,9 +144,9 @@ extern "C" {
 int fnx_abi_version(void) { return 1; }
 const char *fnx_last_error(void) { return g_err; }
 
-size_t fnx_geom_bytes(int P) {
+size_t fnx_geom_bytes(int P, int W, int H) {
     fnx_geom_layout_t L;
-    fnx::geom_layout(P, &L);
+    fnx::geom_layout(P, W, H, &L);
     return L.total;
 }
 size_t fnx_image_bytes(int W, int H) {
@@ -147,7 +159,7 @@ size_t fnx_binning_bytes(int64_t R) {
     fnx::binning_layout(R, &L);
     return L.total;
 }
-void fnx_geom_layout(int P, fnx_geom_layout_t *out) { fnx::geom_layout(P, out); }
+void fnx_geom_layout(int P, int W, int H, fnx_geom_layout_t *out) { fnx::geom_layout(P, W, H, out); }
 void fnx_image_layout(int W, int H, fnx_image_layout_t *out) { fnx::image_layout(W, H, out); }
 void fnx_binning_layout(int64_t R, fnx_binning_layout_t *out) { fnx::binning_layout(R, out); }
 
@@ -162,11 +174,11 @@ int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int 
     hipStream_t s = (hipStream_t)stream;
     Img img = carve_img(image_buffer, width, height);
     const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
-    // header + tile_count must start from zero (header first: it is tiny and separate)
-    hipMemsetAsync(img.header, 0, 32, s);
-    hipMemsetAsync(img.tile_count, 0, (size_t)T * 4, s);
+    if (T > fnx::kMaxTiles)
+        return fail(FNX_ERR_UNSUPPORTED, "%d tiles > %d (image larger than 2048x2048)", T, fnx::kMaxTiles);
+    (void)hipMemsetAsync(img.header, 0, 32, s);
     if (P == 0) {
-        hipMemsetAsync(img.ranges, 0, (size_t)T * 8, s);
+        (void)hipMemsetAsync(img.ranges, 0, (size_t)T * 8, s);
         return hip_check("stage1(P=0)");
     }
     if (!geom_buffer || !means3D || !opacities || !viewmatrix || !projmatrix)
@@ -177,13 +189,14 @@ int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int 
         return fail(FNX_ERR_INVALID_ARG, "neither colors_precomp nor shs+cam_pos given");
     if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
         return fail(FNX_ERR_INVALID_ARG, "neither cov3D_precomp nor scales+rotations given");
-    Geom g = carve_geom(geom_buffer, P);
+    Geom g = carve_geom(geom_buffer, P, width, height);
     int *rad = radii ? radii : g.radii;  // rasterizer_impl.cu:214-216
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                            tan_fovy, rad, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched,
-                           img.tile_count, prefiltered);
-    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.tile_cursor, img.header);
+                           g.blk_hist, g.sort_key0, prefiltered);
+    fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header);
     return hip_check("stage1");
 }
 
@@ -222,15 +235,17 @@ int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, in
     if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     if (binning_capacity > 0 && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
     hipStream_t s = (hipStream_t)stream;
-    Geom g = carve_geom(geom_buffer, P);
+    Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
     Bin bin = carve_bin(binning_buffer, binning_capacity);
     const int *rad = radii ? radii : g.radii;
     const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
     const uint32_t cap = (uint32_t)binning_capacity;
-    fnx::launch_scatter(s, P, g.means2D, g.depths, rad, width, height, img.ranges, img.tile_cursor, bin.pairs,
-                        img.header, cap);
-    fnx::launch_tile_sort(s, T, img.ranges, bin.pairs, bin.point_list, img.header, cap);
+    const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
+    fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
+                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rank_of);
+    fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap);
+    fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap);
     const float *features = colors_precomp ? colors_precomp : g.rgb;  // rasterizer_impl.cu:299
     fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.means2D, features,
                               g.conic_opacity, g.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
@@ -248,7 +263,7 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
                           fnx_stream_t stream, int *num_rendered) {
     if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail(FNX_ERR_INVALID_ARG, "NULL allocator");
     if (num_rendered) *num_rendered = 0;
-    char *geom = geometryBuffer(fnx_geom_bytes(P), geom_user);
+    char *geom = geometryBuffer(fnx_geom_bytes(P, width, height), geom_user);
     char *img = imageBuffer(fnx_image_bytes(width, height), image_user);
     int rc = fnx_forward_stage1(channels, geom, img, P, D, M, width, height, means3D, shs, colors_precomp, opacities,
                                 scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
@@ -281,7 +296,7 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
     if (scales && (!rotations || !dL_dscale || !dL_drot))
         return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
     hipStream_t s = (hipStream_t)stream;
-    Geom g = carve_geom(geom_buffer, P);
+    Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
     // the capacity this blob was filled with is irrelevant here: point_list sits at offset 0
     Bin bin = carve_bin(binning_buffer, 0);

@@ -1,17 +1,7 @@
 // Forward pass of the gfx950 Gaussian rasteriser.
 //
-// Pipeline (one view):  preprocess -> tile_scan -> scatter -> tile_sort -> blend
-//
-// The reference (ch3/cuda_rasterizer/rasterizer_impl.cu:184-319) expands every splat into
-// (tile|depth) 64-bit keys and runs a device-wide radix sort over them.  Here the binning is
-// two-level instead, sized for a 256-CU part with 160 KiB of LDS per CU:
-//   1. preprocess also histograms splats per tile (LDS-privatised counters),
-//   2. one workgroup turns the histogram into the per-tile [start,end) ranges,
-//   3. splats are scattered straight into their tile's segment as (depth bits, id) pairs,
-//   4. every tile sorts its own segment inside LDS (global-memory fallback for huge tiles).
-// (depth bits, id) is a total order, so the resulting list equals the reference's stable
-// radix sort of (tile | depth) keys emitted in id order -- bit for bit -- with 12 B instead of
-// 24+ B of traffic per instance and no host synchronisation.
+// This file: per-splat preprocess (+ per-(splat block, tile) instance counts and depth-sort keys)
+// and the front-to-back blend.  The binning between them lives in raster_binning.hip.
 #include "fnx_device.h"
 #include "fnx_state.h"
 
@@ -94,9 +84,12 @@ __device__ inline float3 cov2d_ewa(const float3 mean, float focal_x, float focal
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: per-Gaussian preprocess (ch3 forward.cu:148-244) + per-tile instance histogram.
-// One thread per Gaussian, 256-thread workgroups.  `lds_tiles` > 0 => the workgroup keeps a
-// private tile histogram in LDS and flushes it with one global atomic per touched tile.
+// K1: per-Gaussian preprocess (ch3 forward.cu:148-244).  A 256-thread workgroup owns a block of
+// kSplatBlock = 1024 consecutive splats (4 per thread, coalesced) and, besides the reference's
+// per-splat state, produces
+//   * blk_hist[block][tile] (u16): how many of the block's splats touch each tile -- counted with
+//     LDS atomics only; this matrix replaces every global atomic of the binning,
+//   * sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones.
 template <int C>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -107,18 +100,18 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float tan_fovy, float focal_x, float focal_y, int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
-                  uint32_t *__restrict__ tile_count, int lds_tiles, int prefiltered) {
+                  uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ sort_key, int T, int prefiltered) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (lds_tiles > 0) {
-        for (int i = threadIdx.x; i < lds_tiles; i += 256) s_hist[i] = 0;
-        __syncthreads();
-    }
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    bool live = false;
-    if (idx < P) {
+    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int k = 0; k < kSplatBlock / 256; k++) {
+        const int idx = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
+        if (idx >= P) break;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        bool live = false;
         radii[idx] = 0;
         tiles_touched[idx] = 0;
+        uint32_t key = 0xFFFFFFFFu;
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         const float3 p_view = xform4x3(p_orig, view);
         // near cull: only view-space z <= 0.2 (ch3 auxiliary.h:138)
@@ -158,37 +151,29 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     means2D[idx] = make_float2(px, py);
                     conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
                     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+                    key = __float_as_uint(p_view.z);
                     live = true;
                 }
             }
         } else if (prefiltered) {
             __builtin_trap();  // ch3 auxiliary.h:140-143
         }
-    }
-    if (live) {
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                const int t = y * gx + x;
-                if (lds_tiles > 0)
-                    atomicAdd(&s_hist[t], 1u);
-                else
-                    atomicAdd(&tile_count[t], 1u);
-            }
-    }
-    if (lds_tiles > 0) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < lds_tiles; i += 256) {
-            const uint32_t c = s_hist[i];
-            if (c) atomicAdd(&tile_count[i], c);
+        sort_key[idx] = key;
+        if (live) {
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * gx + x], 1u);
         }
     }
+    __syncthreads();
+    uint16_t *row = blk_hist + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += 256) row[i] = (uint16_t)s_hist[i];
 }
 
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
-// rasterizer_impl.cu:292), total instance count -> header, cursors zeroed.  One 1024-thread block.
+// rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ ranges,
-                 uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ header) {
+                 uint32_t *__restrict__ header) {
     __shared__ uint32_t s_part[1024];
     const int tid = threadIdx.x;
     const int per = (T + 1023) / 1024;
@@ -209,103 +194,11 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         const uint32_t c = tile_count[i];
         ranges[2 * i] = c ? run : 0u;
         ranges[2 * i + 1] = c ? run + c : 0u;
-        tile_cursor[i] = 0u;
         run += c;
     }
     if (tid == 1023) {
         header[HDR_NUM_RENDERED] = s_part[1023];
         header[HDR_STATUS] = 0u;
-    }
-}
-
-// K3: scatter every (splat, tile) instance into its tile's segment (ch3 rasterizer_impl.cu:67-104
-// emits the same instances; slot order inside a tile is fixed by the sort that follows).
-__global__ void __launch_bounds__(256)
-scatter_kernel(int P, const float2 *__restrict__ means2D, const float *__restrict__ depths,
-               const int *__restrict__ radii, int gx, int gy, const uint32_t *__restrict__ ranges,
-               uint32_t *__restrict__ tile_cursor, uint64_t *__restrict__ pairs, uint32_t *__restrict__ header,
-               uint32_t capacity) {
-    if (header[HDR_NUM_RENDERED] > capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            header[HDR_STATUS] = FNX_ERR_CAPACITY;
-            header[HDR_CAPACITY] = capacity;
-        }
-        return;
-    }
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const int rad = radii[idx];
-    if (rad > 0) {
-        const float2 p = means2D[idx];
-        int x0, y0, x1, y1;
-        tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
-        const uint64_t hi = (uint64_t)__float_as_uint(depths[idx]) << 32;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                const int t = y * gx + x;
-                const uint32_t slot = ranges[2 * t] + atomicAdd(&tile_cursor[t], 1u);
-                pairs[slot] = hi | (uint32_t)idx;
-            }
-    }
-}
-
-// K4: one workgroup sorts one tile's (depth bits, id) pairs ascending.  All compare-exchanges of
-// this bitonic network ("flip" then "disperse" steps) order ascending, so slots past n behave as
-// +inf padding without being materialised.  Segments up to `lds_cap` pairs are sorted in LDS;
-// larger ones in place in global memory by the same workgroup (rare, slow, correct).
-template <typename KeyPtr>
-__device__ inline void bitonic_all_ascending(KeyPtr key, uint32_t n, uint32_t npow2, int tid, int nthreads) {
-    for (uint32_t k = 2; k <= npow2; k <<= 1) {
-        const uint32_t half = k >> 1;
-        for (uint32_t p = tid; p < (npow2 >> 1); p += nthreads) {  // flip
-            const uint32_t blk = p / half, off = p - blk * half;
-            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
-            if (l < n) {
-                const uint64_t a = key[i], b = key[l];
-                if (a > b) {
-                    key[i] = b;
-                    key[l] = a;
-                }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = half >> 1; j >= 1; j >>= 1) {  // disperse
-            for (uint32_t p = tid; p < (npow2 >> 1); p += nthreads) {
-                const uint32_t i = (p / j) * (j << 1) + (p % j), l = i + j;
-                if (l < n) {
-                    const uint64_t a = key[i], b = key[l];
-                    if (a > b) {
-                        key[i] = b;
-                        key[l] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-tile_sort_kernel(const uint32_t *__restrict__ ranges, uint64_t *__restrict__ pairs, uint32_t *__restrict__ point_list,
-                 const uint32_t *__restrict__ header, uint32_t capacity, uint32_t lds_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_key[];
-    if (header[HDR_NUM_RENDERED] > capacity) return;
-    const uint32_t start = ranges[2 * blockIdx.x], end = ranges[2 * blockIdx.x + 1];
-    const uint32_t n = end - start;
-    if (n == 0) return;
-    const int tid = threadIdx.x;
-    uint32_t npow2 = 1;
-    while (npow2 < n) npow2 <<= 1;
-    if (n <= lds_cap) {
-        for (uint32_t i = tid; i < n; i += 256) s_key[i] = pairs[start + i];
-        __syncthreads();
-        if (n > 1) bitonic_all_ascending(s_key, n, npow2, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) point_list[start + i] = (uint32_t)s_key[i];
-    } else {
-        uint64_t *g = pairs + start;
-        __syncthreads();
-        bitonic_all_ascending((volatile uint64_t *)g, n, npow2, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) point_list[start + i] = (uint32_t)g[i];
     }
 }
 
@@ -406,24 +299,21 @@ mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__res
 // Host-side launchers (internal; the C ABI lives in raster_api.hip).
 namespace fnx {
 
-static constexpr int kLdsTilesMax = 8192;    // 32 KiB tile histogram per preprocess workgroup
-static constexpr uint32_t kSortLdsCap = 4096;  // 32 KiB of (depth,id) pairs per sort workgroup
-
 template <int C>
 static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *shs,
                                 uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp,
                                 const float *view, const float *proj, const float *campos, int W, int H, float tan_fovx,
                                 float tan_fovy, int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
-                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *tile_count, int prefiltered) {
+                                float4 *conic_opacity, uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key,
+                                int prefiltered) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:207-208
     const float focal_x = W / (2.0f * tan_fovx);
-    const int lds_tiles = (T <= kLdsTilesMax) ? T : 0;
-    hipLaunchKernelGGL((preprocess_kernel<C>), dim3((P + 255) / 256), dim3(256), (size_t)lds_tiles * 4, s, P, D, M,
-                       means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp,
-                       colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, means2D,
-                       depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched, tile_count, lds_tiles, prefiltered);
+    hipLaunchKernelGGL((preprocess_kernel<C>), dim3(splat_blocks(P)), dim3(256), (size_t)T * 4, s, P, D, M, means3D,
+                       scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view,
+                       proj, campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb,
+                       conic_opacity, gx, gy, tiles_touched, blk_hist, sort_key, T, prefiltered);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -431,33 +321,21 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint32_t *tile_count, int prefiltered) {
+                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, int prefiltered) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, tile_count, prefiltered);
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
+                               prefiltered);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, tile_count, prefiltered);
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
+                               prefiltered);
 }
 
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *tile_cursor,
-                      uint32_t *header) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, tile_cursor, header);
-}
-
-void launch_scatter(hipStream_t s, int P, const float2 *means2D, const float *depths, const int *radii, int W, int H,
-                    const uint32_t *ranges, uint32_t *tile_cursor, uint64_t *pairs, uint32_t *header,
-                    uint32_t capacity) {
-    hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means2D, depths, radii, tiles_x(W),
-                       tiles_y(H), ranges, tile_cursor, pairs, header, capacity);
-}
-
-void launch_tile_sort(hipStream_t s, int T, const uint32_t *ranges, uint64_t *pairs, uint32_t *point_list,
-                      const uint32_t *header, uint32_t capacity) {
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(256), (size_t)kSortLdsCap * 8, s, ranges, pairs, point_list,
-                       header, capacity, kSortLdsCap);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, header);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,

@@ -88,7 +88,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = sh.shape[1] if sh.numel() else 0
         stream = torch.cuda.current_stream().cuda_stream
         u8 = dict(dtype=torch.uint8, device=dev)
-        geom = torch.empty(lib.fnx_geom_bytes(P), **u8)
+        geom = torch.empty(lib.fnx_geom_bytes(P, W, H), **u8)
         img = torch.empty(lib.fnx_image_bytes(W, H), **u8)
         if P == 0:  # rasterize_points.cu:81: zeros, no kernels
             color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)

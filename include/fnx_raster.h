@@ -35,7 +35,7 @@ extern "C" {
 #define FNX_ERR_NON_RGB_NEEDS_COLORS 2 /* rasterizer_impl.cu:226-228 */
 #define FNX_ERR_HIP 3
 #define FNX_ERR_CAPACITY 4 /* binning buffer smaller than num_rendered */
-#define FNX_ERR_UNSUPPORTED 5
+#define FNX_ERR_UNSUPPORTED 5 /* e.g. more than 16384 tiles (image larger than 2048x2048) */
 
 typedef void *fnx_stream_t; /* hipStream_t */
 
@@ -48,7 +48,7 @@ const char *fnx_last_error(void);
 
 /* Scratch sizes [required<GeometryState>(P), required<ImageState>(W*H), required<BinningState>(R),
  * rasterizer_impl.cu:210,222,266]. */
-size_t fnx_geom_bytes(int P);
+size_t fnx_geom_bytes(int P, int width, int height); /* also holds per-(splat block, tile) counters */
 size_t fnx_image_bytes(int width, int height);
 size_t fnx_binning_bytes(int64_t num_rendered);
 
@@ -71,7 +71,8 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
  *   stage 1 = per-Gaussian preprocess + per-tile instance counts + tile ranges (num_rendered stays
  *             on the device, inside image_buffer);
  *   fnx_read_num_rendered = the optional blocking read-back;
- *   stage 2 = instance emission, per-tile depth sort, alpha blending, with a caller-chosen
+ *   stage 2 = global depth sort of the splats, instance emission, per-tile ordering, alpha
+ *             blending, with a caller-chosen
  *             binning capacity.  If num_rendered > capacity nothing is rendered and
  *             fnx_read_status reports FNX_ERR_CAPACITY.
  */
@@ -119,6 +120,14 @@ typedef struct {
     size_t conic_opacity; /* f32[4P]                                                */
     size_t rgb;           /* f32[3P]  SH colours                                    */
     size_t tiles_touched; /* u32[P]                                                 */
+    size_t sort_key0;     /* u32[P]   depth bits (0xFFFFFFFF if culled); sort ping  */
+    size_t sort_key1;     /* u32[P]   sort pong                                     */
+    size_t sort_val0;     /* u32[P]   after the sort: ids in (depth bits, id) order */
+    size_t sort_val1;     /* u32[P]                                                 */
+    size_t rank_of;       /* u32[P]   position of each id in that order             */
+    size_t sort_hist;     /* u32[(2*ceil(P/1024)+1)*256] radix digit histograms + prefixes */
+    size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of block b touching tile t */
+    size_t blk_rel;       /* u32[ceil(P/1024) * T] exclusive prefix over blocks     */
     size_t total;
 } fnx_geom_layout_t;
 typedef struct {
@@ -127,15 +136,14 @@ typedef struct {
     size_t n_contrib;   /* u32[H*W]                                                 */
     size_t ranges;      /* u32[2T] per-tile [start,end)                             */
     size_t tile_count;  /* u32[T]                                                   */
-    size_t tile_cursor; /* u32[T]                                                   */
     size_t total;
 } fnx_image_layout_t;
 typedef struct {
     size_t point_list; /* u32[R] Gaussian ids sorted by (tile, depth bits, id)      */
-    size_t pairs;      /* u64[R] (depth bits << 32 | id), grouped by tile, unsorted */
+    size_t bins;       /* u32[R] depth ranks of the instances, grouped by tile      */
     size_t total;
 } fnx_binning_layout_t;
-void fnx_geom_layout(int P, fnx_geom_layout_t *out);
+void fnx_geom_layout(int P, int width, int height, fnx_geom_layout_t *out);
 void fnx_image_layout(int width, int height, fnx_image_layout_t *out);
 void fnx_binning_layout(int64_t num_rendered, fnx_binning_layout_t *out);
 

@@ -46,7 +46,7 @@ class HipRun:
         self.D, self.M = int(sh_degree), (0 if self.shs is None else self.shs.shape[1])
         self.mod, self.tanx, self.tany = float(scale_modifier), float(tanx), float(tany)
         u8 = dict(dtype=torch.uint8, device=dev)
-        self.geom = torch.zeros(lib.fnx_geom_bytes(P), **u8)
+        self.geom = torch.zeros(lib.fnx_geom_bytes(P, W, H), **u8)
         self.img = torch.zeros(lib.fnx_image_bytes(W, H), **u8)
         self.color = torch.zeros(channels, H, W, device=dev)
         self.depth = torch.zeros(1, H, W, device=dev)
@@ -73,7 +73,7 @@ class HipRun:
     def intermediates(self):
         P, W, H = self.P, self.W, self.H
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        g, im, b = _lib.geom_layout(P), _lib.image_layout(W, H), _lib.binning_layout(self.cap)
+        g, im, b = _lib.geom_layout(P, W, H), _lib.image_layout(W, H), _lib.binning_layout(self.cap)
         out = dict(
             depths=_view(self.geom, g.depths, P, torch.float32), radii=self.radii,
             means2D=_view(self.geom, g.means2D, 2 * P, torch.float32).view(P, 2),
