@@ -1,0 +1,44 @@
+"""ctypes binding of libfnx_physics.so (include/fnx_physics.h).  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
+           "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward")
+
+
+def physics():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "libfnx_physics.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
+                           "fluidnexus_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    p, i, f = C.c_void_p, C.c_int, C.c_float
+    lib.fnx_physics_abi_version.restype = i
+    lib.fnx_physics_last_error.restype = C.c_char_p
+    lib.fnx_grid_bytes.restype = C.c_size_t
+    lib.fnx_grid_bytes.argtypes = [i]
+    lib.fnx_grid_build.restype = i
+    lib.fnx_grid_build.argtypes = [p, i, f, p, p]
+    lib.fnx_density_forward.restype = i
+    lib.fnx_density_forward.argtypes = [p, i, p, f, f, p, p, p]
+    lib.fnx_density_backward.restype = i
+    lib.fnx_density_backward.argtypes = [p, i, p, f, f, p, p, p, p]
+    lib.fnx_visual_interp_forward.restype = i
+    lib.fnx_visual_interp_forward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p]
+    lib.fnx_visual_interp_backward.restype = i
+    lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
+    _LIB = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(physics().fnx_physics_last_error().decode("utf-8", "replace"))

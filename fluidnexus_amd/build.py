@@ -16,6 +16,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # library name -> sources.  -ffp-contract=off is part of the numerics contract.
 LIBS = {
     "libfnx_raster.so": ["raster_forward.hip", "raster_binning.hip", "raster_backward.hip", "raster_api.hip"],
+    "libfnx_physics.so": ["physics.hip"],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-value"]
@@ -34,6 +35,7 @@ def _stale(out: str, srcs: list[str]) -> bool:
     t = os.path.getmtime(out)
     deps = list(srcs) + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "fnx_raster.h"))
+    deps.append(os.path.join(_HERE, "..", "include", "fnx_physics.h"))
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,331 @@
+// Fused particle-physics kernels for gfx950 (C ABI: include/fnx_physics.h).
+//
+// Neighbour search: uniform hash grid with cell edge H.  Points are bucketed by a hash of their
+// integer cell (count -> scan -> fill, LDS-free: the clouds are 10^4..10^5 points and these
+// kernels are latency-, not bandwidth-bound); a query walks the 27 surrounding cells and accepts a
+// candidate only if its own integer cell equals the cell being visited, which makes hash collisions
+// harmless (no double counting).  Bucket records are float4 (x, y, z, id) so a query streams 16 B
+// per candidate, coalesced within a bucket.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/fnx_physics.h"
+#include "../../include/fnx_raster.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct GridView {
+    uint32_t *header;  // [0] M (buckets), [1] N
+    uint32_t *count;   // [M]
+    uint32_t *start;   // [M + 1]
+    uint32_t *cursor;  // [M]
+    float4 *rec;       // [N] (x, y, z, id bits)
+    uint32_t M;
+};
+
+inline uint32_t buckets_for(int N) {
+    uint32_t m = 1024;
+    while (m < (uint32_t)(2 * (N > 0 ? N : 1))) m <<= 1;
+    return m;
+}
+
+inline size_t grid_bytes(int N) {
+    const size_t M = buckets_for(N);
+    size_t off = align_up(64);
+    off = align_up(off + M * 4);
+    off = align_up(off + (M + 1) * 4);
+    off = align_up(off + M * 4);
+    off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
+    return off + kAlign;
+}
+
+inline GridView carve(char *blob, int N) {
+    char *b = (char *)(((uintptr_t)blob + kAlign - 1) / kAlign * kAlign);
+    GridView g;
+    g.M = buckets_for(N);
+    size_t off = 0;
+    g.header = (uint32_t *)(b + off); off = align_up(off + 64);
+    g.count = (uint32_t *)(b + off);  off = align_up(off + (size_t)g.M * 4);
+    g.start = (uint32_t *)(b + off);  off = align_up(off + ((size_t)g.M + 1) * 4);
+    g.cursor = (uint32_t *)(b + off); off = align_up(off + (size_t)g.M * 4);
+    g.rec = (float4 *)(b + off);
+    return g;
+}
+
+__device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cell) {
+    return make_int3((int)floorf(x * inv_cell), (int)floorf(y * inv_cell), (int)floorf(z * inv_cell));
+}
+__device__ __forceinline__ uint32_t cell_hash(int3 c, uint32_t mask) {
+    return (((uint32_t)c.x * 73856093u) ^ ((uint32_t)c.y * 19349663u) ^ ((uint32_t)c.z * 83492791u)) & mask;
+}
+
+__global__ void __launch_bounds__(256)
+grid_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask, uint32_t *__restrict__ count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int3 c = cell_of(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], inv_cell);
+    atomicAdd(&count[cell_hash(c, mask)], 1u);
+}
+
+__global__ void __launch_bounds__(1024)
+grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
+                 uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (M + 1023) / 1024;
+    const uint32_t b = tid * per, e = min(M, b + per);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += count[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t i = b; i < e; i++) {
+        start[i] = run;
+        cursor[i] = 0u;
+        run += count[i];
+    }
+    if (tid == 1023) start[M] = s_part[1023];
+}
+
+__global__ void __launch_bounds__(256)
+grid_fill_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask,
+                 const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, float4 *__restrict__ rec) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const uint32_t h = cell_hash(cell_of(x, y, z, inv_cell), mask);
+    const uint32_t slot = start[h] + atomicAdd(&cursor[h], 1u);
+    rec[slot] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
+}
+
+// Visit every grid point j with |p - x_j|^2 < H2; f(j, dx, dy, dz, r2) with d = p - x_j.
+template <typename F>
+__device__ __forceinline__ void for_neighbours(float px, float py, float pz, float inv_cell, float H2, uint32_t mask,
+                                               const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                                               F &&f) {
+    const int3 c = cell_of(px, py, pz, inv_cell);
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int3 cc = make_int3(c.x + dx, c.y + dy, c.z + dz);
+                const uint32_t h = cell_hash(cc, mask);
+                const uint32_t s0 = start[h], s1 = start[h + 1];
+                for (uint32_t s = s0; s < s1; s++) {
+                    const float4 q = rec[s];
+                    const int3 qc = cell_of(q.x, q.y, q.z, inv_cell);
+                    if (qc.x != cc.x || qc.y != cc.y || qc.z != cc.z) continue;  // hash collision
+                    const float ex = px - q.x, ey = py - q.y, ez = pz - q.z;
+                    const float r2 = ex * ex + ey * ey + ez * ez;
+                    if (r2 < H2) f(__float_as_uint(q.w), ex, ey, ez, r2);
+                }
+            }
+}
+
+// gm_dynamics.py:1269-1294: p_i = sum_j poly6(r2_ij) / imass_i; p_ratio = p_i / p0
+__global__ void __launch_bounds__(256)
+density_forward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
+                       float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
+                       const float4 *__restrict__ rec, float *__restrict__ p_ratio) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float acc = 0.f;
+    for_neighbours(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], inv_cell, H2, mask, start, rec,
+                   [&](uint32_t, float, float, float, float r2) {
+                       const float t = H2 - r2;
+                       acc += term1 * (t * t * t);
+                   });
+    p_ratio[i] = acc / imass[i] / p0;
+}
+
+__global__ void __launch_bounds__(256)
+density_backward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
+                        float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
+                        const float4 *__restrict__ rec, const float *__restrict__ g, float *__restrict__ dL_dxyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float Gi = g[i] / imass[i] / p0;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for_neighbours(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], inv_cell, H2, mask, start, rec,
+                   [&](uint32_t j, float ex, float ey, float ez, float r2) {
+                       const float Gj = g[j] / imass[j] / p0;
+                       const float t = H2 - r2;
+                       const float dW = -3.0f * term1 * (t * t);  // d poly6 / d r2
+                       const float k = (Gi + Gj) * dW * 2.0f;
+                       ax += k * ex;
+                       ay += k * ey;
+                       az += k * ez;
+                   });
+    dL_dxyz[3 * i + 0] = ax;
+    dL_dxyz[3 * i + 1] = ay;
+    dL_dxyz[3 * i + 2] = az;
+}
+
+// gm_dynamics.py:1453-1498
+__global__ void __launch_bounds__(256)
+visual_forward_kernel(const float *__restrict__ visual, int V, const float *__restrict__ hidden,
+                      const float *__restrict__ hidden_prev, float inv_cell, float H2, float term1, float secs,
+                      float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                      float *__restrict__ out, float *__restrict__ sum_w, float *__restrict__ wvel) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float px = visual[3 * v], py = visual[3 * v + 1], pz = visual[3 * v + 2];
+    float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for_neighbours(px, py, pz, inv_cell, H2, mask, start, rec, [&](uint32_t j, float, float, float, float r2) {
+        const float t = H2 - r2;
+        const float w = term1 * (t * t * t);
+        const float ux = (hidden[3 * j] - hidden_prev[3 * j]) / secs;
+        const float uy = (hidden[3 * j + 1] - hidden_prev[3 * j + 1]) / secs;
+        const float uz = (hidden[3 * j + 2] - hidden_prev[3 * j + 2]) / secs;
+        S += w;
+        ax += ux * w;
+        ay += uy * w;
+        az += uz * w;
+    });
+    sum_w[v] = S;
+    wvel[3 * v + 0] = ax;
+    wvel[3 * v + 1] = ay;
+    wvel[3 * v + 2] = az;
+    const float Sc = fmaxf(S, eps);
+    out[3 * v + 0] = px + ax * secs / Sc;
+    out[3 * v + 1] = py + ay * secs / Sc;
+    out[3 * v + 2] = pz + az * secs / Sc;
+}
+
+__global__ void __launch_bounds__(256)
+visual_backward_kernel(const float *__restrict__ visual, const float *__restrict__ hidden,
+                       const float *__restrict__ hidden_prev, int N, float inv_cell, float H2, float term1, float secs,
+                       float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                       const float *__restrict__ sum_w, const float *__restrict__ wvel,
+                       const float *__restrict__ dL_dout, float *__restrict__ dL_dhidden) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float hx = hidden[3 * j], hy = hidden[3 * j + 1], hz = hidden[3 * j + 2];
+    const float ux = (hx - hidden_prev[3 * j]) / secs, uy = (hy - hidden_prev[3 * j + 1]) / secs,
+                uz = (hz - hidden_prev[3 * j + 2]) / secs;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    // the grid holds the VISUAL points: v ranges over visual particles within H of hidden j
+    for_neighbours(hx, hy, hz, inv_cell, H2, mask, start, rec, [&](uint32_t v, float ex, float ey, float ez, float r2) {
+        const float S = sum_w[v];
+        const float Sc = fmaxf(S, eps);
+        const float gx = dL_dout[3 * v], gy = dL_dout[3 * v + 1], gz = dL_dout[3 * v + 2];
+        const float t = H2 - r2;
+        const float w = term1 * (t * t * t);
+        const float dW = -3.0f * term1 * (t * t);
+        // through u_j (1/secs cancels secs): w/S * g
+        const float a = w / Sc;
+        // through w_vj
+        float dLdw = secs * (gx * ux + gy * uy + gz * uz) / Sc;
+        if (S > eps) dLdw -= secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
+        const float k = dLdw * dW * 2.0f;  // d r2 / d hidden_j = 2 (hidden_j - visual_v) = 2 e
+        ax += a * gx + k * ex;
+        ay += a * gy + k * ey;
+        az += a * gz + k * ez;
+    });
+    dL_dhidden[3 * j + 0] = ax;
+    dL_dhidden[3 * j + 1] = ay;
+    dL_dhidden[3 * j + 2] = az;
+}
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return FNX_OK;
+}
+inline float poly6_term1(float H) {  // gm_dynamics.py:130: 315 / (64 pi H^9), evaluated in double
+    const double h = (double)H;
+    return (float)(315.0 / (64.0 * M_PI * std::pow(h, 9.0)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnx_physics_abi_version(void) { return 1; }
+const char *fnx_physics_last_error(void) { return g_err; }
+size_t fnx_grid_bytes(int N) { return grid_bytes(N); }
+
+int fnx_grid_build(const float *xyz, int N, float cell, char *grid, fnx_stream_t stream) {
+    if (N < 0 || !grid || cell <= 0.f || (N > 0 && !xyz)) return fail(FNX_ERR_INVALID_ARG, "grid_build: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    GridView g = carve(grid, N);
+    (void)hipMemsetAsync(g.count, 0, (size_t)g.M * 4, s);
+    const float inv = 1.0f / cell;
+    if (N > 0)
+        hipLaunchKernelGGL(grid_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xyz, N, inv, g.M - 1, g.count);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, g.M, g.count, g.start, g.cursor);
+    if (N > 0)
+        hipLaunchKernelGGL(grid_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xyz, N, inv, g.M - 1, g.start,
+                           g.cursor, g.rec);
+    return hip_check("grid_build");
+}
+
+int fnx_density_forward(const float *xyz, int N, const float *imass, float H, float p0, const char *grid,
+                        float *p_ratio, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !imass || !grid || !p_ratio) return fail(FNX_ERR_INVALID_ARG, "density_forward: bad argument");
+    GridView g = carve(const_cast<char *>(grid), N);
+    hipLaunchKernelGGL(density_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N, imass,
+                       1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, p_ratio);
+    return hip_check("density_forward");
+}
+
+int fnx_density_backward(const float *xyz, int N, const float *imass, float H, float p0, const char *grid,
+                         const float *dL_dp_ratio, float *dL_dxyz, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !imass || !grid || !dL_dp_ratio || !dL_dxyz)
+        return fail(FNX_ERR_INVALID_ARG, "density_backward: bad argument");
+    GridView g = carve(const_cast<char *>(grid), N);
+    hipLaunchKernelGGL(density_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N,
+                       imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, dL_dxyz);
+    return hip_check("density_backward");
+}
+
+int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                              float H, float secs, float eps, const char *hidden_grid, float *out, float *sum_w,
+                              float *wvel, fnx_stream_t stream) {
+    if (V == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !visual || !hidden_grid || !out || !sum_w || !wvel || (N > 0 && (!hidden || !hidden_prev)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward: bad argument");
+    GridView g = carve(const_cast<char *>(hidden_grid), N);
+    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, visual, V,
+                       hidden, hidden_prev, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, out,
+                       sum_w, wvel);
+    return hip_check("visual_interp_forward");
+}
+
+int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                               float H, float secs, float eps, const char *visual_grid, const float *sum_w,
+                               const float *wvel, const float *dL_dout, float *dL_dhidden, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !hidden || !hidden_prev || !visual_grid || !dL_dhidden ||
+        (V > 0 && (!visual || !sum_w || !wvel || !dL_dout)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_backward: bad argument");
+    GridView g = carve(const_cast<char *>(visual_grid), V);
+    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, visual, hidden,
+                       hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, sum_w, wvel,
+                       dL_dout, dL_dhidden);
+    return hip_check("visual_interp_backward");
+}
+
+}  // extern "C"

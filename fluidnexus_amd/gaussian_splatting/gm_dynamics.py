@@ -1,0 +1,198 @@
+"""GaussianModel of the dynamics stage: the state tensors, getters, differentiable physics terms
+and gradient caches that the hot loop (entries_fluid_nexus/train_physical_particle.py:329-432,
+train_visual_particle.py:133-222) and renderer.render_dynamics touch.
+
+Mirrors FluidDynamics/gaussian_splatting/gm_dynamics.py by name: setup_functions :20-40, __init__
+:42-81, the get_* properties :200-341, training_setup_current :372-397,
+training_setup_current_level_two :416-433, gradient caches :451-503, poly6 :188-191,
+get_guess_hidden_particles_from_nn :1014-1030, get_gas_constraints_from_exyz_nn :1269-1294,
+get_gas_constraints_from_vel_nn_guess :1296-1320, get_visual_xyz_from_nn :1453-1498.
+The physics terms run on the fused HIP kernels (fluidnexus_amd.physics) instead of
+torch_cluster edge lists + PyTorch op chains.  Dataset-bound parts of the reference class (PLY
+I/O, emitters, the PBF predictor) are out of scope for this round."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import physics
+from ..utils.general_utils import build_scaling_rotation, get_expon_lr_func, inv_sigmoid, strip_symmetric
+
+# attribute-group prefixes with (xyz, colour, log-scale, raw rotation, logit opacity) storage
+_GROUPS = ("visual", "rigid", "high", "dense", "gs")
+
+
+class GaussianModel:
+    def setup_functions(self):
+        def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+            L = build_scaling_rotation(scaling_modifier * scaling, rotation)
+            return strip_symmetric(L @ L.transpose(1, 2))
+
+        self.scaling_activation = torch.exp
+        self.scaling_inverse_activation = torch.log
+        self.covariance_activation = build_covariance_from_scaling_rotation
+        self.opacity_activation = torch.sigmoid
+        self.opacity_inverse_activation = inv_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    def __init__(self, *args, **kwargs):
+        e = torch.empty(0)
+        self.active_sh_degree = 0
+        # hidden (physics) particles
+        self._xyz = self._estimate_xyz = self._force = self._velocity = self._imass = self._buoyancy = e
+        self._estimate_xyz_nn = e
+        # visual particles + constant Gaussian attributes, static background Gaussians, other groups
+        for g in _GROUPS:
+            for a in ("xyz", "color", "scales", "rotation", "opacity"):
+                setattr(self, f"_{g}_{a}", e)
+        self._color_dummy = self._scales_dummy = self._rotation_dummy = self._opacity_dummy = e
+        self._re_sim_visual_xyz = e
+        self._dense_delta = 0.0
+        self.optimizer = None
+        self.spatial_lr_scale = 1.0
+        self.pos_lr_scale_factor = 1.0
+        self.scale_factor = 100.0  # gm_dynamics.py:129
+        self.total_iterations = 0
+        self._visual_grid = None
+        self.setup_functions()
+
+    # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
+    def setup_constants(self, H=2.0, KNN_K=100, p0=1.5, secs=0.033, k=3, buoyancy_max_y=0.0):
+        self.H, self.KNN_K, self.p0, self._secs, self.k = float(H), int(KNN_K), float(p0), float(secs), int(k)
+        self.H2, self.H6, self.H9 = self.H ** 2, self.H ** 6, self.H ** 9
+        self.EPSILON = 1e-8
+        self.buoyancy_max_y = float(buoyancy_max_y)
+        self.poly6_term1 = 315.0 / (64.0 * np.pi * self.H9)
+        self.spiky_grad_term1 = 45.0 / (np.pi * self.H6)
+
+    # -- getters ------------------------------------------------------------------------------------
+    get_xyz = property(lambda s: s._xyz)
+    get_estimate_xyz = property(lambda s: s._estimate_xyz)
+    get_force = property(lambda s: s._force)
+    get_velocity = property(lambda s: s._velocity)
+    get_imass = property(lambda s: s._imass)
+    get_color_dummy = property(lambda s: s._color_dummy)
+    get_scaling_dummy = property(lambda s: s.scaling_activation(s._scales_dummy))
+    get_rotation_dummy = property(lambda s: s.rotation_activation(s._rotation_dummy))
+    get_opacity_dummy = property(lambda s: s.opacity_activation(s._opacity_dummy))
+    get_re_sim_visual_xyz = property(lambda s: s._re_sim_visual_xyz)
+    get_dense_xyz = property(lambda s: s._dense_xyz + s._dense_delta)
+
+    def get_covariance(self, scaling_modifier=1):
+        return self.covariance_activation(self.get_visual_scaling, scaling_modifier, self._visual_rotation)
+
+    # -- physics ------------------------------------------------------------------------------------
+    def poly6(self, r2):
+        return (r2 < self.H2) * self.poly6_term1 * ((self.H2 - r2) ** 3)
+
+    def get_guess_hidden_particles_from_nn(self):
+        if self.buoyancy_max_y > 0.0:
+            cur_buoyancy = self._buoyancy * (1.0 - (self._estimate_xyz_nn[:, 1:2] / self.buoyancy_max_y))
+        else:
+            cur_buoyancy = self._buoyancy
+        tmp_velocity = (self._estimate_xyz_nn * self.scale_factor - self._xyz) / self._secs
+        estimate_velocity = tmp_velocity + cur_buoyancy * self._secs + self._secs * self._force
+        return self._estimate_xyz_nn * self.scale_factor + self._secs * estimate_velocity
+
+    def get_gas_constraints_from_exyz_nn(self):
+        """p_ratio [N,1] at the optimised positions (fused neighbour search + poly6 density)."""
+        return physics.density_ratio(self._estimate_xyz_nn * self.scale_factor, self._imass, self.H, self.p0)
+
+    def get_gas_constraints_from_vel_nn_guess(self):
+        """p_ratio [N,1] after advecting one tick with the implied velocity."""
+        return physics.density_ratio(self.get_guess_hidden_particles_from_nn(), self._imass, self.H, self.p0)
+
+    def get_visual_xyz_from_nn(self):
+        """Visual particles advected by the poly6-weighted velocity of their hidden neighbours."""
+        visual = self._visual_xyz.detach()
+        if self._visual_grid is None or self._visual_grid[0] is not self._visual_xyz:
+            self._visual_grid = (self._visual_xyz, physics.HashGrid(visual, self.H))
+        return physics.visual_from_hidden(visual, self._estimate_xyz_nn * self.scale_factor, self._xyz, self.H,
+                                          self._secs, self.EPSILON, self._visual_grid[1])
+
+    # -- optimiser set-up and gradient caches ----------------------------------------------------------
+    def _lr_schedule(self, a):
+        return get_expon_lr_func(lr_init=a.position_lr_init * self.spatial_lr_scale,
+                                 lr_final=a.position_lr_final * self.spatial_lr_scale,
+                                 lr_delay_mult=a.position_lr_delay_mult, max_steps=a.position_lr_max_steps)
+
+    def training_setup_first_visual(self, optim_args):
+        self._visual_xyz = nn.Parameter(self._visual_xyz.detach().clone().requires_grad_(True))
+        lr = optim_args.position_lr_init * self.spatial_lr_scale * self.pos_lr_scale_factor
+        self.optimizer = torch.optim.Adam([{"params": [self._visual_xyz], "lr": lr, "name": "visual_xyz"}], lr=0.0,
+                                          eps=1e-15)
+        self.xyz_scheduler_args = self._lr_schedule(optim_args)
+
+    def training_setup_current(self, optim_args):
+        init = self._estimate_xyz.detach().clone() / self.scale_factor
+        self._estimate_xyz_nn = nn.Parameter(init.requires_grad_(True))
+        lr = optim_args.position_lr_init * self.spatial_lr_scale * self.pos_lr_scale_factor
+        self.optimizer = torch.optim.Adam([{"params": [self._estimate_xyz_nn], "lr": lr, "name": "estimate_xyz_nn"}],
+                                          lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = self._lr_schedule(optim_args)
+
+    def training_setup_current_level_two(self, optim_args):
+        groups = []
+        for name, lr in (("color", optim_args.color_lr), ("opacity", optim_args.opacity_lr),
+                         ("scales", optim_args.scaling_lr), ("rotation", optim_args.rotation_lr)):
+            t = getattr(self, f"_visual_{name}")
+            p = nn.Parameter(t.detach().clone().requires_grad_(True))
+            setattr(self, f"_visual_{name}", p)
+            groups.append({"params": [p], "lr": lr, "name": f"visual_{name}"})
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    def update_learning_rate_current(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g["name"] in ("estimate_xyz_nn", "visual_xyz"):
+                g["lr"] = self.xyz_scheduler_args(iteration) * self.pos_lr_scale_factor
+                return g["lr"]
+
+    def zero_gradient_cache_first_visual(self):
+        self._visual_xyz_grad = torch.zeros_like(self._visual_xyz)
+
+    def cache_gradient_first_visual(self):
+        self._visual_xyz_grad += self._visual_xyz.grad
+
+    def set_batch_gradient_first_visual(self, batch_size):
+        self._visual_xyz.grad = self._visual_xyz_grad * (1.0 / batch_size)
+
+    def zero_gradient_cache_current(self):
+        self._estimate_xyz_nn_grad = torch.zeros_like(self._estimate_xyz_nn)
+
+    def cache_gradient_current(self):
+        self._estimate_xyz_nn_grad += self._estimate_xyz_nn.grad
+
+    def set_batch_gradient_current(self, batch_size):
+        self._estimate_xyz_nn.grad = self._estimate_xyz_nn_grad * (1.0 / batch_size)
+
+    _L2 = ("color", "opacity", "scales", "rotation")
+
+    def zero_gradient_cache_current_level_two(self):
+        self._l2_grad = {n: torch.zeros_like(getattr(self, f"_visual_{n}")) for n in self._L2}
+
+    def cache_gradient_current_level_two(self):
+        for n in self._L2:
+            g = getattr(self, f"_visual_{n}").grad
+            if g is not None:
+                self._l2_grad[n] += g
+
+    def set_batch_gradient_current_level_two(self, batch_size):
+        for n in self._L2:
+            getattr(self, f"_visual_{n}").grad = self._l2_grad[n] * (1.0 / batch_size)
+
+
+def _group_properties():
+    for g in _GROUPS:
+        if g != "dense":
+            setattr(GaussianModel, f"get_{g}_xyz", property(lambda s, g=g: getattr(s, f"_{g}_xyz")))
+        setattr(GaussianModel, f"get_{g}_color", property(lambda s, g=g: getattr(s, f"_{g}_color")))
+        setattr(GaussianModel, f"get_{g}_scaling",
+                property(lambda s, g=g: s.scaling_activation(getattr(s, f"_{g}_scales"))))
+        setattr(GaussianModel, f"get_{g}_rotation",
+                property(lambda s, g=g: s.rotation_activation(getattr(s, f"_{g}_rotation"))))
+        setattr(GaussianModel, f"get_{g}_opacity",
+                property(lambda s, g=g: s.opacity_activation(getattr(s, f"_{g}_opacity"))))
+
+
+_group_properties()

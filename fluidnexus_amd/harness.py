@@ -1,0 +1,164 @@
+"""Synthetic driver of the per-frame optimisation hot loop.
+
+Reproduces, op for op, the per-iteration sequence of the reference's physical-particle stage
+(FluidDynamics/entries_fluid_nexus/train_physical_particle.py:329-432):
+  zero grad cache -> for each view of the batch: render_dynamics(pos_type="guess_visual_nn",
+  scale=True) -> grey-mean image loss (L1 + D-SSIM) -> exyz anchor L2 -> gas constraint L2 ->
+  next-tick gas constraint L2 -> backward -> cache gradient -> mean over the batch -> Adam step,
+and of the visual-particle stage (train_visual_particle.py:133-222) for the level-two attributes.
+Dataset loading, TensorBoard and PNG dumps of the entry scripts are out of scope; the optional
+`.item()` logging syncs of the reference (tpp:410-424) are off by default.
+
+Multi-GPU: particles/Gaussians replicated, the views of the batch sharded
+round-robin over ranks, one all-reduce(sum) of the leaf gradient per iteration followed by the
+reference's 1/batch scaling (gm_dynamics.py:461-472)."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import synthetic as S
+from .gaussian_splatting.gm_dynamics import GaussianModel
+from .helpers.helper_pipe import get_render_pipe
+from .utils.loss_utils import l1_loss, l2_loss, ssim
+
+# constants of configs/fluid_nexus_smoke_dynamics.json + arguments/__init__.py
+SMOKE = dict(H=2.0, KNN_K=100, p0=1.5, secs=0.033, k=3, lambda_dssim=0.2, lambda_image=1.0, lambda_exyz=0.1,
+             lambda_gas_constraints=1.0, lambda_next_gas_constraints=0.1, lambda_current_distance=0.0,
+             position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+             position_lr_max_steps=30000)
+
+
+def shard_views(n_views: int, rank: int, world: int):
+    """view v of the iteration's batch -> rank v mod world (5 views on 4 GPUs = 2/1/1/1)."""
+    return [v for v in range(n_views) if v % world == rank]
+
+
+def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62, 20), n_views=5, size=512, seed=0,
+                      device="cuda"):
+    """BASELINE config 3 state: V visual fluid Gaussians + static background Gaussians + N hidden
+    particles on a jittered unit lattice filling the plume (scaled units, < KNN_K neighbours each)."""
+    rng = np.random.RandomState(seed)
+    gm = GaussianModel()
+    gm.setup_constants(H=SMOKE["H"], KNN_K=SMOKE["KNN_K"], p0=SMOKE["p0"], secs=SMOKE["secs"], k=SMOKE["k"])
+    center = np.array([0.34, 0.0, -0.225])
+    fluid = S.plume_gaussians(P_fluid, seed=seed, channels=1)
+    bgd = S.random_gaussians(P_background, seed=seed + 1, box=0.6, log_scale=(-5.0, -3.0), channels=3,
+                             center=(0.34, 0.3, -0.225))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+    sf = gm.scale_factor
+    # visual particles live in scaled units (x100); constant attributes as gm_dynamics.py:171-173
+    gm._visual_xyz = t(fluid["means3D"] * sf)
+    gm._visual_color = t(fluid["colors"])
+    gm._visual_scales = t(np.log(fluid["scales"]))
+    gm._visual_rotation = t(fluid["rotations"])
+    gm._visual_opacity = t(np.log(fluid["opacities"] / (1 - fluid["opacities"])))
+    gm._gs_xyz = t(bgd["means3D"])
+    gm._gs_color = t(bgd["colors"])
+    gm._gs_scales = t(np.log(bgd["scales"]))
+    gm._gs_rotation = t(bgd["rotations"])
+    gm._gs_opacity = t(np.log(bgd["opacities"] / (1 - bgd["opacities"])))
+    nx, ny, nz = hidden_dims
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1).reshape(-1, 3)
+    origin = center * sf + np.array([-nx / 2.0, -2.0, -nz / 2.0])
+    x_prev = g * 1.0 + rng.uniform(-0.15, 0.15, size=g.shape) + origin
+    N = x_prev.shape[0]
+    vel = np.tile(np.array([[0.0, 20.0, 0.0]]), (N, 1)) + rng.normal(size=(N, 3)) * 2.0  # rising smoke, units/s
+    gm._xyz = t(x_prev)
+    gm._velocity = t(vel)
+    gm._estimate_xyz = t(x_prev + SMOKE["secs"] * vel)
+    gm._imass = t(np.ones((N, 1)))
+    gm._buoyancy = t(np.tile(np.array([[0.0, 1.96, 0.0]]), (N, 1)))
+    gm._force = t(np.zeros((N, 3)))
+    cams = S.arc_cameras(n_views, size, size, device=device)
+    return gm, cams
+
+
+class HotLoop:
+    """One frame's optimisation loop over `gm` and `cams` (physical-particle stage)."""
+
+    def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
+                 physics_per_view=True, image_loss="torch"):
+        self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
+        self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
+        self.log_scalars = log_scalars
+        self.physics_per_view = physics_per_view
+        self.image_loss = image_loss
+        dev = gm._xyz.device
+        self.background = torch.zeros(3, device=dev)
+        self.optim_args = SimpleNamespace(**{k: cfg[k] for k in ("position_lr_init", "position_lr_final",
+                                                               "position_lr_delay_mult", "position_lr_max_steps")})
+        gm.training_setup_current(self.optim_args)
+        self.itr = 0
+        self.last = {}
+
+    @torch.no_grad()
+    def make_targets(self, shift=0.3):
+        """Synthetic ground truth: the scene rendered with the hidden particles displaced by `shift`."""
+        gm = self.gm
+        keep = gm._estimate_xyz_nn.data.clone()
+        gm._estimate_xyz_nn.data += shift / gm.scale_factor
+        for cam in self.cams:
+            pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                   pos_type="guess_visual_nn", scale=True)
+            cam.original_image = pkg["render"].detach().clamp(0, 1).clone()
+        gm._estimate_xyz_nn.data.copy_(keep)
+
+    def _image_loss(self, image, gt_image):
+        c = self.cfg
+        # grey-mean both images and replicate to 3 channels (tpp:356-360)
+        gt = torch.cat([torch.mean(gt_image, dim=0, keepdim=True)] * 3, dim=0)
+        im = torch.cat([torch.mean(image, dim=0, keepdim=True)] * 3, dim=0)
+        if self.image_loss == "fused":
+            from .losses import fused_l1_dssim
+            l1_value, ssim_value = fused_l1_dssim(im, gt)
+        else:
+            l1_value = l1_loss(im, gt)
+            ssim_value = 1.0 - ssim(im, gt)
+        return ((1.0 - c["lambda_dssim"]) * l1_value * c["lambda_image"]
+                + c["lambda_dssim"] * ssim_value * c["lambda_image"]), l1_value, ssim_value
+
+    def _physics_loss(self):
+        gm, c = self.gm, self.cfg
+        loss = 0.0
+        if c["lambda_exyz"] > 0:
+            loss = loss + c["lambda_exyz"] * l2_loss(gm._estimate_xyz_nn * gm.scale_factor, gm._estimate_xyz)
+        if c["lambda_gas_constraints"] > 0:
+            pr = gm.get_gas_constraints_from_exyz_nn()
+            loss = loss + c["lambda_gas_constraints"] * l2_loss(pr, torch.ones_like(pr))
+        if c["lambda_next_gas_constraints"] > 0:
+            pn = gm.get_gas_constraints_from_vel_nn_guess()
+            loss = loss + c["lambda_next_gas_constraints"] * l2_loss(pn, torch.ones_like(pn))
+        return loss
+
+    def iteration(self):
+        gm = self.gm
+        self.itr += 1
+        gm.total_iterations += 1
+        gm.update_learning_rate_current(self.itr)
+        gm.zero_gradient_cache_current()
+        batch = len(self.cams)  # the benchmark renders every view each iteration (BASELINE: 5 views/iter)
+        mine = shard_views(batch, self.rank, self.world)
+        for n, v in enumerate(mine):
+            cam = self.cams[v]
+            pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                   pos_type="guess_visual_nn", scale=True)
+            loss, l1_value, ssim_value = self._image_loss(pkg["render"], cam.original_image)
+            if self.physics_per_view:
+                loss = loss + self._physics_loss()          # as the reference: once per view (tpp:368-389)
+            elif n == 0 and self.rank == 0:
+                loss = loss + batch * self._physics_loss()  # same gradient after the 1/batch scaling
+            if self.log_scalars:
+                self.last = dict(l1=l1_value.item(), ssim=ssim_value.item(), total=loss.item())
+            loss.backward()
+            gm.cache_gradient_current()
+            gm.optimizer.zero_grad()
+        if self.world > 1:
+            dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
+        gm.set_batch_gradient_current(batch)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad()

@@ -1,0 +1,2 @@
+"""Render pipes with the call signatures and return dicts of FluidDynamics/renderer/."""
+from .pipes import render, render_background, render_dynamics, render_fluid  # noqa: F401

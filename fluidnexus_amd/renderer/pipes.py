@@ -1,0 +1,134 @@
+"""Per-model adapters between a GaussianModel and the rasteriser, mirroring
+FluidDynamics/renderer/pipe_dynamics.py:8-180 (render_dynamics), pipe_fluid.py:8-135 (render_fluid),
+pipe_background.py:9-95 (render_background) and pipe.py:14-107 (render, the SH pipe): same keyword
+arguments, same pos_type selection, same concatenation order (fluid first, background second), same
+return-dict keys.  The rasteriser classes arrive as GRsetting / GRzer exactly as the reference's
+entry scripts thread them through (train_physical_particle.py:114-122)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+_POS = {
+    "guess_visual_nn": lambda gm: gm.get_visual_xyz_from_nn(),
+    "guess_visual_hidden": lambda gm: gm.get_visual_xyz_from_hidden_guess(),
+    "visual": lambda gm: gm.get_visual_xyz,
+    "hidden": lambda gm: gm.get_xyz,
+    "rigid": lambda gm: gm.get_rigid_xyz,
+    "re_sim_visual": lambda gm: gm.get_re_sim_visual_xyz,
+}
+# pos_type -> attribute family used for opacity / scaling / rotation / colour
+_ATTR = {"hidden": "dummy", "rigid": "rigid", "high": "high", "dense": "dense"}
+
+
+def _positions(gm, pos_type, scale):
+    if pos_type not in _POS:
+        raise ValueError(f"Unknown pos_type: {pos_type}")
+    raw = _POS[pos_type](gm)
+    return raw, (raw / gm.scale_factor if scale else raw)
+
+
+def _attributes(gm, pos_type):
+    fam = _ATTR.get(pos_type, "visual")
+    if fam == "dummy":
+        return gm.get_opacity_dummy, gm.get_scaling_dummy, gm.get_rotation_dummy, gm.get_color_dummy
+    return (getattr(gm, f"get_{fam}_opacity"), getattr(gm, f"get_{fam}_scaling"), getattr(gm, f"get_{fam}_rotation"),
+            getattr(gm, f"get_{fam}_color"))
+
+
+def _screen_space_like(xyz):
+    """Zero tensor whose .grad receives the 2D-mean gradients (pipe_dynamics.py:59-66)."""
+    p = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        p.retain_grad()
+    except Exception:
+        pass
+    return p
+
+
+def _settings(GRsetting, cam, bg_color, scaling_modifier, sh_degree):
+    return GRsetting(image_height=int(cam.image_height), image_width=int(cam.image_width),
+                     tan_fov_x=math.tan(cam.FoVx * 0.5), tan_fov_y=math.tan(cam.FoVy * 0.5), bg=bg_color.float(),
+                     scale_modifier=scaling_modifier, view_matrix=cam.world_view_transform,
+                     proj_matrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center,
+                     prefiltered=False)
+
+
+def _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales):
+    return {"render": image, "viewspace_points": screen, "visibility_filter": radii > 0, "radii": radii,
+            "opacity": opacity, "depth": depth, "render_xyz": render_xyz, "raw_render_xyz": raw_render_xyz,
+            "means3D": means3D, "means2D": screen, "rotations": rotations, "colors_precomp": colors, "scales": scales}
+
+
+def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None,
+                    GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, gpf_only=False, gs_only=False,
+                    debug=False, **kwargs):
+    """Fluid particles (+ static background Gaussians) through the 3-channel rasteriser."""
+    raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    opacity, scales, rotations, colors = _attributes(gm, pos_type)
+    if colors.shape[1] == 1:  # grey fluid particles rendered as RGB (pipe_dynamics.py:113-115)
+        colors = colors.repeat(1, 3)
+    if gpf_only:
+        means3D = render_xyz
+    elif gs_only:
+        means3D = gm.get_gs_xyz
+        opacity, scales, rotations, colors = gm.get_gs_opacity, gm.get_gs_scaling, gm.get_gs_rotation, gm.get_gs_color
+    else:
+        means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
+        opacity = torch.cat([opacity, gm.get_gs_opacity], dim=0)
+        scales = torch.cat([scales, gm.get_gs_scaling], dim=0)
+        rotations = torch.cat([rotations, gm.get_gs_rotation], dim=0)
+        colors = torch.cat([colors, gm.get_gs_color], dim=0)
+    screen = _screen_space_like(means3D)
+    rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
+                                                 gm.active_sh_degree))
+    image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen.float(), shs=None,
+                                     colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
+                                     rotations=rotations.float(), cov3D_precomp=None)
+    return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
+
+
+def render_fluid(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None,
+                 GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, **kwargs):
+    """Fluid particles only, 1-channel rasteriser (ScalarReal)."""
+    raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    opacity, scales, rotations, colors = _attributes(gm, pos_type)
+    screen = _screen_space_like(render_xyz)
+    rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
+                                                 gm.active_sh_degree))
+    image, radii, depth = rasterizer(means3D=render_xyz.float(), means2D=screen.float(), shs=None,
+                                     colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
+                                     rotations=rotations.float(), cov3D_precomp=None)
+    return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, render_xyz, rotations, colors, scales)
+
+
+def render_background(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
+                      GRsetting=None, GRzer=None, **kwargs):
+    """Static background Gaussians with per-Gaussian RGB (pipe_background.py:9-95)."""
+    means3D = gm.get_xyz
+    screen = _screen_space_like(means3D)
+    rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
+                                                 gm.active_sh_degree))
+    colors = gm.get_color if override_color is None else override_color
+    image, radii, depth = rasterizer(means3D=means3D, means2D=screen, shs=None, colors_precomp=colors,
+                                     opacities=gm.get_opacity, scales=gm.get_scaling, rotations=gm.get_rotation,
+                                     cov3D_precomp=None)
+    return {"render": image, "viewspace_points": screen, "visibility_filter": radii > 0, "radii": radii,
+            "depth": depth}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None, GRzer=None,
+           **kwargs):
+    """Vanilla 3DGS pipe with view-dependent SH colour (pipe.py:14-107); returns the 2-tuple-style dict."""
+    from diff_gaussian_rasterization_ch3 import GaussianRasterizationSettings, GaussianRasterizer
+    GRsetting, GRzer = GRsetting or GaussianRasterizationSettings, GRzer or GaussianRasterizer
+    means3D = pc.get_xyz
+    screen = _screen_space_like(means3D)
+    rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
+                                                 pc.active_sh_degree))
+    shs, colors = (pc.get_features, None) if override_color is None else (None, override_color)
+    image, radii, depth = rasterizer(means3D=means3D, means2D=screen, shs=shs, colors_precomp=colors,
+                                     opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation,
+                                     cov3D_precomp=None)
+    return {"render": image, "viewspace_points": screen, "visibility_filter": radii > 0, "radii": radii}

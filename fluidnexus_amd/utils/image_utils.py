@@ -1,0 +1,10 @@
+"""FluidDynamics/utils/image_utils.py:4-10."""
+import torch
+
+
+def mse(img1, img2):
+    return ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+
+
+def psnr(img1, img2):
+    return 20 * torch.log10(1.0 / torch.sqrt(mse(img1, img2)))

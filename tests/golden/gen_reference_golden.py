@@ -1,0 +1,223 @@
+"""Generates the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (it needs /root/reference):
+    python tests/golden/gen_reference_golden.py
+It imports the importable pure-Python parts of FluidNexus/FluidDynamics on the CPU:
+  utils/sh_utils.py (eval_sh), utils/loss_utils.py (l1/l2/ssim/distance_loss/l2_loss_consistency),
+  utils/image_utils.py (psnr), utils/graphics_utils.py (camera matrices), utils/general_utils.py
+  (get_expon_lr_func, inv_sigmoid), and gaussian_splatting/gm_dynamics.py with the four missing
+  third-party modules stubbed (plyfile, simple_knn, torch_cluster = brute-force radius search,
+  torch_scatter), and stores seeded inputs + the reference's outputs (+ autograd gradients).
+Only DATA is written (npz); no reference source travels.  The clouds are built so that every
+particle has fewer than KNN_K neighbours, so the third-party truncation rule cannot matter.
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/FluidDynamics"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+torch.set_num_threads(4)
+
+
+# ---- stubs for un-vendored third-party packages (torch_cluster 1.6.3 semantics) ----
+def _radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_workers=1):
+    """row indexes y (queries), col indexes x; all pairs with ||x - y|| < r."""
+    d = torch.cdist(y.double(), x.double())
+    row, col = torch.nonzero(d < r, as_tuple=True)
+    cnt = torch.bincount(row, minlength=y.shape[0])
+    assert int(cnt.max()) <= max_num_neighbors, "fixture cloud exceeds max_num_neighbors"
+    return torch.stack([row, col], 0)
+
+
+def _radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
+    d = torch.cdist(x.double(), x.double())
+    m = d < r
+    if not loop:
+        m.fill_diagonal_(False)
+    col, row = torch.nonzero(m, as_tuple=True)  # row = neighbour/source, col = query/target
+    cnt = torch.bincount(col, minlength=x.shape[0])
+    assert int(cnt.max()) <= max_num_neighbors + 1, "fixture cloud exceeds max_num_neighbors"
+    return torch.stack([row, col], 0)
+
+
+for name in ("plyfile", "simple_knn", "simple_knn._C", "torch_cluster", "torch_scatter"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["plyfile"].PlyData = object
+sys.modules["plyfile"].PlyElement = object
+sys.modules["simple_knn._C"].distCUDA2 = None
+sys.modules["torch_cluster"].radius = _radius
+sys.modules["torch_cluster"].radius_graph = _radius_graph
+sys.modules["torch_scatter"].scatter_min = None
+
+
+def gen_graphics():
+    from utils.graphics_utils import (focal2fov, fov2focal, get_projection_matrix, get_projection_matrix_cv,
+                                      get_world_2_view2)
+    rng = np.random.RandomState(0)
+    out = {}
+    for i in range(4):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        T = rng.normal(size=3)
+        trans = rng.normal(size=3) * (i % 2)
+        scale = 1.0 + 0.5 * (i // 2)
+        fovx, fovy = 0.5 + 0.2 * i, 0.6 + 0.15 * i
+        out[f"R{i}"], out[f"T{i}"], out[f"trans{i}"], out[f"scale{i}"] = R, T, trans, np.float64(scale)
+        out[f"fov{i}"] = np.array([fovx, fovy])
+        out[f"w2v{i}"] = get_world_2_view2(R, T, trans, scale)
+        out[f"proj{i}"] = get_projection_matrix(0.01, 100.0, fovx, fovy).numpy()
+        out[f"projcv{i}"] = get_projection_matrix_cv(0.01, 100.0, fovx, fovy, cx=0.1 * i - 0.15, cy=0.05 * i).numpy()
+        out[f"focal{i}"] = np.array([fov2focal(fovx, 512), focal2fov(600.0 + i, 512)])
+    np.savez(os.path.join(OUT, "graphics_utils.npz"), **out)
+
+
+def gen_sh():
+    from utils.sh_utils import eval_sh, rgb2sh, sh2rgb
+    rng = np.random.RandomState(1)
+    P = 256
+    sh = torch.tensor(rng.normal(size=(P, 16, 3)) * 0.5, dtype=torch.float32)  # kernel layout [P, M, 3]
+    dirs = torch.tensor(rng.normal(size=(P, 3)), dtype=torch.float32)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    out = dict(sh=sh.numpy(), dirs=dirs.numpy())
+    for deg in range(4):
+        s = sh.clone().requires_grad_(True)
+        rgb = torch.clamp_min(eval_sh(deg, s.transpose(1, 2), dirs) + 0.5, 0.0)  # renderer/pipe.py:77-82
+        w = torch.tensor(rng.normal(size=(P, 3)), dtype=torch.float32)
+        (rgb * w).sum().backward()
+        out[f"rgb{deg}"] = rgb.detach().numpy()
+        out[f"w{deg}"] = w.numpy()
+        out[f"dsh{deg}"] = s.grad.numpy()
+    out["rgb2sh"] = rgb2sh(torch.tensor([0.1, 0.5, 0.9])).numpy()
+    out["sh2rgb"] = sh2rgb(torch.tensor([-1.0, 0.0, 1.0])).numpy()
+    np.savez(os.path.join(OUT, "sh_utils.npz"), **out)
+
+
+def gen_losses():
+    from utils.image_utils import psnr
+    from utils.loss_utils import distance_loss, l1_loss, l2_loss, l2_loss_consistency, ssim
+    rng = np.random.RandomState(2)
+    out = {}
+    for tag, (C, H, W) in dict(a=(3, 64, 64), b=(1, 48, 80), c=(3, 37, 53)).items():
+        x = torch.tensor(rng.uniform(0, 1, size=(C, H, W)), dtype=torch.float32, requires_grad=True)
+        y = torch.tensor(rng.uniform(0, 1, size=(C, H, W)), dtype=torch.float32)
+        out[f"x_{tag}"], out[f"y_{tag}"] = x.detach().numpy(), y.numpy()
+        for nm, fn in (("l1", l1_loss), ("l2", l2_loss), ("ssim", ssim)):
+            x.grad = None
+            v = fn(x, y)
+            v.backward()
+            out[f"{nm}_{tag}"] = np.float32(v.item())
+            out[f"d{nm}_{tag}"] = x.grad.numpy().copy()
+        out[f"psnr_{tag}"] = psnr(x.detach(), y).numpy()
+        # the physical stage's grey-mean image loss (train_physical_particle.py:356-363), lambda_dssim 0.2
+        if C == 3:
+            x.grad = None
+            yg = torch.cat([torch.mean(y, dim=0, keepdim=True)] * 3, dim=0)
+            xg = torch.cat([torch.mean(x, dim=0, keepdim=True)] * 3, dim=0)
+            v = 0.8 * l1_loss(xg, yg) + 0.2 * (1.0 - ssim(xg, yg))
+            v.backward()
+            out[f"grey_{tag}"] = np.float32(v.item())
+            out[f"dgrey_{tag}"] = x.grad.numpy().copy()
+    pos = torch.tensor(rng.uniform(0, 1, size=(200, 3)), dtype=torch.float32, requires_grad=True)
+    v = distance_loss(pos, 0.08)
+    v.backward()
+    out.update(dist_pos=pos.detach().numpy(), dist_thr=np.float32(0.08), dist=np.float32(v.item()), ddist=pos.grad.numpy())
+    a = torch.tensor(rng.normal(size=(50, 3)), dtype=torch.float32)
+    b = torch.tensor(rng.normal(size=(50, 3)), dtype=torch.float32)
+    out.update(cons_a=a.numpy(), cons_b=b.numpy(), cons=np.float32(l2_loss_consistency(a, b).item()))
+    np.savez(os.path.join(OUT, "loss_utils.npz"), **out)
+
+
+def gen_general():
+    from utils.general_utils import get_expon_lr_func, inv_sigmoid
+    out = {}
+    f = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    g = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_steps=100, lr_delay_mult=0.01, max_steps=1000)
+    steps = np.array([0, 1, 10, 100, 500, 999, 1000, 5000, 30000])
+    out["steps"] = steps
+    out["lr_a"] = np.array([f(int(s)) for s in steps])
+    out["lr_b"] = np.array([g(int(s)) for s in steps])
+    x = torch.tensor([0.01, 0.1, 0.5, 0.9])
+    out["inv_sigmoid_x"], out["inv_sigmoid"] = x.numpy(), inv_sigmoid(x).numpy()
+    np.savez(os.path.join(OUT, "general_utils.npz"), **out)
+
+
+def gen_physics():
+    import gaussian_splatting.gm_dynamics as gmd
+    rng = np.random.RandomState(3)
+    out = {}
+    for tag, (n_side, V, buoy_max_y) in dict(a=(6, 300, 0.0), b=(8, 700, 60.0)).items():
+        gm = gmd.GaussianModel.__new__(gmd.GaussianModel)
+        # hand-set constants (setup_constants allocates on "cuda", gm_dynamics.py:84): values of
+        # configs/fluid_nexus_smoke_dynamics.json + arguments/__init__.py:308,312
+        gm.H, gm.KNN_K, gm.p0, gm._secs, gm.scale_factor, gm.EPSILON = 2.0, 100, 1.5, 0.033, 100.0, 1e-8
+        gm.H2, gm.H6, gm.H9 = gm.H ** 2, gm.H ** 6, gm.H ** 9
+        gm.poly6_term1 = 315.0 / (64.0 * np.pi * gm.H9)
+        gm.spiky_grad_term1 = 45.0 / (np.pi * gm.H6)
+        gm.buoyancy_max_y = buoy_max_y
+        N = n_side ** 3
+        grid = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        x_prev = (grid * 0.9 + rng.uniform(-0.15, 0.15, size=(N, 3))).astype(np.float32)
+        x_est = (x_prev + rng.normal(size=(N, 3)) * 0.05).astype(np.float32)
+        x_nn = ((x_est + rng.normal(size=(N, 3)) * 0.03) / 100.0).astype(np.float32)
+        gm._xyz = torch.tensor(x_prev)
+        gm._estimate_xyz = torch.tensor(x_est)
+        gm._imass = torch.tensor(rng.uniform(0.8, 1.2, size=(N, 1)).astype(np.float32))
+        gm._buoyancy = torch.tensor(np.tile(np.array([[0.0, 1.96, 0.0]], np.float32), (N, 1)))
+        gm._force = torch.tensor((rng.normal(size=(N, 3)) * 0.1).astype(np.float32))
+        gm._visual_xyz = torch.tensor(rng.uniform(-1.0, n_side * 0.9 + 1.0, size=(V, 3)).astype(np.float32))
+        gm._estimate_xyz_nn = torch.tensor(x_nn, requires_grad=True)
+        out.update({f"{k}_{tag}": v for k, v in dict(
+            x_prev=x_prev, x_est=x_est, x_nn=x_nn, imass=gm._imass.numpy(), buoyancy=gm._buoyancy.numpy(),
+            force=gm._force.numpy(), visual_xyz=gm._visual_xyz.numpy(),
+            consts=np.array([gm.H, gm.KNN_K, gm.p0, gm._secs, gm.scale_factor, gm.EPSILON, buoy_max_y])).items()})
+
+        def grad_of(fn, w):
+            gm._estimate_xyz_nn.grad = None
+            val = fn()
+            (val * torch.tensor(w)).sum().backward()
+            return val.detach().numpy(), gm._estimate_xyz_nn.grad.numpy().copy()
+
+        w1 = rng.normal(size=(N, 1)).astype(np.float32)
+        out[f"w_gas_{tag}"] = w1
+        out[f"p_ratio_{tag}"], out[f"d_gas_{tag}"] = grad_of(gm.get_gas_constraints_from_exyz_nn, w1)
+        w2 = rng.normal(size=(N, 1)).astype(np.float32)
+        out[f"w_next_{tag}"] = w2
+        out[f"p_ratio_next_{tag}"], out[f"d_next_{tag}"] = grad_of(gm.get_gas_constraints_from_vel_nn_guess, w2)
+        w3 = rng.normal(size=(V, 3)).astype(np.float32)
+        out[f"w_vis_{tag}"] = w3
+        out[f"vis_{tag}"], out[f"d_vis_{tag}"] = grad_of(gm.get_visual_xyz_from_nn, w3)
+        out[f"guess_{tag}"] = gm.get_guess_hidden_particles_from_nn().detach().numpy()
+        r2 = torch.tensor(rng.uniform(0, 5.0, size=(64,)).astype(np.float32))
+        out[f"poly6_r2_{tag}"], out[f"poly6_{tag}"] = r2.numpy(), gm.poly6(r2).numpy()
+        # the physical-stage loss weights of fluid_nexus_smoke_dynamics.json on the same state
+        gm._estimate_xyz_nn.grad = None
+        from utils.loss_utils import l2_loss
+        pr, pn = gm.get_gas_constraints_from_exyz_nn(), gm.get_gas_constraints_from_vel_nn_guess()
+        loss = (0.1 * l2_loss(gm._estimate_xyz_nn * gm.scale_factor, gm._estimate_xyz)
+                + 1.0 * l2_loss(pr, torch.ones_like(pr)) + 0.1 * l2_loss(pn, torch.ones_like(pn)))
+        loss.backward()
+        out[f"phys_loss_{tag}"] = np.float32(loss.item())
+        out[f"d_phys_loss_{tag}"] = gm._estimate_xyz_nn.grad.numpy().copy()
+    np.savez(os.path.join(OUT, "physics.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference is only available in the build container"
+    gen_graphics()
+    gen_sh()
+    gen_losses()
+    gen_general()
+    gen_physics()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,105 @@
+"""-m gpu: fused HIP physics kernels vs the oracle restatement and the reference golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "physics.npz"))
+
+
+def _model(tag, dev="cuda"):
+    from fluidnexus_amd.gaussian_splatting.gm_dynamics import GaussianModel
+    H, K, p0, secs, sf, eps, bmy = G[f"consts_{tag}"]
+    gm = GaussianModel()
+    gm.setup_constants(H=float(H), KNN_K=int(K), p0=float(p0), secs=float(secs), buoyancy_max_y=float(bmy))
+    t = lambda k: torch.tensor(G[f"{k}_{tag}"]).to(dev)  # noqa: E731
+    gm._xyz, gm._estimate_xyz, gm._imass = t("x_prev"), t("x_est"), t("imass")
+    gm._buoyancy, gm._force, gm._visual_xyz = t("buoyancy"), t("force"), t("visual_xyz")
+    gm._estimate_xyz_nn = t("x_nn").requires_grad_(True)
+    return gm
+
+
+def _close(a, b, rtol, name):
+    scale = np.abs(b).max()
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_physics_vs_reference_golden(tag):
+    gm = _model(tag)
+
+    def run(fn, w):
+        gm._estimate_xyz_nn.grad = None
+        val = fn()
+        (val * torch.tensor(w).cuda()).sum().backward()
+        return val.detach().cpu().numpy(), gm._estimate_xyz_nn.grad.cpu().numpy()
+
+    v, g = run(gm.get_gas_constraints_from_exyz_nn, G[f"w_gas_{tag}"])
+    _close(v, G[f"p_ratio_{tag}"], 3e-6, "p_ratio")
+    _close(g, G[f"d_gas_{tag}"], 1e-4, "d p_ratio")
+    v, g = run(gm.get_gas_constraints_from_vel_nn_guess, G[f"w_next_{tag}"])
+    _close(v, G[f"p_ratio_next_{tag}"], 3e-6, "p_ratio_next")
+    _close(g, G[f"d_next_{tag}"], 1e-4, "d p_ratio_next")
+    v, g = run(gm.get_visual_xyz_from_nn, G[f"w_vis_{tag}"])
+    _close(v, G[f"vis_{tag}"], 1e-6, "visual_xyz")
+    _close(g, G[f"d_vis_{tag}"], 1e-4, "d visual_xyz")
+    _close(gm.get_guess_hidden_particles_from_nn().detach().cpu().numpy(), G[f"guess_{tag}"], 1e-6, "guess")
+    # the weighted physical-stage loss of fluid_nexus_smoke_dynamics.json
+    from fluidnexus_amd.utils.loss_utils import l2_loss
+    gm._estimate_xyz_nn.grad = None
+    pr, pn = gm.get_gas_constraints_from_exyz_nn(), gm.get_gas_constraints_from_vel_nn_guess()
+    loss = (0.1 * l2_loss(gm._estimate_xyz_nn * gm.scale_factor, gm._estimate_xyz)
+            + 1.0 * l2_loss(pr, torch.ones_like(pr)) + 0.1 * l2_loss(pn, torch.ones_like(pn)))
+    loss.backward()
+    assert abs(loss.item() - G[f"phys_loss_{tag}"]) < 1e-5 * abs(G[f"phys_loss_{tag}"])
+    _close(gm._estimate_xyz_nn.grad.cpu().numpy(), G[f"d_phys_loss_{tag}"], 1e-4, "d phys loss")
+
+
+def test_physics_larger_cloud_vs_oracle():
+    """20 x 30 x 20 lattice (12k hidden) + 50k visual: HIP vs the oracle's brute-force restatement."""
+    from oracle.physics_oracle import PhysicsOracle
+    from fluidnexus_amd import physics
+    rng = np.random.RandomState(0)
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(20), np.arange(14), indexing="ij"), -1).reshape(-1, 3)
+    x = (g + rng.uniform(-0.2, 0.2, size=g.shape)).astype(np.float32)
+    xp = (x - rng.normal(size=x.shape) * 0.1).astype(np.float32)
+    imass = rng.uniform(0.9, 1.1, size=(x.shape[0], 1)).astype(np.float32)
+    vis = rng.uniform(-1, 15, size=(6000, 3)).astype(np.float32) * np.array([1, 20 / 15, 1], np.float32)
+    o = PhysicsOracle()
+    xt = torch.tensor(x, requires_grad=True)
+    w1 = torch.tensor(rng.normal(size=(x.shape[0], 1)).astype(np.float32))
+    w2 = torch.tensor(rng.normal(size=vis.shape).astype(np.float32))
+    pr = o.p_ratio(xt, torch.tensor(imass))
+    (pr * w1).sum().backward()
+    g_ref = xt.grad.numpy().copy()
+    xt.grad = None
+    vo = o.visual_xyz_from_nn(xt / 100.0, torch.tensor(xp), torch.tensor(vis))
+    (vo * w2).sum().backward()
+    gv_ref = xt.grad.numpy().copy()  # hidden = (xt / 100) * 100, so d hidden / d xt = 1
+    xc = torch.tensor(x).cuda().requires_grad_(True)
+    prh = physics.density_ratio(xc, torch.tensor(imass).cuda(), 2.0, 1.5)
+    (prh * w1.cuda()).sum().backward()
+    _close(prh.detach().cpu().numpy(), pr.detach().numpy(), 3e-6, "p_ratio")
+    _close(xc.grad.cpu().numpy(), g_ref, 1e-4, "d p_ratio")
+    xc.grad = None
+    vh = physics.visual_from_hidden(torch.tensor(vis).cuda(), xc, torch.tensor(xp).cuda(), 2.0, 0.033)
+    (vh * w2.cuda()).sum().backward()
+    _close(vh.detach().cpu().numpy(), vo.detach().numpy(), 1e-6, "visual")
+    _close(xc.grad.cpu().numpy(), gv_ref, 2e-4, "d visual")
+
+
+def test_hot_loop_runs_and_descends():
+    """Small config-3-shaped frame: the loss goes down and nothing syncs/NaNs."""
+    from fluidnexus_amd.harness import HotLoop, build_smoke_frame
+    gm, cams = build_smoke_frame(P_fluid=20000, P_background=5000, hidden_dims=(10, 30, 10), n_views=2, size=128)
+    loop = HotLoop(gm, cams, log_scalars=True)
+    loop.make_targets()
+    loop.iteration()
+    first = loop.last["total"]
+    for _ in range(20):
+        loop.iteration()
+    assert np.isfinite(loop.last["total"]) and loop.last["total"] < first

@@ -1,0 +1,43 @@
+"""CPU: oracle/physics_oracle.py vs golden vectors produced by the reference's own gm_dynamics.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.physics_oracle import PhysicsOracle
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "physics.npz"))
+
+
+def _state(tag):
+    H, K, p0, secs, sf, eps, bmy = G[f"consts_{tag}"]
+    o = PhysicsOracle(H=float(H), p0=float(p0), secs=float(secs), scale_factor=float(sf), eps=float(eps),
+                      buoyancy_max_y=float(bmy))
+    t = {k: torch.tensor(G[f"{k}_{tag}"]) for k in ("x_prev", "x_est", "x_nn", "imass", "buoyancy", "force", "visual_xyz")}
+    return o, t
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_physics_oracle_matches_reference(tag):
+    o, t = _state(tag)
+
+    def run(fn, w):
+        x = t["x_nn"].clone().requires_grad_(True)
+        val = fn(x)
+        (val * torch.tensor(w)).sum().backward()
+        return val.detach().numpy(), x.grad.numpy()
+
+    v, g = run(lambda x: o.gas_constraints_from_exyz_nn(x, t["imass"]), G[f"w_gas_{tag}"])
+    assert np.allclose(v, G[f"p_ratio_{tag}"], rtol=2e-6, atol=1e-7)
+    assert np.allclose(g, G[f"d_gas_{tag}"], rtol=1e-4, atol=1e-4 * np.abs(G[f"d_gas_{tag}"]).max())
+    v, g = run(lambda x: o.gas_constraints_from_vel_nn_guess(x, t["x_prev"], t["imass"], t["buoyancy"], t["force"]),
+               G[f"w_next_{tag}"])
+    assert np.allclose(v, G[f"p_ratio_next_{tag}"], rtol=2e-6, atol=1e-7)
+    assert np.allclose(g, G[f"d_next_{tag}"], rtol=1e-4, atol=1e-4 * np.abs(G[f"d_next_{tag}"]).max())
+    v, g = run(lambda x: o.visual_xyz_from_nn(x, t["x_prev"], t["visual_xyz"]), G[f"w_vis_{tag}"])
+    assert np.allclose(v, G[f"vis_{tag}"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(g, G[f"d_vis_{tag}"], rtol=1e-4, atol=1e-4 * np.abs(G[f"d_vis_{tag}"]).max())
+    guess = o.guess_hidden_particles_from_nn(t["x_nn"], t["x_prev"], t["buoyancy"], t["force"]).numpy()
+    assert np.allclose(guess, G[f"guess_{tag}"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(o.poly6(torch.tensor(G[f"poly6_r2_{tag}"])).numpy(), G[f"poly6_{tag}"], rtol=1e-6)
