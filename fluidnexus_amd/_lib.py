@@ -42,6 +42,7 @@ SYMBOLS = (
     "fnx_abi_version", "fnx_last_error", "fnx_geom_bytes", "fnx_image_bytes", "fnx_binning_bytes",
     "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",
     "fnx_rasterize_backward", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
+    "fnx_profile_enable", "fnx_profile_read",
 )
 
 
@@ -85,6 +86,10 @@ def raster():
                                            p, p, p, p, p, p, p, p, p, p]
     lib.fnx_mark_visible.restype = i
     lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
+    lib.fnx_profile_enable.restype = i
+    lib.fnx_profile_enable.argtypes = [i]
+    lib.fnx_profile_read.restype = i
+    lib.fnx_profile_read.argtypes = [i, C.POINTER(C.c_double), C.POINTER(i)]
     lib.fnx_geom_layout.argtypes = [i, i, i, C.POINTER(GeomLayout)]
     lib.fnx_image_layout.argtypes = [i, i, C.POINTER(ImageLayout)]
     lib.fnx_binning_layout.argtypes = [c_int64, C.POINTER(BinningLayout)]
@@ -102,6 +107,17 @@ def check(rc: int):
     if rc != FNX_OK:
         msg = raster().fnx_last_error().decode("utf-8", "replace")
         raise FnxError(rc, msg)
+
+
+def profile_enable(on: bool):
+    check(raster().fnx_profile_enable(1 if on else 0))
+
+
+def profile_read(which: int):
+    """(total_ms, launches) of kernel class `which` since profile_enable(True)."""
+    ms, n = C.c_double(0.0), c_int(0)
+    check(raster().fnx_profile_read(which, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 def geom_layout(P: int, W: int, H: int) -> GeomLayout:

@@ -31,8 +31,8 @@ struct GridView {
 };
 
 inline uint32_t buckets_for(int N) {
-    uint32_t m = 1024;
-    while (m < (uint32_t)(2 * (N > 0 ? N : 1))) m <<= 1;
+    uint32_t m = 4096;
+    while (m < (uint32_t)(N > 0 ? N : 1)) m <<= 1;
     return m;
 }
 
@@ -74,30 +74,40 @@ grid_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t
     atomicAdd(&count[cell_hash(c, mask)], 1u);
 }
 
+// Exclusive scan of the bucket counts: one 1024-thread workgroup walks the array in chunks of 4096
+// (uint4 per thread, coalesced), wave-scans with shuffles and carries the running total.
 __global__ void __launch_bounds__(1024)
 grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
                  uint32_t *__restrict__ cursor) {
-    __shared__ uint32_t s_part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (M + 1023) / 1024;
-    const uint32_t b = tid * per, e = min(M, b + per);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += count[i];
-    s_part[tid] = sum;
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+    for (uint32_t base = 0; base < M; base += 4096) {  // M is a power of two >= 4096
+        const uint4 c = *reinterpret_cast<const uint4 *>(count + base + tid * 4);
+        const uint32_t sum = c.x + c.y + c.z + c.w;
+        uint32_t inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= (uint32_t)off) inc += v;
+        }
+        if (lane == 63) s_wave[w] = inc;
         __syncthreads();
-        s_part[tid] += v;
+        uint32_t pre = s_carry + inc - sum;
+        for (uint32_t k = 0; k < w; k++) pre += s_wave[k];
+        uint4 o;
+        o.x = pre;
+        o.y = pre + c.x;
+        o.z = o.y + c.y;
+        o.w = o.z + c.z;
+        *reinterpret_cast<uint4 *>(start + base + tid * 4) = o;
+        *reinterpret_cast<uint4 *>(cursor + base + tid * 4) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + sum;
         __syncthreads();
     }
-    uint32_t run = s_part[tid] - sum;
-    for (uint32_t i = b; i < e; i++) {
-        start[i] = run;
-        cursor[i] = 0u;
-        run += count[i];
-    }
-    if (tid == 1023) start[M] = s_part[1023];
+    if (tid == 0) start[M] = s_carry;
 }
 
 __global__ void __launch_bounds__(256)
@@ -111,11 +121,32 @@ grid_fill_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t 
     rec[slot] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
 }
 
-// Visit every grid point j with |p - x_j|^2 < H2; f(j, dx, dy, dz, r2) with d = p - x_j.
-template <typename F>
-__device__ __forceinline__ void for_neighbours(float px, float py, float pz, float inv_cell, float H2, uint32_t mask,
-                                               const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
-                                               F &&f) {
+// Sum over the 64 lanes of a wave (DPP row operations); the total lands in lane 63.
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+// Sum over a 16-lane row; the total lands in lane 15 of the row.
+__device__ __forceinline__ float row_sum15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    return v;
+}
+
+// L lanes (16 = one DPP row, or 64 = one wave) share one query point p and stride over the
+// candidates of the 27 surrounding buckets; f(j, dx, dy, dz, r2) with d = p - x_j for every grid
+// point with r2 < H2 whose own cell is the visited cell (hash collisions filtered).
+template <int L, typename F>
+__device__ __forceinline__ void for_neighbours(int sub, float px, float py, float pz, float inv_cell, float H2,
+                                               uint32_t mask, const uint32_t *__restrict__ start,
+                                               const float4 *__restrict__ rec, F &&f) {
     const int3 c = cell_of(px, py, pz, inv_cell);
     for (int dz = -1; dz <= 1; dz++)
         for (int dy = -1; dy <= 1; dy++)
@@ -123,7 +154,7 @@ __device__ __forceinline__ void for_neighbours(float px, float py, float pz, flo
                 const int3 cc = make_int3(c.x + dx, c.y + dy, c.z + dz);
                 const uint32_t h = cell_hash(cc, mask);
                 const uint32_t s0 = start[h], s1 = start[h + 1];
-                for (uint32_t s = s0; s < s1; s++) {
+                for (uint32_t s = s0 + sub; s < s1; s += L) {
                     const float4 q = rec[s];
                     const int3 qc = cell_of(q.x, q.y, q.z, inv_cell);
                     if (qc.x != cc.x || qc.y != cc.y || qc.z != cc.z) continue;  // hash collision
@@ -134,109 +165,127 @@ __device__ __forceinline__ void for_neighbours(float px, float py, float pz, flo
             }
 }
 
-// gm_dynamics.py:1269-1294: p_i = sum_j poly6(r2_ij) / imass_i; p_ratio = p_i / p0
+// gm_dynamics.py:1269-1294: p_i = sum_j poly6(r2_ij) / imass_i; p_ratio = p_i / p0.  16 lanes per particle.
 __global__ void __launch_bounds__(256)
 density_forward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                        float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
                        const float4 *__restrict__ rec, float *__restrict__ p_ratio) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
     float acc = 0.f;
-    for_neighbours(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], inv_cell, H2, mask, start, rec,
-                   [&](uint32_t, float, float, float, float r2) {
-                       const float t = H2 - r2;
-                       acc += term1 * (t * t * t);
-                   });
-    p_ratio[i] = acc / imass[i] / p0;
+    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, float, float, float, float r2) {
+                           const float t = H2 - r2;
+                           acc += term1 * (t * t * t);
+                       });
+    acc = row_sum15(acc);
+    if (sub == 15 && i < N) p_ratio[i] = acc / imass[i] / p0;
 }
 
 __global__ void __launch_bounds__(256)
 density_backward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                         float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
                         const float4 *__restrict__ rec, const float *__restrict__ g, float *__restrict__ dL_dxyz) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float Gi = g[i] / imass[i] / p0;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    const float Gi = g[ii] / imass[ii] / p0;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], inv_cell, H2, mask, start, rec,
-                   [&](uint32_t j, float ex, float ey, float ez, float r2) {
-                       const float Gj = g[j] / imass[j] / p0;
-                       const float t = H2 - r2;
-                       const float dW = -3.0f * term1 * (t * t);  // d poly6 / d r2
-                       const float k = (Gi + Gj) * dW * 2.0f;
-                       ax += k * ex;
-                       ay += k * ey;
-                       az += k * ez;
-                   });
-    dL_dxyz[3 * i + 0] = ax;
-    dL_dxyz[3 * i + 1] = ay;
-    dL_dxyz[3 * i + 2] = az;
+    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t j, float ex, float ey, float ez, float r2) {
+                           const float Gj = g[j] / imass[j] / p0;
+                           const float t = H2 - r2;
+                           const float dW = -3.0f * term1 * (t * t);  // d poly6 / d r2
+                           const float k = (Gi + Gj) * dW * 2.0f;
+                           ax += k * ex;
+                           ay += k * ey;
+                           az += k * ez;
+                       });
+    ax = row_sum15(ax);
+    ay = row_sum15(ay);
+    az = row_sum15(az);
+    if (sub == 15 && i < N) {
+        dL_dxyz[3 * i + 0] = ax;
+        dL_dxyz[3 * i + 1] = ay;
+        dL_dxyz[3 * i + 2] = az;
+    }
 }
 
-// gm_dynamics.py:1453-1498
+// gm_dynamics.py:1453-1498.  16 lanes per visual particle.
 __global__ void __launch_bounds__(256)
 visual_forward_kernel(const float *__restrict__ visual, int V, const float *__restrict__ hidden,
                       const float *__restrict__ hidden_prev, float inv_cell, float H2, float term1, float secs,
                       float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
                       float *__restrict__ out, float *__restrict__ sum_w, float *__restrict__ wvel) {
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    const float px = visual[3 * v], py = visual[3 * v + 1], pz = visual[3 * v + 2];
+    const int v = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int vv = min(v, V - 1);
+    const float px = visual[3 * vv], py = visual[3 * vv + 1], pz = visual[3 * vv + 2];
     float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours(px, py, pz, inv_cell, H2, mask, start, rec, [&](uint32_t j, float, float, float, float r2) {
-        const float t = H2 - r2;
-        const float w = term1 * (t * t * t);
-        const float ux = (hidden[3 * j] - hidden_prev[3 * j]) / secs;
-        const float uy = (hidden[3 * j + 1] - hidden_prev[3 * j + 1]) / secs;
-        const float uz = (hidden[3 * j + 2] - hidden_prev[3 * j + 2]) / secs;
-        S += w;
-        ax += ux * w;
-        ay += uy * w;
-        az += uz * w;
-    });
-    sum_w[v] = S;
-    wvel[3 * v + 0] = ax;
-    wvel[3 * v + 1] = ay;
-    wvel[3 * v + 2] = az;
-    const float Sc = fmaxf(S, eps);
-    out[3 * v + 0] = px + ax * secs / Sc;
-    out[3 * v + 1] = py + ay * secs / Sc;
-    out[3 * v + 2] = pz + az * secs / Sc;
+    for_neighbours<16>(sub, px, py, pz, inv_cell, H2, mask, start, rec,
+                       [&](uint32_t j, float, float, float, float r2) {
+                           const float t = H2 - r2;
+                           const float w = term1 * (t * t * t);
+                           const float ux = (hidden[3 * j] - hidden_prev[3 * j]) / secs;
+                           const float uy = (hidden[3 * j + 1] - hidden_prev[3 * j + 1]) / secs;
+                           const float uz = (hidden[3 * j + 2] - hidden_prev[3 * j + 2]) / secs;
+                           S += w;
+                           ax += ux * w;
+                           ay += uy * w;
+                           az += uz * w;
+                       });
+    S = row_sum15(S);
+    ax = row_sum15(ax);
+    ay = row_sum15(ay);
+    az = row_sum15(az);
+    if (sub == 15 && v < V) {
+        sum_w[v] = S;
+        wvel[3 * v + 0] = ax;
+        wvel[3 * v + 1] = ay;
+        wvel[3 * v + 2] = az;
+        const float Sc = fmaxf(S, eps);
+        out[3 * v + 0] = px + ax * secs / Sc;
+        out[3 * v + 1] = py + ay * secs / Sc;
+        out[3 * v + 2] = pz + az * secs / Sc;
+    }
 }
 
+// One wave per hidden particle: the grid holds the VISUAL points (thousands of candidates each).
 __global__ void __launch_bounds__(256)
 visual_backward_kernel(const float *__restrict__ visual, const float *__restrict__ hidden,
                        const float *__restrict__ hidden_prev, int N, float inv_cell, float H2, float term1, float secs,
                        float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
                        const float *__restrict__ sum_w, const float *__restrict__ wvel,
                        const float *__restrict__ dL_dout, float *__restrict__ dL_dhidden) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const float hx = hidden[3 * j], hy = hidden[3 * j + 1], hz = hidden[3 * j + 2];
-    const float ux = (hx - hidden_prev[3 * j]) / secs, uy = (hy - hidden_prev[3 * j + 1]) / secs,
-                uz = (hz - hidden_prev[3 * j + 2]) / secs;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
+    const int jj = min(j, N - 1);
+    const float hx = hidden[3 * jj], hy = hidden[3 * jj + 1], hz = hidden[3 * jj + 2];
+    const float ux = (hx - hidden_prev[3 * jj]) / secs, uy = (hy - hidden_prev[3 * jj + 1]) / secs,
+                uz = (hz - hidden_prev[3 * jj + 2]) / secs;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    // the grid holds the VISUAL points: v ranges over visual particles within H of hidden j
-    for_neighbours(hx, hy, hz, inv_cell, H2, mask, start, rec, [&](uint32_t v, float ex, float ey, float ez, float r2) {
-        const float S = sum_w[v];
-        const float Sc = fmaxf(S, eps);
-        const float gx = dL_dout[3 * v], gy = dL_dout[3 * v + 1], gz = dL_dout[3 * v + 2];
-        const float t = H2 - r2;
-        const float w = term1 * (t * t * t);
-        const float dW = -3.0f * term1 * (t * t);
-        // through u_j (1/secs cancels secs): w/S * g
-        const float a = w / Sc;
-        // through w_vj
-        float dLdw = secs * (gx * ux + gy * uy + gz * uz) / Sc;
-        if (S > eps) dLdw -= secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
-        const float k = dLdw * dW * 2.0f;  // d r2 / d hidden_j = 2 (hidden_j - visual_v) = 2 e
-        ax += a * gx + k * ex;
-        ay += a * gy + k * ey;
-        az += a * gz + k * ez;
-    });
-    dL_dhidden[3 * j + 0] = ax;
-    dL_dhidden[3 * j + 1] = ay;
-    dL_dhidden[3 * j + 2] = az;
+    for_neighbours<64>(sub, hx, hy, hz, inv_cell, H2, mask, start, rec,
+                       [&](uint32_t v, float ex, float ey, float ez, float r2) {
+                           const float S = sum_w[v];
+                           const float Sc = fmaxf(S, eps);
+                           const float gx = dL_dout[3 * v], gy = dL_dout[3 * v + 1], gz = dL_dout[3 * v + 2];
+                           const float t = H2 - r2;
+                           const float w = term1 * (t * t * t);
+                           const float dW = -3.0f * term1 * (t * t);
+                           const float a = w / Sc;  // through u_j: (1/secs) * secs * w/S * g
+                           float dLdw = secs * (gx * ux + gy * uy + gz * uz) / Sc;
+                           if (S > eps)
+                               dLdw -= secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
+                           const float k = dLdw * dW * 2.0f;  // d r2 / d hidden_j = 2 (hidden_j - visual_v) = 2 e
+                           ax += a * gx + k * ex;
+                           ay += a * gy + k * ey;
+                           az += a * gz + k * ez;
+                       });
+    ax = wave_sum63(ax);
+    ay = wave_sum63(ay);
+    az = wave_sum63(az);
+    if (sub == 63 && j < N) {
+        dL_dhidden[3 * j + 0] = ax;
+        dL_dhidden[3 * j + 1] = ay;
+        dL_dhidden[3 * j + 2] = az;
+    }
 }
 
 thread_local char g_err[512] = "";
@@ -285,7 +334,7 @@ int fnx_density_forward(const float *xyz, int N, const float *imass, float H, fl
     if (N == 0) return FNX_OK;
     if (N < 0 || !xyz || !imass || !grid || !p_ratio) return fail(FNX_ERR_INVALID_ARG, "density_forward: bad argument");
     GridView g = carve(const_cast<char *>(grid), N);
-    hipLaunchKernelGGL(density_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N, imass,
+    hipLaunchKernelGGL(density_forward_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N, imass,
                        1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, p_ratio);
     return hip_check("density_forward");
 }
@@ -296,7 +345,7 @@ int fnx_density_backward(const float *xyz, int N, const float *imass, float H, f
     if (N < 0 || !xyz || !imass || !grid || !dL_dp_ratio || !dL_dxyz)
         return fail(FNX_ERR_INVALID_ARG, "density_backward: bad argument");
     GridView g = carve(const_cast<char *>(grid), N);
-    hipLaunchKernelGGL(density_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N,
+    hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N,
                        imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, dL_dxyz);
     return hip_check("density_backward");
 }
@@ -308,7 +357,7 @@ int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, c
     if (V < 0 || N < 0 || !visual || !hidden_grid || !out || !sum_w || !wvel || (N > 0 && (!hidden || !hidden_prev)))
         return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward: bad argument");
     GridView g = carve(const_cast<char *>(hidden_grid), N);
-    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, visual, V,
+    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 15) / 16), dim3(256), 0, (hipStream_t)stream, visual, V,
                        hidden, hidden_prev, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, out,
                        sum_w, wvel);
     return hip_check("visual_interp_forward");
@@ -322,7 +371,7 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
         (V > 0 && (!visual || !sum_w || !wvel || !dL_dout)))
         return fail(FNX_ERR_INVALID_ARG, "visual_interp_backward: bad argument");
     GridView g = carve(const_cast<char *>(visual_grid), V);
-    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, visual, hidden,
+    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, visual, hidden,
                        hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, sum_w, wvel,
                        dL_dout, dL_dhidden);
     return hip_check("visual_interp_backward");

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "fnx_state.h"
 
@@ -137,6 +139,37 @@ Bin carve_bin(char *blob, int64_t R) {
 
 bool channels_ok(int c) { return c == 1 || c == 3; }
 
+// Optional in-library kernel timing (bench.py roofline): HIP events recorded on the caller's
+// stream around one kernel class; elapsed times are summed when read.
+constexpr int kProfClasses = 4;  // 0 blend_forward, 1 blend_backward, 2 binning (sort+emit+order), 3 preprocess
+struct ProfClass {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+};
+bool g_prof_on = false;
+ProfClass g_prof[kProfClasses];
+
+struct ProfScope {
+    hipEvent_t stop = nullptr;
+    hipStream_t s;
+    ProfScope(int cls, hipStream_t stream) : s(stream) {
+        if (!g_prof_on) return;
+        ProfClass &c = g_prof[cls];
+        if (c.used == c.pool.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            c.pool.emplace_back(a, b);
+        }
+        auto &pr = c.pool[c.used++];
+        (void)hipEventRecord(pr.first, s);
+        stop = pr.second;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, s);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -191,10 +224,13 @@ int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int 
         return fail(FNX_ERR_INVALID_ARG, "neither cov3D_precomp nor scales+rotations given");
     Geom g = carve_geom(geom_buffer, P, width, height);
     int *rad = radii ? radii : g.radii;  // rasterizer_impl.cu:214-216
+    {
+    ProfScope ps(3, s);
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                            tan_fovy, rad, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched,
                            g.blk_hist, g.sort_key0, prefiltered);
+    }
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header);
     return hip_check("stage1");
@@ -241,15 +277,21 @@ int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, in
     const int *rad = radii ? radii : g.radii;
     const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
     const uint32_t cap = (uint32_t)binning_capacity;
+    {
+    ProfScope ps(2, s);
     const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
     fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
                            g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rank_of);
     fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap);
     fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap);
+    }
     const float *features = colors_precomp ? colors_precomp : g.rgb;  // rasterizer_impl.cu:299
-    fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.means2D, features,
-                              g.conic_opacity, g.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
-                              img.header, cap);
+    {
+        ProfScope ps(0, s);
+        fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.means2D, features,
+                                  g.conic_opacity, g.depths, background, img.final_T, img.n_contrib, out_color,
+                                  out_depth, img.header, cap);
+    }
     return hip_check("stage2");
 }
 
@@ -303,13 +345,38 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
     const int *rad = radii ? radii : g.radii;
     const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;      // rasterizer_impl.cu:367
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
-    fnx::launch_blend_backward(channels, s, width, height, img.ranges, bin.point_list, background, g.means2D,
-                               g.conic_opacity, color_ptr, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic,
-                               dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu);
+    {
+        ProfScope ps(1, s);
+        fnx::launch_blend_backward(channels, s, width, height, img.ranges, bin.point_list, background, g.means2D,
+                                   g.conic_opacity, color_ptr, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
+                                   dL_dconic, dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu);
+    }
     fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
                               cov3D_ptr, viewmatrix, projmatrix, width, height, tan_fovx, tan_fovy, campos, dL_dmean2D,
                               dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     return hip_check("backward");
+}
+
+int fnx_profile_enable(int on) {
+    g_prof_on = on != 0;
+    for (auto &c : g_prof) c.used = 0;
+    return FNX_OK;
+}
+
+int fnx_profile_read(int which, double *total_ms, int *launches) {
+    if (which < 0 || which >= kProfClasses || !total_ms || !launches) return fail(FNX_ERR_INVALID_ARG, "bad argument");
+    ProfClass &c = g_prof[which];
+    double tot = 0.0;
+    for (size_t i = 0; i < c.used; i++) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(c.pool[i].second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c.pool[i].first, c.pool[i].second);
+        if (e != hipSuccess) return fail(FNX_ERR_HIP, "profile_read: %s", hipGetErrorString(e));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int)c.used;
+    return FNX_OK;
 }
 
 int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -55,6 +55,7 @@ class GaussianModel:
         self.scale_factor = 100.0  # gm_dynamics.py:129
         self.total_iterations = 0
         self._visual_grid = None
+        self._grid_cache = {}
         self.setup_functions()
 
     # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
@@ -95,21 +96,34 @@ class GaussianModel:
         estimate_velocity = tmp_velocity + cur_buoyancy * self._secs + self._secs * self._force
         return self._estimate_xyz_nn * self.scale_factor + self._secs * estimate_velocity
 
+    def _cached_grid(self, slot, xyz):
+        """Neighbour grids depend only on the current value of _estimate_xyz_nn: rebuild when the
+        optimiser has stepped (tensor version bump), reuse across the views of one iteration."""
+        key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version)
+        hit = self._grid_cache.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, physics.HashGrid(xyz.detach(), self.H))
+            self._grid_cache[slot] = hit
+        return hit[1]
+
     def get_gas_constraints_from_exyz_nn(self):
         """p_ratio [N,1] at the optimised positions (fused neighbour search + poly6 density)."""
-        return physics.density_ratio(self._estimate_xyz_nn * self.scale_factor, self._imass, self.H, self.p0)
+        x = self._estimate_xyz_nn * self.scale_factor
+        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("est", x))
 
     def get_gas_constraints_from_vel_nn_guess(self):
         """p_ratio [N,1] after advecting one tick with the implied velocity."""
-        return physics.density_ratio(self.get_guess_hidden_particles_from_nn(), self._imass, self.H, self.p0)
+        x = self.get_guess_hidden_particles_from_nn()
+        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("guess", x))
 
     def get_visual_xyz_from_nn(self):
         """Visual particles advected by the poly6-weighted velocity of their hidden neighbours."""
         visual = self._visual_xyz.detach()
         if self._visual_grid is None or self._visual_grid[0] is not self._visual_xyz:
             self._visual_grid = (self._visual_xyz, physics.HashGrid(visual, self.H))
-        return physics.visual_from_hidden(visual, self._estimate_xyz_nn * self.scale_factor, self._xyz, self.H,
-                                          self._secs, self.EPSILON, self._visual_grid[1])
+        x = self._estimate_xyz_nn * self.scale_factor
+        return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
+                                          self._visual_grid[1], self._cached_grid("est", x))
 
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):

@@ -38,11 +38,12 @@ class HashGrid:
 
 class _DensityRatio(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, imass, H, p0):
+    def forward(ctx, xyz, imass, H, p0, grid):
         lib = PL.physics()
         xyz, imass = _req(xyz), _req(imass)
         N = xyz.shape[0]
-        grid = HashGrid(xyz, H)
+        if grid is None:
+            grid = HashGrid(xyz, H)
         out = torch.empty(N, 1, dtype=torch.float32, device=xyz.device)
         PL.check(lib.fnx_density_forward(xyz.data_ptr(), N, imass.data_ptr(), H, p0, grid.blob.data_ptr(),
                                          out.data_ptr(), _stream()))
@@ -60,21 +61,23 @@ class _DensityRatio(torch.autograd.Function):
         dx = torch.empty_like(xyz)
         PL.check(lib.fnx_density_backward(xyz.data_ptr(), N, imass.data_ptr(), H, p0, blob.data_ptr(), g.data_ptr(),
                                           dx.data_ptr(), _stream()))
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def density_ratio(xyz, imass, H, p0):
-    """p_ratio [N,1] of positions xyz [N,3] (scaled units), inverse masses imass [N,1]."""
-    return _DensityRatio.apply(xyz, imass, float(H), float(p0))
+def density_ratio(xyz, imass, H, p0, grid=None):
+    """p_ratio [N,1] of positions xyz [N,3] (scaled units), inverse masses imass [N,1].
+    `grid`: an up-to-date HashGrid over xyz (cell = H) to reuse; built here when None."""
+    return _DensityRatio.apply(xyz, imass, float(H), float(p0), grid)
 
 
 class _VisualFromHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, visual, hidden, hidden_prev, H, secs, eps, visual_grid):
+    def forward(ctx, visual, hidden, hidden_prev, H, secs, eps, visual_grid, hgrid):
         lib = PL.physics()
         visual, hidden, hidden_prev = _req(visual), _req(hidden), _req(hidden_prev)
         V, N = visual.shape[0], hidden.shape[0]
-        hgrid = HashGrid(hidden, H)
+        if hgrid is None:
+            hgrid = HashGrid(hidden, H)
         out = torch.empty_like(visual)
         sum_w = torch.empty(V, dtype=torch.float32, device=visual.device)
         wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
@@ -98,10 +101,12 @@ class _VisualFromHidden(torch.autograd.Function):
                                                 hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
                                                 vblob.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
                                                 dh.data_ptr(), _stream()))
-        return None, dh, None, None, None, None, None
+        return None, dh, None, None, None, None, None, None
 
 
-def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None):
+def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None):
     """visual [V,3] (constant), hidden [N,3] (differentiable), hidden_prev [N,3] -> advected visual [V,3].
-    `visual_grid`: a HashGrid over `visual` to reuse across iterations (visual is fixed within a frame)."""
-    return _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid)
+    `visual_grid`: a HashGrid over `visual` to reuse across iterations (visual is fixed within a frame);
+    `hidden_grid`: an up-to-date HashGrid over `hidden`."""
+    return _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
+                                   hidden_grid)

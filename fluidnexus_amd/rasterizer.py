@@ -28,6 +28,7 @@ _HOST_SYNC = True          # True = reference behaviour (exact-size binning buff
 _CAP_SLACK = 1.3           # head-room over the high-water mark when host sync is off
 _capacity_hwm: dict = {}   # (device, W, H, channels) -> capacity in instances
 _pending_status: list = []  # image blobs whose overflow status has not been read yet
+last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
 def set_host_sync(enabled: bool, initial_capacity: int | None = None):
@@ -40,12 +41,16 @@ def set_host_sync(enabled: bool, initial_capacity: int | None = None):
 
 def check_status():
     """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity."""
+    global last_num_rendered
     lib = _lib.raster()
     stream = torch.cuda.current_stream().cuda_stream
+    first = True
     while _pending_status:
         img, W, H, key = _pending_status.pop()
         n = C.c_int(0)
         _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
+        if first:
+            last_num_rendered, first = int(n.value), False
         _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n.value * _CAP_SLACK) + 1024)
         _lib.check(lib.fnx_read_status(img.data_ptr(), W, H, stream))
 
@@ -105,13 +110,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3Ds_precomp), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), float(rs.tan_fov_x),
                 float(rs.tan_fov_y), int(bool(rs.prefiltered)), radii.data_ptr(), stream))
-            if _HOST_SYNC:
+            key = (dev.index, W, H, Cn, P)
+            known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
+            if _HOST_SYNC or not known:
+                # reference behaviour; also the first sync-free call of a shape (seeds the high-water mark)
                 n = C.c_int(0)
                 _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
                 num_rendered = cap = int(n.value)
+                if not _HOST_SYNC:
+                    _capacity_hwm[key] = cap = int(num_rendered * _CAP_SLACK) + 1024
             else:
-                key = (dev.index, W, H, Cn, P)
-                cap = _capacity_hwm.get(key) or _capacity_hwm.get("default") or max(4 * P, 1 << 20)
+                cap = known
                 _capacity_hwm[key] = cap
                 num_rendered = -1
                 _pending_status.append((img, W, H, key))

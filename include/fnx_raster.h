@@ -108,6 +108,15 @@ int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const
                      fnx_stream_t stream);
 
 /*
+ * Optional kernel timing for benchmarks: when enabled, HIP events are recorded on the caller's
+ * stream around one kernel class per launch (0 blend forward, 1 blend backward, 2 binning =
+ * depth sort + emission + tile ordering, 3 preprocess).  fnx_profile_read blocks on those events
+ * and returns the summed duration and the number of launches since fnx_profile_enable(1).
+ */
+int fnx_profile_enable(int on);
+int fnx_profile_read(int which, double *total_ms, int *launches);
+
+/*
  * Byte offsets of the named arrays inside the opaque scratch blobs, for parity tests and tools
  * (the reference re-derives the same pointers with fromChunk, rasterizer_impl.cu:144-180).
  */
