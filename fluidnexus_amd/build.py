@@ -17,6 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIBS = {
     "libfnx_raster.so": ["raster_forward.hip", "raster_binning.hip", "raster_backward.hip", "raster_api.hip"],
     "libfnx_physics.so": ["physics.hip"],
+    "libfnx_losses.so": ["losses.hip"],
 }
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-value"]
@@ -36,6 +37,7 @@ def _stale(out: str, srcs: list[str]) -> bool:
     deps = list(srcs) + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "fnx_raster.h"))
     deps.append(os.path.join(_HERE, "..", "include", "fnx_physics.h"))
+    deps.append(os.path.join(_HERE, "..", "include", "fnx_losses.h"))
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,227 @@
+// Fused L1 + SSIM image loss for gfx950 (C ABI: include/fnx_losses.h).
+// One 256-thread workgroup per 16x16 output tile: the 26x26 halo of both images is staged in LDS
+// once, the 11-tap Gaussian runs as a row pass then a column pass (both in LDS), and the SSIM map,
+// its three partial derivatives and the L1 term come out of the same pass -- one read of each image
+// instead of the reference's five depthwise convolutions plus ~15 elementwise kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/fnx_losses.h"
+#include "../../include/fnx_raster.h"
+
+namespace {
+
+constexpr int TS = 16, R = 5, K = 11, HS = TS + 2 * R;  // tile, radius, taps, halo tile = 26
+
+struct Win {
+    float g[K];
+};
+
+// normalised 1-D Gaussian, sigma = 1.5, fp32 like loss_utils.py:21-23
+Win make_window() {
+    Win w;
+    float s = 0.f;
+    for (int i = 0; i < K; i++) {
+        w.g[i] = (float)std::exp(-((double)((i - K / 2) * (i - K / 2))) / (2.0 * 1.5 * 1.5));
+        s += w.g[i];
+    }
+    for (int i = 0; i < K; i++) w.g[i] = w.g[i] / s;
+    return w;
+}
+
+__device__ __forceinline__ float load_px(const float *__restrict__ im, int C, int H, int W, int grey, int c, int y,
+                                         int x) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;  // zero padding
+    const size_t o = (size_t)y * W + x, hw = (size_t)H * W;
+    if (grey) return ((im[o] + im[hw + o]) + im[2 * hw + o]) / 3.0f;  // torch.mean over the 3 channels
+    return im[(size_t)c * hw + o];
+}
+
+__global__ void __launch_bounds__(256)
+l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, int grey,
+                       Win win, float *__restrict__ partials, float *__restrict__ dmaps) {
+    __shared__ float s_x[HS][HS + 1], s_y[HS][HS + 1];
+    __shared__ float s_h[5][HS][TS + 1];
+    __shared__ float s_red[2][4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int c = blockIdx.z, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int Ce = grey ? 1 : C;
+    for (int i = tid; i < HS * HS; i += 256) {
+        const int ly = i / HS, lx = i - ly * HS;
+        s_x[ly][lx] = load_px(img, C, H, W, grey, c, y0 + ly - R, x0 + lx - R);
+        s_y[ly][lx] = load_px(gt, C, H, W, grey, c, y0 + ly - R, x0 + lx - R);
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += 256) {  // row pass
+        const int ly = i / TS, lx = i - ly * TS;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float g = win.g[k], x = s_x[ly][lx + k], y = s_y[ly][lx + k];
+            a += g * x;
+            b += g * y;
+            aa += g * (x * x);
+            bb += g * (y * y);
+            ab += g * (x * y);
+        }
+        s_h[0][ly][lx] = a;
+        s_h[1][ly][lx] = b;
+        s_h[2][ly][lx] = aa;
+        s_h[3][ly][lx] = bb;
+        s_h[4][ly][lx] = ab;
+    }
+    __syncthreads();
+    float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {  // column pass
+        const float g = win.g[k];
+        mu1 += g * s_h[0][ty + k][tx];
+        mu2 += g * s_h[1][ty + k][tx];
+        exx += g * s_h[2][ty + k][tx];
+        eyy += g * s_h[3][ty + k][tx];
+        exy += g * s_h[4][ty + k][tx];
+    }
+    const int px = x0 + tx, py = y0 + ty;
+    const bool inside = px < W && py < H;
+    float l1 = 0.f, sm = 0.f;
+    if (inside) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+        const float inv = 1.f / (Cc * D);
+        sm = (A * B) * inv;
+        // partials of the map w.r.t. mu1 (E[x^2], E[xy] held fixed), E[x^2] and E[xy]
+        const float dmu1 = (2.f * mu2 * (B - A)) * inv - sm * (2.f * mu1 * (D - Cc)) * inv;
+        const float dexx = -sm / D;
+        const float dexy = 2.f * A * inv;
+        const size_t hw = (size_t)H * W, o = (size_t)c * hw + (size_t)py * W + px;
+        dmaps[o] = dmu1;
+        dmaps[(size_t)Ce * hw + o] = dexx;
+        dmaps[2 * (size_t)Ce * hw + o] = dexy;
+        l1 = fabsf(s_x[ty + R][tx + R] - s_y[ty + R][tx + R]);
+    }
+    // workgroup sums (shuffle within waves, then 4 partials)
+    for (int off = 32; off >= 1; off >>= 1) {
+        l1 += __shfl_xor(l1, off);
+        sm += __shfl_xor(sm, off);
+    }
+    if ((tid & 63) == 0) {
+        s_red[0][tid >> 6] = l1;
+        s_red[1][tid >> 6] = sm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+        partials[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, int grey,
+                        Win win, const float *__restrict__ dmaps, const float *__restrict__ g_l1,
+                        const float *__restrict__ g_ssim, float *__restrict__ dL_dimg) {
+    __shared__ float s_d[3][HS][HS + 1];
+    __shared__ float s_h[3][HS][TS + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int c = blockIdx.z, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int Ce = grey ? 1 : C;
+    const size_t hw = (size_t)H * W;
+    for (int i = tid; i < HS * HS; i += 256) {
+        const int ly = i / HS, lx = i - ly * HS;
+        const int x = x0 + lx - R, y = y0 + ly - R;
+        const bool in = x >= 0 && y >= 0 && x < W && y < H;
+        const size_t o = (size_t)c * hw + (size_t)(in ? y : 0) * W + (in ? x : 0);
+#pragma unroll
+        for (int m = 0; m < 3; m++) s_d[m][ly][lx] = in ? dmaps[(size_t)m * Ce * hw + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float g = win.g[k];
+            a0 += g * s_d[0][ly][lx + k];
+            a1 += g * s_d[1][ly][lx + k];
+            a2 += g * s_d[2][ly][lx + k];
+        }
+        s_h[0][ly][lx] = a0;
+        s_h[1][ly][lx] = a1;
+        s_h[2][ly][lx] = a2;
+    }
+    __syncthreads();
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float g = win.g[k];
+        v0 += g * s_h[0][ty + k][tx];
+        v1 += g * s_h[1][ty + k][tx];
+        v2 += g * s_h[2][ty + k][tx];
+    }
+    const int px = x0 + tx, py = y0 + ty;
+    if (px >= W || py >= H) return;
+    const float x = load_px(img, C, H, W, grey, c, py, px), y = load_px(gt, C, H, W, grey, c, py, px);
+    const float n = (float)((size_t)Ce * hw);
+    const float d = x - y;
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    float grad = g_l1[0] * sgn / n + g_ssim[0] / n * (v0 + 2.f * x * v1 + y * v2);
+    const size_t o = (size_t)py * W + px;
+    if (grey) {
+        grad = grad / 3.0f;
+        dL_dimg[o] = grad;
+        dL_dimg[hw + o] = grad;
+        dL_dimg[2 * hw + o] = grad;
+    } else {
+        dL_dimg[(size_t)c * hw + o] = grad;
+    }
+}
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return FNX_OK;
+}
+bool args_ok(int C, int H, int W, int grey) { return C > 0 && H > 0 && W > 0 && (!grey || C == 3); }
+
+}  // namespace
+
+extern "C" {
+int fnx_losses_abi_version(void) { return 1; }
+const char *fnx_losses_last_error(void) { return g_err; }
+int fnx_l1_ssim_tiles(int C, int H, int W, int grey) {
+    return (grey ? 1 : C) * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+}
+int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
+                        float *dmaps, fnx_stream_t stream) {
+    if (!args_ok(C, H, W, grey) || !img || !gt || !partials || !dmaps)
+        return fail(FNX_ERR_INVALID_ARG, "l1_ssim_forward: bad argument (grey needs C == 3)");
+    static const Win win = make_window();
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, grey ? 1 : C);
+    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
+                       partials, dmaps);
+    return hip_check("l1_ssim_forward");
+}
+int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
+                         const float *g_l1, const float *g_ssim, float *dL_dimg, fnx_stream_t stream) {
+    if (!args_ok(C, H, W, grey) || !img || !gt || !dmaps || !g_l1 || !g_ssim || !dL_dimg)
+        return fail(FNX_ERR_INVALID_ARG, "l1_ssim_backward: bad argument");
+    static const Win win = make_window();
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, grey ? 1 : C);
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
+                       dmaps, g_l1, g_ssim, dL_dimg);
+    return hip_check("l1_ssim_backward");
+}
+}

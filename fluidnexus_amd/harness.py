@@ -110,13 +110,13 @@ class HotLoop:
 
     def _image_loss(self, image, gt_image):
         c = self.cfg
-        # grey-mean both images and replicate to 3 channels (tpp:356-360)
-        gt = torch.cat([torch.mean(gt_image, dim=0, keepdim=True)] * 3, dim=0)
-        im = torch.cat([torch.mean(image, dim=0, keepdim=True)] * 3, dim=0)
         if self.image_loss == "fused":
-            from .losses import fused_l1_dssim
-            l1_value, ssim_value = fused_l1_dssim(im, gt)
+            from .losses import fused_l1_dssim_grey
+            l1_value, ssim_value = fused_l1_dssim_grey(image, gt_image)  # grey-mean fused in
         else:
+            # grey-mean both images and replicate to 3 channels (tpp:356-360)
+            gt = torch.cat([torch.mean(gt_image, dim=0, keepdim=True)] * 3, dim=0)
+            im = torch.cat([torch.mean(image, dim=0, keepdim=True)] * 3, dim=0)
             l1_value = l1_loss(im, gt)
             ssim_value = 1.0 - ssim(im, gt)
         return ((1.0 - c["lambda_dssim"]) * l1_value * c["lambda_image"]

@@ -1,0 +1,85 @@
+"""Fused L1 + SSIM image loss (include/fnx_losses.h) as one autograd node.
+
+`fused_l1_ssim(img, gt)` returns (l1_loss(img, gt), ssim(img, gt)) of FluidDynamics/utils/
+loss_utils.py:9,33-64; `fused_l1_dssim_grey(img, gt)` returns (l1, 1 - ssim) of the grey-mean,
+3x replicated images exactly as the physical stage forms them (train_physical_particle.py:356-363).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
+           "fnx_l1_ssim_backward")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libfnx_losses.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
+                               "fluidnexus_amd has no CPU fallback.")
+        L = C.CDLL(path)
+        p, i = C.c_void_p, C.c_int
+        L.fnx_losses_last_error.restype = C.c_char_p
+        L.fnx_l1_ssim_tiles.argtypes = [i, i, i, i]
+        L.fnx_l1_ssim_forward.argtypes = [p, p, i, i, i, i, p, p, p]
+        L.fnx_l1_ssim_backward.argtypes = [p, p, i, i, i, i, p, p, p, p, p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().fnx_losses_last_error().decode("utf-8", "replace"))
+
+
+class _L1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, grey):
+        L = lib()
+        if not img.is_cuda:
+            raise RuntimeError("fluidnexus_amd losses: tensors must be on a HIP device (no CPU path)")
+        img = img.float().contiguous()
+        gt = gt.float().contiguous()
+        Cn, H, W = img.shape[-3:]
+        Ce = 1 if grey else Cn
+        nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
+        partials = torch.empty(nt, 2, dtype=torch.float32, device=img.device)
+        dmaps = torch.empty(3, Ce, H, W, dtype=torch.float32, device=img.device)
+        s = torch.cuda.current_stream().cuda_stream
+        _check(L.fnx_l1_ssim_forward(img.data_ptr(), gt.data_ptr(), Cn, H, W, int(grey), partials.data_ptr(),
+                                     dmaps.data_ptr(), s))
+        sums = partials.sum(dim=0) / float(Ce * H * W)
+        ctx.save_for_backward(img, gt, dmaps)
+        ctx.grey = bool(grey)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        L = lib()
+        img, gt, dmaps = ctx.saved_tensors
+        Cn, H, W = img.shape[-3:]
+        g_l1 = g_l1.float().contiguous()
+        g_ssim = g_ssim.float().contiguous()
+        out = torch.empty_like(img)
+        s = torch.cuda.current_stream().cuda_stream
+        _check(L.fnx_l1_ssim_backward(img.data_ptr(), gt.data_ptr(), Cn, H, W, int(ctx.grey), dmaps.data_ptr(),
+                                      g_l1.data_ptr(), g_ssim.data_ptr(), out.data_ptr(), s))
+        return out, None, None
+
+
+def fused_l1_ssim(img, gt):
+    """(mean |img - gt|, SSIM(img, gt)) for [C,H,W] images."""
+    return _L1SSIM.apply(img, gt, False)
+
+
+def fused_l1_dssim_grey(img, gt):
+    """Physical-stage image terms: grey-mean both [3,H,W] images, then (L1, 1 - SSIM)."""
+    l1, s = _L1SSIM.apply(img, gt, True)
+    return l1, 1.0 - s

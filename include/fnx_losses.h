@@ -1,0 +1,36 @@
+/*
+ * fnx_losses.h -- C ABI of the fused image loss (L1 + SSIM) for gfx950.
+ *
+ * Replaces, for the hot loop, the un-fused PyTorch chain of the reference
+ *   FluidDynamics/utils/loss_utils.py: l1_loss :9-10, ssim/_ssim :33-64 (11x11 Gaussian window,
+ *   sigma 1.5, zero padding 5, five depthwise conv2d, C1 = 0.01^2, C2 = 0.03^2, mean),
+ * and, with grey = 1, the grey-mean + 3x replication that precedes it in the physical stage
+ *   (entries_fluid_nexus/train_physical_particle.py:356-363).
+ * The window is applied separably (row pass then column pass through LDS); values agree with the
+ * reference's 2-D window to fp32 rounding (pinned by tests/golden/loss_utils.npz).
+ *
+ * forward : partials[b] = (sum |x - y|, sum ssim_map) of tile b; dmaps = the three per-pixel
+ *           partial derivatives d map / d mu1, d map / d E[x^2], d map / d E[xy] for the backward.
+ * backward: dL_dimg = g_l1 * sign(x - y) / n + g_ssim / n * (window (*) dmaps combined with x, y),
+ *           g_l1 / g_ssim are DEVICE scalars (the upstream gradients of the two means).
+ * n = Ce*H*W with Ce = 1 if grey else C.  All pointers are device pointers; work goes to `stream`.
+ */
+#ifndef FNX_LOSSES_H
+#define FNX_LOSSES_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef void *fnx_stream_t;
+int fnx_losses_abi_version(void);
+const char *fnx_losses_last_error(void);
+/* number of 16x16 tiles = length of `partials` / 2 */
+int fnx_l1_ssim_tiles(int C, int H, int W, int grey);
+int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
+                        float *dmaps /* [3, Ce, H, W] */, fnx_stream_t stream);
+int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
+                         const float *g_l1, const float *g_ssim, float *dL_dimg /* [C, H, W] */, fnx_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif
