@@ -37,6 +37,39 @@ def _attributes(gm, pos_type):
             getattr(gm, f"get_{fam}_color"))
 
 
+_STATIC_CACHE: dict = {}
+
+
+def _static_attributes(gm, pos_type, gs_only):
+    """(opacity, scales, rotations, colours) of fluid + background Gaussians, activated and
+    concatenated in the reference's order (pipe_dynamics.py:88-148).  While none of the raw tensors
+    requires grad (the physical-particle stage: only positions are optimised) the result is the same
+    for every view, so it is computed once per tensor version and kept resident instead of re-running
+    ~25 small kernels per view."""
+    fam = _ATTR.get(pos_type, "visual")
+    names = ([f"_{n}_dummy" for n in ("opacity", "scales", "rotation", "color")] if fam == "dummy"
+             else [f"_{fam}_{n}" for n in ("opacity", "scales", "rotation", "color")])
+    names += [f"_gs_{n}" for n in ("opacity", "scales", "rotation", "color")]
+    raws = [getattr(gm, n) for n in names]
+    cacheable = not any(t.requires_grad for t in raws)
+    key = (id(gm), pos_type, gs_only) + tuple((id(t), t._version) for t in raws)
+    if cacheable:
+        hit = _STATIC_CACHE.get(id(gm))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    if gs_only:
+        out = (gm.get_gs_opacity, gm.get_gs_scaling, gm.get_gs_rotation, gm.get_gs_color)
+    else:
+        opacity, scales, rotations, colors = _attributes(gm, pos_type)
+        if colors.shape[1] == 1:  # grey fluid particles rendered as RGB (pipe_dynamics.py:113-115)
+            colors = colors.repeat(1, 3)
+        out = (torch.cat([opacity, gm.get_gs_opacity], dim=0).float(), torch.cat([scales, gm.get_gs_scaling], dim=0).float(),
+               torch.cat([rotations, gm.get_gs_rotation], dim=0).float(), torch.cat([colors, gm.get_gs_color], dim=0).float())
+    if cacheable:
+        _STATIC_CACHE[id(gm)] = (key, out)
+    return out
+
+
 def _screen_space_like(xyz):
     """Zero tensor whose .grad receives the 2D-mean gradients (pipe_dynamics.py:59-66)."""
     p = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -66,20 +99,17 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
                     debug=False, **kwargs):
     """Fluid particles (+ static background Gaussians) through the 3-channel rasteriser."""
     raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
-    opacity, scales, rotations, colors = _attributes(gm, pos_type)
-    if colors.shape[1] == 1:  # grey fluid particles rendered as RGB (pipe_dynamics.py:113-115)
-        colors = colors.repeat(1, 3)
     if gpf_only:
         means3D = render_xyz
+        opacity, scales, rotations, colors = _attributes(gm, pos_type)
+        if colors.shape[1] == 1:  # grey fluid particles rendered as RGB (pipe_dynamics.py:113-115)
+            colors = colors.repeat(1, 3)
     elif gs_only:
         means3D = gm.get_gs_xyz
-        opacity, scales, rotations, colors = gm.get_gs_opacity, gm.get_gs_scaling, gm.get_gs_rotation, gm.get_gs_color
+        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, True)
     else:
         means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
-        opacity = torch.cat([opacity, gm.get_gs_opacity], dim=0)
-        scales = torch.cat([scales, gm.get_gs_scaling], dim=0)
-        rotations = torch.cat([rotations, gm.get_gs_rotation], dim=0)
-        colors = torch.cat([colors, gm.get_gs_color], dim=0)
+        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, False)
     screen = _screen_space_like(means3D)
     rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
                                                  gm.active_sh_degree))
