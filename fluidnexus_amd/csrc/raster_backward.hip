@@ -17,14 +17,61 @@ namespace fnx {
 
 // Sum over the 64 lanes of a wave; the total lands in lane 63.  DPP steps: quad swaps, row
 // shifts by 4 and 8, then row broadcasts 15 and 31 (gfx9 DPP encodings).
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+#define FNX_DPP(v, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ float row_sum_to_lane15(float v) {  // per 16-lane row
+    v += FNX_DPP(v, 0xb1, 0xf);
+    v += FNX_DPP(v, 0x4e, 0xf);
+    v += FNX_DPP(v, 0x114, 0xf);
+    v += FNX_DPP(v, 0x118, 0xf);
     return v;
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = row_sum_to_lane15(v);
+    v += FNX_DPP(v, 0x142, 0xa);
+    v += FNX_DPP(v, 0x143, 0xc);
+    return v;
+}
+// gfx950 lane-swap instructions: swap32(a, b) exchanges a's upper 32 lanes with b's lower 32 lanes,
+// swap16(a, b) exchanges a's odd 16-lane rows with b's even rows; adding the two results folds two
+// values at once (a's sums land in the lower half / even rows, b's in the upper half / odd rows).
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Cross-lane sums of NV per-lane values of one wave, added into acc[v][slot] (LDS).  Folding tree:
+// 64 -> 32 lanes pairs values (v0|v1), 32 -> 16 pairs the pairs, then a row reduction: 26 VALU
+// operations for 9 values instead of 54, and 3 LDS atomics instead of 9.
+template <int NV>
+__device__ __forceinline__ void wave_fold_accumulate(const float (&val)[NV], float (*acc)[256], uint32_t slot, int lane) {
+    constexpr int NP = NV / 2;   // pairs after the 32-fold
+    constexpr int NQ = NP / 2;   // quads after the 16-fold
+    float s[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int p = 0; p < NP; p++) s[p] = fold32(val[2 * p], val[2 * p + 1]);
+    const int row = lane >> 4;
+    const bool tail = (lane & 15) == 15;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        // rows of t: [val[4k], val[4k+2], val[4k+1], val[4k+3]]
+        const float t = row_sum_to_lane15(fold16(s[2 * k], s[2 * k + 1]));
+        const int vi = 4 * k + ((row & 1) << 1) + (row >> 1);
+        if (tail) atomicAdd(&acc[vi][slot], t);
+    }
+    if constexpr (NP % 2 == 1) {  // one (lo | hi) pair left: rows 0,1 hold val[2*(NP-1)], rows 2,3 the next
+        float t = row_sum_to_lane15(s[NP - 1]);
+        t += FNX_DPP(t, 0x142, 0xa);  // lanes 31 / 63 = sums of the two halves
+        if ((lane & 31) == 31) atomicAdd(&acc[2 * (NP - 1) + (lane >> 5)][slot], t);
+    }
+    if constexpr (NV % 2 == 1) {
+        const float t = wave_sum_to_lane63(val[NV - 1]);
+        if (lane == 63) atomicAdd(&acc[NV - 1][slot], t);
+    }
 }
 
 __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
@@ -34,6 +81,8 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
     return base + k;
 }
 
+// Back-to-front pass of one tile.  Same quadrant / compacted-list structure as the forward blend;
+// additionally a wave only receives entries in front of its own deepest contributor.
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
@@ -45,21 +94,25 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const uint32_t *__restrict__ header, uint32_t capacity) {
     constexpr int NV = 6 + C;  // mean2D.xy | conic.xyw | opacity | colour[C]
     __shared__ uint32_t s_id[256];
-    __shared__ float2 s_xy[256];
-    __shared__ float4 s_co[256];
+    __shared__ float4 s_ra[256];  // x, y, conic a, conic b
+    __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
     __shared__ float s_col[C][256];
     __shared__ float s_acc[NV][256];
+    __shared__ uint8_t s_list[4][256];
+    __shared__ uint32_t s_cnt[4][4];
     __shared__ uint32_t s_max[4];
     if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] != 0u) return;
     const int tile = xcd_tile_b(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = tx * FNX_TILE_X + (tid & 15), py = ty * FNX_TILE_Y + (tid >> 4);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     if (r1 == r0) return;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     const float T_final = inside ? final_Ts[pix_id] : 0.f;
     float Tr = T_final;
@@ -77,45 +130,72 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
 
-    // No pixel of this tile looks past list position max(n_contrib): start there (positions are
-    // 0-based from the front; entry q is used by a pixel iff q < its n_contrib, backward.cu:467-469).
+    // entry q (0-based from the front) is used by a pixel iff q < its n_contrib (backward.cu:467-469):
+    // a wave needs nothing behind its own max, the tile nothing behind the max of its waves
     uint32_t m = last_contributor;
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) s_max[wave] = m;
+    if (lane == 0) s_max[w] = m;
     __syncthreads();
     const uint32_t qmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
     for (uint32_t top = qmax; top > 0;) {
         const uint32_t cnt = min(256u, top);
-        // stage entries q = top-1 ... top-cnt (slot j <-> q = top-1-j), zero the slot accumulators
+        // stage entries q = top-1 ... top-cnt (slot t <-> q = top-1-t), zero the slot accumulators
         __syncthreads();
+        uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
-            const uint32_t id = point_list[r0 + top - 1 - tid];
+            const uint32_t q = top - 1 - tid;
+            const uint32_t id = point_list[r0 + q];
+            const float2 xy = means2D[id];
+            const float4 co = conic_opacity[id];
+            float thr;
+            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0, thr);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (q >= s_max[k]) qm &= ~(1u << k);
             s_id[tid] = id;
-            s_xy[tid] = means2D[id];
-            s_co[tid] = conic_opacity[id];
+            s_ra[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_rb[tid] = make_float4(co.z, co.w, thr, 0.f);
 #pragma unroll
             for (int ch = 0; ch < C; ch++) s_col[ch][tid] = colors[(size_t)id * C + ch];
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
+        uint32_t rank[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long bm = __ballot((qm >> q) & 1u);
+            rank[q] = (uint32_t)__popcll(bm & lt_mask);
+            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(bm);
+        }
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((qm >> q) & 1u) {
+                uint32_t off = rank[q];
+                for (int k = 0; k < w; k++) off += s_cnt[k][q];
+                s_list[q][off] = (uint8_t)tid;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
 
-        for (uint32_t j = 0; j < cnt; j++) {
+        for (uint32_t i = 0; i < n_w; i++) {
+            const uint32_t j = s_list[w][i];
             const uint32_t q = top - 1 - j;
             float val[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) val[v] = 0.f;
             bool active = q < last_contributor;
             if (active) {
-                const float2 xy = s_xy[j];
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float4 co = s_co[j];
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                active = !(power > 0.0f);
+                const float4 ra = s_ra[j];
+                const float4 rb = s_rb[j];
+                const float dx = ra.x - pxf, dy = ra.y - pyf;
+                const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
+                active = !(power > 0.0f) && !(power < rb.z);
                 if (active) {
                     const float G = exp_fixed(power);
-                    const float alpha = fminf(0.99f, co.w * G);
+                    const float alpha = fminf(0.99f, rb.y * G);
                     active = !(alpha < 1.0f / 255.0f);
                     if (active) {
                         Tr = Tr / (1.f - alpha);
@@ -133,11 +213,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                         dL_dalpha *= Tr;
                         last_alpha = alpha;
                         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                        const float dL_dG = co.w * dL_dalpha;
+                        const float dL_dG = rb.y * dL_dalpha;
                         const float gdx = G * dx;
                         const float gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        const float dG_ddelx = -gdx * ra.z - gdy * ra.w;
+                        const float dG_ddely = -gdy * rb.x - gdx * ra.w;
                         val[0] = dL_dG * dG_ddelx * ddelx_dx;
                         val[1] = dL_dG * dG_ddely * ddely_dy;
                         val[2] = -0.5f * gdx * dx * dL_dG;
@@ -147,13 +227,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     }
                 }
             }
-            if (__ballot(active) != 0ull) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    const float s = wave_sum_to_lane63(val[v]);
-                    if (lane == 63) atomicAdd(&s_acc[v][j], s);
-                }
-            }
+            if (__ballot(active) != 0ull) wave_fold_accumulate<NV>(val, s_acc, j, lane);
         }
         __syncthreads();
         if ((uint32_t)tid < cnt) {

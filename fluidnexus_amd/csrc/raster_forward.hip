@@ -212,7 +212,11 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
 }
 
 // K5: front-to-back alpha blending, one 256-thread workgroup per 16x16 tile
-// (ch3 forward.cu:249-373).  Splat records of a batch are staged once in LDS, colours included.
+// (ch3 forward.cu:249-373).  Wave w owns the 8x8 quadrant (w & 1, w >> 1).  A batch of 256 list
+// entries is staged once in LDS; while staging, each entry is tested against the four quadrants
+// (quadrant_mask) and every wave gets its own compacted, still depth-ordered index list, so a wave
+// only walks entries that can reach one of its pixels.  Per pixel the arithmetic and its order are
+// exactly the reference's; culled pairs are pairs it would have skipped (alpha < 1/255).
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
@@ -221,22 +225,25 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
                      const float *__restrict__ bg, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
                      uint32_t capacity) {
-    __shared__ float2 s_xy[256];
-    __shared__ float4 s_co[256];
-    __shared__ float s_depth[256];
+    __shared__ float4 s_ra[256];  // x, y, conic a, conic b
+    __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
     __shared__ float s_col[C][256];
+    __shared__ uint8_t s_list[4][256];
+    __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
     if (header[HDR_NUM_RENDERED] > capacity) return;
     const int tile = xcd_tile(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
-    const int px = tx * FNX_TILE_X + (tid & 15), py = ty * FNX_TILE_Y + (tid >> 4);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool done = !inside;
     float Tr = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
     float acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
@@ -244,23 +251,46 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
     for (uint32_t base = r0; base < r1; base += 256) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t cnt = min(256u, r1 - base);
+        uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
             const uint32_t id = point_list[base + tid];
-            s_xy[tid] = means2D[id];
-            s_co[tid] = conic_opacity[id];
-            s_depth[tid] = depths[id];
+            const float2 xy = means2D[id];
+            const float4 co = conic_opacity[id];
+            float thr;
+            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0, thr);
+            s_ra[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_rb[tid] = make_float4(co.z, co.w, thr, depths[id]);
 #pragma unroll
             for (int ch = 0; ch < C; ch++) s_col[ch][tid] = features[(size_t)id * C + ch];
         }
+        uint32_t rank[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long m = __ballot((qm >> q) & 1u);
+            rank[q] = (uint32_t)__popcll(m & lt_mask);
+            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(m);
+        }
         __syncthreads();
-        for (uint32_t j = 0; !done && j < cnt; j++) {
-            contributor++;
-            const float2 xy = s_xy[j];
-            const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float4 co = s_co[j];
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((qm >> q) & 1u) {
+                uint32_t off = rank[q];
+                for (int k = 0; k < w; k++) off += s_cnt[k][q];
+                s_list[q][off] = (uint8_t)tid;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
+        const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
+        for (uint32_t i = 0; !done && i < n_w; i++) {
+            const uint32_t j = s_list[w][i];
+            const float4 ra = s_ra[j];
+            const float4 rb = s_rb[j];
+            const float dx = ra.x - pxf, dy = ra.y - pyf;
+            const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
             if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * exp_fixed(power));
+            if (power < rb.z) continue;  // alpha would be < 1/255 (see quadrant_mask)
+            const float alpha = fminf(0.99f, rb.y * exp_fixed(power));
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = Tr * (1 - alpha);
             if (test_T < 0.0001f) {
@@ -269,9 +299,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
             }
 #pragma unroll
             for (int ch = 0; ch < C; ch++) acc[ch] += s_col[ch][j] * alpha * Tr;
-            if (Tr > 0.5f && test_T < 0.5f) Dm = s_depth[j];
+            if (Tr > 0.5f && test_T < 0.5f) Dm = rb.w;
             Tr = test_T;
-            last_contributor = contributor;
+            last_contributor = pos0 + j;
         }
     }
     if (inside) {

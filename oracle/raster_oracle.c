@@ -381,7 +381,8 @@ void fnx_oracle_bin(int P, int W, int H, const float *means2D, const float *dept
  */
 void fnx_oracle_render(int C, int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *means2D,
                        const float *features, const float *conic_opacity, const float *depths, const float *bg,
-                       float *final_T, uint32_t *n_contrib, float *out_color, float *out_depth) {
+                       float *final_T, uint32_t *n_contrib, float *out_color, float *out_depth,
+                       uint32_t *examined /* optional diagnostics: list entries walked per pixel */) {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
@@ -413,6 +414,7 @@ void fnx_oracle_render(int C, int W, int H, const uint32_t *ranges, const uint32
                 }
                 final_T[pix_id] = T;
                 n_contrib[pix_id] = last_contributor;
+                if (examined) examined[pix_id] = contributor;
                 for (int ch = 0; ch < C; ch++) out_color[(size_t)ch * H * W + pix_id] = Cacc[ch] + T * bg[ch];
                 out_depth[pix_id] = Dm;
             }

@@ -111,6 +111,7 @@ def forward(means3D, opacities, bg, viewmatrix, projmatrix, campos, W, H, tan_fo
     out["ranges"] = np.zeros((T, 2), np.uint32)
     out["final_T"] = np.zeros((H, W), np.float32)
     out["n_contrib"] = np.zeros((H, W), np.uint32)
+    out["examined"] = np.zeros((H, W), np.uint32)
     if P == 0:  # rasterize_points.cu:81
         out["num_rendered"] = 0
         out["keys_sorted"] = np.zeros((0,), np.uint64)
@@ -133,7 +134,8 @@ def forward(means3D, opacities, bg, viewmatrix, projmatrix, campos, W, H, tan_fo
     out["features"] = feats
     L.fnx_oracle_render(C.c_int(Cn), C.c_int(W), C.c_int(H), _p(out["ranges"]), _p(out["point_list"]),
                         _p(out["means2D"]), _p(feats), _p(out["conic_opacity"]), _p(out["depths"]), _p(bg),
-                        _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["depth"]))
+                        _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["depth"]),
+                        _p(out["examined"]))
     out["_inputs"] = dict(means3D=means3D, opacities=opacities, bg=bg, viewmatrix=viewmatrix, projmatrix=projmatrix,
                           campos=campos, tan_fovx=tan_fovx, tan_fovy=tan_fovy, colors_precomp=colors_precomp, shs=shs,
                           scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
