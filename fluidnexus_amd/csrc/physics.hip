@@ -27,6 +27,8 @@ struct GridView {
     uint32_t *start;   // [M + 1]
     uint32_t *cursor;  // [M]
     float4 *rec;       // [N] (x, y, z, id bits)
+    float4 *aux0;      // [N] per-slot payload (kernel-specific, rewritten by each call)
+    float4 *aux1;      // [N]
     uint32_t M;
 };
 
@@ -43,6 +45,8 @@ inline size_t grid_bytes(int N) {
     off = align_up(off + (M + 1) * 4);
     off = align_up(off + M * 4);
     off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
+    off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
+    off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
     return off + kAlign;
 }
 
@@ -55,15 +59,23 @@ inline GridView carve(char *blob, int N) {
     g.count = (uint32_t *)(b + off);  off = align_up(off + (size_t)g.M * 4);
     g.start = (uint32_t *)(b + off);  off = align_up(off + ((size_t)g.M + 1) * 4);
     g.cursor = (uint32_t *)(b + off); off = align_up(off + (size_t)g.M * 4);
-    g.rec = (float4 *)(b + off);
+    g.rec = (float4 *)(b + off);  off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
+    g.aux0 = (float4 *)(b + off); off = align_up(off + (size_t)(N > 0 ? N : 0) * 16);
+    g.aux1 = (float4 *)(b + off);
     return g;
 }
 
 __device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cell) {
     return make_int3((int)floorf(x * inv_cell), (int)floorf(y * inv_cell), (int)floorf(z * inv_cell));
 }
+// Bucket of an integer cell.  The low 9 bits are (cx, cy, cz) mod 8, so the 27 cells around any
+// query land in 27 DIFFERENT buckets: a point within H of the query lies in exactly one of those
+// cells, hence is met exactly once; points of far cells that share a bucket fail the distance test.
 __device__ __forceinline__ uint32_t cell_hash(int3 c, uint32_t mask) {
-    return (((uint32_t)c.x * 73856093u) ^ ((uint32_t)c.y * 19349663u) ^ ((uint32_t)c.z * 83492791u)) & mask;
+    const uint32_t lo = ((uint32_t)c.x & 7u) | (((uint32_t)c.y & 7u) << 3) | (((uint32_t)c.z & 7u) << 6);
+    const uint32_t hi = ((uint32_t)(c.x >> 3) * 73856093u) ^ ((uint32_t)(c.y >> 3) * 19349663u) ^
+                        ((uint32_t)(c.z >> 3) * 83492791u);
+    return (lo | (hi << 9)) & mask;
 }
 
 __global__ void __launch_bounds__(256)
@@ -141,8 +153,8 @@ __device__ __forceinline__ float row_sum15(float v) {
 }
 
 // L lanes (16 = one DPP row, or 64 = one wave) share one query point p and stride over the
-// candidates of the 27 surrounding buckets; f(j, dx, dy, dz, r2) with d = p - x_j for every grid
-// point with r2 < H2 whose own cell is the visited cell (hash collisions filtered).
+// candidates of the 27 surrounding buckets; f(slot, j, dx, dy, dz, r2) with d = p - x_j for every
+// grid point with r2 < H2 (see cell_hash for why no candidate is met twice).
 template <int L, typename F>
 __device__ __forceinline__ void for_neighbours(int sub, float px, float py, float pz, float inv_cell, float H2,
                                                uint32_t mask, const uint32_t *__restrict__ start,
@@ -156,11 +168,9 @@ __device__ __forceinline__ void for_neighbours(int sub, float px, float py, floa
                 const uint32_t s0 = start[h], s1 = start[h + 1];
                 for (uint32_t s = s0 + sub; s < s1; s += L) {
                     const float4 q = rec[s];
-                    const int3 qc = cell_of(q.x, q.y, q.z, inv_cell);
-                    if (qc.x != cc.x || qc.y != cc.y || qc.z != cc.z) continue;  // hash collision
                     const float ex = px - q.x, ey = py - q.y, ez = pz - q.z;
                     const float r2 = ex * ex + ey * ey + ez * ez;
-                    if (r2 < H2) f(__float_as_uint(q.w), ex, ey, ez, r2);
+                    if (r2 < H2) f(s, __float_as_uint(q.w), ex, ey, ez, r2);
                 }
             }
 }
@@ -174,7 +184,7 @@ density_forward_kernel(const float *__restrict__ xyz, int N, const float *__rest
     const int ii = min(i, N - 1);
     float acc = 0.f;
     for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
-                       [&](uint32_t, float, float, float, float r2) {
+                       [&](uint32_t, uint32_t, float, float, float, float r2) {
                            const float t = H2 - r2;
                            acc += term1 * (t * t * t);
                        });
@@ -191,7 +201,7 @@ density_backward_kernel(const float *__restrict__ xyz, int N, const float *__res
     const float Gi = g[ii] / imass[ii] / p0;
     float ax = 0.f, ay = 0.f, az = 0.f;
     for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
-                       [&](uint32_t j, float ex, float ey, float ez, float r2) {
+                       [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
                            const float Gj = g[j] / imass[j] / p0;
                            const float t = H2 - r2;
                            const float dW = -3.0f * term1 * (t * t);  // d poly6 / d r2
@@ -210,33 +220,56 @@ density_backward_kernel(const float *__restrict__ xyz, int N, const float *__res
     }
 }
 
-// gm_dynamics.py:1453-1498.  16 lanes per visual particle.
+// Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
+__device__ __forceinline__ float oct_sum7(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xa, false));
+    return v;
+}
+// Sum over 32 consecutive lanes; totals land in lanes 31 and 63.
+__device__ __forceinline__ float half_sum31(float v) {
+    v = row_sum15(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    return v;
+}
+
+// per grid slot: velocity of the hidden particle stored there, u = (x - x_prev) / secs
 __global__ void __launch_bounds__(256)
-visual_forward_kernel(const float *__restrict__ visual, int V, const float *__restrict__ hidden,
-                      const float *__restrict__ hidden_prev, float inv_cell, float H2, float term1, float secs,
+slot_velocity_kernel(const float4 *__restrict__ rec, int N, const float *__restrict__ prev, float secs,
+                     float4 *__restrict__ u) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= N) return;
+    const float4 q = rec[s];
+    const uint32_t j = __float_as_uint(q.w);
+    u[s] = make_float4((q.x - prev[3 * j]) / secs, (q.y - prev[3 * j + 1]) / secs, (q.z - prev[3 * j + 2]) / secs, 0.f);
+}
+
+// gm_dynamics.py:1453-1498.  8 lanes per visual particle (a hidden bucket holds ~8 particles).
+__global__ void __launch_bounds__(256)
+visual_forward_kernel(const float *__restrict__ visual, int V, float inv_cell, float H2, float term1, float secs,
                       float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
-                      float *__restrict__ out, float *__restrict__ sum_w, float *__restrict__ wvel) {
-    const int v = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+                      const float4 *__restrict__ u, float *__restrict__ out, float *__restrict__ sum_w,
+                      float *__restrict__ wvel) {
+    const int v = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     const int vv = min(v, V - 1);
     const float px = visual[3 * vv], py = visual[3 * vv + 1], pz = visual[3 * vv + 2];
     float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours<16>(sub, px, py, pz, inv_cell, H2, mask, start, rec,
-                       [&](uint32_t j, float, float, float, float r2) {
-                           const float t = H2 - r2;
-                           const float w = term1 * (t * t * t);
-                           const float ux = (hidden[3 * j] - hidden_prev[3 * j]) / secs;
-                           const float uy = (hidden[3 * j + 1] - hidden_prev[3 * j + 1]) / secs;
-                           const float uz = (hidden[3 * j + 2] - hidden_prev[3 * j + 2]) / secs;
-                           S += w;
-                           ax += ux * w;
-                           ay += uy * w;
-                           az += uz * w;
-                       });
-    S = row_sum15(S);
-    ax = row_sum15(ax);
-    ay = row_sum15(ay);
-    az = row_sum15(az);
-    if (sub == 15 && v < V) {
+    for_neighbours<8>(sub, px, py, pz, inv_cell, H2, mask, start, rec,
+                      [&](uint32_t s, uint32_t, float, float, float, float r2) {
+                          const float t = H2 - r2;
+                          const float w = term1 * (t * t * t);
+                          const float4 uj = u[s];
+                          S += w;
+                          ax += uj.x * w;
+                          ay += uj.y * w;
+                          az += uj.z * w;
+                      });
+    S = oct_sum7(S);
+    ax = oct_sum7(ax);
+    ay = oct_sum7(ay);
+    az = oct_sum7(az);
+    if (sub == 7 && v < V) {
         sum_w[v] = S;
         wvel[3 * v + 0] = ax;
         wvel[3 * v + 1] = ay;
@@ -248,40 +281,52 @@ visual_forward_kernel(const float *__restrict__ visual, int V, const float *__re
     }
 }
 
-// One wave per hidden particle: the grid holds the VISUAL points (thousands of candidates each).
+// per visual-grid slot: (g, S) and (wvel, -) of the visual particle stored there
 __global__ void __launch_bounds__(256)
-visual_backward_kernel(const float *__restrict__ visual, const float *__restrict__ hidden,
-                       const float *__restrict__ hidden_prev, int N, float inv_cell, float H2, float term1, float secs,
-                       float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
-                       const float *__restrict__ sum_w, const float *__restrict__ wvel,
-                       const float *__restrict__ dL_dout, float *__restrict__ dL_dhidden) {
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
+slot_visual_payload_kernel(const float4 *__restrict__ rec, int V, const float *__restrict__ sum_w,
+                           const float *__restrict__ wvel, const float *__restrict__ g, float4 *__restrict__ a0,
+                           float4 *__restrict__ a1) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= V) return;
+    const uint32_t v = __float_as_uint(rec[s].w);
+    a0[s] = make_float4(g[3 * v], g[3 * v + 1], g[3 * v + 2], sum_w[v]);
+    a1[s] = make_float4(wvel[3 * v], wvel[3 * v + 1], wvel[3 * v + 2], 0.f);
+}
+
+// 32 lanes per hidden particle; the grid holds the VISUAL points (~80 per bucket) with their
+// per-slot payload, so the candidate loop streams 48 contiguous bytes per candidate.
+__global__ void __launch_bounds__(256)
+visual_backward_kernel(const float *__restrict__ hidden, const float *__restrict__ hidden_prev, int N, float inv_cell,
+                       float H2, float term1, float secs, float eps, uint32_t mask,
+                       const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                       const float4 *__restrict__ a0, const float4 *__restrict__ a1, float *__restrict__ dL_dhidden) {
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
     const int jj = min(j, N - 1);
     const float hx = hidden[3 * jj], hy = hidden[3 * jj + 1], hz = hidden[3 * jj + 2];
     const float ux = (hx - hidden_prev[3 * jj]) / secs, uy = (hy - hidden_prev[3 * jj + 1]) / secs,
                 uz = (hz - hidden_prev[3 * jj + 2]) / secs;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours<64>(sub, hx, hy, hz, inv_cell, H2, mask, start, rec,
-                       [&](uint32_t v, float ex, float ey, float ez, float r2) {
-                           const float S = sum_w[v];
+    for_neighbours<32>(sub, hx, hy, hz, inv_cell, H2, mask, start, rec,
+                       [&](uint32_t s, uint32_t, float ex, float ey, float ez, float r2) {
+                           const float4 gs = a0[s];
+                           const float4 wv = a1[s];
+                           const float S = gs.w;
                            const float Sc = fmaxf(S, eps);
-                           const float gx = dL_dout[3 * v], gy = dL_dout[3 * v + 1], gz = dL_dout[3 * v + 2];
                            const float t = H2 - r2;
                            const float w = term1 * (t * t * t);
                            const float dW = -3.0f * term1 * (t * t);
                            const float a = w / Sc;  // through u_j: (1/secs) * secs * w/S * g
-                           float dLdw = secs * (gx * ux + gy * uy + gz * uz) / Sc;
-                           if (S > eps)
-                               dLdw -= secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
+                           float dLdw = secs * (gs.x * ux + gs.y * uy + gs.z * uz) / Sc;
+                           if (S > eps) dLdw -= secs * (gs.x * wv.x + gs.y * wv.y + gs.z * wv.z) / (Sc * Sc);
                            const float k = dLdw * dW * 2.0f;  // d r2 / d hidden_j = 2 (hidden_j - visual_v) = 2 e
-                           ax += a * gx + k * ex;
-                           ay += a * gy + k * ey;
-                           az += a * gz + k * ez;
+                           ax += a * gs.x + k * ex;
+                           ay += a * gs.y + k * ey;
+                           az += a * gs.z + k * ez;
                        });
-    ax = wave_sum63(ax);
-    ay = wave_sum63(ay);
-    az = wave_sum63(az);
-    if (sub == 63 && j < N) {
+    ax = half_sum31(ax);
+    ay = half_sum31(ay);
+    az = half_sum31(az);
+    if (sub == 31 && j < N) {
         dL_dhidden[3 * j + 0] = ax;
         dL_dhidden[3 * j + 1] = ay;
         dL_dhidden[3 * j + 2] = az;
@@ -357,9 +402,11 @@ int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, c
     if (V < 0 || N < 0 || !visual || !hidden_grid || !out || !sum_w || !wvel || (N > 0 && (!hidden || !hidden_prev)))
         return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward: bad argument");
     GridView g = carve(const_cast<char *>(hidden_grid), N);
-    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 15) / 16), dim3(256), 0, (hipStream_t)stream, visual, V,
-                       hidden, hidden_prev, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, out,
-                       sum_w, wvel);
+    if (N > 0)
+        hipLaunchKernelGGL(slot_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec, N,
+                           hidden_prev, secs, g.aux0);
+    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 31) / 32), dim3(256), 0, (hipStream_t)stream, visual, V,
+                       1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel);
     return hip_check("visual_interp_forward");
 }
 
@@ -371,9 +418,12 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
         (V > 0 && (!visual || !sum_w || !wvel || !dL_dout)))
         return fail(FNX_ERR_INVALID_ARG, "visual_interp_backward: bad argument");
     GridView g = carve(const_cast<char *>(visual_grid), V);
-    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, visual, hidden,
-                       hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, sum_w, wvel,
-                       dL_dout, dL_dhidden);
+    if (V > 0)
+        hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
+                           V, sum_w, wvel, dL_dout, g.aux0, g.aux1);
+    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, hidden,
+                       hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0,
+                       g.aux1, dL_dhidden);
     return hip_check("visual_interp_backward");
 }
 

@@ -33,7 +33,9 @@ typedef void *fnx_stream_t;
 int fnx_physics_abi_version(void);
 const char *fnx_physics_last_error(void);
 
-/* Uniform hash grid over N points, cell edge = `cell`.  The blob is opaque. */
+/* Uniform hash grid over N points, cell edge = `cell`.  The blob is opaque; it also holds per-call
+ * scratch (per-slot payloads) that the visual_interp entry points rewrite, so one grid must not be
+ * used from two streams at once. */
 size_t fnx_grid_bytes(int N);
 int fnx_grid_build(const float *xyz, int N, float cell, char *grid, fnx_stream_t stream);
 
