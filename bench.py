@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--image-loss", default="auto", choices=["auto", "torch", "fused"])
     ap.add_argument("--physics-once", action="store_true",
                     help="evaluate the view-independent physics terms once per iteration instead of once per view")
+    ap.add_argument("--unfused-physics", action="store_true",
+                    help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +106,8 @@ def main():
             image_loss = "fused"
         except Exception:
             image_loss = "torch"
-    loop = HotLoop(gm, cams, rank=rank, world=world, physics_per_view=not a.physics_once, image_loss=image_loss)
+    loop = HotLoop(gm, cams, rank=rank, world=world, physics_per_view=not a.physics_once, image_loss=image_loss,
+                   fused_physics=not a.unfused_physics)
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)
@@ -171,7 +174,8 @@ def main():
                    "num_rendered_per_view": R, "visible_per_view": P_vis,
                    "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
                    "host_sync": bool(a.host_sync), "image_loss": image_loss,
-                   "physics": "once per iteration" if a.physics_once else "per view (as the reference)"},
+                   "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
+                   + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
         "roofline": roofline,
         "rasterise_ms_per_view": {"forward": sum(prof[k][0] for k in ("preprocess", "binning", "blend_forward"))
                                   / max(prof["blend_forward"][1], 1),

@@ -56,6 +56,7 @@ class GaussianModel:
         self.total_iterations = 0
         self._visual_grid = None
         self._grid_cache = {}
+        self._visual_memo = (None, {})
         self.setup_functions()
 
     # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
@@ -122,8 +123,11 @@ class GaussianModel:
         if self._visual_grid is None or self._visual_grid[0] is not self._visual_xyz:
             self._visual_grid = (self._visual_xyz, physics.HashGrid(visual, self.H))
         x = self._estimate_xyz_nn * self.scale_factor
+        key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version, id(self._visual_xyz))
+        if self._visual_memo[0] != key:
+            self._visual_memo = (key, {})
         return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
-                                          self._visual_grid[1], self._cached_grid("est", x))
+                                          self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1])
 
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):

@@ -82,12 +82,13 @@ class HotLoop:
     """One frame's optimisation loop over `gm` and `cams` (physical-particle stage)."""
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
-                 physics_per_view=True, image_loss="torch"):
+                 physics_per_view=True, image_loss="torch", fused_physics=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
         self.physics_per_view = physics_per_view
         self.image_loss = image_loss
+        self.fused_physics = fused_physics
         dev = gm._xyz.device
         self.background = torch.zeros(3, device=dev)
         self.optim_args = SimpleNamespace(**{k: cfg[k] for k in ("position_lr_init", "position_lr_final",
@@ -124,6 +125,10 @@ class HotLoop:
 
     def _physics_loss(self):
         gm, c = self.gm, self.cfg
+        if self.fused_physics:
+            from .physics import physical_stage_loss
+            return physical_stage_loss(gm, c["lambda_exyz"], c["lambda_gas_constraints"],
+                                       c["lambda_next_gas_constraints"])
         loss = 0.0
         if c["lambda_exyz"] > 0:
             loss = loss + c["lambda_exyz"] * l2_loss(gm._estimate_xyz_nn * gm.scale_factor, gm._estimate_xyz)

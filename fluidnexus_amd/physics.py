@@ -72,18 +72,24 @@ def density_ratio(xyz, imass, H, p0, grid=None):
 
 class _VisualFromHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, visual, hidden, hidden_prev, H, secs, eps, visual_grid, hgrid):
+    def forward(ctx, visual, hidden, hidden_prev, H, secs, eps, visual_grid, hgrid, memo):
         lib = PL.physics()
         visual, hidden, hidden_prev = _req(visual), _req(hidden), _req(hidden_prev)
         V, N = visual.shape[0], hidden.shape[0]
-        if hgrid is None:
-            hgrid = HashGrid(hidden, H)
-        out = torch.empty_like(visual)
-        sum_w = torch.empty(V, dtype=torch.float32, device=visual.device)
-        wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
-        PL.check(lib.fnx_visual_interp_forward(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N, H,
-                                               secs, eps, hgrid.blob.data_ptr(), out.data_ptr(), sum_w.data_ptr(),
-                                               wvel.data_ptr(), _stream()))
+        if memo is not None and "out" in memo:
+            # same inputs as an earlier call (caller's guarantee): reuse the forward results
+            out, sum_w, wvel = memo["out"], memo["sum_w"], memo["wvel"]
+        else:
+            if hgrid is None:
+                hgrid = HashGrid(hidden, H)
+            out = torch.empty_like(visual)
+            sum_w = torch.empty(V, dtype=torch.float32, device=visual.device)
+            wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
+            PL.check(lib.fnx_visual_interp_forward(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N,
+                                                   H, secs, eps, hgrid.blob.data_ptr(), out.data_ptr(),
+                                                   sum_w.data_ptr(), wvel.data_ptr(), _stream()))
+            if memo is not None:
+                memo.update(out=out, sum_w=sum_w, wvel=wvel)
         if visual_grid is None:
             visual_grid = HashGrid(visual, H)
         ctx.save_for_backward(visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob)
@@ -101,12 +107,82 @@ class _VisualFromHidden(torch.autograd.Function):
                                                 hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
                                                 vblob.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
                                                 dh.data_ptr(), _stream()))
-        return None, dh, None, None, None, None, None, None
+        return None, dh, None, None, None, None, None, None, None
 
 
-def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None):
+def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,
+                       memo=None):
     """visual [V,3] (constant), hidden [N,3] (differentiable), hidden_prev [N,3] -> advected visual [V,3].
     `visual_grid`: a HashGrid over `visual` to reuse across iterations (visual is fixed within a frame);
-    `hidden_grid`: an up-to-date HashGrid over `hidden`."""
-    return _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
-                                   hidden_grid)
+    `hidden_grid`: an up-to-date HashGrid over `hidden`; `memo`: a dict the caller keeps for as long as
+    the inputs are unchanged -- the forward kernel then runs once and later calls only add an autograd
+    node (the views of one iteration all see the same particle state)."""
+    out = _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
+                                  hidden_grid, memo)
+    return out.clone() if memo is not None else out
+
+
+
+class _PhysicalStageLoss(torch.autograd.Function):
+    """lambda_exyz * l2(x_nn * sf, x_est) + lambda_gas * l2(p_ratio(x), 1) + lambda_next * l2(p_ratio(x'), 1)
+    (train_physical_particle.py:368-404) as ONE autograd node: the forward runs the reference's op
+    sequence without recording a graph, the backward is analytic (density kernel backward + the
+    affine Jacobian of the one-tick advection, gm_dynamics.py:1014-1030)."""
+
+    @staticmethod
+    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, grids):
+        with torch.no_grad():
+            sf, secs = gm.scale_factor, gm._secs
+            x = x_nn * sf
+            N = x.shape[0]
+            loss = x.new_zeros(())
+            e = d1 = d2 = xg = None
+            if lam_e > 0:
+                e = x - gm._estimate_xyz
+                loss = loss + lam_e * (e ** 2).mean()
+            if lam_g > 0:
+                d1 = _DensityRatio.apply(x, gm._imass, gm.H, gm.p0, grids("est", x)) - 1.0
+                loss = loss + lam_g * (d1 ** 2).mean()
+            if lam_n > 0:
+                xg = gm.get_guess_hidden_particles_from_nn()
+                d2 = _DensityRatio.apply(xg, gm._imass, gm.H, gm.p0, grids("guess", xg)) - 1.0
+                loss = loss + lam_n * (d2 ** 2).mean()
+        ctx.gm, ctx.lams, ctx.grids = gm, (lam_e, lam_g, lam_n), grids
+        ctx.save_for_backward(x, e if e is not None else x.new_empty(0), d1 if d1 is not None else x.new_empty(0),
+                              d2 if d2 is not None else x.new_empty(0), xg if xg is not None else x.new_empty(0))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = PL.physics()
+        gm, (lam_e, lam_g, lam_n), grids = ctx.gm, ctx.lams, ctx.grids
+        x, e, d1, d2, xg = ctx.saved_tensors
+        N = x.shape[0]
+        sf, secs = gm.scale_factor, gm._secs
+        gx = torch.zeros_like(x)  # dL / d(x_nn * sf)
+        if lam_e > 0:
+            gx += e * (2.0 * lam_e / (3 * N))
+        if lam_g > 0:
+            up = (d1 * (2.0 * lam_g / N)).contiguous()
+            dx = torch.empty_like(x)
+            PL.check(lib.fnx_density_backward(x.data_ptr(), N, gm._imass.data_ptr(), gm.H, gm.p0,
+                                              grids("est", x).blob.data_ptr(), up.data_ptr(), dx.data_ptr(), _stream()))
+            gx += dx
+        out = gx * sf
+        if lam_n > 0:
+            up = (d2 * (2.0 * lam_n / N)).contiguous()
+            dg = torch.empty_like(x)
+            PL.check(lib.fnx_density_backward(xg.data_ptr(), N, gm._imass.data_ptr(), gm.H, gm.p0,
+                                              grids("guess", xg).blob.data_ptr(), up.data_ptr(), dg.data_ptr(),
+                                              _stream()))
+            # x' = x_nn sf + secs ((x_nn sf - x_prev) / secs + b secs + secs f)  =>  d x' / d x_nn = 2 sf I (+ buoyancy)
+            out = out + dg * (2.0 * sf)
+            if gm.buoyancy_max_y > 0.0:
+                out[:, 1] += (dg * gm._buoyancy).sum(dim=1) * (-(secs * secs) / gm.buoyancy_max_y)
+        return out * g, None, None, None, None, None
+
+
+def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next):
+    """Weighted physics terms of the physical-particle stage for GaussianModel `gm` (one autograd node)."""
+    return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next),
+                                    gm._cached_grid)

@@ -57,6 +57,20 @@ def test_physics_vs_reference_golden(tag):
     loss.backward()
     assert abs(loss.item() - G[f"phys_loss_{tag}"]) < 1e-5 * abs(G[f"phys_loss_{tag}"])
     _close(gm._estimate_xyz_nn.grad.cpu().numpy(), G[f"d_phys_loss_{tag}"], 1e-4, "d phys loss")
+    # the same three terms as one fused autograd node
+    from fluidnexus_amd.physics import physical_stage_loss
+    gm._estimate_xyz_nn.grad = None
+    fl = physical_stage_loss(gm, 0.1, 1.0, 0.1)
+    (fl * 1.0).backward()
+    assert abs(fl.item() - G[f"phys_loss_{tag}"]) < 1e-5 * abs(G[f"phys_loss_{tag}"])
+    _close(gm._estimate_xyz_nn.grad.cpu().numpy(), G[f"d_phys_loss_{tag}"], 1e-4, "d fused phys loss")
+    # memoised visual interpolation: second call reuses the forward, gradients still flow
+    gm._estimate_xyz_nn.grad = None
+    v1 = gm.get_visual_xyz_from_nn()
+    v2 = gm.get_visual_xyz_from_nn()
+    (v2 * torch.tensor(G[f"w_vis_{tag}"]).cuda()).sum().backward()
+    assert torch.equal(v1, v2)
+    _close(gm._estimate_xyz_nn.grad.cpu().numpy(), G[f"d_vis_{tag}"], 1e-4, "d visual_xyz (memo)")
 
 
 def test_physics_larger_cloud_vs_oracle():
