@@ -47,7 +47,8 @@ SYMBOLS = (
 
 
 def raster_path() -> str:
-    return os.path.join(_HERE, "libfnx_raster.so")
+    # FNX_RASTER_LIB: developer override used for kernel timing experiments (tools/)
+    return os.environ.get("FNX_RASTER_LIB") or os.path.join(_HERE, "libfnx_raster.so")
 
 
 def raster():

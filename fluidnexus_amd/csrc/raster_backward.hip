@@ -13,6 +13,10 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
+#ifndef FNX_ABLATE
+#define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
+#endif
+
 namespace fnx {
 
 // Sum over the 64 lanes of a wave; the total lands in lane 63.  DPP steps: quad swaps, row
@@ -180,7 +184,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         __syncthreads();
         const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
 
-        for (uint32_t i = 0; i < n_w; i++) {
+        for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
             const uint32_t j = s_list[w][i];
             const uint32_t q = top - 1 - j;
             float val[NV];
@@ -227,7 +231,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     }
                 }
             }
+#if FNX_ABLATE == 2
+            { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
+#else
             if (__ballot(active) != 0ull) wave_fold_accumulate<NV>(val, s_acc, j, lane);
+#endif
         }
         __syncthreads();
         if ((uint32_t)tid < cnt) {
@@ -239,7 +247,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 a[v] = s_acc[v][tid];
                 any |= (a[v] != 0.f);
             }
-            if (any) {
+            if (any && FNX_ABLATE != 1) {
                 unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], a[0]);
                 unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], a[1]);
                 unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], a[2]);

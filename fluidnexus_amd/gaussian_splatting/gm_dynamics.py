@@ -57,6 +57,7 @@ class GaussianModel:
         self._visual_grid = None
         self._grid_cache = {}
         self._visual_memo = (None, {})
+        self._state_memos = {}
         self.setup_functions()
 
     # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
@@ -105,6 +106,15 @@ class GaussianModel:
         if hit is None or hit[0] != key:
             hit = (key, physics.HashGrid(xyz.detach(), self.H))
             self._grid_cache[slot] = hit
+        return hit[1]
+
+    def state_memo(self, slot):
+        """A dict that lives as long as _estimate_xyz_nn keeps its current value (tensor version)."""
+        key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version)
+        hit = self._state_memos.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, {})
+            self._state_memos[slot] = hit
         return hit[1]
 
     def get_gas_constraints_from_exyz_nn(self):

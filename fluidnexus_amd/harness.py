@@ -128,7 +128,7 @@ class HotLoop:
         if self.fused_physics:
             from .physics import physical_stage_loss
             return physical_stage_loss(gm, c["lambda_exyz"], c["lambda_gas_constraints"],
-                                       c["lambda_next_gas_constraints"])
+                                       c["lambda_next_gas_constraints"], gm.state_memo("physics_loss"))
         loss = 0.0
         if c["lambda_exyz"] > 0:
             loss = loss + c["lambda_exyz"] * l2_loss(gm._estimate_xyz_nn * gm.scale_factor, gm._estimate_xyz)

@@ -130,7 +130,12 @@ class _PhysicalStageLoss(torch.autograd.Function):
     affine Jacobian of the one-tick advection, gm_dynamics.py:1014-1030)."""
 
     @staticmethod
-    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, grids):
+    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, grids, memo):
+        ctx.memo = memo
+        if memo is not None and "loss" in memo:  # same particle state as an earlier call of this iteration
+            ctx.gm, ctx.lams, ctx.grids = gm, (lam_e, lam_g, lam_n), grids
+            ctx.save_for_backward(*memo["saved"])
+            return memo["loss"].clone()
         with torch.no_grad():
             sf, secs = gm.scale_factor, gm._secs
             x = x_nn * sf
@@ -148,14 +153,21 @@ class _PhysicalStageLoss(torch.autograd.Function):
                 d2 = _DensityRatio.apply(xg, gm._imass, gm.H, gm.p0, grids("guess", xg)) - 1.0
                 loss = loss + lam_n * (d2 ** 2).mean()
         ctx.gm, ctx.lams, ctx.grids = gm, (lam_e, lam_g, lam_n), grids
-        ctx.save_for_backward(x, e if e is not None else x.new_empty(0), d1 if d1 is not None else x.new_empty(0),
-                              d2 if d2 is not None else x.new_empty(0), xg if xg is not None else x.new_empty(0))
+        saved = (x, e if e is not None else x.new_empty(0), d1 if d1 is not None else x.new_empty(0),
+                 d2 if d2 is not None else x.new_empty(0), xg if xg is not None else x.new_empty(0))
+        ctx.save_for_backward(*saved)
+        if memo is not None:
+            memo.update(loss=loss, saved=saved)
+            return loss.clone()
         return loss
 
     @staticmethod
     def backward(ctx, g):
         lib = PL.physics()
         gm, (lam_e, lam_g, lam_n), grids = ctx.gm, ctx.lams, ctx.grids
+        memo = ctx.memo
+        if memo is not None and "grad" in memo:
+            return memo["grad"] * g, None, None, None, None, None, None
         x, e, d1, d2, xg = ctx.saved_tensors
         N = x.shape[0]
         sf, secs = gm.scale_factor, gm._secs
@@ -179,10 +191,14 @@ class _PhysicalStageLoss(torch.autograd.Function):
             out = out + dg * (2.0 * sf)
             if gm.buoyancy_max_y > 0.0:
                 out[:, 1] += (dg * gm._buoyancy).sum(dim=1) * (-(secs * secs) / gm.buoyancy_max_y)
-        return out * g, None, None, None, None, None
+        if memo is not None:
+            memo["grad"] = out
+        return out * g, None, None, None, None, None, None
 
 
-def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next):
-    """Weighted physics terms of the physical-particle stage for GaussianModel `gm` (one autograd node)."""
+def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
+    """Weighted physics terms of the physical-particle stage for GaussianModel `gm` (one autograd node).
+    `memo`: dict kept by the caller while the particle state is unchanged; the terms are view-independent,
+    so the views of one iteration share one evaluation (value and gradient are reused bit for bit)."""
     return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next),
-                                    gm._cached_grid)
+                                    gm._cached_grid, memo)
