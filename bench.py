@@ -107,7 +107,7 @@ def main():
         except Exception:
             image_loss = "torch"
     loop = HotLoop(gm, cams, rank=rank, world=world, physics_per_view=not a.physics_once, image_loss=image_loss,
-                   fused_physics=not a.unfused_physics)
+                   fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics)
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)

@@ -58,6 +58,7 @@ class GaussianModel:
         self._grid_cache = {}
         self._visual_memo = (None, {})
         self._state_memos = {}
+        self.defer_visual_backward = False  # opt-in: see flush_deferred_gradients
         self.setup_functions()
 
     # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
@@ -135,7 +136,8 @@ class GaussianModel:
         x = self._estimate_xyz_nn * self.scale_factor
         key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version, id(self._visual_xyz))
         if self._visual_memo[0] != key:
-            self._visual_memo = (key, {})
+            self.flush_deferred_gradients()
+            self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
         return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
                                           self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1])
 
@@ -189,9 +191,19 @@ class GaussianModel:
         self._estimate_xyz_nn_grad = torch.zeros_like(self._estimate_xyz_nn)
 
     def cache_gradient_current(self):
-        self._estimate_xyz_nn_grad += self._estimate_xyz_nn.grad
+        if self._estimate_xyz_nn.grad is not None:
+            self._estimate_xyz_nn_grad += self._estimate_xyz_nn.grad
+
+    def flush_deferred_gradients(self):
+        """With defer_visual_backward the hidden->visual interpolation back-propagates once per
+        iteration on the summed per-view gradients (the map is linear); add that term to the cache.
+        Called by set_batch_gradient_current, and by the multi-GPU loop before its all-reduce."""
+        dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
+        if dh is not None:
+            self._estimate_xyz_nn_grad += dh * self.scale_factor  # hidden = x_nn * scale_factor
 
     def set_batch_gradient_current(self, batch_size):
+        self.flush_deferred_gradients()
         self._estimate_xyz_nn.grad = self._estimate_xyz_nn_grad * (1.0 / batch_size)
 
     _L2 = ("color", "opacity", "scales", "rotation")

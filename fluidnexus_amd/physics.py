@@ -94,6 +94,9 @@ class _VisualFromHidden(torch.autograd.Function):
             visual_grid = HashGrid(visual, H)
         ctx.save_for_backward(visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob)
         ctx.consts = (H, secs, eps)
+        ctx.memo = memo
+        if memo is not None and memo.get("defer"):
+            memo["saved"] = (visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob, (H, secs, eps))
         return out
 
     @staticmethod
@@ -102,12 +105,35 @@ class _VisualFromHidden(torch.autograd.Function):
         visual, hidden, hidden_prev, sum_w, wvel, vblob = ctx.saved_tensors
         H, secs, eps = ctx.consts
         g = _req(g)
+        memo = ctx.memo
+        if memo is not None and memo.get("defer"):
+            # the map g -> dL/dhidden is linear: sum the upstream gradients of all views that share this
+            # forward and run the kernel once (flush_deferred_visual_backward)
+            if "g_sum" in memo:
+                memo["g_sum"] += g
+            else:
+                memo["g_sum"] = g.clone()
+            return None, None, None, None, None, None, None, None, None
         dh = torch.empty_like(hidden)
         PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
                                                 hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
                                                 vblob.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
                                                 dh.data_ptr(), _stream()))
         return None, dh, None, None, None, None, None, None, None
+
+
+def flush_deferred_visual_backward(memo):
+    """dL/dhidden [N,3] for the gradients accumulated in `memo` by deferred backward calls (or None)."""
+    if memo is None or "g_sum" not in memo:
+        return None
+    lib = PL.physics()
+    visual, hidden, hidden_prev, sum_w, wvel, vblob, (H, secs, eps) = memo["saved"]
+    g = memo.pop("g_sum")
+    dh = torch.empty_like(hidden)
+    PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
+                                            hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
+                                            sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(), dh.data_ptr(), _stream()))
+    return dh
 
 
 def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,

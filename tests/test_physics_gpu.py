@@ -106,6 +106,26 @@ def test_physics_larger_cloud_vs_oracle():
     _close(xc.grad.cpu().numpy(), gv_ref, 2e-4, "d visual")
 
 
+def test_deferred_visual_backward_equals_per_view():
+    """Summing the per-view upstream gradients and back-propagating once == per-view back-propagation."""
+    gm = _model("b")
+    w = torch.tensor(G["w_vis_b"]).cuda()
+    grads = []
+    for defer in (False, True):
+        gm.defer_visual_backward = defer
+        gm._visual_memo = (None, {})
+        gm._estimate_xyz_nn.grad = None
+        gm.zero_gradient_cache_current()
+        for k in range(3):  # three "views" with different upstream gradients
+            (gm.get_visual_xyz_from_nn() * (w * (k + 1))).sum().backward()
+            gm.cache_gradient_current()
+            gm._estimate_xyz_nn.grad = None
+        gm.set_batch_gradient_current(3)
+        grads.append(gm._estimate_xyz_nn.grad.cpu().numpy().copy())
+    _close(grads[1], grads[0], 1e-5, "deferred vs per-view")
+    _close(grads[0], G["d_vis_b"] * 2.0, 1e-4, "per-view vs reference (1+2+3)/3")
+
+
 def test_hot_loop_runs_and_descends():
     """Small config-3-shaped frame: the loss goes down and nothing syncs/NaNs."""
     from fluidnexus_amd.harness import HotLoop, build_smoke_frame
