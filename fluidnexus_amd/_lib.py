@@ -41,7 +41,7 @@ ALLOC_FN = C.CFUNCTYPE(c_void_p, c_size_t, c_void_p)
 SYMBOLS = (
     "fnx_abi_version", "fnx_last_error", "fnx_geom_bytes", "fnx_image_bytes", "fnx_binning_bytes",
     "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",
-    "fnx_rasterize_backward", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
+    "fnx_rasterize_backward", "fnx_rasterize_backward_ex", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
     "fnx_profile_enable", "fnx_profile_read",
 )
 
@@ -85,6 +85,8 @@ def raster():
     lib.fnx_rasterize_backward.restype = i
     lib.fnx_rasterize_backward.argtypes = [i, i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, f, f, p, p, p, p, p,
                                            p, p, p, p, p, p, p, p, p, p]
+    lib.fnx_rasterize_backward_ex.restype = i
+    lib.fnx_rasterize_backward_ex.argtypes = lib.fnx_rasterize_backward.argtypes[:-1] + [i, i, p]
     lib.fnx_mark_visible.restype = i
     lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
     lib.fnx_profile_enable.restype = i

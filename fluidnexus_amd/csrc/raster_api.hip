@@ -34,17 +34,18 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           const float *depths, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
                           float *out_depth, const uint32_t *header, uint32_t capacity);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
-void launch_blend_backward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
-                           const float *bg, const float2 *means2D, const float4 *conic_opacity, const float *colors,
-                           const float *final_Ts, const uint32_t *n_contrib, const float *dL_dpixels,
-                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
-                           const uint32_t *header, uint32_t capacity);
+void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
+                           const uint32_t *point_list, const float *bg, const float2 *means2D,
+                           const float4 *conic_opacity, const float *colors, const float *final_Ts,
+                           const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
+                           uint32_t grad_limit);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
                           float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
                           const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
-                          float *dL_dscale, float *dL_drot);
+                          float *dL_dscale, float *dL_drot, int grad_limit);
 }  // namespace fnx
 
 namespace {
@@ -320,14 +321,15 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
                               out_color, out_depth, stream);
 }
 
-int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,
+int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,
                            const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
                            float scale_modifier, const float *rotations, const float *cov3D_precomp,
                            const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
                            float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
                            char *image_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
-                           float *dL_dscale, float *dL_drot, fnx_stream_t stream) {
+                           float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                              fnx_stream_t stream) {
     (void)R;
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // rasterize_points.cu:160
@@ -337,6 +339,8 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
     if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
     if (scales && (!rotations || !dL_dscale || !dL_drot))
         return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
+    if (geometry_only && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
+    const int limit = (grad_splat_limit < 0 || grad_splat_limit > P) ? P : grad_splat_limit;
     hipStream_t s = (hipStream_t)stream;
     Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
@@ -347,14 +351,29 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
     {
         ProfScope ps(1, s);
-        fnx::launch_blend_backward(channels, s, width, height, img.ranges, bin.point_list, background, g.means2D,
+        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, width, height, img.ranges, bin.point_list, background, g.means2D,
                                    g.conic_opacity, color_ptr, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
-                                   dL_dconic, dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu);
+                                   dL_dconic, dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu, (uint32_t)limit);
     }
     fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
                               cov3D_ptr, viewmatrix, projmatrix, width, height, tan_fovx, tan_fovy, campos, dL_dmean2D,
-                              dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                              dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, limit);
     return hip_check("backward");
+}
+
+int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,
+                           const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                           float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                           char *image_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                           float *dL_dscale, float *dL_drot, fnx_stream_t stream) {
+    return fnx_rasterize_backward_ex(channels, P, D, M, R, background, width, height, means3D, shs, colors_precomp,
+                                     scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos,
+                                     tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
+                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                     dL_dscale, dL_drot, -1, 0, stream);
 }
 
 int fnx_profile_enable(int on) {

@@ -87,7 +87,10 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
 
 // Back-to-front pass of one tile.  Same quadrant / compacted-list structure as the forward blend;
 // additionally a wave only receives entries in front of its own deepest contributor.
-template <int C>
+// MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
+// MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients.
+// Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
+template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                       int H, const float *__restrict__ bg, const float2 *__restrict__ means2D,
@@ -95,8 +98,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
                       const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
                       float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
-                      const uint32_t *__restrict__ header, uint32_t capacity) {
-    constexpr int NV = 6 + C;  // mean2D.xy | conic.xyw | opacity | colour[C]
+                      const uint32_t *__restrict__ header, uint32_t capacity, uint32_t grad_limit) {
+    constexpr int NV = MODE == 0 ? 6 + C : 5;
     __shared__ uint32_t s_id[256];
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
@@ -187,6 +190,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
             const uint32_t j = s_list[w][i];
             const uint32_t q = top - 1 - j;
+            const bool wants = s_id[j] < grad_limit;  // wave-uniform
             float val[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) val[v] = 0.f;
@@ -212,29 +216,31 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                             last_color[ch] = c;
                             const float dL_dchannel = dL_dpixel[ch];
                             dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-                            val[6 + ch] = dchannel_dcolor * dL_dchannel;
+                            if (MODE == 0) val[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)] = dchannel_dcolor * dL_dchannel;
                         }
-                        dL_dalpha *= Tr;
                         last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                        const float dL_dG = rb.y * dL_dalpha;
-                        const float gdx = G * dx;
-                        const float gdy = G * dy;
-                        const float dG_ddelx = -gdx * ra.z - gdy * ra.w;
-                        const float dG_ddely = -gdy * rb.x - gdx * ra.w;
-                        val[0] = dL_dG * dG_ddelx * ddelx_dx;
-                        val[1] = dL_dG * dG_ddely * ddely_dy;
-                        val[2] = -0.5f * gdx * dx * dL_dG;
-                        val[3] = -0.5f * gdx * dy * dL_dG;
-                        val[4] = -0.5f * gdy * dy * dL_dG;
-                        val[5] = G * dL_dalpha;
+                        if (wants) {
+                            dL_dalpha *= Tr;
+                            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                            const float dL_dG = rb.y * dL_dalpha;
+                            const float gdx = G * dx;
+                            const float gdy = G * dy;
+                            const float dG_ddelx = -gdx * ra.z - gdy * ra.w;
+                            const float dG_ddely = -gdy * rb.x - gdx * ra.w;
+                            val[0] = dL_dG * dG_ddelx * ddelx_dx;
+                            val[1] = dL_dG * dG_ddely * ddely_dy;
+                            val[2] = -0.5f * gdx * dx * dL_dG;
+                            val[3] = -0.5f * gdx * dy * dL_dG;
+                            val[4] = -0.5f * gdy * dy * dL_dG;
+                            if (MODE == 0) val[MODE == 0 ? 5 : 0] = G * dL_dalpha;
+                        }
                     }
                 }
             }
 #if FNX_ABLATE == 2
             { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
 #else
-            if (__ballot(active) != 0ull) wave_fold_accumulate<NV>(val, s_acc, j, lane);
+            if (wants && __ballot(active) != 0ull) wave_fold_accumulate<NV>(val, s_acc, j, lane);
 #endif
         }
         __syncthreads();
@@ -253,9 +259,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], a[2]);
                 unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], a[3]);
                 unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 3], a[4]);
-                unsafeAtomicAdd(&dL_dopacity[id], a[5]);
+                if (MODE == 0) {
+                    unsafeAtomicAdd(&dL_dopacity[id], a[MODE == 0 ? 5 : 0]);
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) unsafeAtomicAdd(&dL_dcolors[(size_t)id * C + ch], a[6 + ch]);
+                    for (int ch = 0; ch < C; ch++)
+                        unsafeAtomicAdd(&dL_dcolors[(size_t)id * C + ch], a[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)]);
+                }
             }
         }
         top -= cnt;
@@ -415,9 +424,10 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
                      float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ campos,
                      const float *__restrict__ dL_dmean2D, const float *__restrict__ dL_dconics,
                      float *__restrict__ dL_dmeans, float *__restrict__ dL_dcolor, float *__restrict__ dL_dcov,
-                     float *__restrict__ dL_dsh, float *__restrict__ dL_dscale, float *__restrict__ dL_drot) {
+                     float *__restrict__ dL_dsh, float *__restrict__ dL_dscale, float *__restrict__ dL_drot,
+                     int grad_limit) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    if (idx >= P || idx >= grad_limit || !(radii[idx] > 0)) return;
     const float *cov3D = cov3Ds + 6 * (size_t)idx;
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float gc0 = dL_dconics[4 * (size_t)idx], gc1 = dL_dconics[4 * (size_t)idx + 1],
@@ -514,20 +524,22 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_blend_backward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
-                           const float *bg, const float2 *means2D, const float4 *conic_opacity, const float *colors,
-                           const float *final_Ts, const uint32_t *n_contrib, const float *dL_dpixels,
-                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
-                           const uint32_t *header, uint32_t capacity) {
+void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
+                           const uint32_t *point_list, const float *bg, const float2 *means2D,
+                           const float4 *conic_opacity, const float *colors, const float *final_Ts,
+                           const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
+                           uint32_t grad_limit) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
-    if (C == 3)
-        hipLaunchKernelGGL((blend_backward_kernel<3>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg,
-                           means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolors, header, capacity);
-    else
-        hipLaunchKernelGGL((blend_backward_kernel<1>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg,
-                           means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolors, header, capacity);
+#define FNX_LAUNCH_BB(CC, MM)                                                                                         \
+    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg, \
+                       means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,        \
+                       dL_dopacity, dL_dcolors, header, capacity, grad_limit)
+    if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
+    else if (C == 3) FNX_LAUNCH_BB(3, 1);
+    else if (mode == 0) FNX_LAUNCH_BB(1, 0);
+    else FNX_LAUNCH_BB(1, 1);
+#undef FNX_LAUNCH_BB
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
@@ -535,19 +547,21 @@ void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float
                           float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
                           float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
                           const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
-                          float *dL_dscale, float *dL_drot) {
+                          float *dL_dscale, float *dL_drot, int grad_limit) {
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:360-361
     const float focal_x = W / (2.0f * tan_fovx);
+    const int n = grad_limit < P ? grad_limit : P;
+    if (n <= 0) return;
     if (C == 3)
-        hipLaunchKernelGGL((geom_backward_kernel<3>), dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
+        hipLaunchKernelGGL((geom_backward_kernel<3>), dim3((n + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
                            shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
                            tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
-                           dL_dscale, dL_drot);
+                           dL_dscale, dL_drot, grad_limit);
     else
-        hipLaunchKernelGGL((geom_backward_kernel<1>), dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
+        hipLaunchKernelGGL((geom_backward_kernel<1>), dim3((n + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
                            shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
                            tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
-                           dL_dscale, dL_drot);
+                           dL_dscale, dL_drot, grad_limit);
 }
 
 }  // namespace fnx

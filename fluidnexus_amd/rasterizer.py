@@ -67,15 +67,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, channels=3):
+                        raster_settings, channels=3, grad_splat_limit=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, channels)
+                                     cov3Ds_precomp, raster_settings, channels, grad_splat_limit)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, channels):
+                raster_settings, channels, grad_splat_limit=None):
         lib = _lib.raster()
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:56-58
@@ -133,6 +133,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.channels = Cn
+        ctx.grad_splat_limit = -1 if grad_splat_limit is None else int(grad_splat_limit)
         ctx.aux = (bg, view, proj, campos)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)  # the reference ignores their grads (__init__.py:83)
@@ -160,17 +161,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P != 0:
             dL = _f32c(grad_out_color)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(lib.fnx_rasterize_backward(
+            # skip what autograd would throw away: opacity / colour / SH gradients nobody asked for, and
+            # splats the caller declared gradient-free (GaussianRasterizer.grad_splat_limit)
+            need = ctx.needs_input_grad  # (means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, ...)
+            geometry_only = int(not (need[2] or need[3] or need[4]) and M == 0)
+            _lib.check(lib.fnx_rasterize_backward_ex(
                 Cn, P, int(rs.sh_degree), M, max(ctx.num_rendered, 0), bg.data_ptr(), W, H, means3D.data_ptr(),
                 _ptr(sh), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3Ds_precomp), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), float(rs.tan_fov_x),
                 float(rs.tan_fov_y), radii.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr(), dL.data_ptr(),
                 g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity.data_ptr(), g_colors.data_ptr(),
                 g_means3D.data_ptr(), g_cov3D.data_ptr(), g_sh.data_ptr() if M else None, g_scales.data_ptr(),
-                g_rot.data_ptr(), stream))
+                g_rot.data_ptr(), ctx.grad_splat_limit, geometry_only, stream))
         # same order and shapes as ch3 __init__.py:128-138 / rasterize_points.cu:150-158
         return (g_means3D.view(P, 3), g_means2D.view(P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
-                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None)
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -192,6 +197,9 @@ class GaussianRasterizer(nn.Module):
     """ch3 __init__.py:157-215.  `channels` selects the ch3 (3) or ch1 (1) behaviour."""
 
     channels = 3
+    # Optional hint (not in the reference): only splats with index < grad_splat_limit need gradients,
+    # e.g. when static background Gaussians are concatenated behind the optimised ones.
+    grad_splat_limit = None
 
     def __init__(self, raster_settings, channels=None):
         super().__init__()
@@ -235,4 +243,4 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = empty
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings, self.channels)
+                                   raster_settings, self.channels, self.grad_splat_limit)

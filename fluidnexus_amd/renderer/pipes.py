@@ -113,6 +113,10 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
     screen = _screen_space_like(means3D)
     rasterizer = GRzer(raster_settings=_settings(GRsetting, viewpoint_camera, bg_color, scaling_modifier,
                                                  gm.active_sh_degree))
+    if not (gpf_only or gs_only) and hasattr(rasterizer, "grad_splat_limit") and not any(
+            getattr(gm, f"_gs_{n}").requires_grad for n in ("xyz", "opacity", "scales", "rotation", "color")):
+        # static background Gaussians sit behind the fluid ones in the concatenation and take no gradient
+        rasterizer.grad_splat_limit = render_xyz.shape[0]
     image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen.float(), shs=None,
                                      colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
                                      rotations=rotations.float(), cov3D_precomp=None)

@@ -103,6 +103,22 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                            float *dL_dscale, float *dL_drot, fnx_stream_t stream);
 
+/*
+ * Extension of fnx_rasterize_backward for callers that discard part of the result (the reference
+ * always computes everything): only splats with id < grad_splat_limit receive gradients (-1 = all;
+ * the others still take part in the blending recurrences), and with geometry_only != 0 the
+ * opacity / colour gradients are not produced (dL_dopacity, dL_dcolor stay as passed in).
+ */
+int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,
+                              const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
+                              float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                              const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                              float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                              char *image_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                              float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                              float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                              fnx_stream_t stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-25): present[i] = view-space z > 0.2 (auxiliary.h:138). */
 int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                      fnx_stream_t stream);

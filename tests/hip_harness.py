@@ -89,19 +89,20 @@ class HipRun:
             color=self.color, depth=self.depth)
         return {k: v.cpu().numpy() for k, v in out.items()}
 
-    def backward(self, dL_dcolor):
+    def backward(self, dL_dcolor, grad_splat_limit=-1, geometry_only=0):
         P, Cn, M, dev = self.P, self.C, self.M, self.dev
         z = lambda *s: torch.zeros(*s, device=dev)
         g = dict(dL_dmeans2D=z(P, 3), dL_dconic=z(P, 2, 2), dL_dopacity=z(P, 1), dL_dcolors=z(P, Cn),
                  dL_dmeans3D=z(P, 3), dL_dcov3D=z(P, 6), dL_dsh=z(P, M, 3), dL_dscales=z(P, 3), dL_drotations=z(P, 4))
         dL = _t(dL_dcolor, dev).reshape(Cn, self.H, self.W).contiguous()
-        _lib.check(self.lib.fnx_rasterize_backward(
+        _lib.check(self.lib.fnx_rasterize_backward_ex(
             Cn, P, self.D, M, self.R, _p(self.bg), self.W, self.H, _p(self.means3D), _p(self.shs), _p(self.colors),
             _p(self.scales), self.mod, _p(self.rots), _p(self.cov), _p(self.view), _p(self.proj), _p(self.campos),
             self.tanx, self.tany, _p(self.radii), self.geom.data_ptr(), _p(self.binning), self.img.data_ptr(),
             dL.data_ptr(), g["dL_dmeans2D"].data_ptr(), g["dL_dconic"].data_ptr(), g["dL_dopacity"].data_ptr(),
             g["dL_dcolors"].data_ptr(), g["dL_dmeans3D"].data_ptr(), g["dL_dcov3D"].data_ptr(), _p(g["dL_dsh"]),
-            g["dL_dscales"].data_ptr(), g["dL_drotations"].data_ptr(), torch.cuda.current_stream().cuda_stream))
+            g["dL_dscales"].data_ptr(), g["dL_drotations"].data_ptr(), int(grad_splat_limit), int(geometry_only),
+            torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         return {k: v.cpu().numpy() for k, v in g.items()}
 

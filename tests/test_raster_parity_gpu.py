@@ -107,6 +107,30 @@ def test_cov3d_precomp(oracle):
     _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
 
 
+def test_backward_extension_limit_and_geometry_only(oracle):
+    """fnx_rasterize_backward_ex: gradients only for splats below the limit, optionally geometry only --
+    the kept entries equal the full backward's, the rest stay zero."""
+    P, W, H = 4000, 96, 96
+    g = S.random_gaussians(P, seed=31, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    f, h = _run_pair(oracle, g, cam, W, H, np.array([0.2, 0.3, 0.4], np.float32))
+    dL = np.random.RandomState(5).normal(size=(3, H, W)).astype(np.float32)
+    ref = oracle.backward(f, dL)
+    lim = 1500
+    part = h.backward(dL, grad_splat_limit=lim, geometry_only=1)
+    for k in ("dL_dmeans2D", "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dcov3D", "dL_dconic"):
+        r = ref[k].reshape(P, -1)
+        got = part[k].reshape(P, -1)
+        assert np.abs(got[:lim] - r[:lim]).max() <= 2e-4 * np.abs(r).max(), k
+        assert (got[lim:] == 0).all(), k
+    assert (part["dL_dopacity"] == 0).all() and (part["dL_dcolors"] == 0).all()
+    part2 = h.backward(dL, grad_splat_limit=lim, geometry_only=0)
+    for k in ("dL_dopacity", "dL_dcolors"):
+        r, got = ref[k].reshape(P, -1), part2[k].reshape(P, -1)
+        assert np.abs(got[:lim] - r[:lim]).max() <= 2e-4 * np.abs(r).max(), k
+        assert (got[lim:] == 0).all(), k
+
+
 def test_edge_cases(oracle):
     """behind-camera and off-screen splats, opaque stacks that saturate T, a tile list longer
     than one 256-entry staging round, an LDS-overflowing tile (global-memory sort fallback)."""
