@@ -88,9 +88,13 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FNX_FORCE_DIST") == "1"  # the latter: 1-rank smoke of the RCCL path
+    if use_dist:
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # keep stdout to the one JSON line (the banner goes to stdout)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fluidnexus_amd import _lib, rasterizer
     from fluidnexus_amd.harness import HotLoop, build_smoke_frame
@@ -106,7 +110,7 @@ def main():
             image_loss = "fused"
         except Exception:
             image_loss = "torch"
-    loop = HotLoop(gm, cams, rank=rank, world=world, physics_per_view=not a.physics_once, image_loss=image_loss,
+    loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
                    fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics)
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
@@ -119,7 +123,7 @@ def main():
     if not a.host_sync:
         rasterizer.check_status()  # also records the binning high-water mark
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     _lib.profile_enable(True)
     torch.cuda.synchronize()
@@ -127,12 +131,12 @@ def main():
     for _ in range(a.steps):
         loop.iteration()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     if not a.host_sync:
         rasterizer.check_status()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -185,7 +189,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

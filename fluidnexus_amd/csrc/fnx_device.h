@@ -88,25 +88,37 @@ __device__ __forceinline__ float exp_fixed(float x) {
     return y * __uint_as_float((uint32_t)(ni + 127) << 23);
 }
 
-// Which 8x8 quadrants of a 16x16 tile can receive a contribution (alpha >= 1/255) from a splat with
-// centre (x, y), conic (a, b, c) and opacity o?  Bit q <-> quadrant (q & 1, q >> 1).  Conservative by
-// construction: alpha >= 1/255 needs power >= -ln(255 o); that ellipse's axis-aligned bounding box
-// (half extents sqrt(2 tau c / det), sqrt(2 tau a / det)) is inflated by 1e-3 relative + 0.01 px,
-// orders of magnitude above fp32 evaluation error, so culled (pixel, splat) pairs are exactly the
-// pairs the un-culled loop would have skipped.  `thr` is the matching power threshold below which
-// exp() need not be evaluated (-inf when nothing can be said).
-__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float a, float b, float c, float o, float tile_x0,
-                                                 float tile_y0, float &thr) {
+// Footprint of a splat for culling, computed once per splat in preprocess.  A pixel can receive a
+// contribution (alpha >= 1/255) only if power >= -ln(255 o); that ellipse's axis-aligned bounding
+// box has half extents sqrt(2 tau c / det), sqrt(2 tau a / det) (conic (a, b, c), det = ac - b^2).
+// The extents are inflated by 1e-3 relative + 0.01 px and tau by 1e-4 relative + 1e-3, orders of
+// magnitude above fp32 evaluation error, so culled (pixel, splat) pairs are exactly pairs the
+// un-culled loop would have skipped.  Outputs: thr = power threshold below which exp() need not be
+// evaluated; (ex, ey) half extents, ex < 0 meaning "never contributes" (o < 1/255: alpha = min(.99,
+// o G) with G <= 1 stays below 1/255), +huge meaning "cannot be culled".
+__device__ __forceinline__ void splat_footprint(float a, float b, float c, float o, float &thr, float &ex, float &ey) {
     thr = -3.0e38f;
-    if (o < 1.0f / 255.0f) return 0u;  // alpha = min(.99, o * G) with G <= 1 stays below 1/255
+    ex = ey = 3.0e38f;
+    if (o < 1.0f / 255.0f) {
+        ex = ey = -1.0f;
+        return;
+    }
     const float tau = __logf(255.0f * o) * 1.0001f + 1.0e-3f;
-    if (!(tau > 0.0f)) return 0xFu;
+    if (!(tau > 0.0f)) return;
     thr = -tau;
     const float det = a * c - b * b;
-    if (!(det > 0.0f)) return 0xFu;
+    if (!(det > 0.0f)) return;
     const float k = 2.0f * tau / det;
-    const float ex = sqrtf(k * c) * 1.001f + 0.01f, ey = sqrtf(k * a) * 1.001f + 0.01f;
-    if (!(ex >= 0.0f) || !(ey >= 0.0f)) return 0xFu;  // NaN guard
+    const float fx = sqrtf(k * c) * 1.001f + 0.01f, fy = sqrtf(k * a) * 1.001f + 0.01f;
+    if (!(fx >= 0.0f) || !(fy >= 0.0f)) return;  // NaN guard
+    ex = fx;
+    ey = fy;
+}
+
+// Which 8x8 quadrants of the 16x16 tile at (tile_x0, tile_y0) the footprint box touches.
+// Bit q <-> quadrant (q & 1, q >> 1).
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ex, float ey, float tile_x0, float tile_y0) {
+    if (ex < 0.0f) return 0u;
     const float xl = x - ex, xh = x + ex, yl = y - ey, yh = y + ey;
     const bool cx0 = (xl <= tile_x0 + 7.0f) && (xh >= tile_x0), cx1 = (xl <= tile_x0 + 15.0f) && (xh >= tile_x0 + 8.0f);
     const bool cy0 = (yl <= tile_y0 + 7.0f) && (yh >= tile_y0), cy1 = (yl <= tile_y0 + 15.0f) && (yh >= tile_y0 + 8.0f);

@@ -43,6 +43,7 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     o->sort_hist = off;     off = align_up(off + (2 * 256 * nsb + 256) * 4);
     o->blk_hist = off;      off = align_up(off + nb * t * 2);
     o->blk_rel = off;       off = align_up(off + nb * t * 4);
+    o->blend_rec = off;     off = align_up(off + p * 64);
     o->total = off + kAlign;
 }
 

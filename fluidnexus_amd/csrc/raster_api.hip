@@ -18,7 +18,8 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, int prefiltered);
+                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec,
+                       int prefiltered);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count);
@@ -30,13 +31,11 @@ void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, cons
 void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
                        const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
-                          const float2 *means2D, const float *features, const float4 *conic_opacity,
-                          const float *depths, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
-                          float *out_depth, const uint32_t *header, uint32_t capacity);
+                          const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
-                           const uint32_t *point_list, const float *bg, const float2 *means2D,
-                           const float4 *conic_opacity, const float *colors, const float *final_Ts,
+                           const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit);
@@ -81,6 +80,7 @@ struct Geom {
     uint32_t *sort_key0, *sort_key1, *sort_val0, *sort_val1, *rank_of, *sort_hist;
     uint16_t *blk_hist;
     uint32_t *blk_rel;
+    float4 *blend_rec;
 };
 Geom carve_geom(char *blob, int P, int W, int H) {
     fnx_geom_layout_t L;
@@ -103,6 +103,7 @@ Geom carve_geom(char *blob, int P, int W, int H) {
     g.sort_hist = (uint32_t *)(b + L.sort_hist);
     g.blk_hist = (uint16_t *)(b + L.blk_hist);
     g.blk_rel = (uint32_t *)(b + L.blk_rel);
+    g.blend_rec = (float4 *)(b + L.blend_rec);
     return g;
 }
 struct Img {
@@ -230,7 +231,7 @@ int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int 
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
                            tan_fovy, rad, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched,
-                           g.blk_hist, g.sort_key0, prefiltered);
+                           g.blk_hist, g.sort_key0, g.blend_rec, prefiltered);
     }
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header);
@@ -286,12 +287,11 @@ int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, in
     fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap);
     fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap);
     }
-    const float *features = colors_precomp ? colors_precomp : g.rgb;  // rasterizer_impl.cu:299
+    (void)colors_precomp;  // colours were packed into the blend records by stage 1 (rasterizer_impl.cu:299)
     {
         ProfScope ps(0, s);
-        fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.means2D, features,
-                                  g.conic_opacity, g.depths, background, img.final_T, img.n_contrib, out_color,
-                                  out_depth, img.header, cap);
+        fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
+                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap);
     }
     return hip_check("stage2");
 }
@@ -347,12 +347,12 @@ int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const fl
     // the capacity this blob was filled with is irrelevant here: point_list sits at offset 0
     Bin bin = carve_bin(binning_buffer, 0);
     const int *rad = radii ? radii : g.radii;
-    const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;      // rasterizer_impl.cu:367
+    (void)colors_precomp;  // colours live in the blend records (rasterizer_impl.cu:367)
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
     {
         ProfScope ps(1, s);
-        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, width, height, img.ranges, bin.point_list, background, g.means2D,
-                                   g.conic_opacity, color_ptr, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
+        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, width, height, img.ranges, bin.point_list,
+                                   background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
                                    dL_dconic, dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu, (uint32_t)limit);
     }
     fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,

@@ -93,8 +93,7 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
 template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
-                      int H, const float *__restrict__ bg, const float2 *__restrict__ means2D,
-                      const float4 *__restrict__ conic_opacity, const float *__restrict__ colors,
+                      int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
                       const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
                       const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
                       float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
@@ -153,18 +152,18 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         if ((uint32_t)tid < cnt) {
             const uint32_t q = top - 1 - tid;
             const uint32_t id = point_list[r0 + q];
-            const float2 xy = means2D[id];
-            const float4 co = conic_opacity[id];
-            float thr;
-            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0, thr);
+            const float4 *rec = blend_rec + 4 * (size_t)id;
+            const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+            qm = quadrant_mask(ra.x, ra.y, rc.x, rc.y, tile_x0, tile_y0);
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);
             s_id[tid] = id;
-            s_ra[tid] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_rb[tid] = make_float4(co.z, co.w, thr, 0.f);
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) s_col[ch][tid] = colors[(size_t)id * C + ch];
+            s_ra[tid] = ra;
+            s_rb[tid] = rb;
+            s_col[0][tid] = rc.z;
+            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = rc.w;
+            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = rec[3].x;
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
@@ -525,16 +524,15 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 
 // ---------------------------------------------------------------------------------------------
 void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
-                           const uint32_t *point_list, const float *bg, const float2 *means2D,
-                           const float4 *conic_opacity, const float *colors, const float *final_Ts,
+                           const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
 #define FNX_LAUNCH_BB(CC, MM)                                                                                         \
     hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg, \
-                       means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic,        \
-                       dL_dopacity, dL_dcolors, header, capacity, grad_limit)
+                       blend_rec, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors,    \
+                       header, capacity, grad_limit)
     if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
     else if (C == 3) FNX_LAUNCH_BB(3, 1);
     else if (mode == 0) FNX_LAUNCH_BB(1, 0);

@@ -100,7 +100,8 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float tan_fovy, float focal_x, float focal_y, int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
-                  uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ sort_key, int T, int prefiltered) {
+                  uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ sort_key, float4 *__restrict__ blend_rec,
+                  int T, int prefiltered) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -139,17 +140,29 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                 const float px = ndc2pix(p_proj.x, W), py = ndc2pix(p_proj.y, H);
                 tile_rect(px, py, (int)my_radius, gx, gy, x0, y0, x1, y1);
                 if ((uint32_t)(x1 - x0) * (uint32_t)(y1 - y0) != 0) {
+                    float col[3] = {0.f, 0.f, 0.f};
                     if (colors_precomp == nullptr) {
-                        float res[3];
-                        sh_to_rgb(idx, D, M, means3D, campos, shs, clamped, res);
-                        rgb[(size_t)idx * C + 0] = res[0];
-                        if (C > 1) rgb[(size_t)idx * C + 1] = res[1];
-                        if (C > 2) rgb[(size_t)idx * C + 2] = res[2];
+                        sh_to_rgb(idx, D, M, means3D, campos, shs, clamped, col);
+                        rgb[(size_t)idx * C + 0] = col[0];
+                        if (C > 1) rgb[(size_t)idx * C + 1] = col[1];
+                        if (C > 2) rgb[(size_t)idx * C + 2] = col[2];
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) col[ch] = colors_precomp[(size_t)idx * C + ch];
                     }
+                    const float opac = opacities[idx];
                     depths[idx] = p_view.z;
                     radii[idx] = (int)my_radius;
                     means2D[idx] = make_float2(px, py);
-                    conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
+                    conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opac);
+                    // packed record for the blend kernels (one 64-byte line per splat)
+                    float thr, ex, ey;
+                    splat_footprint(conic.x, conic.y, conic.z, opac, thr, ex, ey);
+                    float4 *rec = blend_rec + 4 * (size_t)idx;
+                    rec[0] = make_float4(px, py, conic.x, conic.y);
+                    rec[1] = make_float4(conic.z, opac, thr, p_view.z);
+                    rec[2] = make_float4(ex, ey, col[0], col[1]);
+                    rec[3] = make_float4(col[2], 0.f, 0.f, 0.f);
                     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
                     key = __float_as_uint(p_view.z);
                     live = true;
@@ -220,9 +233,8 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
-                     int H, const float2 *__restrict__ means2D, const float *__restrict__ features,
-                     const float4 *__restrict__ conic_opacity, const float *__restrict__ depths,
-                     const float *__restrict__ bg, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                     int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
+                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
                      uint32_t capacity) {
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
@@ -253,15 +265,14 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
-            const uint32_t id = point_list[base + tid];
-            const float2 xy = means2D[id];
-            const float4 co = conic_opacity[id];
-            float thr;
-            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tile_x0, tile_y0, thr);
-            s_ra[tid] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_rb[tid] = make_float4(co.z, co.w, thr, depths[id]);
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) s_col[ch][tid] = features[(size_t)id * C + ch];
+            const float4 *rec = blend_rec + 4 * (size_t)point_list[base + tid];
+            const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+            qm = quadrant_mask(ra.x, ra.y, rc.x, rc.y, tile_x0, tile_y0);
+            s_ra[tid] = ra;
+            s_rb[tid] = rb;
+            s_col[0][tid] = rc.z;
+            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = rc.w;
+            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = rec[3].x;
         }
         uint32_t rank[4];
 #pragma unroll
@@ -336,14 +347,14 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 const float *view, const float *proj, const float *campos, int W, int H, float tan_fovx,
                                 float tan_fovy, int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key,
-                                int prefiltered) {
+                                float4 *blend_rec, int prefiltered) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:207-208
     const float focal_x = W / (2.0f * tan_fovx);
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(splat_blocks(P)), dim3(256), (size_t)T * 4, s, P, D, M, means3D,
                        scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view,
                        proj, campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb,
-                       conic_opacity, gx, gy, tiles_touched, blk_hist, sort_key, T, prefiltered);
+                       conic_opacity, gx, gy, tiles_touched, blk_hist, sort_key, blend_rec, T, prefiltered);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -351,17 +362,18 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, int prefiltered) {
+                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec,
+                       int prefiltered) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
-                               prefiltered);
+                               blend_rec, prefiltered);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
-                               prefiltered);
+                               blend_rec, prefiltered);
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header) {
@@ -369,18 +381,15 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
-                          const float2 *means2D, const float *features, const float4 *conic_opacity,
-                          const float *depths, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
-                          float *out_depth, const uint32_t *header, uint32_t capacity) {
+                          const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     if (C == 3)
         hipLaunchKernelGGL((blend_forward_kernel<3>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           means2D, features, conic_opacity, depths, bg, final_T, n_contrib, out_color, out_depth,
-                           header, capacity);
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity);
     else
         hipLaunchKernelGGL((blend_forward_kernel<1>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           means2D, features, conic_opacity, depths, bg, final_T, n_contrib, out_color, out_depth,
-                           header, capacity);
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity);
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

@@ -82,13 +82,15 @@ class HotLoop:
     """One frame's optimisation loop over `gm` and `cams` (physical-particle stage)."""
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
-                 physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False):
+                 physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
+                 force_all_reduce=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
         self.physics_per_view = physics_per_view
         self.image_loss = image_loss
         self.fused_physics = fused_physics
+        self.force_all_reduce = force_all_reduce
         gm.defer_visual_backward = bool(defer_visual_backward)
         dev = gm._xyz.device
         self.background = torch.zeros(3, device=dev)
@@ -164,7 +166,7 @@ class HotLoop:
             gm.cache_gradient_current()
             gm.optimizer.zero_grad()
         gm.flush_deferred_gradients()
-        if self.world > 1:
+        if self.world > 1 or self.force_all_reduce:
             dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
         gm.set_batch_gradient_current(batch)
         gm.optimizer.step()

@@ -153,6 +153,8 @@ typedef struct {
     size_t sort_hist;     /* u32[(2*ceil(P/1024)+1)*256] radix digit histograms + prefixes */
     size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of block b touching tile t */
     size_t blk_rel;       /* u32[ceil(P/1024) * T] exclusive prefix over blocks     */
+    size_t blend_rec;     /* f32[16P] packed per-splat record read by the blend kernels:
+                             x y a b | c o thr depth | ex ey col0 col1 | col2 - - -   */
     size_t total;
 } fnx_geom_layout_t;
 typedef struct {
