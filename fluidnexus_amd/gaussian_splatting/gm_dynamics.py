@@ -59,6 +59,7 @@ class GaussianModel:
         self._visual_memo = (None, {})
         self._state_memos = {}
         self.defer_visual_backward = False  # opt-in: see flush_deferred_gradients
+        self.fit_color = self.fit_opacity = self.fit_scales = self.fit_rotation = True
         self.setup_functions()
 
     # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
@@ -163,20 +164,29 @@ class GaussianModel:
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
     def training_setup_current_level_two(self, optim_args):
+        """Visual-particle stage: colour / opacity / scales / rotation of the visual particles become
+        leaves, each behind its fit_* switch (gm_dynamics.py:416-433)."""
         groups = []
-        for name, lr in (("color", optim_args.color_lr), ("opacity", optim_args.opacity_lr),
-                         ("scales", optim_args.scaling_lr), ("rotation", optim_args.rotation_lr)):
-            t = getattr(self, f"_visual_{name}")
-            p = nn.Parameter(t.detach().clone().requires_grad_(True))
+        for name in self._L2:
+            if not getattr(self, f"fit_{name}", True):
+                continue
+            p = nn.Parameter(getattr(self, f"_visual_{name}").detach().clone().requires_grad_(True))
             setattr(self, f"_visual_{name}", p)
-            groups.append({"params": [p], "lr": lr, "name": f"visual_{name}"})
+            groups.append({"params": [p], "lr": getattr(optim_args, f"visual_{name}_lr"), "name": f"visual_{name}"})
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
-    def update_learning_rate_current(self, iteration):
+    def update_learning_rate_first_visual(self, iteration):
+        """Returns the scheduled rate; like the reference (gm_dynamics.py:435-441) it does NOT write it
+        into the optimiser -- the group keeps the rate set at training_setup time."""
         for g in self.optimizer.param_groups:
-            if g["name"] in ("estimate_xyz_nn", "visual_xyz"):
-                g["lr"] = self.xyz_scheduler_args(iteration) * self.pos_lr_scale_factor
-                return g["lr"]
+            if g["name"] == "visual_xyz":
+                return self.xyz_scheduler_args(iteration)
+
+    def update_learning_rate_current(self, iteration):
+        """gm_dynamics.py:443-449: returns the scheduled rate, leaves the optimiser untouched."""
+        for g in self.optimizer.param_groups:
+            if g["name"] == "estimate_xyz_nn":
+                return self.xyz_scheduler_args(iteration)
 
     def zero_gradient_cache_first_visual(self):
         self._visual_xyz_grad = torch.zeros_like(self._visual_xyz)
@@ -208,17 +218,20 @@ class GaussianModel:
 
     _L2 = ("color", "opacity", "scales", "rotation")
 
+    def _l2_active(self):
+        return [n for n in self._L2 if getattr(self, f"fit_{n}", True) and getattr(self, f"_visual_{n}").requires_grad]
+
     def zero_gradient_cache_current_level_two(self):
-        self._l2_grad = {n: torch.zeros_like(getattr(self, f"_visual_{n}")) for n in self._L2}
+        self._l2_grad = {n: torch.zeros_like(getattr(self, f"_visual_{n}")) for n in self._l2_active()}
 
     def cache_gradient_current_level_two(self):
-        for n in self._L2:
+        for n in self._l2_active():
             g = getattr(self, f"_visual_{n}").grad
             if g is not None:
                 self._l2_grad[n] += g
 
     def set_batch_gradient_current_level_two(self, batch_size):
-        for n in self._L2:
+        for n in self._l2_active():
             getattr(self, f"_visual_{n}").grad = self._l2_grad[n] * (1.0 / batch_size)
 
 

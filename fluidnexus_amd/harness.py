@@ -33,6 +33,13 @@ SMOKE = dict(H=2.0, KNN_K=100, p0=1.5, secs=0.033, k=3, lambda_dssim=0.2, lambda
              position_lr_max_steps=30000)
 
 
+# visual-particle ("level two") stage constants of the same config
+SMOKE_L2 = dict(lambda_dssim=0.2, lambda_image=1.0, lambda_consistency_color=0.1, lambda_consistency_opacity=0.1,
+                lambda_consistency_scales=0.1, lambda_consistency_rotation=0.1, lambda_reg_scaling=0.0,
+                scaling_reg_ratio_threshold=5.0, visual_color_lr=0.0025, visual_opacity_lr=0.05,
+                visual_scales_lr=0.005, visual_rotation_lr=0.001)
+
+
 def shard_views(n_views: int, rank: int, world: int):
     """view v of the iteration's batch -> rank v mod world (5 views on 4 GPUs = 2/1/1/1)."""
     return [v for v in range(n_views) if v % world == rank]
@@ -169,5 +176,76 @@ class HotLoop:
         if self.world > 1 or self.force_all_reduce:
             dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
         gm.set_batch_gradient_current(batch)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad()
+
+
+class HotLoopLevelTwo:
+    """Visual-particle stage of one frame (train_visual_particle.py:133-222): positions fixed, the
+    visual particles' colour / opacity / scales / rotation are optimised against all views with
+    L1 + D-SSIM on the RGB image plus consistency-to-previous-frame L2 terms; gradients are cached per
+    view, averaged over the batch (gm_dynamics.py:474-503) and applied with Adam(eps = 1e-15)."""
+
+    def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, cfg=SMOKE_L2, image_loss="fused",
+                 log_scalars=False):
+        from .utils.loss_utils import l2_loss_consistency
+        self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
+        self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
+        self.image_loss, self.log_scalars = image_loss, log_scalars
+        self.background = torch.zeros(3, device=gm._visual_xyz.device)
+        self.prev = {n: getattr(gm, f"_visual_{n}").detach().clone() for n in gm._L2}
+        self._cons = l2_loss_consistency
+        gm.training_setup_current_level_two(SimpleNamespace(**{k: cfg[k] for k in cfg if k.endswith("_lr")}))
+        self.last = {}
+
+    @torch.no_grad()
+    def make_targets(self, noise=0.3, seed=0):
+        """Synthetic ground truth: the scene rendered with perturbed visual colours / opacities."""
+        gm = self.gm
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        keep = {n: getattr(gm, f"_visual_{n}").data.clone() for n in ("color", "opacity")}
+        for n in keep:
+            t = getattr(gm, f"_visual_{n}")
+            t.data += noise * torch.randn(t.shape, generator=g).to(t.device)
+        gm._visual_color.data.clamp_(0.0, 1.0)
+        for cam in self.cams:
+            pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                   pos_type="visual", scale=True)
+            cam.original_image = pkg["render"].detach().clamp(0, 1).clone()
+        for n, v in keep.items():
+            getattr(gm, f"_visual_{n}").data.copy_(v)
+
+    def iteration(self):
+        gm, c = self.gm, self.cfg
+        gm.total_iterations += 1
+        gm.zero_gradient_cache_current_level_two()
+        batch = len(self.cams)
+        for v in shard_views(batch, self.rank, self.world):
+            cam = self.cams[v]
+            pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                   pos_type="visual", scale=True)
+            image, gt = pkg["render"], cam.original_image
+            if self.image_loss == "fused":
+                from .losses import fused_l1_ssim
+                l1_value, s = fused_l1_ssim(image, gt)
+                ssim_value = 1.0 - s
+            else:
+                l1_value, ssim_value = l1_loss(image, gt), 1.0 - ssim(image, gt)
+            loss = ((1.0 - c["lambda_dssim"]) * l1_value + c["lambda_dssim"] * ssim_value) * c["lambda_image"]
+            for n in gm._l2_active():
+                loss = loss + c[f"lambda_consistency_{n}"] * self._cons(getattr(gm, f"_visual_{n}"), self.prev[n])
+            if "scales" in gm._l2_active() and c["lambda_reg_scaling"] > 0:
+                sc = gm.get_visual_scaling
+                ratio = torch.max(sc, dim=1).values / torch.min(sc, dim=1).values
+                loss = loss + c["lambda_reg_scaling"] * torch.clamp_min(ratio - c["scaling_reg_ratio_threshold"], 0).mean()
+            if self.log_scalars:
+                self.last = dict(l1=l1_value.item(), ssim=ssim_value.item(), total=loss.item())
+            loss.backward()
+            gm.cache_gradient_current_level_two()
+            gm.optimizer.zero_grad()
+        if self.world > 1:
+            for n in gm._l2_active():
+                dist.all_reduce(gm._l2_grad[n], op=dist.ReduceOp.SUM)
+        gm.set_batch_gradient_current_level_two(batch)
         gm.optimizer.step()
         gm.optimizer.zero_grad()
