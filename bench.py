@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--image-loss", default="auto", choices=["auto", "torch", "fused"])
     ap.add_argument("--physics-once", action="store_true",
                     help="evaluate the view-independent physics terms once per iteration instead of once per view")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
@@ -111,7 +112,8 @@ def main():
         except Exception:
             image_loss = "torch"
     loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
-                   fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics)
+                   fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics,
+                   capturable=not (a.no_graph or a.host_sync))
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)
@@ -122,10 +124,22 @@ def main():
         loop.iteration()
     if not a.host_sync:
         rasterizer.check_status()  # also records the binning high-water mark
+    graph_mode = False
+    if loop.capturable:
+        try:
+            loop.capture(warmup=1)
+            for _ in range(2):
+                loop.iteration()
+            rasterizer.check_status()
+            graph_mode = True
+        except Exception as e:  # fall back to eager launches, say so in the JSON
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            loop.use_graph(False)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    _lib.profile_enable(True)
+    if not graph_mode:
+        _lib.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -141,7 +155,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # roofline of the dominant kernel (blend backward), measured live with HIP events on its stream
+    # roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events
+    # cannot be read back from a replayed graph, so in graph mode the same iteration is run eagerly a
+    # few more times (outside the timed region) with the event hooks on.
+    if graph_mode:
+        loop.use_graph(False)
+        _lib.profile_enable(True)
+        for _ in range(5):
+            loop.iteration()
+        torch.cuda.synchronize()
     prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "binning",
                                                                  "preprocess"))}
     _lib.profile_enable(False)
@@ -178,6 +200,7 @@ def main():
                    "num_rendered_per_view": R, "visible_per_view": P_vis,
                    "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
                    "host_sync": bool(a.host_sync), "image_loss": image_loss,
+                   "launch": "hipGraph replay of one whole iteration" if graph_mode else "eager",
                    "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
                    + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
         "roofline": roofline,

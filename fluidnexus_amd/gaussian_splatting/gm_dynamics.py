@@ -100,6 +100,12 @@ class GaussianModel:
         estimate_velocity = tmp_velocity + cur_buoyancy * self._secs + self._secs * self._force
         return self._estimate_xyz_nn * self.scale_factor + self._secs * estimate_velocity
 
+    def invalidate_caches(self):
+        """Forget everything derived from the current particle state (grids, memoised forwards)."""
+        self._grid_cache.clear()
+        self._state_memos.clear()
+        self._visual_memo = (None, {})
+
     def _cached_grid(self, slot, xyz):
         """Neighbour grids depend only on the current value of _estimate_xyz_nn: rebuild when the
         optimiser has stepped (tensor version bump), reuse across the views of one iteration."""
@@ -155,12 +161,13 @@ class GaussianModel:
                                           eps=1e-15)
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
-    def training_setup_current(self, optim_args):
+    def training_setup_current(self, optim_args, capturable=False):
+        """`capturable`: build the Adam state on the device so the step can live inside a hipGraph."""
         init = self._estimate_xyz.detach().clone() / self.scale_factor
         self._estimate_xyz_nn = nn.Parameter(init.requires_grad_(True))
         lr = optim_args.position_lr_init * self.spatial_lr_scale * self.pos_lr_scale_factor
         self.optimizer = torch.optim.Adam([{"params": [self._estimate_xyz_nn], "lr": lr, "name": "estimate_xyz_nn"}],
-                                          lr=0.0, eps=1e-15)
+                                          lr=0.0, eps=1e-15, capturable=bool(capturable))
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
     def training_setup_current_level_two(self, optim_args):

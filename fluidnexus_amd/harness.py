@@ -90,7 +90,7 @@ class HotLoop:
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
-                 force_all_reduce=False):
+                 force_all_reduce=False, capturable=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
@@ -103,13 +103,25 @@ class HotLoop:
         self.background = torch.zeros(3, device=dev)
         self.optim_args = SimpleNamespace(**{k: cfg[k] for k in ("position_lr_init", "position_lr_final",
                                                                "position_lr_delay_mult", "position_lr_max_steps")})
-        gm.training_setup_current(self.optim_args)
+        self.capturable = capturable
+        gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
         self.last = {}
+        self.graph = None
+        self._replay = False
+        # Graph mode keeps every iteration (eager or captured) on one dedicated stream: autograd's gradient
+        # accumulation is bound to the stream a leaf was first used on, and a leaf first used on the
+        # default stream would drag that stream into the capture.
+        self.stream = torch.cuda.Stream(device=dev) if capturable else None
 
     @torch.no_grad()
     def make_targets(self, shift=0.3):
         """Synthetic ground truth: the scene rendered with the hidden particles displaced by `shift`."""
+        if self.stream is not None and torch.cuda.current_stream() != self.stream:
+            with torch.cuda.stream(self.stream):
+                self.make_targets(shift)
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return
         gm = self.gm
         keep = gm._estimate_xyz_nn.data.clone()
         gm._estimate_xyz_nn.data += shift / gm.scale_factor
@@ -150,7 +162,48 @@ class HotLoop:
             loss = loss + c["lambda_next_gas_constraints"] * l2_loss(pn, torch.ones_like(pn))
         return loss
 
+    def capture(self, warmup=3):
+        """Record one whole iteration (all views forward + losses + backward + gradient mean + Adam) as a
+        hipGraph; later iteration() calls replay it.  Needs the sync-free rasteriser mode with a seeded
+        binning capacity (run a few eager iterations first) and capturable=True.  The launch sequence is
+        frozen: the binning capacity and every cache decision are those of the recorded iteration;
+        rasterizer.check_status() after replays still reports a capacity overflow."""
+        assert self.capturable, "HotLoop(capturable=True) is required for graph capture"
+        from . import rasterizer
+        assert not rasterizer._HOST_SYNC, "graph capture needs rasterizer.set_host_sync(False)"
+        for _ in range(warmup):
+            self.iteration()
+        torch.cuda.synchronize()
+        self.gm.invalidate_caches()
+        rasterizer._pending_status.clear()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            self._iteration_body()
+        self.graph = g
+        self._replay = True
+        return g
+
+    def use_graph(self, enabled: bool):
+        """Switch between replaying the captured graph and eager launches.  The graph (and the memory
+        pool behind every tensor allocated while capturing) stays alive; state derived from the
+        particle positions is forgotten because replays do not bump tensor version counters."""
+        self._replay = bool(enabled) and self.graph is not None
+        self.gm.invalidate_caches()
+
     def iteration(self):
+        if self.stream is None:
+            return self._iteration_body()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if self.graph is not None and self._replay:
+                self.itr += 1
+                self.gm.total_iterations += 1
+                self.graph.replay()
+            else:
+                self._iteration_body()
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def _iteration_body(self):
         gm = self.gm
         self.itr += 1
         gm.total_iterations += 1

@@ -27,7 +27,10 @@ from . import _lib
 _HOST_SYNC = True          # True = reference behaviour (exact-size binning buffer, one sync per forward)
 _CAP_SLACK = 1.3           # head-room over the high-water mark when host sync is off
 _capacity_hwm: dict = {}   # (device, W, H, channels) -> capacity in instances
-_pending_status: list = []  # image blobs whose overflow status has not been read yet
+_pending_status: list = []  # (ring slot, key) of sync-free forwards whose status has not been read yet
+_status_ring: dict = {}     # device index -> persistent int32[_RING, 8] copy of each forward's header words
+_RING = 256
+_ring_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
@@ -39,20 +42,37 @@ def set_host_sync(enabled: bool, initial_capacity: int | None = None):
         _capacity_hwm["default"] = int(initial_capacity)
 
 
+def _ring(dev: torch.device) -> torch.Tensor:
+    """Header words of sync-free forwards are copied (device to device, on the forward's stream) into
+    this persistent buffer and read back from here: it lives outside any hipGraph memory pool, so
+    reading it never touches memory a captured graph owns."""
+    r = _status_ring.get(dev.index)
+    if r is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("run one sync-free forward eagerly before capturing a graph")
+        r = torch.zeros(_RING, 8, dtype=torch.int32, device=dev)
+        _status_ring[dev.index] = r
+    return r
+
+
 def check_status():
-    """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity."""
+    """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity;
+    also refreshes the binning high-water marks and `last_num_rendered`."""
     global last_num_rendered
-    lib = _lib.raster()
-    stream = torch.cuda.current_stream().cuda_stream
-    first = True
+    if not _pending_status:
+        return
+    host = {d: r.cpu() for d, r in _status_ring.items()}  # one small D2H copy per device, synchronising
+    first, err = True, None
     while _pending_status:
-        img, W, H, key = _pending_status.pop()
-        n = C.c_int(0)
-        _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
+        dev_index, slot, key = _pending_status.pop()
+        n, status, cap = (int(x) for x in host[dev_index][slot][:3])
+        _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n * _CAP_SLACK) + 1024)
         if first:
-            last_num_rendered, first = int(n.value), False
-        _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n.value * _CAP_SLACK) + 1024)
-        _lib.check(lib.fnx_read_status(img.data_ptr(), W, H, stream))
+            last_num_rendered, first = n, False
+        if status == _lib.FNX_ERR_CAPACITY and err is None:
+            err = _lib.FnxError(status, f"binning capacity {cap} < num_rendered {n}")
+    if err is not None:
+        raise err
 
 
 def _ptr(t: torch.Tensor):
@@ -123,13 +143,20 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cap = known
                 _capacity_hwm[key] = cap
                 num_rendered = -1
-                _pending_status.append((img, W, H, key))
-                if len(_pending_status) > 64:
-                    del _pending_status[0]
             binning = torch.empty(lib.fnx_binning_bytes(cap), **u8)
             _lib.check(lib.fnx_forward_stage2(Cn, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H,
                                               bg.data_ptr(), _ptr(colors_precomp), radii.data_ptr(),
                                               color.data_ptr(), depth.data_ptr(), stream))
+            if num_rendered < 0:
+                global _ring_next
+                ring = _ring(dev)
+                slot = _ring_next % _RING
+                _ring_next += 1
+                al = (-img.data_ptr()) % 256  # the header sits at the first 256-byte boundary of the blob
+                ring[slot].copy_(img[al:al + 32].view(torch.int32))
+                _pending_status.append((dev.index, slot, key))
+                if len(_pending_status) > _RING:
+                    del _pending_status[0]
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.channels = Cn
