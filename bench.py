@@ -181,8 +181,18 @@ def main():
     alg_bytes = R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)
     avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    # HBM traffic of the same kernel from the PMC counters: a separate rocprofv3 --pmc run of this command
+    # (profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes); null if absent
+    traffic, kname = None, "fnx::blend_backward_kernel<3, 1>" if not a.unfused_physics else "fnx::blend_backward_kernel<3, 0>"
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f).get("void " + kname)
+        if t:
+            traffic = t["fetch_bytes"] + t["write_bytes"]
+    except OSError:
+        pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "fnx::blend_backward_kernel<3>",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                 "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "algorithmic_bytes_per_launch": alg_bytes,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
 
