@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--physics-once", action="store_true",
                     help="evaluate the view-independent physics terms once per iteration instead of once per view")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--serial-views", action="store_true", help="keep the views of an iteration on one stream")
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
@@ -113,7 +114,8 @@ def main():
             image_loss = "torch"
     loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
                    fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics,
-                   capturable=not (a.no_graph or a.host_sync))
+                   capturable=not (a.no_graph or a.host_sync),
+                   parallel_views=not (a.no_graph or a.host_sync or a.unfused_physics or a.serial_views))
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)
@@ -135,6 +137,7 @@ def main():
         except Exception as e:  # fall back to eager launches, say so in the JSON
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             loop.use_graph(False)
+            loop.parallel_views = False
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -158,8 +161,10 @@ def main():
     # roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events
     # cannot be read back from a replayed graph, so in graph mode the same iteration is run eagerly a
     # few more times (outside the timed region) with the event hooks on.
+    parallel_branches = bool(loop.parallel_views)
     if graph_mode:
         loop.use_graph(False)
+        loop.parallel_views = False  # kernels one at a time, so the event pairs time single kernels
         _lib.profile_enable(True)
         for _ in range(5):
             loop.iteration()
@@ -210,7 +215,8 @@ def main():
                    "num_rendered_per_view": R, "visible_per_view": P_vis,
                    "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
                    "host_sync": bool(a.host_sync), "image_loss": image_loss,
-                   "launch": "hipGraph replay of one whole iteration" if graph_mode else "eager",
+                   "launch": ("hipGraph replay of one whole iteration" + (", views as parallel branches" if parallel_branches
+                                                                           else "")) if graph_mode else "eager",
                    "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
                    + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
         "roofline": roofline,

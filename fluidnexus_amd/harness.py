@@ -90,7 +90,7 @@ class HotLoop:
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
-                 force_all_reduce=False, capturable=False):
+                 force_all_reduce=False, capturable=False, parallel_views=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
@@ -104,6 +104,10 @@ class HotLoop:
         self.optim_args = SimpleNamespace(**{k: cfg[k] for k in ("position_lr_init", "position_lr_final",
                                                                "position_lr_delay_mult", "position_lr_max_steps")})
         self.capturable = capturable
+        self.parallel_views = bool(parallel_views)
+        if self.parallel_views:
+            assert fused_physics and defer_visual_backward, "parallel_views needs the fused physics node and the deferred visual backward"
+        self.view_streams = []
         gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
         self.last = {}
@@ -203,7 +207,52 @@ class HotLoop:
                 self._iteration_body()
         torch.cuda.current_stream().wait_stream(self.stream)
 
+    def _iteration_body_parallel(self):
+        """Same iteration with the views of the batch on separate streams (fork after the work every
+        view shares, join before the gradient mean).  Inside a captured graph the views become parallel
+        branches, so the tail of one view's blend kernels overlaps the next view's kernels.  The physics
+        gradient is identical for every view: it is evaluated once and added once per local view."""
+        gm = self.gm
+        self.itr += 1
+        gm.total_iterations += 1
+        gm.update_learning_rate_current(self.itr)
+        gm.zero_gradient_cache_current()
+        batch = len(self.cams)
+        mine = shard_views(batch, self.rank, self.world)
+        main = torch.cuda.current_stream()
+        while len(self.view_streams) < len(mine):
+            self.view_streams.append(torch.cuda.Stream(device=gm._xyz.device))
+        with torch.no_grad():
+            gm.get_visual_xyz_from_nn()  # fills the per-state memo (forward kernel runs once, here)
+        if self.physics_per_view or self.rank == 0:
+            gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
+            n_phys = len(mine) if self.physics_per_view else batch
+        else:
+            gp, n_phys = None, 0
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for k, v in enumerate(mine):
+            s = self.view_streams[k]
+            s.wait_event(fork)
+            with torch.cuda.stream(s):
+                cam = self.cams[v]
+                pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                       pos_type="guess_visual_nn", scale=True)
+                loss, _, _ = self._image_loss(pkg["render"], cam.original_image)
+                torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
+            main.wait_stream(s)
+        if gp is not None:
+            gm._estimate_xyz_nn_grad += gp * float(n_phys)
+        gm.flush_deferred_gradients()
+        if self.world > 1 or self.force_all_reduce:
+            dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
+        gm.set_batch_gradient_current(batch)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad()
+
     def _iteration_body(self):
+        if self.parallel_views:
+            return self._iteration_body_parallel()
         gm = self.gm
         self.itr += 1
         gm.total_iterations += 1

@@ -109,10 +109,8 @@ class _VisualFromHidden(torch.autograd.Function):
         if memo is not None and memo.get("defer"):
             # the map g -> dL/dhidden is linear: sum the upstream gradients of all views that share this
             # forward and run the kernel once (flush_deferred_visual_backward)
-            if "g_sum" in memo:
-                memo["g_sum"] += g
-            else:
-                memo["g_sum"] = g.clone()
+            # (kept as a list: the views may run on different streams; they are summed after the join)
+            memo.setdefault("g_list", []).append(g)
             return None, None, None, None, None, None, None, None, None
         dh = torch.empty_like(hidden)
         PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
@@ -124,11 +122,13 @@ class _VisualFromHidden(torch.autograd.Function):
 
 def flush_deferred_visual_backward(memo):
     """dL/dhidden [N,3] for the gradients accumulated in `memo` by deferred backward calls (or None)."""
-    if memo is None or "g_sum" not in memo:
+    if memo is None or not memo.get("g_list"):
         return None
     lib = PL.physics()
     visual, hidden, hidden_prev, sum_w, wvel, vblob, (H, secs, eps) = memo["saved"]
-    g = memo.pop("g_sum")
+    gl = memo.pop("g_list")
+    g = gl[0] if len(gl) == 1 else torch.stack(gl).sum(dim=0)
+    g = g.contiguous()
     dh = torch.empty_like(hidden)
     PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
                                             hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
