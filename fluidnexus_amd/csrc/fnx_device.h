@@ -70,11 +70,12 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 // [-87, 0]) so the blend is reproducible on any IEEE machine; the parity oracle evaluates the same
 // sequence on the CPU.  v_rndne_f32 + 8 v_fma_f32 + a few VALU ops.
 __device__ __forceinline__ float exp_fixed(float x) {
-    if (x < -87.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
-    const float t = x * 1.44269504088896341f;
+    // branch-free (selects only) so that several evaluations can be interleaved by the scheduler;
+    // the arithmetic on [-87, 88] is the fixed sequence, x < -87 gives exactly 0, x > 88 saturates
+    const float xc = fminf(x, 88.0f);
+    const float t = xc * 1.44269504088896341f;
     const float n = __builtin_rintf(t);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    float r = __builtin_fmaf(n, -0.693145751953125f, xc);
     r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -85,7 +86,8 @@ __device__ __forceinline__ float exp_fixed(float x) {
     const float r2 = r * r;
     const float y = __builtin_fmaf(p, r2, r) + 1.0f;
     const int ni = (int)n;
-    return y * __uint_as_float((uint32_t)(ni + 127) << 23);
+    const float v = y * __uint_as_float((uint32_t)(ni + 127) << 23);
+    return (x < -87.0f) ? 0.0f : v;
 }
 
 // Footprint of a splat for culling, computed once per splat in preprocess.  A pixel can receive a

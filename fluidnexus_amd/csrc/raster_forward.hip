@@ -240,7 +240,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
     __shared__ float s_col[C][256];
-    __shared__ uint8_t s_list[4][256];
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 4];
     __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
     if (header[HDR_NUM_RENDERED] > capacity) return;
     const int tile = xcd_tile(blockIdx.x, T);
@@ -293,26 +293,50 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
         __syncthreads();
         const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
-        for (uint32_t i = 0; !done && i < n_w; i++) {
-            const uint32_t j = s_list[w][i];
-            const float4 ra = s_ra[j];
-            const float4 rb = s_rb[j];
-            const float dx = ra.x - pxf, dy = ra.y - pyf;
-            const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
-            if (power > 0.0f) continue;
-            if (power < rb.z) continue;  // alpha would be < 1/255 (see quadrant_mask)
-            const float alpha = fminf(0.99f, rb.y * exp_fixed(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = Tr * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        // The only state carried from entry to entry is (T, colour, depth, done); power / exp / alpha
+        // of an entry do not depend on it.  A lone wave runs ~500 cycles per entry when everything is
+        // evaluated in list order (dependent LDS reads + a 60-instruction chain), and the kernel time
+        // is the time of the deepest tile.  So: kGroup entries per step, all LDS reads issued
+        // together, the alphas evaluated as straight-line predicated code (the scheduler interleaves
+        // the independent chains), then a short select-only recurrence in list order.  Per pixel the
+        // arithmetic and its order are unchanged.
+        constexpr int kGroup = 4;
+        for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
+            if (__all(done)) break;
+            const uint32_t j4 = *reinterpret_cast<const uint32_t *>(&s_list[w][i0]);
+            float alpha[kGroup], depth[kGroup], col[kGroup][C];
+            bool hit[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t j = (j4 >> (8 * k)) & 255u;
+                const float4 ra = s_ra[j];
+                const float4 rb = s_rb[j];
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) col[k][ch] = s_col[ch][j];
+                const float dx = ra.x - pxf, dy = ra.y - pyf;
+                const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
+                const bool ok = !(power > 0.0f) && !(power < rb.z) && (i0 + k < n_w);
+                alpha[k] = fminf(0.99f, rb.y * exp_fixed(power));
+                hit[k] = ok && !(alpha[k] < 1.0f / 255.0f);
+                depth[k] = rb.w;
             }
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) acc[ch] += s_col[ch][j] * alpha * Tr;
-            if (Tr > 0.5f && test_T < 0.5f) Dm = rb.w;
-            Tr = test_T;
-            last_contributor = pos0 + j;
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t j = (j4 >> (8 * k)) & 255u;
+                const float test_T = Tr * (1 - alpha[k]);
+                const bool live = hit[k] && !done;
+                const bool stop = live && (test_T < 0.0001f);
+                const bool take = live && !stop;
+                done = done || stop;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    const float a_new = acc[ch] + col[k][ch] * alpha[k] * Tr;
+                    acc[ch] = take ? a_new : acc[ch];
+                }
+                Dm = (take && Tr > 0.5f && test_T < 0.5f) ? depth[k] : Dm;
+                Tr = take ? test_T : Tr;
+                last_contributor = take ? pos0 + j : last_contributor;
+            }
         }
     }
     if (inside) {
