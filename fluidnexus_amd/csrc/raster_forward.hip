@@ -260,20 +260,40 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
     float Dm = 15.0f;  // median depth default (ch3 forward.cu:295)
+    // Software pipeline over batches: the records of batch b+1 (and the list ids of batch b+2) are
+    // requested from memory before batch b is blended, so only the first batch pays the two
+    // dependent global-memory latencies (id -> record) on the tile's critical path.
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+    float pd = 0.f;
+    uint32_t id_ahead = 0;
+    if (r0 + (uint32_t)tid < r1) {
+        const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
+        pa = rec[0];
+        pb = rec[1];
+        pc = rec[2];
+        if (C > 2) pd = rec[3].x;
+    }
+    if (r0 + 256u + (uint32_t)tid < r1) id_ahead = point_list[r0 + 256u + tid];
     for (uint32_t base = r0; base < r1; base += 256) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
-            const float4 *rec = blend_rec + 4 * (size_t)point_list[base + tid];
-            const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-            qm = quadrant_mask(ra.x, ra.y, rc.x, rc.y, tile_x0, tile_y0);
-            s_ra[tid] = ra;
-            s_rb[tid] = rb;
-            s_col[0][tid] = rc.z;
-            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = rc.w;
-            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = rec[3].x;
+            qm = quadrant_mask(pa.x, pa.y, pc.x, pc.y, tile_x0, tile_y0);
+            s_ra[tid] = pa;
+            s_rb[tid] = pb;
+            s_col[0][tid] = pc.z;
+            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = pc.w;
+            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = pd;
         }
+        if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
+            const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
+            pa = rec[0];
+            pb = rec[1];
+            pc = rec[2];
+            if (C > 2) pd = rec[3].x;
+        }
+        if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
         uint32_t rank[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
