@@ -78,7 +78,10 @@ def main():
     ap.add_argument("--physics-once", action="store_true",
                     help="evaluate the view-independent physics terms once per iteration instead of once per view")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--serial-views", action="store_true", help="keep the views of an iteration on one stream")
+    ap.add_argument("--views", default="batched", choices=["batched", "branches", "serial"],
+                    help="the views of an iteration: one view-batched launch sequence (default), one rasteriser call "
+                         "per view on parallel streams / graph branches, or one call per view in series")
+    ap.add_argument("--serial-views", action="store_true", help="same as --views serial")
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
@@ -112,10 +115,15 @@ def main():
             image_loss = "fused"
         except Exception:
             image_loss = "torch"
+    view_mode = "serial" if a.serial_views else a.views
+    if a.unfused_physics or image_loss != "fused":
+        view_mode = "serial"  # the batched / branch modes build on the fused loss nodes
+    if view_mode == "branches" and (a.no_graph or a.host_sync):
+        view_mode = "serial"
     loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
                    fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics,
                    capturable=not (a.no_graph or a.host_sync),
-                   parallel_views=not (a.no_graph or a.host_sync or a.unfused_physics or a.serial_views))
+                   parallel_views=view_mode == "branches", batched_views=view_mode == "batched")
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)
@@ -161,7 +169,6 @@ def main():
     # roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events
     # cannot be read back from a replayed graph, so in graph mode the same iteration is run eagerly a
     # few more times (outside the timed region) with the event hooks on.
-    parallel_branches = bool(loop.parallel_views)
     if graph_mode:
         loop.use_graph(False)
         loop.parallel_views = False  # kernels one at a time, so the event pairs time single kernels
@@ -172,18 +179,24 @@ def main():
     prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "binning",
                                                                  "preprocess"))}
     _lib.profile_enable(False)
-    # instance / visible counts of this rank's most recent view (for the algorithmic byte count)
+    # instance / visible counts of this rank's views (for the algorithmic byte count)
+    R_views, P_vis_views = [], []
     with torch.no_grad():
-        pkg = loop.render_func(cams[loop_views[-1]], gm, None, loop.background, GRsetting=loop.GRsetting,
-                               GRzer=loop.GRzer, pos_type="guess_visual_nn", scale=True)
-        P_vis = int((pkg["radii"] > 0).sum().item())
-    rasterizer.check_status()
-    R = rasterizer.last_num_rendered
+        for v in loop_views:
+            pkg = loop.render_func(cams[v], gm, None, loop.background, GRsetting=loop.GRsetting,
+                                   GRzer=loop.GRzer, pos_type="guess_visual_nn", scale=True)
+            P_vis_views.append(int((pkg["radii"] > 0).sum().item()))
+            rasterizer.check_status()
+            R_views.append(rasterizer.last_num_rendered)
+    views_per_launch = len(loop_views) if view_mode == "batched" else 1
+    R = sum(R_views) / len(R_views)
+    P_vis = sum(P_vis_views) / len(P_vis_views)
     Cn = 3
     bwd_ms, bwd_n = prof["blend_backward"]
     # blend backward reads per instance id 4 + xy 8 + conic_opacity 16 + depth 4 + colour 4C,
-    # per pixel dL_dpix C + final_T + n_contrib, and writes per visible splat 2+3+1+C accumulated gradients
-    alg_bytes = R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)
+    # per pixel dL_dpix C + final_T + n_contrib, and writes per visible splat 2+3+1+C accumulated gradients;
+    # a view-batched launch processes all of the rank's views
+    alg_bytes = int(views_per_launch * (R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)))
     avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM traffic of the same kernel from the PMC counters: a separate rocprofv3 --pmc run of this command
@@ -198,7 +211,8 @@ def main():
         pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "views_per_launch": views_per_launch,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
 
     views_per_step = VIEWS * world
@@ -212,17 +226,19 @@ def main():
                                f"{HIDDEN_DIMS[0] * HIDDEN_DIMS[1] * HIDDEN_DIMS[2]} hidden particles, ch3, "
                                "L1+D-SSIM + exyz + gas + next-gas losses, Adam",
                    "views_per_rank": VIEWS, "global_views_per_step": views_per_step, "image": f"{SIZE}x{SIZE}",
-                   "num_rendered_per_view": R, "visible_per_view": P_vis,
+                   "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
                    "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
                    "host_sync": bool(a.host_sync), "image_loss": image_loss,
-                   "launch": ("hipGraph replay of one whole iteration" + (", views as parallel branches" if parallel_branches
-                                                                           else "")) if graph_mode else "eager",
+                   "launch": "hipGraph replay of one whole iteration" if graph_mode else "eager",
+                   "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
+                             "branches": "one rasteriser call per view, views as parallel graph branches",
+                             "serial": "one rasteriser call per view, in series"}[view_mode],
                    "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
                    + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
         "roofline": roofline,
         "rasterise_ms_per_view": {"forward": sum(prof[k][0] for k in ("preprocess", "binning", "blend_forward"))
-                                  / max(prof["blend_forward"][1], 1),
-                                  "backward_blend": bwd_ms / max(bwd_n, 1)},
+                                  / max(prof["blend_forward"][1], 1) / views_per_launch,
+                                  "backward_blend": bwd_ms / max(bwd_n, 1) / views_per_launch},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

@@ -14,6 +14,7 @@ _RASTER = None
 c_void_p, c_int, c_float, c_int64, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
 FNX_OK = 0
+FNX_MAX_VIEWS = 16
 FNX_ERR_INVALID_ARG = 1
 FNX_ERR_NON_RGB_NEEDS_COLORS = 2
 FNX_ERR_HIP = 3
@@ -43,6 +44,7 @@ SYMBOLS = (
     "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",
     "fnx_rasterize_backward", "fnx_rasterize_backward_ex", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
     "fnx_profile_enable", "fnx_profile_read",
+    "fnx_forward_stage1_views", "fnx_forward_stage2_views", "fnx_rasterize_backward_views",
 )
 
 
@@ -87,6 +89,14 @@ def raster():
                                            p, p, p, p, p, p, p, p, p, p]
     lib.fnx_rasterize_backward_ex.restype = i
     lib.fnx_rasterize_backward_ex.argtypes = lib.fnx_rasterize_backward.argtypes[:-1] + [i, i, p]
+    fp = C.POINTER(f)  # host arrays of per-view tan(fov/2)
+    lib.fnx_forward_stage1_views.restype = i
+    lib.fnx_forward_stage1_views.argtypes = [i, i, p, p, i, i, i, i, i, p, p, p, p, p, f, p, p, p, p, p, fp, fp, i, p, p]
+    lib.fnx_forward_stage2_views.restype = i
+    lib.fnx_forward_stage2_views.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p]
+    lib.fnx_rasterize_backward_views.restype = i
+    lib.fnx_rasterize_backward_views.argtypes = [i, i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, fp, fp, p,
+                                                 p, p, c_int64, p, p, p, p, p, p, p, p, p, p, p, p, p, i, i, p]
     lib.fnx_mark_visible.restype = i
     lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
     lib.fnx_profile_enable.restype = i

@@ -14,6 +14,12 @@
 
 namespace fnx {
 
+// Slice of a per-view array: `stride_bytes` between consecutive views (see ViewBatch in fnx_state.h).
+template <class T>
+__device__ __forceinline__ T *view_at(T *p, size_t stride_bytes, int v) {
+    return (T *)((uintptr_t)p + stride_bytes * (size_t)v);
+}
+
 // 3x3 matrix stored as columns (c0,c1,c2), element m[c][r]; the product keeps the k = 0,1,2
 // left-to-right summation order of the maths library the reference uses (glm mat3 operator*).
 struct M3 {

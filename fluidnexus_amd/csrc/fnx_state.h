@@ -66,6 +66,15 @@ inline void binning_layout(int64_t R, fnx_binning_layout_t *o) {
     o->total = off + kAlign;
 }
 
+// View-batched launches: V cameras over the same Gaussians, the view is grid dimension y of every
+// kernel.  Per-view scratch (the three blobs) and per-view user arrays are V equal slices; the blob
+// strides in bytes live here, the user-array strides follow from P, W, H and the channel count.
+constexpr int kMaxViews = FNX_MAX_VIEWS;
+struct ViewBatch {
+    size_t geom, img, bin;  // bytes between consecutive views' blobs (0 for a single view)
+    float tan_fovx[kMaxViews], tan_fovy[kMaxViews], focal_x[kMaxViews], focal_y[kMaxViews];
+};
+
 // header words inside the image blob
 enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2 };
 

@@ -47,8 +47,11 @@ l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
     __shared__ float s_h[5][HS][TS + 1];
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int c = blockIdx.z, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const int Ce = grey ? 1 : C;
+    const int n = blockIdx.z / Ce, c = blockIdx.z - n * Ce, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    img += (size_t)n * C * H * W;  // image n of the batch
+    gt += (size_t)n * C * H * W;
+    dmaps += (size_t)n * 3 * Ce * H * W;
     for (int i = tid; i < HS * HS; i += 256) {
         const int ly = i / HS, lx = i - ly * HS;
         s_x[ly][lx] = load_px(img, C, H, W, grey, c, y0 + ly - R, x0 + lx - R);
@@ -128,9 +131,15 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     __shared__ float s_d[3][HS][HS + 1];
     __shared__ float s_h[3][HS][TS + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int c = blockIdx.z, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const int Ce = grey ? 1 : C;
+    const int n = blockIdx.z / Ce, c = blockIdx.z - n * Ce, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const size_t hw = (size_t)H * W;
+    img += (size_t)n * C * hw;
+    gt += (size_t)n * C * hw;
+    dmaps += (size_t)n * 3 * Ce * hw;
+    dL_dimg += (size_t)n * C * hw;
+    g_l1 += n;
+    g_ssim += n;
     for (int i = tid; i < HS * HS; i += 256) {
         const int ly = i / HS, lx = i - ly * HS;
         const int x = x0 + lx - R, y = y0 + ly - R;
@@ -166,10 +175,10 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     const int px = x0 + tx, py = y0 + ty;
     if (px >= W || py >= H) return;
     const float x = load_px(img, C, H, W, grey, c, py, px), y = load_px(gt, C, H, W, grey, c, py, px);
-    const float n = (float)((size_t)Ce * hw);
+    const float cnt = (float)((size_t)Ce * hw);
     const float d = x - y;
     const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    float grad = g_l1[0] * sgn / n + g_ssim[0] / n * (v0 + 2.f * x * v1 + y * v2);
+    float grad = g_l1[0] * sgn / cnt + g_ssim[0] / cnt * (v0 + 2.f * x * v1 + y * v2);
     const size_t o = (size_t)py * W + px;
     if (grey) {
         grad = grad / 3.0f;
@@ -204,24 +213,33 @@ const char *fnx_losses_last_error(void) { return g_err; }
 int fnx_l1_ssim_tiles(int C, int H, int W, int grey) {
     return (grey ? 1 : C) * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
 }
-int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
-                        float *dmaps, fnx_stream_t stream) {
-    if (!args_ok(C, H, W, grey) || !img || !gt || !partials || !dmaps)
+int fnx_l1_ssim_forward_batch(const float *img, const float *gt, int N, int C, int H, int W, int grey, float *partials,
+                              float *dmaps, fnx_stream_t stream) {
+    if (N < 1 || !args_ok(C, H, W, grey) || !img || !gt || !partials || !dmaps)
         return fail(FNX_ERR_INVALID_ARG, "l1_ssim_forward: bad argument (grey needs C == 3)");
     static const Win win = make_window();
-    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, grey ? 1 : C);
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
     hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
                        partials, dmaps);
     return hip_check("l1_ssim_forward");
 }
-int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
-                         const float *g_l1, const float *g_ssim, float *dL_dimg, fnx_stream_t stream) {
-    if (!args_ok(C, H, W, grey) || !img || !gt || !dmaps || !g_l1 || !g_ssim || !dL_dimg)
+int fnx_l1_ssim_backward_batch(const float *img, const float *gt, int N, int C, int H, int W, int grey,
+                               const float *dmaps, const float *g_l1, const float *g_ssim, float *dL_dimg,
+                               fnx_stream_t stream) {
+    if (N < 1 || !args_ok(C, H, W, grey) || !img || !gt || !dmaps || !g_l1 || !g_ssim || !dL_dimg)
         return fail(FNX_ERR_INVALID_ARG, "l1_ssim_backward: bad argument");
     static const Win win = make_window();
-    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, grey ? 1 : C);
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
                        dmaps, g_l1, g_ssim, dL_dimg);
     return hip_check("l1_ssim_backward");
+}
+int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
+                        float *dmaps, fnx_stream_t stream) {
+    return fnx_l1_ssim_forward_batch(img, gt, 1, C, H, W, grey, partials, dmaps, stream);
+}
+int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
+                         const float *g_l1, const float *g_ssim, float *dL_dimg, fnx_stream_t stream) {
+    return fnx_l1_ssim_backward_batch(img, gt, 1, C, H, W, grey, dmaps, g_l1, g_ssim, dL_dimg, stream);
 }
 }

@@ -12,39 +12,45 @@
 #include "fnx_state.h"
 
 namespace fnx {
-// launchers defined in raster_forward.hip / raster_backward.hip
+// launchers defined in raster_forward.hip / raster_binning.hip / raster_backward.hip; V = number of views
+// (grid dimension y), vb = per-view blob strides and camera intrinsics
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
                        float scale_modifier, const float *rotations, const float *opacities, const float *shs,
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
-                       const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
-                       float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec,
-                       int prefiltered);
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header);
+                       const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
+                       float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
+                       uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec, int prefiltered, int V,
+                       const ViewBatch &vb);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
+                      const ViewBatch &vb);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
-                         uint32_t *tile_count);
+                         uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of);
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of, int V,
+                       const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, const int *radii, const uint32_t *ranges,
                  const uint32_t *blk_rel, const uint32_t *rank_of, uint32_t *bins, uint32_t *header,
-                 uint32_t capacity);
+                 uint32_t capacity, int V, const ViewBatch &vb);
 void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
-                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity);
+                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity,
+                       int V, const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity);
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity, int V,
+                          const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
-void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
+void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit);
+                           uint32_t grad_limit, int V, const ViewBatch &vb);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
-                          float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
-                          float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
-                          const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
-                          float *dL_dscale, float *dL_drot, int grad_limit);
+                          float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
+                          const float *proj, const float *campos, const float *dL_dmean2D, const float *dL_dconic,
+                          const float *dL_dopacity_views, const float *dL_dcolor_views, float *dL_dopacity,
+                          float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale,
+                          float *dL_drot, int grad_limit, int V, int sum_appearance, const ViewBatch &vb);
 }  // namespace fnx
 
 namespace {
@@ -141,6 +147,24 @@ Bin carve_bin(char *blob, int64_t R) {
 
 bool channels_ok(int c) { return c == 1 || c == 3; }
 
+// Strides and intrinsics of a batch of V views (focal lengths as rasterizer_impl.cu:207-208).
+int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *tan_fovx, const float *tan_fovy,
+                    fnx::ViewBatch *vb) {
+    if (V < 1 || V > fnx::kMaxViews) return fail(FNX_ERR_INVALID_ARG, "V must be in [1, %d] (got %d)", fnx::kMaxViews, V);
+    if (!tan_fovx || !tan_fovy) return fail(FNX_ERR_INVALID_ARG, "tan_fovx / tan_fovy is NULL");
+    memset(vb, 0, sizeof(*vb));
+    vb->geom = fnx_geom_bytes(P, W, H);
+    vb->img = fnx_image_bytes(W, H);
+    vb->bin = fnx_binning_bytes(capacity);
+    for (int v = 0; v < V; v++) {
+        vb->tan_fovx[v] = tan_fovx[v];
+        vb->tan_fovy[v] = tan_fovy[v];
+        vb->focal_y[v] = H / (2.0f * tan_fovy[v]);
+        vb->focal_x[v] = W / (2.0f * tan_fovx[v]);
+    }
+    return FNX_OK;
+}
+
 // Optional in-library kernel timing (bench.py roofline): HIP events recorded on the caller's
 // stream around one kernel class; elapsed times are summed when read.
 constexpr int kProfClasses = 4;  // 0 blend_forward, 1 blend_backward, 2 binning (sort+emit+order), 3 preprocess
@@ -198,22 +222,26 @@ void fnx_geom_layout(int P, int W, int H, fnx_geom_layout_t *out) { fnx::geom_la
 void fnx_image_layout(int W, int H, fnx_image_layout_t *out) { fnx::image_layout(W, H, out); }
 void fnx_binning_layout(int64_t R, fnx_binning_layout_t *out) { fnx::binning_layout(R, out); }
 
-int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
-                       const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
-                       const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                       const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
-                       float tan_fovy, int prefiltered, int *radii, fnx_stream_t stream) {
+int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M, int width,
+                             int height, const float *means3D, const float *shs, const float *colors_precomp,
+                             const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                             const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                             const float *cam_pos, const float *tan_fovx, const float *tan_fovy, int prefiltered,
+                             int *radii, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
     if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
+    fnx::ViewBatch vb;
+    if (int rc = make_view_batch(V, P, width, height, 0, tan_fovx, tan_fovy, &vb)) return rc;
+    if (V > 1 && P > 0 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
     hipStream_t s = (hipStream_t)stream;
     Img img = carve_img(image_buffer, width, height);
     const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
     if (T > fnx::kMaxTiles)
         return fail(FNX_ERR_UNSUPPORTED, "%d tiles > %d (image larger than 2048x2048)", T, fnx::kMaxTiles);
-    (void)hipMemsetAsync(img.header, 0, 32, s);
+    for (int v = 0; v < V; v++) (void)hipMemsetAsync((char *)img.header + v * vb.img, 0, 32, s);
     if (P == 0) {
-        (void)hipMemsetAsync(img.ranges, 0, (size_t)T * 8, s);
+        for (int v = 0; v < V; v++) (void)hipMemsetAsync((char *)img.ranges + v * vb.img, 0, (size_t)T * 8, s);
         return hip_check("stage1(P=0)");
     }
     if (!geom_buffer || !means3D || !opacities || !viewmatrix || !projmatrix)
@@ -229,13 +257,23 @@ int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int 
     {
     ProfScope ps(3, s);
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
-                           cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx,
-                           tan_fovy, rad, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched,
-                           g.blk_hist, g.sort_key0, g.blend_rec, prefiltered);
+                           cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
+                           g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.blk_hist,
+                           g.sort_key0, g.blend_rec, prefiltered, V, vb);
     }
-    fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count);
-    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header);
+    fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, V, vb);
     return hip_check("stage1");
+}
+
+int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
+                       const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                       const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                       const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, int *radii, fnx_stream_t stream) {
+    return fnx_forward_stage1_views(channels, 1, geom_buffer, image_buffer, P, D, M, width, height, means3D, shs,
+                                    colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                    viewmatrix, projmatrix, cam_pos, &tan_fovx, &tan_fovy, prefiltered, radii, stream);
 }
 
 int fnx_read_num_rendered(const char *image_buffer, int width, int height, fnx_stream_t stream, int *num_rendered) {
@@ -262,16 +300,19 @@ int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_
     return FNX_OK;
 }
 
-int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
-                       char *image_buffer, int P, int width, int height, const float *background,
-                       const float *colors_precomp, const int *radii, float *out_color, float *out_depth,
-                       fnx_stream_t stream) {
+int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
+                             char *image_buffer, int P, int width, int height, const float *background,
+                             const int *radii, float *out_color, float *out_depth, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
     if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
         return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
     if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     if (binning_capacity > 0 && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
+    fnx::ViewBatch vb;
+    const float unused[fnx::kMaxViews] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (int rc = make_view_batch(V, P, width, height, binning_capacity, unused, unused, &vb)) return rc;
+    if (V > 1 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
     hipStream_t s = (hipStream_t)stream;
     Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
@@ -283,17 +324,26 @@ int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, in
     ProfScope ps(2, s);
     const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
     fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
-                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rank_of);
-    fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap);
-    fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap);
+                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rank_of, V, vb);
+    fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap,
+                     V, vb);
+    fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap, V, vb);
     }
-    (void)colors_precomp;  // colours were packed into the blend records by stage 1 (rasterizer_impl.cu:299)
     {
         ProfScope ps(0, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
-                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap);
+                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, V, vb);
     }
     return hip_check("stage2");
+}
+
+int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
+                       char *image_buffer, int P, int width, int height, const float *background,
+                       const float *colors_precomp, const int *radii, float *out_color, float *out_depth,
+                       fnx_stream_t stream) {
+    (void)colors_precomp;  // colours were packed into the blend records by stage 1 (rasterizer_impl.cu:299)
+    return fnx_forward_stage2_views(channels, 1, geom_buffer, binning_buffer, binning_capacity, image_buffer, P, width,
+                                    height, background, radii, out_color, out_depth, stream);
 }
 
 int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_user, fnx_alloc_fn binningBuffer,
@@ -321,6 +371,54 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
                               out_color, out_depth, stream);
 }
 
+int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
+                                 int height, const float *means3D, const float *shs, const float *colors_precomp,
+                                 const float *scales, float scale_modifier, const float *rotations,
+                                 const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                 const float *campos, const float *tan_fovx, const float *tan_fovy, const int *radii,
+                                 char *geom_buffer, char *binning_buffer, int64_t binning_capacity, char *image_buffer,
+                                 const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity_views,
+                                 float *dL_dcolor_views, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D,
+                                 float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                 int grad_splat_limit, int geometry_only, fnx_stream_t stream) {
+    if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
+    if (P == 0) return FNX_OK;  // rasterize_points.cu:160
+    if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix ||
+        !dL_dmean2D || !dL_dconic || !dL_dopacity_views || !dL_dcolor_views || !dL_dopacity || !dL_dmean3D ||
+        !dL_dcov3D)
+        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
+    if (scales && (!rotations || !dL_dscale || !dL_drot))
+        return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
+    if (geometry_only && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
+    if (binning_capacity < 0) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
+    fnx::ViewBatch vb;
+    if (int rc = make_view_batch(V, P, width, height, binning_capacity, tan_fovx, tan_fovy, &vb)) return rc;
+    if (V > 1 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
+    const int limit = (grad_splat_limit < 0 || grad_splat_limit > P) ? P : grad_splat_limit;
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = carve_geom(geom_buffer, P, width, height);
+    Img img = carve_img(image_buffer, width, height);
+    // point_list sits at offset 0 of each view's binning blob
+    Bin bin = carve_bin(binning_buffer, 0);
+    const int *rad = radii ? radii : g.radii;
+    const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
+    const size_t cov3D_stride = cov3D_precomp ? 0 : vb.geom;
+    {
+        ProfScope ps(1, s);
+        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P, width, height, img.ranges, bin.point_list,
+                                   background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
+                                   dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
+                                   (uint32_t)limit, V, vb);
+    }
+    const int sum_appearance = (V > 1 && !geometry_only) ? 1 : 0;
+    fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
+                              cov3D_ptr, cov3D_stride, viewmatrix, projmatrix, campos, dL_dmean2D, dL_dconic,
+                              dL_dopacity_views, dL_dcolor_views, dL_dopacity, shs ? nullptr : dL_dcolor, dL_dmean3D,
+                              dL_dcov3D, dL_dsh, dL_dscale, dL_drot, limit, V, sum_appearance, vb);
+    return hip_check("backward");
+}
+
 int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,
                            const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
                            float scale_modifier, const float *rotations, const float *cov3D_precomp,
@@ -331,34 +429,13 @@ int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const fl
                            float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
                               fnx_stream_t stream) {
     (void)R;
-    if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
-    if (P == 0) return FNX_OK;  // rasterize_points.cu:160
-    if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix ||
-        !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
-        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
-    if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
-    if (scales && (!rotations || !dL_dscale || !dL_drot))
-        return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
-    if (geometry_only && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
-    const int limit = (grad_splat_limit < 0 || grad_splat_limit > P) ? P : grad_splat_limit;
-    hipStream_t s = (hipStream_t)stream;
-    Geom g = carve_geom(geom_buffer, P, width, height);
-    Img img = carve_img(image_buffer, width, height);
-    // the capacity this blob was filled with is irrelevant here: point_list sits at offset 0
-    Bin bin = carve_bin(binning_buffer, 0);
-    const int *rad = radii ? radii : g.radii;
-    (void)colors_precomp;  // colours live in the blend records (rasterizer_impl.cu:367)
-    const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
-    {
-        ProfScope ps(1, s);
-        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, width, height, img.ranges, bin.point_list,
-                                   background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
-                                   dL_dconic, dL_dopacity, dL_dcolor, img.header, 0xFFFFFFFFu, (uint32_t)limit);
-    }
-    fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
-                              cov3D_ptr, viewmatrix, projmatrix, width, height, tan_fovx, tan_fovy, campos, dL_dmean2D,
-                              dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, limit);
-    return hip_check("backward");
+    if (P != 0 && !dL_dcolor) return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    return fnx_rasterize_backward_views(channels, 1, P, D, M, background, width, height, means3D, shs, colors_precomp,
+                                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                        campos, &tan_fovx, &tan_fovy, radii, geom_buffer, binning_buffer, 0,
+                                        image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                                        grad_splat_limit, geometry_only, stream);
 }
 
 int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,

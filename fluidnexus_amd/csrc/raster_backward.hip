@@ -97,8 +97,25 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
                       const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
                       float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
-                      const uint32_t *__restrict__ header, uint32_t capacity, uint32_t grad_limit) {
+                      const uint32_t *__restrict__ header, uint32_t capacity, uint32_t grad_limit, int P,
+                      const ViewBatch vb) {
     constexpr int NV = MODE == 0 ? 6 + C : 5;
+    {
+        const int vw = blockIdx.y;  // per-view scratch, pixel gradients and screen-space accumulators
+        ranges = view_at(ranges, vb.img, vw);
+        final_Ts = view_at(final_Ts, vb.img, vw);
+        n_contrib = view_at(n_contrib, vb.img, vw);
+        header = view_at(header, vb.img, vw);
+        point_list = view_at(point_list, vb.bin, vw);
+        blend_rec = view_at(blend_rec, vb.geom, vw);
+        dL_dpixels += (size_t)vw * C * H * W;
+        dL_dmean2D += (size_t)vw * P * 3;
+        dL_dconic += (size_t)vw * P * 4;
+        if (MODE == 0) {
+            dL_dopacity += (size_t)vw * P;
+            dL_dcolors += (size_t)vw * P * C;
+        }
+    }
     __shared__ uint32_t s_id[256];
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
@@ -272,8 +289,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 
 // ---------------------------------------------------------------------------------------------
 // SH colour backward (ch3 backward.cu:20-132)
+// dL_dsh is accumulated (+=) into the caller's zero-filled array, so the views of a batch add up; the
+// mean-gradient term is returned in gmean[3].
 __device__ inline void sh_backward(int idx, int deg, int M, const float *means, const float *campos, const float *shs,
-                                   const uint8_t *clamped, const float *dL_dcolor, float *dL_dmeans, float *dL_dshs) {
+                                   const uint8_t *clamped, const float *dL_dcolor, float *gmean, float *dL_dshs) {
     const float ox = means[3 * idx] - campos[0], oy = means[3 * idx + 1] - campos[1], oz = means[3 * idx + 2] - campos[2];
     const float len = sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox / len, y = oy / len, z = oz / len;
@@ -286,14 +305,14 @@ __device__ inline void sh_backward(int idx, int deg, int M, const float *means, 
 #define SH(k, c) sh[(k) * 3 + (c)]
 #define DSH(k, c) dL_dsh[(k) * 3 + (c)]
 #pragma unroll
-    for (int c = 0; c < 3; c++) DSH(0, c) = kSH0 * g[c];
+    for (int c = 0; c < 3; c++) DSH(0, c) += kSH0 * g[c];
     if (deg > 0) {
         const float d1 = -kSH1 * y, d2 = kSH1 * z, d3 = -kSH1 * x;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            DSH(1, c) = d1 * g[c];
-            DSH(2, c) = d2 * g[c];
-            DSH(3, c) = d3 * g[c];
+            DSH(1, c) += d1 * g[c];
+            DSH(2, c) += d2 * g[c];
+            DSH(3, c) += d3 * g[c];
             ddx[c] = -kSH1 * SH(3, c);
             ddy[c] = -kSH1 * SH(1, c);
             ddz[c] = kSH1 * SH(2, c);
@@ -305,11 +324,11 @@ __device__ inline void sh_backward(int idx, int deg, int M, const float *means, 
                         d8 = kSH2[4] * (xx - yy);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                DSH(4, c) = d4 * g[c];
-                DSH(5, c) = d5 * g[c];
-                DSH(6, c) = d6 * g[c];
-                DSH(7, c) = d7 * g[c];
-                DSH(8, c) = d8 * g[c];
+                DSH(4, c) += d4 * g[c];
+                DSH(5, c) += d5 * g[c];
+                DSH(6, c) += d6 * g[c];
+                DSH(7, c) += d7 * g[c];
+                DSH(8, c) += d8 * g[c];
                 ddx[c] += kSH2[0] * y * SH(4, c) + kSH2[2] * 2.f * -x * SH(6, c) + kSH2[3] * z * SH(7, c) +
                           kSH2[4] * 2.f * x * SH(8, c);
                 ddy[c] += kSH2[0] * x * SH(4, c) + kSH2[1] * z * SH(5, c) + kSH2[2] * 2.f * -y * SH(6, c) +
@@ -324,13 +343,13 @@ __device__ inline void sh_backward(int idx, int deg, int M, const float *means, 
                             d15 = kSH3[6] * x * (xx - 3.f * yy);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    DSH(9, c) = d9 * g[c];
-                    DSH(10, c) = d10 * g[c];
-                    DSH(11, c) = d11 * g[c];
-                    DSH(12, c) = d12 * g[c];
-                    DSH(13, c) = d13 * g[c];
-                    DSH(14, c) = d14 * g[c];
-                    DSH(15, c) = d15 * g[c];
+                    DSH(9, c) += d9 * g[c];
+                    DSH(10, c) += d10 * g[c];
+                    DSH(11, c) += d11 * g[c];
+                    DSH(12, c) += d12 * g[c];
+                    DSH(13, c) += d13 * g[c];
+                    DSH(14, c) += d14 * g[c];
+                    DSH(15, c) += d15 * g[c];
                     ddx[c] += (kSH3[0] * SH(9, c) * 3.f * 2.f * xy + kSH3[1] * SH(10, c) * yz +
                                kSH3[2] * SH(11, c) * -2.f * xy + kSH3[3] * SH(12, c) * -3.f * 2.f * xz +
                                kSH3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy) + kSH3[5] * SH(14, c) * 2.f * xz +
@@ -357,9 +376,9 @@ __device__ inline void sh_backward(int idx, int deg, int M, const float *means, 
     const float o0 = ((+sum2 - ox * ox) * vx - oy * ox * vy - oz * ox * vz) * invsum32;
     const float o1 = (-ox * oy * vx + (sum2 - oy * oy) * vy - oz * oy * vz) * invsum32;
     const float o2 = (-ox * oz * vx - oy * oz * vy + (sum2 - oz * oz) * vz) * invsum32;
-    dL_dmeans[3 * idx + 0] += o0;
-    dL_dmeans[3 * idx + 1] += o1;
-    dL_dmeans[3 * idx + 2] += o2;
+    gmean[0] = o0;
+    gmean[1] = o1;
+    gmean[2] = o2;
 }
 
 __device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -412,25 +431,11 @@ __device__ inline void cov3d_backward(int idx, const float *scale, float mod, co
     dL_drots[4 * (size_t)idx + 3] = qw;
 }
 
-// One thread per visible splat: conic gradient -> cov2D -> cov3D and mean (EWA Jacobian, clamp
-// masks), then projection Jacobian of the 2D mean, then SH and scale/rotation.
-template <int C>
-__global__ void __launch_bounds__(256)
-geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, const int *__restrict__ radii,
-                     const float *__restrict__ shs, const uint8_t *__restrict__ clamped,
-                     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
-                     const float *__restrict__ cov3Ds, const float *__restrict__ view, const float *__restrict__ proj,
-                     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ campos,
-                     const float *__restrict__ dL_dmean2D, const float *__restrict__ dL_dconics,
-                     float *__restrict__ dL_dmeans, float *__restrict__ dL_dcolor, float *__restrict__ dL_dcov,
-                     float *__restrict__ dL_dsh, float *__restrict__ dL_dscale, float *__restrict__ dL_drot,
-                     int grad_limit) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || idx >= grad_limit || !(radii[idx] > 0)) return;
-    const float *cov3D = cov3Ds + 6 * (size_t)idx;
-    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    const float gc0 = dL_dconics[4 * (size_t)idx], gc1 = dL_dconics[4 * (size_t)idx + 1],
-                gc2 = dL_dconics[4 * (size_t)idx + 3];
+// Screen-space gradients of one splat in one view -> contribution to the mean (gm) and the world
+// covariance (dcv): EWA Jacobian with clamp masks, then the projection Jacobian of the 2D mean.
+__device__ inline void geom_backward_view(const float3 mean, const float *cov3D, const float *view, const float *proj,
+                                          float h_x, float h_y, float tan_fovx, float tan_fovy, float gc0, float gc1,
+                                          float gc2, float g0, float g1, float *gm, float *dcv) {
     float3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx;
     const float limy = 1.3f * tan_fovy;
@@ -454,7 +459,6 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
     const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
 #define Tm(i, j) Tm_.m[i][j]
 #define Vm(i, j) Vrk.m[i][j]
-    float *dcv = dL_dcov + 6 * (size_t)idx;
     if (denom2inv != 0) {
         dL_da = denom2inv * (-c * c * gc0 + 2 * b * c * gc1 + (denom - a * c) * gc2);
         dL_dc = denom2inv * (-a * a * gc2 + 2 * a * b * gc1 + (denom - a * c) * gc0);
@@ -507,32 +511,89 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
     const float m_w = 1.0f / (m_hom.w + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float g0 = dL_dmean2D[3 * (size_t)idx], g1 = dL_dmean2D[3 * (size_t)idx + 1];
     const float dmx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
     const float dmy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
     const float dmz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
-    gm0 += dmx;
-    gm1 += dmy;
-    gm2 += dmz;
-    dL_dmeans[3 * (size_t)idx + 0] = gm0;
-    dL_dmeans[3 * (size_t)idx + 1] = gm1;
-    dL_dmeans[3 * (size_t)idx + 2] = gm2;
-    // term 3: view-dependent colour
-    if (shs) sh_backward(idx, D, M, means3D, campos, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
+    gm[0] = gm0 + dmx;
+    gm[1] = gm1 + dmy;
+    gm[2] = gm2 + dmz;
+}
+
+// One thread per splat, all views of the batch in turn (a splat's result is a sum over the views
+// that see it, formed in view order in registers and written once): conic gradient -> cov2D ->
+// cov3D and mean, view-dependent colour (SH), then scale / rotation from the summed cov3D gradient
+// (linear in it).  With one view this is the reference's per-call arithmetic, term for term.
+template <int C>
+__global__ void __launch_bounds__(256)
+geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, const int *__restrict__ radii,
+                     const float *__restrict__ shs, const uint8_t *__restrict__ clamped,
+                     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
+                     const float *__restrict__ cov3Ds, size_t cov3D_stride, const float *__restrict__ view,
+                     const float *__restrict__ proj, const float *__restrict__ campos,
+                     const float *__restrict__ dL_dmean2D, const float *__restrict__ dL_dconics,
+                     const float *__restrict__ dL_dopacity_views, const float *__restrict__ dL_dcolor_views,
+                     float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmeans,
+                     float *__restrict__ dL_dcov, float *__restrict__ dL_dsh, float *__restrict__ dL_dscale,
+                     float *__restrict__ dL_drot, int grad_limit, int V, int sum_appearance, const ViewBatch vb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || idx >= grad_limit) return;
+    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float gm[3] = {0.f, 0.f, 0.f}, dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool seen = false;
+    for (int v = 0; v < V; v++) {
+        if (!(radii[(size_t)v * P + idx] > 0)) continue;
+        const size_t o = (size_t)v * P + idx;
+        const float *cov3D = view_at(cov3Ds, cov3D_stride, v) + 6 * (size_t)idx;
+        float gv[3], dv[6];
+        geom_backward_view(mean, cov3D, view + 16 * v, proj + 16 * v, vb.focal_x[v], vb.focal_y[v], vb.tan_fovx[v],
+                           vb.tan_fovy[v], dL_dconics[4 * o], dL_dconics[4 * o + 1], dL_dconics[4 * o + 3],
+                           dL_dmean2D[3 * o], dL_dmean2D[3 * o + 1], gv, dv);
+        if (shs) {  // term 3: view-dependent colour (ch3 backward.cu:374-376)
+            float gs[3];
+            sh_backward(idx, D, M, means3D, campos + 3 * v, shs, view_at(clamped, vb.geom, v),
+                        dL_dcolor_views + (size_t)v * P * 3, gs, dL_dsh);
+            gv[0] += gs[0];
+            gv[1] += gs[1];
+            gv[2] += gs[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) gm[k] = seen ? gm[k] + gv[k] : gv[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) dcv[k] = seen ? dcv[k] + dv[k] : dv[k];
+        seen = true;
+    }
+    if (!seen) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmeans[3 * (size_t)idx + k] = gm[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov[6 * (size_t)idx + k] = dcv[k];
     if (scales) cov3d_backward(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov, dL_dscale, dL_drot);
+    if (sum_appearance) {  // V > 1: fold the per-view opacity / colour accumulators
+        float so = 0.f;
+        for (int v = 0; v < V; v++) so += dL_dopacity_views[(size_t)v * P + idx];
+        dL_dopacity[idx] = so;
+        if (dL_dcolor) {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                float sc = 0.f;
+                for (int v = 0; v < V; v++) sc += dL_dcolor_views[((size_t)v * P + idx) * C + ch];
+                dL_dcolor[(size_t)idx * C + ch] = sc;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const uint32_t *ranges,
+void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit) {
+                           uint32_t grad_limit, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
-#define FNX_LAUNCH_BB(CC, MM)                                                                                         \
-    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H, bg, \
-                       blend_rec, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors,    \
-                       header, capacity, grad_limit)
+#define FNX_LAUNCH_BB(CC, MM)                                                                                           \
+    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,    \
+                       bg, blend_rec, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, \
+                       header, capacity, grad_limit, P, vb)
     if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
     else if (C == 3) FNX_LAUNCH_BB(3, 1);
     else if (mode == 0) FNX_LAUNCH_BB(1, 0);
@@ -542,24 +603,21 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int W, int H, const u
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
-                          float scale_modifier, const float *cov3Ds, const float *view, const float *proj, int W, int H,
-                          float tan_fovx, float tan_fovy, const float *campos, const float *dL_dmean2D,
-                          const float *dL_dconic, float *dL_dmean3D, float *dL_dcolor, float *dL_dcov3D, float *dL_dsh,
-                          float *dL_dscale, float *dL_drot, int grad_limit) {
-    const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:360-361
-    const float focal_x = W / (2.0f * tan_fovx);
+                          float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
+                          const float *proj, const float *campos, const float *dL_dmean2D, const float *dL_dconic,
+                          const float *dL_dopacity_views, const float *dL_dcolor_views, float *dL_dopacity,
+                          float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale,
+                          float *dL_drot, int grad_limit, int V, int sum_appearance, const ViewBatch &vb) {
     const int n = grad_limit < P ? grad_limit : P;
     if (n <= 0) return;
-    if (C == 3)
-        hipLaunchKernelGGL((geom_backward_kernel<3>), dim3((n + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
-                           shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
-                           tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
-                           dL_dscale, dL_drot, grad_limit);
-    else
-        hipLaunchKernelGGL((geom_backward_kernel<1>), dim3((n + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii,
-                           shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, focal_x, focal_y,
-                           tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
-                           dL_dscale, dL_drot, grad_limit);
+#define FNX_LAUNCH_GB(CC)                                                                                              \
+    hipLaunchKernelGGL((geom_backward_kernel<CC>), dim3((n + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii, shs, \
+                       clamped, scales, rotations, scale_modifier, cov3Ds, cov3D_stride, view, proj, campos,           \
+                       dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, dL_dopacity, dL_dcolor, dL_dmean3D,  \
+                       dL_dcov3D, dL_dsh, dL_dscale, dL_drot, grad_limit, V, sum_appearance, vb)
+    if (C == 3) FNX_LAUNCH_GB(3);
+    else FNX_LAUNCH_GB(1);
+#undef FNX_LAUNCH_GB
 }
 
 }  // namespace fnx

@@ -31,8 +31,11 @@ namespace fnx {
 template <typename CountT>
 __global__ void __launch_bounds__(1024)
 colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__restrict__ blk_rel,
-               uint32_t *__restrict__ tile_count) {
+               uint32_t *__restrict__ tile_count, size_t hist_stride, size_t count_stride) {
     __shared__ uint32_t s_band[16][64];
+    blk_hist = view_at(blk_hist, hist_stride, blockIdx.y);
+    blk_rel = view_at(blk_rel, hist_stride, blockIdx.y);
+    tile_count = view_at(tile_count, count_stride, blockIdx.y);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
     const int per = (NB + 15) / 16;
@@ -62,8 +65,11 @@ colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__r
 // Depth sort: LSD radix, 8-bit digits, stable.  Workgroup = 256 threads = 4 waves over a chunk of
 // kSortChunk = 1024 keys; wave w owns keys [256 w, 256 w + 256) of the chunk in 4 steps of 64.
 __global__ void __launch_bounds__(256)
-sort_hist_kernel(int P, const uint32_t *__restrict__ keys, int shift, int NSB, uint32_t *__restrict__ hist) {
+sort_hist_kernel(int P, const uint32_t *__restrict__ keys, int shift, int NSB, uint32_t *__restrict__ hist,
+                 size_t geom_stride) {
     __shared__ uint32_t s_h[256];
+    keys = view_at(keys, geom_stride, blockIdx.y);
+    hist = view_at(hist, geom_stride, blockIdx.y);
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * kSortChunk;
@@ -82,8 +88,18 @@ __global__ void __launch_bounds__(256)
 sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift,
                     const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total,
-                    uint32_t *__restrict__ rank_of, int first_pass, int last_pass) {
+                    uint32_t *__restrict__ rank_of, int first_pass, int last_pass, size_t geom_stride) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave running offsets
+    {
+        const int vw = blockIdx.y;
+        keys_in = view_at(keys_in, geom_stride, vw);
+        vals_in = view_at(vals_in, geom_stride, vw);
+        keys_out = view_at(keys_out, geom_stride, vw);
+        vals_out = view_at(vals_out, geom_stride, vw);
+        hist_rel = view_at(hist_rel, geom_stride, vw);
+        digit_total = view_at(digit_total, geom_stride, vw);
+        rank_of = view_at(rank_of, geom_stride, vw);
+    }
     __shared__ uint32_t s_wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int base = blockIdx.x * kSortChunk + w * 256;
@@ -154,8 +170,18 @@ __global__ void __launch_bounds__(256)
 emit_kernel(int P, int T, const float2 *__restrict__ means2D, const int *__restrict__ radii, int gx, int gy,
             const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ blk_rel,
             const uint32_t *__restrict__ rank_of, uint32_t *__restrict__ bins, uint32_t *__restrict__ header,
-            uint32_t capacity) {
+            uint32_t capacity, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
+    {
+        const int vw = blockIdx.y;
+        means2D = view_at(means2D, vb.geom, vw);
+        blk_rel = view_at(blk_rel, vb.geom, vw);
+        rank_of = view_at(rank_of, vb.geom, vw);
+        radii += (size_t)vw * P;
+        ranges = view_at(ranges, vb.img, vw);
+        header = view_at(header, vb.img, vw);
+        bins = view_at(bins, vb.bin, vw);
+    }
     if (header[HDR_NUM_RENDERED] > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             header[HDR_STATUS] = FNX_ERR_CAPACITY;
@@ -186,8 +212,16 @@ emit_kernel(int P, int T, const float2 *__restrict__ means2D, const int *__restr
 __global__ void __launch_bounds__(256)
 tile_order_kernel(int P, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ bins,
                   const uint32_t *__restrict__ sorted_ids, uint32_t *__restrict__ point_list,
-                  const uint32_t *__restrict__ header, uint32_t capacity, int win_words) {
+                  const uint32_t *__restrict__ header, uint32_t capacity, int win_words, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];  // win_words words + 4 wave totals
+    {
+        const int vw = blockIdx.y;
+        ranges = view_at(ranges, vb.img, vw);
+        header = view_at(header, vb.img, vw);
+        bins = view_at(bins, vb.bin, vw);
+        point_list = view_at(point_list, vb.bin, vw);
+        sorted_ids = view_at(sorted_ids, vb.geom, vw);
+    }
     __shared__ uint32_t s_wave[4];
     if (header[HDR_NUM_RENDERED] > capacity) return;
     const uint32_t start = ranges[2 * blockIdx.x], end = ranges[2 * blockIdx.x + 1];
@@ -239,23 +273,25 @@ tile_order_kernel(int P, const uint32_t *__restrict__ ranges, const uint32_t *__
 
 // ---------------------------------------------------------------------------------------------
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
-                         uint32_t *tile_count) {
-    hipLaunchKernelGGL((colscan_kernel<uint16_t>), dim3((T + 63) / 64), dim3(1024), 0, s, T, splat_blocks(P), blk_hist,
-                       blk_rel, tile_count);
+                         uint32_t *tile_count, int V, const ViewBatch &vb) {
+    hipLaunchKernelGGL((colscan_kernel<uint16_t>), dim3((T + 63) / 64, V), dim3(1024), 0, s, T, splat_blocks(P),
+                       blk_hist, blk_rel, tile_count, vb.geom, vb.img);
 }
 
 // keys0 holds the depth keys; after the call vals0 = ids in (depth bits, id) order, rank_of = inverse.
 // hist: u32[NSB*256] chunk histograms, hist_rel: u32[NSB*256] their prefix over chunks, totals: u32[256].
 void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of) {
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of, int V,
+                       const ViewBatch &vb) {
     const int NSB = sort_blocks(P);
     uint32_t *kin = keys0, *kout = keys1, *vin = vals0, *vout = vals1;
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(NSB), dim3(256), 0, s, P, kin, shift, NSB, hist);
-        hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(4), dim3(1024), 0, s, 256, NSB, hist, hist_rel, totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB), dim3(256), 0, s, P, kin, vin, kout, vout, shift, hist_rel,
-                           totals, rank_of, pass == 0 ? 1 : 0, pass == 3 ? 1 : 0);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, shift, NSB, hist, vb.geom);
+        hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(4, V), dim3(1024), 0, s, 256, NSB, hist, hist_rel, totals,
+                           vb.geom, vb.geom);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, vin, kout, vout, shift, hist_rel,
+                           totals, rank_of, pass == 0 ? 1 : 0, pass == 3 ? 1 : 0, vb.geom);
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
@@ -264,14 +300,15 @@ void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, u
 
 void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, const int *radii, const uint32_t *ranges,
                  const uint32_t *blk_rel, const uint32_t *rank_of, uint32_t *bins, uint32_t *header,
-                 uint32_t capacity) {
+                 uint32_t capacity, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
-    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P)), dim3(256), (size_t)T * 4, s, P, T, means2D, radii, gx, gy,
-                       ranges, blk_rel, rank_of, bins, header, capacity);
+    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, means2D, radii, gx, gy,
+                       ranges, blk_rel, rank_of, bins, header, capacity, vb);
 }
 
 void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
-                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity) {
+                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity,
+                       int V, const ViewBatch &vb) {
     const int words_total = (P + 31) >> 5;
     const int kMaxWinWords = 36 * 1024;  // 144 KiB bitmap window (1.18 M ranks)
     const int win_words = words_total < kMaxWinWords ? words_total : kMaxWinWords;
@@ -281,8 +318,8 @@ void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, cons
                                   kMaxWinWords * 4);
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(T), dim3(256), (size_t)win_words * 4, s, P, ranges, bins, sorted_ids,
-                       point_list, header, capacity, win_words);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(T, V), dim3(256), (size_t)win_words * 4, s, P, ranges, bins, sorted_ids,
+                       point_list, header, capacity, win_words, vb);
 }
 
 }  // namespace fnx

@@ -96,13 +96,30 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ opacities,
                   const float *__restrict__ shs, uint8_t *__restrict__ clamped, const float *__restrict__ cov3D_precomp,
                   const float *__restrict__ colors_precomp, const float *__restrict__ view,
-                  const float *__restrict__ proj, const float *__restrict__ campos, int W, int H, float tan_fovx,
-                  float tan_fovy, float focal_x, float focal_y, int *__restrict__ radii, float2 *__restrict__ means2D,
+                  const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
+                  int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ sort_key, float4 *__restrict__ blend_rec,
-                  int T, int prefiltered) {
+                  int T, int prefiltered, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
+    view += 16 * vw;
+    proj += 16 * vw;
+    if (campos) campos += 3 * vw;
+    radii += (size_t)vw * P;
+    clamped = view_at(clamped, vb.geom, vw);
+    means2D = view_at(means2D, vb.geom, vw);
+    depths = view_at(depths, vb.geom, vw);
+    cov3Ds = view_at(cov3Ds, vb.geom, vw);
+    rgb = view_at(rgb, vb.geom, vw);
+    conic_opacity = view_at(conic_opacity, vb.geom, vw);
+    tiles_touched = view_at(tiles_touched, vb.geom, vw);
+    blk_hist = view_at(blk_hist, vb.geom, vw);
+    sort_key = view_at(sort_key, vb.geom, vw);
+    blend_rec = view_at(blend_rec, vb.geom, vw);
+    const float tan_fovx = vb.tan_fovx[vw], tan_fovy = vb.tan_fovy[vw];
+    const float focal_x = vb.focal_x[vw], focal_y = vb.focal_y[vw];
     for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
     __syncthreads();
     for (int k = 0; k < kSplatBlock / 256; k++) {
@@ -186,8 +203,11 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
 // rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ ranges,
-                 uint32_t *__restrict__ header) {
+                 uint32_t *__restrict__ header, size_t img_stride) {
     __shared__ uint32_t s_part[1024];
+    tile_count = view_at(tile_count, img_stride, blockIdx.y);
+    ranges = view_at(ranges, img_stride, blockIdx.y);
+    header = view_at(header, img_stride, blockIdx.y);
     const int tid = threadIdx.x;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
@@ -236,7 +256,18 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
-                     uint32_t capacity) {
+                     uint32_t capacity, const ViewBatch vb) {
+    {
+        const int vw = blockIdx.y;
+        ranges = view_at(ranges, vb.img, vw);
+        final_T = view_at(final_T, vb.img, vw);
+        n_contrib = view_at(n_contrib, vb.img, vw);
+        header = view_at(header, vb.img, vw);
+        point_list = view_at(point_list, vb.bin, vw);
+        blend_rec = view_at(blend_rec, vb.geom, vw);
+        out_color += (size_t)vw * C * H * W;
+        out_depth += (size_t)vw * H * W;
+    }
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
     __shared__ float s_col[C][256];
@@ -388,52 +419,52 @@ template <int C>
 static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *shs,
                                 uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp,
-                                const float *view, const float *proj, const float *campos, int W, int H, float tan_fovx,
-                                float tan_fovy, int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
+                                const float *view, const float *proj, const float *campos, int W, int H,
+                                int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key,
-                                float4 *blend_rec, int prefiltered) {
+                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
-    const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:207-208
-    const float focal_x = W / (2.0f * tan_fovx);
-    hipLaunchKernelGGL((preprocess_kernel<C>), dim3(splat_blocks(P)), dim3(256), (size_t)T * 4, s, P, D, M, means3D,
+    hipLaunchKernelGGL((preprocess_kernel<C>), dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, D, M, means3D,
                        scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view,
-                       proj, campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb,
-                       conic_opacity, gx, gy, tiles_touched, blk_hist, sort_key, blend_rec, T, prefiltered);
+                       proj, campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
+                       blk_hist, sort_key, blend_rec, T, prefiltered, vb);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
                        float scale_modifier, const float *rotations, const float *opacities, const float *shs,
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
-                       const float *proj, const float *campos, int W, int H, float tan_fovx, float tan_fovy, int *radii,
+                       const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec,
-                       int prefiltered) {
+                       int prefiltered, int V, const ViewBatch &vb) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
-                               cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
+                               cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
-                               blend_rec, prefiltered);
+                               blend_rec, prefiltered, V, vb);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
-                               cov3D_precomp, colors_precomp, view, proj, campos, W, H, tan_fovx, tan_fovy, radii,
+                               cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
-                               blend_rec, prefiltered);
+                               blend_rec, prefiltered, V, vb);
 }
 
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, header);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
+                      const ViewBatch &vb) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, header, vb.img);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity) {
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity, int V,
+                          const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     if (C == 3)
-        hipLaunchKernelGGL((blend_forward_kernel<3>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity);
+        hipLaunchKernelGGL((blend_forward_kernel<3>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, vb);
     else
-        hipLaunchKernelGGL((blend_forward_kernel<1>), dim3(T), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity);
+        hipLaunchKernelGGL((blend_forward_kernel<1>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, vb);
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

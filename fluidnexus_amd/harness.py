@@ -90,7 +90,7 @@ class HotLoop:
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
-                 force_all_reduce=False, capturable=False, parallel_views=False):
+                 force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
@@ -107,6 +107,11 @@ class HotLoop:
         self.parallel_views = bool(parallel_views)
         if self.parallel_views:
             assert fused_physics and defer_visual_backward, "parallel_views needs the fused physics node and the deferred visual backward"
+        self.batched_views = bool(batched_views)
+        if self.batched_views:
+            assert fused_physics and defer_visual_backward and image_loss == "fused" and rd_pipe == "render_dynamics", \
+                "batched_views needs render_dynamics, the fused image loss / physics node and the deferred visual backward"
+        self._gt_cache = None
         self.view_streams = []
         gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
@@ -250,7 +255,53 @@ class HotLoop:
         gm.optimizer.step()
         gm.optimizer.zero_grad()
 
+    def _gt_stack(self, mine):
+        """Ground-truth images of this rank's views as one [V,3,H,W] tensor (stacked once)."""
+        key = tuple((v, id(self.cams[v].original_image)) for v in mine)
+        if self._gt_cache is None or self._gt_cache[0] != key:
+            self._gt_cache = (key, torch.stack([self.cams[v].original_image for v in mine]).contiguous())
+        return self._gt_cache[1]
+
+    def _iteration_body_batched(self):
+        """Same iteration with this rank's views rendered, compared and back-propagated by ONE launch
+        sequence (rasteriser / loss kernels take the view as a grid dimension).  Mathematically the sum
+        over the views of the per-view losses of `_iteration_body`; the physics gradient, identical for
+        every view, is evaluated once and added once per local view."""
+        from .losses import fused_l1_dssim_grey
+        from .renderer.pipes import render_dynamics_views
+        gm, c = self.gm, self.cfg
+        self.itr += 1
+        gm.total_iterations += 1
+        gm.update_learning_rate_current(self.itr)
+        gm.zero_gradient_cache_current()
+        batch = len(self.cams)
+        mine = shard_views(batch, self.rank, self.world)
+        if self.physics_per_view or self.rank == 0:
+            gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
+            n_phys = len(mine) if self.physics_per_view else batch
+        else:
+            gp, n_phys = None, 0
+        if mine:
+            pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
+                                        GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
+                                        scale=True)
+            l1_value, ssim_value = fused_l1_dssim_grey(pkg["render"], self._gt_stack(mine))  # per view, [V]
+            loss = (((1.0 - c["lambda_dssim"]) * l1_value + c["lambda_dssim"] * ssim_value) * c["lambda_image"]).sum()
+            if self.log_scalars:
+                self.last = dict(l1=l1_value[-1].item(), ssim=ssim_value[-1].item(), total=loss.item())
+            torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
+        if gp is not None and n_phys:
+            gm._estimate_xyz_nn_grad += gp * float(n_phys)
+        gm.flush_deferred_gradients()
+        if self.world > 1 or self.force_all_reduce:
+            dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
+        gm.set_batch_gradient_current(batch)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad()
+
     def _iteration_body(self):
+        if self.batched_views:
+            return self._iteration_body_batched()
         if self.parallel_views:
             return self._iteration_body_parallel()
         gm = self.gm

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
-           "fnx_l1_ssim_backward")
+           "fnx_l1_ssim_backward", "fnx_l1_ssim_forward_batch", "fnx_l1_ssim_backward_batch")
 
 
 def lib():
@@ -30,6 +30,8 @@ def lib():
         L.fnx_l1_ssim_tiles.argtypes = [i, i, i, i]
         L.fnx_l1_ssim_forward.argtypes = [p, p, i, i, i, i, p, p, p]
         L.fnx_l1_ssim_backward.argtypes = [p, p, i, i, i, i, p, p, p, p, p]
+        L.fnx_l1_ssim_forward_batch.argtypes = [p, p, i, i, i, i, i, p, p, p]
+        L.fnx_l1_ssim_backward_batch.argtypes = [p, p, i, i, i, i, i, p, p, p, p, p]
         _LIB = L
     return _LIB
 
@@ -47,39 +49,47 @@ class _L1SSIM(torch.autograd.Function):
             raise RuntimeError("fluidnexus_amd losses: tensors must be on a HIP device (no CPU path)")
         img = img.float().contiguous()
         gt = gt.float().contiguous()
+        if img.shape != gt.shape:
+            raise RuntimeError(f"image {tuple(img.shape)} and target {tuple(gt.shape)} differ in shape")
         Cn, H, W = img.shape[-3:]
+        batched = img.dim() == 4
+        N = img.shape[0] if batched else 1
         Ce = 1 if grey else Cn
         nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
-        partials = torch.empty(nt, 2, dtype=torch.float32, device=img.device)
-        dmaps = torch.empty(3, Ce, H, W, dtype=torch.float32, device=img.device)
+        partials = torch.empty(N, nt, 2, dtype=torch.float32, device=img.device)
+        dmaps = torch.empty(N, 3, Ce, H, W, dtype=torch.float32, device=img.device)
         s = torch.cuda.current_stream().cuda_stream
-        _check(L.fnx_l1_ssim_forward(img.data_ptr(), gt.data_ptr(), Cn, H, W, int(grey), partials.data_ptr(),
-                                     dmaps.data_ptr(), s))
-        sums = partials.sum(dim=0) / float(Ce * H * W)
+        _check(L.fnx_l1_ssim_forward_batch(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey),
+                                           partials.data_ptr(), dmaps.data_ptr(), s))
+        sums = partials.sum(dim=1) / float(Ce * H * W)  # [N, 2]
         ctx.save_for_backward(img, gt, dmaps)
         ctx.grey = bool(grey)
-        return sums[0], sums[1]
+        if batched:
+            return sums[:, 0], sums[:, 1]
+        return sums[0, 0], sums[0, 1]
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim):
         L = lib()
         img, gt, dmaps = ctx.saved_tensors
         Cn, H, W = img.shape[-3:]
+        N = img.shape[0] if img.dim() == 4 else 1
         g_l1 = g_l1.float().contiguous()
         g_ssim = g_ssim.float().contiguous()
         out = torch.empty_like(img)
         s = torch.cuda.current_stream().cuda_stream
-        _check(L.fnx_l1_ssim_backward(img.data_ptr(), gt.data_ptr(), Cn, H, W, int(ctx.grey), dmaps.data_ptr(),
-                                      g_l1.data_ptr(), g_ssim.data_ptr(), out.data_ptr(), s))
+        _check(L.fnx_l1_ssim_backward_batch(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(ctx.grey),
+                                            dmaps.data_ptr(), g_l1.data_ptr(), g_ssim.data_ptr(), out.data_ptr(), s))
         return out, None, None
 
 
 def fused_l1_ssim(img, gt):
-    """(mean |img - gt|, SSIM(img, gt)) for [C,H,W] images."""
+    """(mean |img - gt|, SSIM(img, gt)) for [C,H,W] images; [N,C,H,W] batches give per-image [N] vectors."""
     return _L1SSIM.apply(img, gt, False)
 
 
 def fused_l1_dssim_grey(img, gt):
-    """Physical-stage image terms: grey-mean both [3,H,W] images, then (L1, 1 - SSIM)."""
+    """Physical-stage image terms: grey-mean both [3,H,W] images, then (L1, 1 - SSIM); [N,3,H,W] batches
+    give per-image [N] vectors (one launch for all views of a training batch)."""
     l1, s = _L1SSIM.apply(img, gt, True)
     return l1, 1.0 - s

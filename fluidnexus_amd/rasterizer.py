@@ -205,6 +205,166 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None)
 
 
+class ViewBatch:
+    """The cameras of one training batch, stacked once for the view-batched entry points
+    (include/fnx_raster.h, fnx_*_views): V raster settings that share image size, background, scale
+    modifier, SH degree and the prefiltered flag."""
+
+    def __init__(self, settings_list):
+        if not settings_list:
+            raise ValueError("ViewBatch needs at least one view")
+        if len(settings_list) > _lib.FNX_MAX_VIEWS:
+            raise ValueError(f"at most {_lib.FNX_MAX_VIEWS} views per batch (got {len(settings_list)})")
+        rs0 = settings_list[0]
+        for rs in settings_list[1:]:
+            same = (int(rs.image_height) == int(rs0.image_height) and int(rs.image_width) == int(rs0.image_width)
+                    and float(rs.scale_modifier) == float(rs0.scale_modifier) and int(rs.sh_degree) == int(rs0.sh_degree)
+                    and bool(rs.prefiltered) == bool(rs0.prefiltered)
+                    and (rs.bg is rs0.bg or torch.equal(rs.bg, rs0.bg)))
+            if not same:
+                raise ValueError("the views of a batch must share image size, bg, scale_modifier, sh_degree, prefiltered")
+        self.settings = list(settings_list)
+        self.V = len(settings_list)
+        self.view = torch.stack([_f32c(rs.view_matrix).reshape(16) for rs in settings_list]).contiguous()
+        self.proj = torch.stack([_f32c(rs.proj_matrix).reshape(16) for rs in settings_list]).contiguous()
+        self.campos = torch.stack([_f32c(rs.campos).reshape(3) for rs in settings_list]).contiguous()
+        self.bg = _f32c(rs0.bg)
+        self.tan_x = (C.c_float * self.V)(*[float(rs.tan_fov_x) for rs in settings_list])
+        self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
+
+
+def rasterize_gaussians_views(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                              view_batch, channels=3, grad_splat_limit=None):
+    return _RasterizeGaussiansViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit)
+
+
+class _RasterizeGaussiansViews(torch.autograd.Function):
+    """All views of a batch through one launch sequence.  Outputs [V,C,H,W] colour, [V,P] radii,
+    [V,1,H,W] depth, each slice bit-identical to _RasterizeGaussians with that view's settings; the
+    gradients of the shared inputs are the sums over the views, `means2D` ([V,P,3]) receives the
+    per-view screen-space gradients."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch,
+                channels, grad_splat_limit=None):
+        lib = _lib.raster()
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        if not means3D.is_cuda:
+            raise RuntimeError("fluidnexus_amd rasteriser: tensors must be on a HIP device (no CPU path)")
+        dev = means3D.device
+        rs = vbatch.settings[0]
+        V, P = vbatch.V, means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        Cn = int(channels)
+        means3D = _f32c(means3D)
+        sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
+        scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
+        M = sh.shape[1] if sh.numel() else 0
+        stream = torch.cuda.current_stream().cuda_stream
+        u8 = dict(dtype=torch.uint8, device=dev)
+        gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
+        geom = torch.empty(V * gbytes, **u8)
+        img = torch.empty(V * ibytes, **u8)
+        cap = 0
+        if P == 0:
+            color = torch.zeros(V, Cn, H, W, dtype=torch.float32, device=dev)
+            depth = torch.zeros(V, 1, H, W, dtype=torch.float32, device=dev)
+            radii = torch.zeros(V, 0, dtype=torch.int32, device=dev)
+            binning = torch.empty(0, **u8)
+        else:
+            color = torch.empty(V, Cn, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
+            radii = torch.empty(V, P, dtype=torch.int32, device=dev)
+            _lib.check(lib.fnx_forward_stage1_views(
+                Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
+                _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
+                vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), stream))
+            key = (dev.index, W, H, Cn, P)
+            known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
+            synced = _HOST_SYNC or not known
+            if synced:
+                # one capacity for all views = the largest instance count (reference: exact size per call)
+                n, cap = C.c_int(0), 0
+                for v in range(V):
+                    _lib.check(lib.fnx_read_num_rendered(img.data_ptr() + v * ibytes, W, H, stream, C.byref(n)))
+                    cap = max(cap, int(n.value))
+                if not _HOST_SYNC:
+                    cap = int(cap * _CAP_SLACK) + 1024
+                    _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), cap)
+            else:
+                cap = known
+                _capacity_hwm[key] = cap
+            bbytes = lib.fnx_binning_bytes(cap)
+            binning = torch.empty(V * bbytes, **u8)
+            _lib.check(lib.fnx_forward_stage2_views(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P,
+                                                    W, H, vbatch.bg.data_ptr(), radii.data_ptr(), color.data_ptr(),
+                                                    depth.data_ptr(), stream))
+            if not synced:
+                global _ring_next
+                ring = _ring(dev)
+                if _ring_next % _RING + V > _RING:  # keep the V slots contiguous
+                    _ring_next += _RING - _ring_next % _RING
+                slot = _ring_next % _RING
+                _ring_next += V
+                al = (-img.data_ptr()) % 256  # each view's header sits at the first 256-byte boundary of its blob
+                ring[slot:slot + V].copy_(img.view(V, ibytes)[:, al:al + 32].view(torch.int32))
+                for v in range(V):
+                    _pending_status.append((dev.index, slot + v, key))
+                while len(_pending_status) > _RING:
+                    del _pending_status[0]
+        ctx.vbatch = vbatch
+        ctx.capacity = cap
+        ctx.channels = Cn
+        ctx.grad_splat_limit = -1 if grad_splat_limit is None else int(grad_splat_limit)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        lib = _lib.raster()
+        vbatch, Cn = ctx.vbatch, ctx.channels
+        rs = vbatch.settings[0]
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        dev = means3D.device
+        V, P = vbatch.V, means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = sh.shape[1] if sh.numel() else 0
+        need = ctx.needs_input_grad
+        geometry_only = int(not (need[2] or need[3] or need[4]) and M == 0)
+        # per-view accumulators first, then the arrays summed over the views; one zero-filled slab
+        widths = [V * 3, V * 4] + ([] if geometry_only else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
+        flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)
+        parts, off = [], 0
+        for w in widths:
+            parts.append(flat[off:off + P * w])
+            off += P * w
+        if geometry_only:
+            g_means2D, g_conic, g_means3D, g_colors, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
+            g_opacity_v, g_colors_v = g_opacity, g_colors  # never written in this mode
+        else:
+            g_means2D, g_conic, g_opacity_v, g_colors_v, g_means3D, g_colors, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
+        if P != 0:
+            dL = _f32c(grad_out_color)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.fnx_rasterize_backward_views(
+                Cn, V, P, int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H, means3D.data_ptr(), _ptr(sh),
+                _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp),
+                vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(), vbatch.tan_x, vbatch.tan_y,
+                radii.data_ptr(), geom.data_ptr(), _ptr(binning), ctx.capacity, img.data_ptr(), dL.data_ptr(),
+                g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity_v.data_ptr(), g_colors_v.data_ptr(),
+                g_opacity.data_ptr(), g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr(),
+                g_sh.data_ptr() if M else None, g_scales.data_ptr(), g_rot.data_ptr(), ctx.grad_splat_limit,
+                geometry_only, stream))
+        if V == 1 and not geometry_only:  # a single view accumulates straight into its per-view arrays
+            g_opacity, g_colors = g_opacity_v, g_colors_v
+        return (g_means3D.view(P, 3), g_means2D.view(V, P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     """Field names as in ch3 __init__.py:143-154 (not upstream 3DGS's tanfovx/viewmatrix/...)."""
     image_height: int
@@ -271,3 +431,36 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = empty
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    raster_settings, self.channels, self.grad_splat_limit)
+
+
+class GaussianRasterizerViews(nn.Module):
+    """GaussianRasterizer over all views of a training batch at once (extension, see ViewBatch):
+    forward(...) takes the same arguments, `means2D` being [V,P,3], and returns
+    (color [V,C,H,W], radii [V,P], depth [V,1,H,W])."""
+
+    channels = 3
+    grad_splat_limit = None
+
+    def __init__(self, raster_settings_list, channels=None):
+        super().__init__()
+        self.view_batch = raster_settings_list if isinstance(raster_settings_list, ViewBatch) else ViewBatch(raster_settings_list)
+        if channels is not None:
+            self.channels = int(channels)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if self.channels != 3 and colors_precomp is None:
+            raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians_views(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3D_precomp, self.view_batch, self.channels, self.grad_splat_limit)

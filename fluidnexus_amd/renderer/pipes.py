@@ -123,6 +123,55 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
     return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
 
 
+_VIEW_BATCH_CACHE: dict = {}
+
+
+def _view_batch(GRsetting, cameras, bg_color, scaling_modifier, sh_degree):
+    """Stacked camera tensors of a training batch, built once per (camera set, background)."""
+    from ..rasterizer import ViewBatch
+    key = (tuple(id(c) for c in cameras), id(bg_color), bg_color._version, float(scaling_modifier), int(sh_degree))
+    hit = _VIEW_BATCH_CACHE.get(key)
+    if hit is None:
+        if len(_VIEW_BATCH_CACHE) > 64:
+            _VIEW_BATCH_CACHE.clear()
+        hit = ViewBatch([_settings(GRsetting, cam, bg_color, scaling_modifier, sh_degree) for cam in cameras])
+        _VIEW_BATCH_CACHE[key] = hit
+    return hit
+
+
+def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
+                          GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
+                          gpf_only=False, gs_only=False, debug=False, **kwargs):
+    """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
+    reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
+    per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
+    [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3]); render[v] equals render_dynamics(camera v)."""
+    from ..rasterizer import GaussianRasterizerViews
+    raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    if gpf_only:
+        means3D = render_xyz
+        opacity, scales, rotations, colors = _attributes(gm, pos_type)
+        if colors.shape[1] == 1:
+            colors = colors.repeat(1, 3)
+    elif gs_only:
+        means3D = gm.get_gs_xyz
+        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, True)
+    else:
+        means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
+        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, False)
+    V = len(viewpoint_cameras)
+    screen = torch.zeros((V,) + tuple(means3D.shape), dtype=means3D.dtype, device=means3D.device, requires_grad=True)
+    rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
+                                                     gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
+    if not (gpf_only or gs_only) and not any(
+            getattr(gm, f"_gs_{n}").requires_grad for n in ("xyz", "opacity", "scales", "rotation", "color")):
+        rasterizer.grad_splat_limit = render_xyz.shape[0]
+    image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
+                                     opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
+                                     cov3D_precomp=None)
+    return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
+
+
 def render_fluid(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None,
                  GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, **kwargs):
     """Fluid particles only, 1-channel rasteriser (ScalarReal)."""

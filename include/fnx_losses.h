@@ -30,6 +30,13 @@ int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, 
                         float *dmaps /* [3, Ce, H, W] */, fnx_stream_t stream);
 int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
                          const float *g_l1, const float *g_ssim, float *dL_dimg /* [C, H, W] */, fnx_stream_t stream);
+/* The same over a batch of N image pairs [N,C,H,W] in one launch (the views of a training batch):
+ * partials [N, tiles, 2], dmaps [N, 3, Ce, H, W], g_l1 / g_ssim DEVICE arrays of N, dL_dimg [N,C,H,W]. */
+int fnx_l1_ssim_forward_batch(const float *img, const float *gt, int N, int C, int H, int W, int grey,
+                              float *partials, float *dmaps, fnx_stream_t stream);
+int fnx_l1_ssim_backward_batch(const float *img, const float *gt, int N, int C, int H, int W, int grey,
+                               const float *dmaps, const float *g_l1, const float *g_ssim, float *dL_dimg,
+                               fnx_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

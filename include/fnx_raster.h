@@ -119,6 +119,52 @@ int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const fl
                               float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
                               fnx_stream_t stream);
 
+/*
+ * View-batched extension.  The reference renders the views of a training batch one forward/backward
+ * call at a time (train_physical_particle.py:338-405); here V cameras looking at the SAME Gaussians
+ * go through ONE launch sequence, the view being the second grid dimension of every kernel, so that a
+ * small image still fills the 256 compute units and the tail of one view's deep tiles overlaps the
+ * other views' work.  Each view's slice of every output and scratch blob is bit-identical to what
+ * the single-view calls produce for that camera.
+ *
+ * Per-view arrays are the single-view arrays repeated V times (V <= FNX_MAX_VIEWS, equal image size):
+ *   viewmatrices [V,16], projmatrices [V,16], cam_pos [V,3]  (device);
+ *   tan_fovx, tan_fovy: HOST arrays of V floats;
+ *   radii [V,P], out_color [V,C,H,W], out_depth [V,1,H,W], dL_dpix [V,C,H,W];
+ *   geom_buffers = V * fnx_geom_bytes(P,W,H) bytes, view v at byte offset v * fnx_geom_bytes(P,W,H);
+ *   image_buffers likewise with fnx_image_bytes; binning_buffers = V * fnx_binning_bytes(capacity).
+ * background, scale_modifier, D, M and `prefiltered` are shared by the views.
+ *
+ * Backward: dL_dmean2D [V,P,3] (the per-view screen-space gradients, returned), dL_dconic [V,P,4],
+ * dL_dopacity_views [V,P] and dL_dcolor_views [V,P,C] are zero-filled per-view accumulators; the
+ * remaining outputs are SUMS over the views, written once per splat in view order (no atomics):
+ * dL_dopacity [P], dL_dcolor [P,C] (only when colors_precomp is given; may be NULL otherwise),
+ * dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot.  With V == 1 dL_dopacity / dL_dcolor may alias
+ * their *_views arrays (that is how the single-view entry points are implemented).
+ */
+#define FNX_MAX_VIEWS 16
+int fnx_forward_stage1_views(int channels, int V, char *geom_buffers, char *image_buffers, int P, int D, int M,
+                             int width, int height, const float *means3D, const float *shs,
+                             const float *colors_precomp, const float *opacities, const float *scales,
+                             float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                             const float *viewmatrices, const float *projmatrices, const float *cam_pos,
+                             const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                             fnx_stream_t stream);
+int fnx_forward_stage2_views(int channels, int V, char *geom_buffers, char *binning_buffers, int64_t binning_capacity,
+                             char *image_buffers, int P, int width, int height, const float *background,
+                             const int *radii, float *out_color, float *out_depth, fnx_stream_t stream);
+int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
+                                 int height, const float *means3D, const float *shs, const float *colors_precomp,
+                                 const float *scales, float scale_modifier, const float *rotations,
+                                 const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+                                 const float *campos, const float *tan_fovx, const float *tan_fovy, const int *radii,
+                                 char *geom_buffers, char *binning_buffers, int64_t binning_capacity,
+                                 char *image_buffers, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                                 float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
+                                 float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                 float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                                 fnx_stream_t stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-25): present[i] = view-space z > 0.2 (auxiliary.h:138). */
 int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                      fnx_stream_t stream);

@@ -63,10 +63,11 @@ def test_render_fluid_ch1_pipe_matches_oracle(oracle):
     assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
 
 
-@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("parallel", [False, True, "batched"])
 def test_graph_replay_matches_eager(parallel):
     """A captured iteration replayed K times moves the particles like K eager iterations -- also with the
-    views forked onto parallel streams / graph branches."""
+    views forked onto parallel streams / graph branches, and with the view-batched launch sequence
+    (graph) against the per-view calls (eager)."""
     from fluidnexus_amd import rasterizer
     from fluidnexus_amd.harness import HotLoop, build_smoke_frame
     results = []
@@ -76,7 +77,8 @@ def test_graph_replay_matches_eager(parallel):
             rasterizer._capacity_hwm.clear()
             gm, cams = build_smoke_frame(P_fluid=20000, P_background=5000, hidden_dims=(8, 20, 8), n_views=2, size=128)
             loop = HotLoop(gm, cams, fused_physics=True, defer_visual_backward=True, image_loss="fused",
-                           capturable=True, parallel_views=parallel and use_graph)
+                           capturable=True, parallel_views=parallel is True and use_graph,
+                           batched_views=parallel == "batched" and use_graph)
             loop.make_targets()
             for _ in range(2):
                 loop.iteration()
