@@ -239,9 +239,11 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
     if (T > fnx::kMaxTiles)
         return fail(FNX_ERR_UNSUPPORTED, "%d tiles > %d (image larger than 2048x2048)", T, fnx::kMaxTiles);
-    for (int v = 0; v < V; v++) (void)hipMemsetAsync((char *)img.header + v * vb.img, 0, 32, s);
-    if (P == 0) {
-        for (int v = 0; v < V; v++) (void)hipMemsetAsync((char *)img.ranges + v * vb.img, 0, (size_t)T * 8, s);
+    if (P == 0) {  // no kernels: zero instance count / status and empty ranges
+        for (int v = 0; v < V; v++) {
+            (void)hipMemsetAsync((char *)img.header + v * vb.img, 0, 32, s);
+            (void)hipMemsetAsync((char *)img.ranges + v * vb.img, 0, (size_t)T * 8, s);
+        }
         return hip_check("stage1(P=0)");
     }
     if (!geom_buffer || !means3D || !opacities || !viewmatrix || !projmatrix)

@@ -232,6 +232,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
     if (tid == 1023) {
         header[HDR_NUM_RENDERED] = s_part[1023];
         header[HDR_STATUS] = 0u;
+        header[HDR_CAPACITY] = 0u;
     }
 }
 

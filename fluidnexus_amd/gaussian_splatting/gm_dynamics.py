@@ -162,12 +162,16 @@ class GaussianModel:
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
     def training_setup_current(self, optim_args, capturable=False):
-        """`capturable`: build the Adam state on the device so the step can live inside a hipGraph."""
+        """`capturable`: build the Adam state on the device so the step can live inside a hipGraph (and use
+        torch's single-kernel fused step: same update rule as the reference's default Adam)."""
         init = self._estimate_xyz.detach().clone() / self.scale_factor
         self._estimate_xyz_nn = nn.Parameter(init.requires_grad_(True))
         lr = optim_args.position_lr_init * self.spatial_lr_scale * self.pos_lr_scale_factor
         self.optimizer = torch.optim.Adam([{"params": [self._estimate_xyz_nn], "lr": lr, "name": "estimate_xyz_nn"}],
-                                          lr=0.0, eps=1e-15, capturable=bool(capturable))
+                                          lr=0.0, eps=1e-15, capturable=bool(capturable), fused=bool(capturable))
+        # torch's fused Adam updates the parameter without bumping its version counter, which the
+        # state caches key on: drop them explicitly after every step
+        self.optimizer.register_step_post_hook(lambda *_: self.invalidate_caches())
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
     def training_setup_current_level_two(self, optim_args):

@@ -112,6 +112,7 @@ class HotLoop:
             assert fused_physics and defer_visual_backward and image_loss == "fused" and rd_pipe == "render_dynamics", \
                 "batched_views needs render_dynamics, the fused image loss / physics node and the deferred visual backward"
         self._gt_cache = None
+        self.side_stream = None
         self.view_streams = []
         gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
@@ -276,11 +277,21 @@ class HotLoop:
         gm.zero_gradient_cache_current()
         batch = len(self.cams)
         mine = shard_views(batch, self.rank, self.world)
+        with torch.no_grad():
+            gm.get_visual_xyz_from_nn()  # hidden-particle grid + the one visual forward of this iteration (memoised)
+        # The physics terms depend on the particle state only: their ~50 small kernels run on a side
+        # stream (a parallel branch of the captured graph) underneath the rasteriser's launch sequence.
+        main = torch.cuda.current_stream()
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=gm._xyz.device)
+        gp, n_phys = None, 0
         if self.physics_per_view or self.rank == 0:
-            gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self.side_stream.wait_event(fork)
+            with torch.cuda.stream(self.side_stream):
+                gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
-        else:
-            gp, n_phys = None, 0
         if mine:
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
@@ -290,8 +301,10 @@ class HotLoop:
             if self.log_scalars:
                 self.last = dict(l1=l1_value[-1].item(), ssim=ssim_value[-1].item(), total=loss.item())
             torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
-        if gp is not None and n_phys:
-            gm._estimate_xyz_nn_grad += gp * float(n_phys)
+        if gp is not None:
+            main.wait_stream(self.side_stream)
+            if n_phys:
+                gm._estimate_xyz_nn_grad += gp * float(n_phys)
         gm.flush_deferred_gradients()
         if self.world > 1 or self.force_all_reduce:
             dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
