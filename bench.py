@@ -176,8 +176,8 @@ def main():
         for _ in range(5):
             loop.iteration()
         torch.cuda.synchronize()
-    prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "binning",
-                                                                 "preprocess"))}
+    prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "sort_and_counts",
+                                                                 "preprocess", "emit"))}
     _lib.profile_enable(False)
     # instance / visible counts of this rank's views (for the algorithmic byte count)
     R_views, P_vis_views = [], []
@@ -236,7 +236,7 @@ def main():
                    "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
                    + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
         "roofline": roofline,
-        "rasterise_ms_per_view": {"forward": sum(prof[k][0] for k in ("preprocess", "binning", "blend_forward"))
+        "rasterise_ms_per_view": {"forward": sum(prof[k][0] for k in ("preprocess", "sort_and_counts", "emit", "blend_forward"))
                                   / max(prof["blend_forward"][1], 1) / views_per_launch,
                                   "backward_blend": bwd_ms / max(bwd_n, 1) / views_per_launch},
     }

@@ -20,6 +20,11 @@ __device__ __forceinline__ T *view_at(T *p, size_t stride_bytes, int v) {
     return (T *)((uintptr_t)p + stride_bytes * (size_t)v);
 }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations, not for
+// its global stores (a plain __syncthreads() also drains those, i.e. an L2 round trip per barrier).
+// Only for phases whose global stores are not read again by the workgroup.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 3x3 matrix stored as columns (c0,c1,c2), element m[c][r]; the product keeps the k = 0,1,2
 // left-to-right summation order of the maths library the reference uses (glm mat3 operator*).
 struct M3 {

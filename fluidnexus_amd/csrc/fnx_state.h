@@ -14,8 +14,8 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 inline int tiles_x(int W) { return (W + 15) / 16; }
 inline int tiles_y(int H) { return (H + 15) / 16; }
 
-// Splats are processed in blocks of kSplatBlock consecutive ids (preprocess, instance emission);
-// the depth sort works on chunks of kSortChunk keys per workgroup.
+// Instances are counted and emitted per block of kSplatBlock consecutive depth ranks; the depth
+// sort works on chunks of kSortChunk keys per workgroup.
 constexpr int kSplatBlock = 1024;
 constexpr int kSortChunk = 1024;
 constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB
@@ -39,7 +39,6 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     o->sort_key1 = off;     off = align_up(off + p * 4);
     o->sort_val0 = off;     off = align_up(off + p * 4);
     o->sort_val1 = off;     off = align_up(off + p * 4);
-    o->rank_of = off;       off = align_up(off + p * 4);
     o->sort_hist = off;     off = align_up(off + (2 * 256 * nsb + 256) * 4);
     o->blk_hist = off;      off = align_up(off + nb * t * 2);
     o->blk_rel = off;       off = align_up(off + nb * t * 4);
@@ -62,7 +61,6 @@ inline void binning_layout(int64_t R, fnx_binning_layout_t *o) {
     size_t r = (size_t)(R > 0 ? R : 0);
     size_t off = 0;
     o->point_list = off; off = align_up(off + r * 4);
-    o->bins = off;       off = align_up(off + r * 4);
     o->total = off + kAlign;
 }
 

@@ -19,21 +19,18 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
-                       uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb);
+                       uint32_t *sort_key, float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
                       const ViewBatch &vb);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of, int V,
-                       const ViewBatch &vb);
-void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, const int *radii, const uint32_t *ranges,
-                 const uint32_t *blk_rel, const uint32_t *rank_of, uint32_t *bins, uint32_t *header,
-                 uint32_t capacity, int V, const ViewBatch &vb);
-void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
-                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity,
-                       int V, const ViewBatch &vb);
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, int V, const ViewBatch &vb);
+void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
+                      const int *radii, uint16_t *blk_hist, int V, const ViewBatch &vb);
+void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
+                 const int *radii, const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list,
+                 uint32_t *header, uint32_t capacity, int V, const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity, int V,
@@ -83,7 +80,7 @@ struct Geom {
     float4 *conic_opacity;
     float *rgb;
     uint32_t *tiles_touched;
-    uint32_t *sort_key0, *sort_key1, *sort_val0, *sort_val1, *rank_of, *sort_hist;
+    uint32_t *sort_key0, *sort_key1, *sort_val0, *sort_val1, *sort_hist;
     uint16_t *blk_hist;
     uint32_t *blk_rel;
     float4 *blend_rec;
@@ -105,7 +102,6 @@ Geom carve_geom(char *blob, int P, int W, int H) {
     g.sort_key1 = (uint32_t *)(b + L.sort_key1);
     g.sort_val0 = (uint32_t *)(b + L.sort_val0);
     g.sort_val1 = (uint32_t *)(b + L.sort_val1);
-    g.rank_of = (uint32_t *)(b + L.rank_of);
     g.sort_hist = (uint32_t *)(b + L.sort_hist);
     g.blk_hist = (uint16_t *)(b + L.blk_hist);
     g.blk_rel = (uint32_t *)(b + L.blk_rel);
@@ -133,7 +129,6 @@ Img carve_img(char *blob, int W, int H) {
 }
 struct Bin {
     uint32_t *point_list;
-    uint32_t *bins;
 };
 Bin carve_bin(char *blob, int64_t R) {
     fnx_binning_layout_t L;
@@ -141,7 +136,6 @@ Bin carve_bin(char *blob, int64_t R) {
     char *b = aligned(blob);
     Bin o;
     o.point_list = (uint32_t *)(b + L.point_list);
-    o.bins = (uint32_t *)(b + L.bins);
     return o;
 }
 
@@ -167,7 +161,7 @@ int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *t
 
 // Optional in-library kernel timing (bench.py roofline): HIP events recorded on the caller's
 // stream around one kernel class; elapsed times are summed when read.
-constexpr int kProfClasses = 4;  // 0 blend_forward, 1 blend_backward, 2 binning (sort+emit+order), 3 preprocess
+constexpr int kProfClasses = 5;  // 0 blend_forward, 1 blend_backward, 2 sort + counts + scans, 3 preprocess, 4 emit
 struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
@@ -260,11 +254,18 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     ProfScope ps(3, s);
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
-                           g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.blk_hist,
-                           g.sort_key0, g.blend_rec, prefiltered, V, vb);
+                           g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
+                           g.blend_rec, prefiltered, V, vb);
     }
+    {
+    ProfScope ps(2, s);
+    const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
+    fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
+                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, V, vb);
+    fnx::launch_rank_hist(s, P, width, height, g.sort_val0, g.means2D, rad, g.blk_hist, V, vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, V, vb);
+    }
     return hip_check("stage1");
 }
 
@@ -320,16 +321,11 @@ int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binni
     Img img = carve_img(image_buffer, width, height);
     Bin bin = carve_bin(binning_buffer, binning_capacity);
     const int *rad = radii ? radii : g.radii;
-    const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
     const uint32_t cap = (uint32_t)binning_capacity;
     {
-    ProfScope ps(2, s);
-    const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
-    fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
-                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rank_of, V, vb);
-    fnx::launch_emit(s, P, width, height, g.means2D, rad, img.ranges, g.blk_rel, g.rank_of, bin.bins, img.header, cap,
-                     V, vb);
-    fnx::launch_tile_order(s, P, T, img.ranges, bin.bins, g.sort_val0, bin.point_list, img.header, cap, V, vb);
+    ProfScope ps(4, s);
+    fnx::launch_emit(s, P, width, height, g.sort_val0, g.means2D, rad, img.ranges, g.blk_rel, bin.point_list,
+                     img.header, cap, V, vb);
     }
     {
         ProfScope ps(0, s);

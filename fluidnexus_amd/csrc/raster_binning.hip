@@ -3,20 +3,20 @@
 // (ch3/cuda_rasterizer/rasterizer_impl.cu:67-128,259-296).
 //
 // The reference sorts R = sum(tiles touched) 64-bit (tile | depth) keys.  Here only the P splats
-// are sorted, once, by depth; the R instances are never sorted:
+// are sorted, once, by depth; the R instances are never sorted globally:
 //
-//   preprocess      (raster_forward.hip) counts, per block of 1024 splats, how many touch each tile
-//                   -> blk_hist[block][tile]                                   (LDS atomics only)
+//   depth sort      stable LSD radix sort of (depth bits -> id), 4 x 8-bit passes, wave64 ballot
+//                   ranking: sorted_ids[rank] = splat id in (depth bits, id) order
+//   rank_hist       splats in RANK order, blocks of 1024 consecutive ranks: how many splats of the
+//                   block touch each tile -> blk_hist[block][tile]               (LDS atomics only)
 //   tile_colscan    column prefix of that matrix -> blk_rel[block][tile], tile totals
 //   tile_scan       (raster_forward.hip) tile totals -> [start,end) ranges, num_rendered
-//   depth sort      stable LSD radix sort of (depth bits -> id), 4 x 8-bit passes, wave64 ballot
-//                   ranking; gives every splat its rank in the (depth bits, id) order
-//   emit            each splat block writes the ranks of its instances into its reserved slice of
-//                   every tile's segment (slot = range start + blk_rel + LDS cursor; no global atomic)
-//   tile_order      one workgroup per tile sets one bit per instance in an LDS bitmap over the
-//                   ranks and walks the bitmap: the instances come out in depth order, O(n + P/32)
-//                   per tile, no comparison sort.  160 KiB of LDS holds the bitmap for 1.2 M splats;
-//                   beyond that the rank range is processed in windows.
+//   emit            each rank block owns the slice [start + blk_rel, +blk_hist) of every tile's
+//                   segment.  Slices of consecutive blocks are consecutive in depth, so a tile's list
+//                   is ordered as soon as every slice is: the block bucket-sorts its instances by
+//                   tile in LDS (counting sort, LDS atomics), orders each (block, tile) slice -- ~10
+//                   entries on average -- by counting smaller ranks, and writes splat ids straight to
+//                   their final position.  No global atomics, no per-tile sort pass.
 //
 // (depth bits, id) is a total order and the reference's radix sort is stable over keys emitted in
 // id order, so the resulting lists are bit-identical to the reference's point_list.
@@ -26,8 +26,8 @@
 namespace fnx {
 
 // ---------------------------------------------------------------------------------------------
-// Column prefix over splat blocks.  Workgroup = 64 tiles x 16 waves; wave w owns a contiguous
-// band of blocks, lane = tile.  Pass 1 sums the band, LDS combines bands, pass 2 writes prefixes.
+// Column prefix over blocks.  Workgroup = 64 columns x 16 waves; wave w owns a contiguous
+// band of blocks, lane = column.  Pass 1 sums the band, LDS combines bands, pass 2 writes prefixes.
 template <typename CountT>
 __global__ void __launch_bounds__(1024)
 colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__restrict__ blk_rel,
@@ -87,8 +87,8 @@ sort_hist_kernel(int P, const uint32_t *__restrict__ keys, int shift, int NSB, u
 __global__ void __launch_bounds__(256)
 sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift,
-                    const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total,
-                    uint32_t *__restrict__ rank_of, int first_pass, int last_pass, size_t geom_stride) {
+                    const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total, int first_pass,
+                    size_t geom_stride) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave running offsets
     {
         const int vw = blockIdx.y;
@@ -98,7 +98,6 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
         vals_out = view_at(vals_out, geom_stride, vw);
         hist_rel = view_at(hist_rel, geom_stride, vw);
         digit_total = view_at(digit_total, geom_stride, vw);
-        rank_of = view_at(rank_of, geom_stride, vw);
     }
     __shared__ uint32_t s_wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -153,10 +152,8 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
             const uint32_t r = (uint32_t)__popcll(same & lt_mask);
             const uint32_t pos = run_off[d] + r;
             const int i = base + k * 64 + lane;
-            const uint32_t v = first_pass ? (uint32_t)i : vals_in[i];
             keys_out[pos] = key[k];
-            vals_out[pos] = v;
-            if (last_pass) rank_of[v] = pos;
+            vals_out[pos] = first_pass ? (uint32_t)i : vals_in[i];
         }
         // the wave's LDS reads above are issued before this write (in-order per wave)
         if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
@@ -164,111 +161,318 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Instance emission.  Same splat blocks as preprocess; LDS cursor per tile starts at the block's
-// reserved offset inside the tile segment.
+// Per-(rank block, tile) instance counts.  A 256-thread workgroup owns kSplatBlock = 1024
+// consecutive depth ranks (4 per thread); counts go through an LDS histogram over the tiles.
 __global__ void __launch_bounds__(256)
-emit_kernel(int P, int T, const float2 *__restrict__ means2D, const int *__restrict__ radii, int gx, int gy,
-            const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ blk_rel,
-            const uint32_t *__restrict__ rank_of, uint32_t *__restrict__ bins, uint32_t *__restrict__ header,
-            uint32_t capacity, const ViewBatch vb) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];
+rank_hist_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 *__restrict__ means2D,
+                 const int *__restrict__ radii, int gx, int gy, uint16_t *__restrict__ blk_hist, const ViewBatch vb) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     {
         const int vw = blockIdx.y;
+        sorted_ids = view_at(sorted_ids, vb.geom, vw);
+        means2D = view_at(means2D, vb.geom, vw);
+        blk_hist = view_at(blk_hist, vb.geom, vw);
+        radii += (size_t)vw * P;
+    }
+    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSplatBlock / 256; k++) {
+        const int rank = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
+        if (rank >= P) break;
+        const uint32_t id = sorted_ids[rank];
+        const int rad = radii[id];
+        if (rad > 0) {
+            const float2 p = means2D[id];
+            int x0, y0, x1, y1;
+            tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint16_t *row = blk_hist + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += 256) row[i] = (uint16_t)s_hist[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instance emission, final order.  Same rank blocks as rank_hist.  A block's splats are handled in
+// sub-batches of at most kEmitSpan consecutive ranks (and at most kEmitStage instances); for every
+// tile an LDS bitmask over the sub-batch's ranks records which of them touch the tile (atomicOr),
+// and an instance's place inside the block's slice of its tile is the number of set bits below its
+// own: depth order without sorting and without ordered atomics.  Tiles are handled in windows of at
+// most kEmitTileWindow (the LDS arrays are per window).
+#ifndef FNX_EMIT_THREADS
+#define FNX_EMIT_THREADS 1024
+#endif
+#ifndef FNX_EXP_EMIT
+#define FNX_EXP_EMIT 0  // timing experiments (tools/build_variant.py): 10 loads only, 11 no bitmask / output
+#endif
+#ifdef FNX_EXP_CLOCK  // developer timing: per-workgroup [start, end, sub-batches, instances] of the last emit launch
+__device__ unsigned long long g_emit_clock[4 * 16384];
+extern "C" int fnx_debug_emit_clock(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_emit_clock), (size_t)n * 8);
+}
+#endif
+constexpr int kEmitThreads = FNX_EMIT_THREADS;          // many waves per workgroup: the passes are latency-bound
+constexpr int kEmitPer = kSplatBlock / kEmitThreads;   // splats loaded per thread
+constexpr int kEmitChunk = 8;                          // instances per thread and sub-batch (kept in registers)
+constexpr int kEmitStage = kEmitChunk * kEmitThreads;  // instances per sub-batch
+constexpr int kEmitMaskWords = 8;                      // per-tile bitmask: 8 x 32 ranks
+constexpr int kEmitSpan = 32 * kEmitMaskWords;         // ranks per sub-batch
+constexpr int kEmitTileWindow = 2048;                  // <= kEmitStage: one splat never overflows a sub-batch
+static_assert(kSplatBlock == 1024, "emit packs the rank-in-block into 10 bits");
+static_assert(kEmitTileWindow <= kEmitStage && kEmitTileWindow <= (1 << 22), "entry packing");
+
+// Cursor over the instances of a rank block in (splat, tile row, tile column) order, restricted to
+// the tile window [tw0, tw1).  s_pre = inclusive prefix of the per-splat instance counts.
+struct InstanceWalk {
+    int l, x, y, x0, x1, y1;
+    __device__ __forceinline__ void load(const uint2 *s_rect, int ll) {
+        const uint2 r = s_rect[ll];
+        l = ll;
+        x0 = r.x & 0xFFFFu;
+        x1 = r.x >> 16;
+        y = r.y & 0xFFFFu;
+        y1 = r.y >> 16;
+        x = x0;
+    }
+    __device__ __forceinline__ int tile(int gx) const { return y * gx + x; }
+    // position on instance number `target` (0-based over the whole block, window-restricted counts)
+    __device__ __forceinline__ void seek(const uint32_t *s_pre, const uint2 *s_rect, int l_lo, uint32_t target, int gx,
+                                         int tw0, int tw1, bool whole) {
+        int lo = l_lo, hi = kSplatBlock - 1;  // first splat whose inclusive prefix exceeds target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] > target) hi = mid; else lo = mid + 1;
+        }
+        load(s_rect, lo);
+        uint32_t skip = target - (lo > 0 ? s_pre[lo - 1] : 0u);
+        if (whole) {
+            const uint32_t wdt = (uint32_t)max(x1 - x0, 1);
+            y += (int)(skip / wdt);
+            x += (int)(skip % wdt);
+        } else {
+            if (!in_window(gx, tw0, tw1)) advance_to_window(s_rect, gx, tw0, tw1);
+            for (; skip > 0; skip--) next(s_rect, gx, tw0, tw1, false);
+        }
+    }
+    __device__ __forceinline__ bool in_window(int gx, int tw0, int tw1) const {
+        const int t = y * gx + x;
+        return t >= tw0 && t < tw1 && x < x1 && y < y1;
+    }
+    __device__ __forceinline__ void step(const uint2 *s_rect) {
+        if (++x >= x1) {
+            x = x0;
+            if (++y >= y1) {
+                int ll = l + 1;
+                while (ll < kSplatBlock - 1 && s_rect[ll].x == 0u && s_rect[ll].y == 0u) ll++;
+                load(s_rect, min(ll, kSplatBlock - 1));
+            }
+        }
+    }
+    __device__ __forceinline__ void advance_to_window(const uint2 *s_rect, int gx, int tw0, int tw1) {
+        for (int guard = 0; guard < (1 << 24) && !in_window(gx, tw0, tw1); guard++) {
+            if (l >= kSplatBlock - 1 && (y >= y1 || x1 <= x0)) break;
+            step(s_rect);
+        }
+    }
+    __device__ __forceinline__ void next(const uint2 *s_rect, int gx, int tw0, int tw1, bool whole) {
+        step(s_rect);
+        if (!whole) advance_to_window(s_rect, gx, tw0, tw1);
+    }
+};
+
+__global__ void __launch_bounds__(kEmitThreads)
+emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 *__restrict__ means2D,
+            const int *__restrict__ radii, int gx, int gy, const uint32_t *__restrict__ ranges,
+            const uint32_t *__restrict__ blk_rel, uint32_t *__restrict__ point_list, uint32_t *__restrict__ header,
+            uint32_t capacity, int TW, int V, const ViewBatch vb) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_mask[TW][kEmitMaskWords] | s_cur[TW]
+    __shared__ uint32_t s_id[kSplatBlock];
+    __shared__ uint2 s_rect[kSplatBlock];    // (x0 | x1 << 16, y0 | y1 << 16), tile coordinates
+    __shared__ uint32_t s_pre[kSplatBlock];  // inclusive prefix of the per-splat instance counts (current window)
+    __shared__ uint32_t s_wsum[kEmitThreads / 64];
+    // 1-D grid, block-major: the front blocks (nearest, largest splats, most instances) of ALL views
+    // are dispatched first, so the long workgroups do not end up in the tail of the launch
+    const int vw = blockIdx.x % V, blk = blockIdx.x / V;
+    {
+        sorted_ids = view_at(sorted_ids, vb.geom, vw);
         means2D = view_at(means2D, vb.geom, vw);
         blk_rel = view_at(blk_rel, vb.geom, vw);
-        rank_of = view_at(rank_of, vb.geom, vw);
         radii += (size_t)vw * P;
         ranges = view_at(ranges, vb.img, vw);
         header = view_at(header, vb.img, vw);
-        bins = view_at(bins, vb.bin, vw);
+        point_list = view_at(point_list, vb.bin, vw);
     }
     if (header[HDR_NUM_RENDERED] > capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blk == 0 && threadIdx.x == 0) {
             header[HDR_STATUS] = FNX_ERR_CAPACITY;
             header[HDR_CAPACITY] = capacity;
         }
         return;
     }
-    const uint32_t *rel = blk_rel + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += 256) s_cur[i] = ranges[2 * i] + rel[i];
-    __syncthreads();
-    for (int k = 0; k < kSplatBlock / 256; k++) {
-        const int idx = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
-        if (idx >= P) break;
-        const int rad = radii[idx];
-        if (rad > 0) {
-            const float2 p = means2D[idx];
-            int x0, y0, x1, y1;
-            tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
-            const uint32_t rk = rank_of[idx];
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) bins[atomicAdd(&s_cur[y * gx + x], 1u)] = rk;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-tile ordering through an LDS bitmap over depth ranks.
-__global__ void __launch_bounds__(256)
-tile_order_kernel(int P, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ bins,
-                  const uint32_t *__restrict__ sorted_ids, uint32_t *__restrict__ point_list,
-                  const uint32_t *__restrict__ header, uint32_t capacity, int win_words, const ViewBatch vb) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];  // win_words words + 4 wave totals
-    {
-        const int vw = blockIdx.y;
-        ranges = view_at(ranges, vb.img, vw);
-        header = view_at(header, vb.img, vw);
-        bins = view_at(bins, vb.bin, vw);
-        point_list = view_at(point_list, vb.bin, vw);
-        sorted_ids = view_at(sorted_ids, vb.geom, vw);
-    }
-    __shared__ uint32_t s_wave[4];
-    if (header[HDR_NUM_RENDERED] > capacity) return;
-    const uint32_t start = ranges[2 * blockIdx.x], end = ranges[2 * blockIdx.x + 1];
-    const uint32_t n = end - start;
-    if (n == 0) return;
+    uint32_t *s_mask = s_dyn, *s_cur = s_dyn + (size_t)TW * kEmitMaskWords;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int words_total = (P + 31) >> 5;
-    // words per thread, odd => consecutive threads hit distinct LDS banks
-    const int wpt = ((win_words + 255) / 256) | 1;
-    uint32_t out = start;
-    for (int wbase = 0; wbase < words_total; wbase += win_words) {
-        const int nw = min(win_words, words_total - wbase);
-        for (int i = tid; i < nw; i += 256) s_bits[i] = 0u;
-        __syncthreads();
-        const uint32_t lo = (uint32_t)wbase << 5, hi = lo + ((uint32_t)nw << 5);
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint32_t r = bins[start + i];
-            if (r >= lo && r < hi) atomicOr(&s_bits[(r - lo) >> 5], 1u << (r & 31u));
+    const uint32_t *rel = blk_rel + (size_t)blk * T;
+#ifdef FNX_EXP_CLOCK
+    const unsigned long long clk0 = wall_clock64();
+    unsigned long long n_sub = 0, n_inst = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define FNX_PH(i) { const unsigned long long tn = clock64(); ph[i] += tn - tlast; tlast = tn; }
+#else
+#define FNX_PH(i)
+#endif
+    // the block's splats: local index l = kEmitPer tid + k (consecutive ranks per thread, so the
+    // workgroup-wide prefix over l is a per-thread running sum on top of a prefix over threads)
+#pragma unroll
+    for (int k = 0; k < kEmitPer; k++) {
+        const int l = kEmitPer * tid + k;
+        const int rank = blk * kSplatBlock + l;
+        uint32_t id = 0;
+        uint2 rect = make_uint2(0u, 0u);
+        if (rank < P) {
+            id = sorted_ids[rank];
+            const int rad = radii[id];
+            if (rad > 0) {
+                const float2 p = means2D[id];
+                int x0, y0, x1, y1;
+                tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
+                rect = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+            }
         }
-        __syncthreads();
-        const int w0 = tid * wpt, w1 = min(nw, w0 + wpt);
-        uint32_t cnt = 0;
-        for (int i = w0; i < w1; i++) cnt += __popc(s_bits[i]);
-        // workgroup exclusive scan of cnt: wave scan with shuffles, then 4 wave totals
-        uint32_t inc = cnt;
+        s_id[l] = id;
+        s_rect[l] = rect;
+    }
+    if (FNX_EXP_EMIT == 10) return;
+    FNX_PH(0)
+    for (int tw0 = 0; tw0 < T; tw0 += TW) {
+        const int tw1 = min(T, tw0 + TW);
+        const bool whole = (tw0 == 0 && tw1 == T);
+        lds_barrier();
+        for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
+            s_cur[i] = ranges[2 * (tw0 + i)] + rel[tw0 + i];
+#pragma unroll
+            for (int q = 0; q < kEmitMaskWords; q++) s_mask[q * TW + i] = 0u;  // word-major: lanes = tiles, no bank conflicts
+        }
+        // per-splat instance counts inside this tile window, and their prefix over the block
+        uint32_t c[kEmitPer], run = 0;
+#pragma unroll
+        for (int k = 0; k < kEmitPer; k++) {
+            const uint2 rect = s_rect[kEmitPer * tid + k];
+            const int x0 = rect.x & 0xFFFFu, x1 = rect.x >> 16, y0 = rect.y & 0xFFFFu, y1 = rect.y >> 16;
+            uint32_t n = 0;
+            if (whole) {
+                n = (uint32_t)((x1 - x0) * (y1 - y0));
+            } else {
+                for (int y = y0; y < y1; y++) {  // tiles of row y inside [tw0, tw1)
+                    const int a = max(y * gx + x0, tw0), b = min(y * gx + x1, tw1);
+                    n += (uint32_t)max(b - a, 0);
+                }
+            }
+            c[k] = n;
+            run += n;
+        }
+        uint32_t inc = run;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
             if (lane >= off) inc += v;
         }
-        if (lane == 63) s_wave[w] = inc;
-        __syncthreads();
-        uint32_t pre = inc - cnt;
-        for (int k = 0; k < w; k++) pre += s_wave[k];
-        const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        uint32_t o = out + pre;
-        for (int i = w0; i < w1; i++) {
-            uint32_t m = s_bits[i];
-            const uint32_t rbase = lo + ((uint32_t)i << 5);
-            while (m) {
-                const int b = __ffs((int)m) - 1;
-                point_list[o++] = sorted_ids[rbase + b];
-                m &= m - 1u;
-            }
+        if (lane == 63) s_wsum[w] = inc;
+        lds_barrier();
+        uint32_t pre = inc - run;
+        for (int k = 0; k < w; k++) pre += s_wsum[k];
+#pragma unroll
+        for (int k = 0; k < kEmitPer; k++) {
+            pre += c[k];
+            s_pre[kEmitPer * tid + k] = pre;
         }
-        out += total;
-        __syncthreads();
+        lds_barrier();
+        const uint32_t total = s_pre[kSplatBlock - 1];
+        FNX_PH(1)
+        uint32_t done = 0;  // instances of splats < l0
+        for (int l0 = 0; done < total;) {
+            // sub-batch [l0, l1): at most kEmitSpan ranks and kEmitStage instances
+            int lo = l0, hi = min(kSplatBlock, l0 + kEmitSpan);  // l1 = first l with s_pre[l] - done > kEmitStage
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] - done > (uint32_t)kEmitStage) hi = mid; else lo = mid + 1;
+            }
+            const int l1 = lo;
+            const uint32_t batch = s_pre[l1 - 1] - done;
+            FNX_PH(2)
+            // The batch's instances, enumerated in (splat, row, column) order, are dealt out in equal
+            // contiguous chunks of at most kEmitChunk: a thread finds the splat of its first instance by
+            // binary search in the prefix, then walks rectangles, so the work per thread is the same
+            // whatever the splat sizes.  The entries (window tile << 10 | rank in block) stay in registers.
+            const uint32_t chunk = (batch + (uint32_t)kEmitThreads - 1u) / (uint32_t)kEmitThreads;
+            const uint32_t i0 = min(batch, (uint32_t)tid * chunk), i1 = min(batch, i0 + chunk);
+            uint32_t ent[kEmitChunk];
+            if (batch > 0) {
+                InstanceWalk wk;
+                wk.load(s_rect, l0);
+                if (i0 < i1) wk.seek(s_pre, s_rect, l0, done + i0, gx, tw0, tw1, whole);
+#pragma unroll
+                for (int k = 0; k < kEmitChunk; k++) {
+                    ent[k] = 0xFFFFFFFFu;
+                    if (i0 + k < i1) {
+                        ent[k] = ((uint32_t)(wk.tile(gx) - tw0) << 10) | (uint32_t)wk.l;
+                        if (i0 + k + 1 < i1) wk.next(s_rect, gx, tw0, tw1, whole);
+                    }
+                }
+                FNX_PH(3)
+                const int nw = (l1 - l0 + 31) >> 5;  // bitmask words in use in this sub-batch
+#pragma unroll
+                for (int k = 0; k < kEmitChunk; k++)
+                    if (ent[k] != 0xFFFFFFFFu && FNX_EXP_EMIT != 11) {
+                        const uint32_t b = (ent[k] & 1023u) - (uint32_t)l0;
+                        atomicOr(&s_mask[(b >> 5) * TW + (ent[k] >> 10)], 1u << (b & 31u));
+                    }
+                lds_barrier();
+                FNX_PH(4)
+#pragma unroll
+                for (int k = 0; k < kEmitChunk; k++)
+                    if (ent[k] != 0xFFFFFFFFu && FNX_EXP_EMIT != 11) {
+                        const uint32_t t = ent[k] >> 10, l = ent[k] & 1023u, b = l - (uint32_t)l0;
+                        const uint32_t bw = b >> 5;
+                        uint32_t r = __popc(s_mask[bw * TW + t] & ((1u << (b & 31u)) - 1u));
+                        for (uint32_t q = 0; q < bw; q++) r += __popc(s_mask[q * TW + t]);
+                        point_list[s_cur[t] + r] = s_id[l];
+                    }
+                lds_barrier();
+                FNX_PH(5)
+                for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
+                    uint32_t n = 0;
+                    for (int q = 0; q < nw; q++) n += __popc(s_mask[q * TW + i]);
+                    if (n) {
+                        s_cur[i] += n;
+                        for (int q = 0; q < nw; q++) s_mask[q * TW + i] = 0u;
+                    }
+                }
+                lds_barrier();
+                FNX_PH(6)
+            }
+            done += batch;
+            l0 = l1;
+#ifdef FNX_EXP_CLOCK
+            n_sub++;
+            n_inst += batch;
+#endif
+        }
     }
+#ifdef FNX_EXP_CLOCK
+    if (tid == 0) {
+        const int wg = vw * (gridDim.x / V) + blk;
+        if (wg < 16000) {
+            g_emit_clock[4 * wg] = clk0;
+            g_emit_clock[4 * wg + 1] = wall_clock64();
+            g_emit_clock[4 * wg + 2] = n_sub;
+            g_emit_clock[4 * wg + 3] = n_inst;
+        }
+        if (wg == 0 || wg == 200)
+            for (int i = 0; i < 8; i++) g_emit_clock[4 * 16000 + (wg ? 8 : 0) + i] = ph[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -278,11 +482,10 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
                        blk_hist, blk_rel, tile_count, vb.geom, vb.img);
 }
 
-// keys0 holds the depth keys; after the call vals0 = ids in (depth bits, id) order, rank_of = inverse.
+// keys0 holds the depth keys; after the call vals0 = ids in (depth bits, id) order.
 // hist: u32[NSB*256] chunk histograms, hist_rel: u32[NSB*256] their prefix over chunks, totals: u32[256].
 void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, uint32_t *rank_of, int V,
-                       const ViewBatch &vb) {
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, int V, const ViewBatch &vb) {
     const int NSB = sort_blocks(P);
     uint32_t *kin = keys0, *kout = keys1, *vin = vals0, *vout = vals1;
     for (int pass = 0; pass < 4; pass++) {
@@ -291,35 +494,34 @@ void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, u
         hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(4, V), dim3(1024), 0, s, 256, NSB, hist, hist_rel, totals,
                            vb.geom, vb.geom);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, vin, kout, vout, shift, hist_rel,
-                           totals, rank_of, pass == 0 ? 1 : 0, pass == 3 ? 1 : 0, vb.geom);
+                           totals, pass == 0 ? 1 : 0, vb.geom);
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
     // 4 passes: the result is back in (keys0, vals0)
 }
 
-void launch_emit(hipStream_t s, int P, int W, int H, const float2 *means2D, const int *radii, const uint32_t *ranges,
-                 const uint32_t *blk_rel, const uint32_t *rank_of, uint32_t *bins, uint32_t *header,
-                 uint32_t capacity, int V, const ViewBatch &vb) {
+void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
+                      const int *radii, uint16_t *blk_hist, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
-    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, means2D, radii, gx, gy,
-                       ranges, blk_rel, rank_of, bins, header, capacity, vb);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, sorted_ids,
+                       means2D, radii, gx, gy, blk_hist, vb);
 }
 
-void launch_tile_order(hipStream_t s, int P, int T, const uint32_t *ranges, const uint32_t *bins,
-                       const uint32_t *sorted_ids, uint32_t *point_list, const uint32_t *header, uint32_t capacity,
-                       int V, const ViewBatch &vb) {
-    const int words_total = (P + 31) >> 5;
-    const int kMaxWinWords = 36 * 1024;  // 144 KiB bitmap window (1.18 M ranks)
-    const int win_words = words_total < kMaxWinWords ? words_total : kMaxWinWords;
+void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
+                 const int *radii, const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list,
+                 uint32_t *header, uint32_t capacity, int V, const ViewBatch &vb) {
+    const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
+    const int TW = T < kEmitTileWindow ? T : kEmitTileWindow;
     static bool attr_set = false;
-    if (!attr_set) {  // allow > 64 KiB of dynamic LDS for the bitmap window
-        (void)hipFuncSetAttribute((const void *)tile_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kMaxWinWords * 4);
+    const size_t lds = (size_t)TW * 4 * (kEmitMaskWords + 1);
+    if (!attr_set && TW > 1024) {  // large images: static + dynamic LDS exceeds the default 64 KiB limit
+        (void)hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kEmitTileWindow * 4 * (kEmitMaskWords + 1));
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(T, V), dim3(256), (size_t)win_words * 4, s, P, ranges, bins, sorted_ids,
-                       point_list, header, capacity, win_words, vb);
+    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P) * V), dim3(kEmitThreads), lds, s, P, T, sorted_ids,
+                       means2D, radii, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
 }
 
 }  // namespace fnx

@@ -84,12 +84,9 @@ __device__ inline float3 cov2d_ewa(const float3 mean, float focal_x, float focal
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: per-Gaussian preprocess (ch3 forward.cu:148-244).  A 256-thread workgroup owns a block of
-// kSplatBlock = 1024 consecutive splats (4 per thread, coalesced) and, besides the reference's
-// per-splat state, produces
-//   * blk_hist[block][tile] (u16): how many of the block's splats touch each tile -- counted with
-//     LDS atomics only; this matrix replaces every global atomic of the binning,
-//   * sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones.
+// K1: per-Gaussian preprocess (ch3 forward.cu:148-244), one thread per splat.  Besides the
+// reference's per-splat state it writes the packed 64-byte record the blend kernels read and
+//   sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones (raster_binning.hip).
 template <int C>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -100,9 +97,8 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
-                  uint16_t *__restrict__ blk_hist, uint32_t *__restrict__ sort_key, float4 *__restrict__ blend_rec,
-                  int T, int prefiltered, const ViewBatch vb) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+                  uint32_t *__restrict__ sort_key, float4 *__restrict__ blend_rec, int prefiltered,
+                  const ViewBatch vb) {
     const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
     view += 16 * vw;
     proj += 16 * vw;
@@ -115,18 +111,14 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     rgb = view_at(rgb, vb.geom, vw);
     conic_opacity = view_at(conic_opacity, vb.geom, vw);
     tiles_touched = view_at(tiles_touched, vb.geom, vw);
-    blk_hist = view_at(blk_hist, vb.geom, vw);
     sort_key = view_at(sort_key, vb.geom, vw);
     blend_rec = view_at(blend_rec, vb.geom, vw);
     const float tan_fovx = vb.tan_fovx[vw], tan_fovy = vb.tan_fovy[vw];
     const float focal_x = vb.focal_x[vw], focal_y = vb.focal_y[vw];
-    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    for (int k = 0; k < kSplatBlock / 256; k++) {
-        const int idx = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
-        if (idx >= P) break;
+    {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= P) return;
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-        bool live = false;
         radii[idx] = 0;
         tiles_touched[idx] = 0;
         uint32_t key = 0xFFFFFFFFu;
@@ -182,21 +174,13 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     rec[3] = make_float4(col[2], 0.f, 0.f, 0.f);
                     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
                     key = __float_as_uint(p_view.z);
-                    live = true;
                 }
             }
         } else if (prefiltered) {
             __builtin_trap();  // ch3 auxiliary.h:140-143
         }
         sort_key[idx] = key;
-        if (live) {
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * gx + x], 1u);
-        }
     }
-    __syncthreads();
-    uint16_t *row = blk_hist + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += 256) row[i] = (uint16_t)s_hist[i];
 }
 
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
@@ -422,13 +406,13 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp,
                                 const float *view, const float *proj, const float *campos, int W, int H,
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
-                                float4 *conic_opacity, uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key,
+                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
-    const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
-    hipLaunchKernelGGL((preprocess_kernel<C>), dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, D, M, means3D,
-                       scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view,
-                       proj, campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       blk_hist, sort_key, blend_rec, T, prefiltered, vb);
+    const int gx = tiles_x(W), gy = tiles_y(H);
+    hipLaunchKernelGGL((preprocess_kernel<C>), dim3((P + 255) / 256, V), dim3(256), 0, s, P, D, M, means3D, scales,
+                       scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
+                       campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
+                       sort_key, blend_rec, prefiltered, vb);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -436,17 +420,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint16_t *blk_hist, uint32_t *sort_key, float4 *blend_rec,
+                       uint32_t *tiles_touched, uint32_t *sort_key, float4 *blend_rec,
                        int prefiltered, int V, const ViewBatch &vb) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key,
                                blend_rec, prefiltered, V, vb);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, blk_hist, sort_key,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key,
                                blend_rec, prefiltered, V, vb);
 }
 

@@ -68,12 +68,11 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
 
 /*
  * The same forward split at the reference's host sync so that a caller can avoid it:
- *   stage 1 = per-Gaussian preprocess + per-tile instance counts + tile ranges (num_rendered stays
- *             on the device, inside image_buffer);
+ *   stage 1 = per-Gaussian preprocess, depth sort of the splats, per-tile instance counts and tile
+ *             ranges (num_rendered stays on the device, inside image_buffer);
  *   fnx_read_num_rendered = the optional blocking read-back;
- *   stage 2 = global depth sort of the splats, instance emission, per-tile ordering, alpha
- *             blending, with a caller-chosen
- *             binning capacity.  If num_rendered > capacity nothing is rendered and
+ *   stage 2 = instance emission (straight into depth order) and alpha blending, with a
+ *             caller-chosen binning capacity.  If num_rendered > capacity nothing is rendered and
  *             fnx_read_status reports FNX_ERR_CAPACITY.
  */
 int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
@@ -171,8 +170,8 @@ int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const
 
 /*
  * Optional kernel timing for benchmarks: when enabled, HIP events are recorded on the caller's
- * stream around one kernel class per launch (0 blend forward, 1 blend backward, 2 binning =
- * depth sort + emission + tile ordering, 3 preprocess).  fnx_profile_read blocks on those events
+ * stream around one kernel class per launch (0 blend forward, 1 blend backward, 2 depth sort +
+ * instance counting + scans, 3 preprocess, 4 instance emission).  fnx_profile_read blocks on those events
  * and returns the summed duration and the number of launches since fnx_profile_enable(1).
  */
 int fnx_profile_enable(int on);
@@ -195,9 +194,8 @@ typedef struct {
     size_t sort_key1;     /* u32[P]   sort pong                                     */
     size_t sort_val0;     /* u32[P]   after the sort: ids in (depth bits, id) order */
     size_t sort_val1;     /* u32[P]                                                 */
-    size_t rank_of;       /* u32[P]   position of each id in that order             */
     size_t sort_hist;     /* u32[(2*ceil(P/1024)+1)*256] radix digit histograms + prefixes */
-    size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of block b touching tile t */
+    size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of depth-rank block b touching tile t */
     size_t blk_rel;       /* u32[ceil(P/1024) * T] exclusive prefix over blocks     */
     size_t blend_rec;     /* f32[16P] packed per-splat record read by the blend kernels:
                              x y a b | c o thr depth | ex ey col0 col1 | col2 - - -   */
@@ -213,7 +211,6 @@ typedef struct {
 } fnx_image_layout_t;
 typedef struct {
     size_t point_list; /* u32[R] Gaussian ids sorted by (tile, depth bits, id)      */
-    size_t bins;       /* u32[R] depth ranks of the instances, grouped by tile      */
     size_t total;
 } fnx_binning_layout_t;
 void fnx_geom_layout(int P, int width, int height, fnx_geom_layout_t *out);

@@ -34,3 +34,32 @@ e1.record()
 torch.cuda.synchronize()
 rasterizer.check_status()
 print(f"{e0.elapsed_time(e1) / a.iters:.3f} ms per batched pass; num_rendered(last view) {rasterizer.last_num_rendered}")
+
+import ctypes as C, numpy as np
+from fluidnexus_amd import _lib
+lib = _lib.raster()
+if hasattr(lib, "fnx_debug_emit_clock"):
+    nb = (gm._visual_xyz.shape[0] + gm._gs_xyz.shape[0] + 1023) // 1024
+    n = nb * a.views
+    buf = (C.c_ulonglong * (4 * n))()
+    lib.fnx_debug_emit_clock(buf, 4 * n)
+    arr = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).astype(np.int64)
+    t0 = arr[:, 0].min()
+    st, en = (arr[:, 0] - t0) / 100.0, (arr[:, 1] - t0) / 100.0  # wall_clock64: 100 MHz -> microseconds
+    dur = en - st
+    print("emit WGs", n, "kernel span us", en.max(), "dur mean", dur.mean(), "median", np.median(dur), "max", dur.max(),
+          "start max", st.max())
+    order = np.argsort(-dur)[:8]
+    for i in order:
+        print("  wg", i, "view", i // nb, "block", i % nb, "start", st[i], "dur", dur[i], "sub-batches", arr[i, 2], "instances", arr[i, 3])
+    print("  sub-batches total", arr[:, 2].sum(), "instances", arr[:, 3].sum())
+    # time per sub-batch / per instance regression
+    A = np.stack([np.ones(n), arr[:, 2], arr[:, 3]], 1).astype(np.float64)
+    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+    print("  fit dur = %.2f + %.2f * sub_batches + %.5f * instances (us)" % tuple(coef))
+    big = (C.c_ulonglong * (4 * 16384))()
+    lib.fnx_debug_emit_clock(big, 4 * 16384)
+    names = ["setup loads", "prefix", "search", "walk", "atomicOr+barrier", "position+store+barrier", "cursor update", "-"]
+    for off, label in ((0, "wg 0 (heavy)"), (8, "wg 200")):
+        ph = [big[4 * 16000 + off + i] for i in range(8)]
+        print(" ", label, "phase cycles:", {n: int(v) for n, v in zip(names, ph)}, "total", sum(ph))
