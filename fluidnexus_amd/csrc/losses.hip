@@ -127,7 +127,8 @@ l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
 __global__ void __launch_bounds__(256)
 l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, int grey,
                         Win win, const float *__restrict__ dmaps, const float *__restrict__ g_l1,
-                        const float *__restrict__ g_ssim, float *__restrict__ dL_dimg) {
+                        const float *__restrict__ g_ssim, int g_stride, float scale_l1, float scale_ssim,
+                        float *__restrict__ dL_dimg) {
     __shared__ float s_d[3][HS][HS + 1];
     __shared__ float s_h[3][HS][TS + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -138,8 +139,8 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     gt += (size_t)n * C * hw;
     dmaps += (size_t)n * 3 * Ce * hw;
     dL_dimg += (size_t)n * C * hw;
-    g_l1 += n;
-    g_ssim += n;
+    g_l1 += (size_t)n * g_stride;
+    g_ssim += (size_t)n * g_stride;
     for (int i = tid; i < HS * HS; i += 256) {
         const int ly = i / HS, lx = i - ly * HS;
         const int x = x0 + lx - R, y = y0 + ly - R;
@@ -178,7 +179,7 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     const float cnt = (float)((size_t)Ce * hw);
     const float d = x - y;
     const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    float grad = g_l1[0] * sgn / cnt + g_ssim[0] / cnt * (v0 + 2.f * x * v1 + y * v2);
+    float grad = (g_l1[0] * scale_l1) * sgn / cnt + (g_ssim[0] * scale_ssim) / cnt * (v0 + 2.f * x * v1 + y * v2);
     const size_t o = (size_t)py * W + px;
     if (grey) {
         grad = grad / 3.0f;
@@ -188,6 +189,41 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     } else {
         dL_dimg[(size_t)c * hw + o] = grad;
     }
+}
+
+// per_image[n] = (mean |x - y|, mean ssim_map) of image n; loss = sum_n (w_l1 * l1_n + w_dssim * (1 - ssim_n)).
+// One workgroup; fixed summation order (tile index ascending per thread, then a tree) -> deterministic.
+__global__ void __launch_bounds__(256)
+image_loss_combine_kernel(const float *__restrict__ partials, int N, int nt, float inv_count, float w_l1, float w_dssim,
+                          float *__restrict__ per_image, float *__restrict__ loss) {
+    __shared__ float s_a[256], s_b[256];
+    const int tid = threadIdx.x;
+    float total = 0.f;
+    for (int n = 0; n < N; n++) {
+        float a = 0.f, b = 0.f;
+        for (int i = tid; i < nt; i += 256) {
+            a += partials[2 * ((size_t)n * nt + i)];
+            b += partials[2 * ((size_t)n * nt + i) + 1];
+        }
+        s_a[tid] = a;
+        s_b[tid] = b;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (tid < off) {
+                s_a[tid] += s_a[tid + off];
+                s_b[tid] += s_b[tid + off];
+            }
+            __syncthreads();
+        }
+        const float l1 = s_a[0] * inv_count, ss = s_b[0] * inv_count;
+        if (tid == 0) {
+            per_image[2 * n] = l1;
+            per_image[2 * n + 1] = ss;
+        }
+        total += w_l1 * l1 + w_dssim * (1.0f - ss);
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = total;
 }
 
 thread_local char g_err[512] = "";
@@ -231,8 +267,32 @@ int fnx_l1_ssim_backward_batch(const float *img, const float *gt, int N, int C, 
     static const Win win = make_window();
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
-                       dmaps, g_l1, g_ssim, dL_dimg);
+                       dmaps, g_l1, g_ssim, 1, 1.0f, 1.0f, dL_dimg);
     return hip_check("l1_ssim_backward");
+}
+int fnx_image_loss_forward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                           float w_dssim, float *partials, float *dmaps, float *per_image, float *loss,
+                           fnx_stream_t stream) {
+    if (!per_image || !loss) return fail(FNX_ERR_INVALID_ARG, "image_loss_forward: bad argument");
+    int rc = fnx_l1_ssim_forward_batch(img, gt, N, C, H, W, grey, partials, dmaps, stream);
+    if (rc) return rc;
+    const int nt = fnx_l1_ssim_tiles(C, H, W, grey);
+    const float inv = 1.0f / (float)((size_t)(grey ? 1 : C) * H * W);
+    hipLaunchKernelGGL(image_loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, N, nt, inv, w_l1,
+                       w_dssim, per_image, loss);
+    return hip_check("image_loss_forward");
+}
+int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                            float w_dssim, const float *dmaps, const float *g_loss, float *dL_dimg,
+                            fnx_stream_t stream) {
+    if (N < 1 || !args_ok(C, H, W, grey) || !img || !gt || !dmaps || !g_loss || !dL_dimg)
+        return fail(FNX_ERR_INVALID_ARG, "image_loss_backward: bad argument");
+    static const Win win = make_window();
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
+    // d loss / d l1_n = w_l1, d loss / d ssim_n = -w_dssim; the upstream scalar multiplies both
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
+                       dmaps, g_loss, g_loss, 0, w_l1, -w_dssim, dL_dimg);
+    return hip_check("image_loss_backward");
 }
 int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
                         float *dmaps, fnx_stream_t stream) {

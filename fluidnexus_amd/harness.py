@@ -268,7 +268,7 @@ class HotLoop:
         sequence (rasteriser / loss kernels take the view as a grid dimension).  Mathematically the sum
         over the views of the per-view losses of `_iteration_body`; the physics gradient, identical for
         every view, is evaluated once and added once per local view."""
-        from .losses import fused_l1_dssim_grey
+        from .losses import fused_image_loss
         from .renderer.pipes import render_dynamics_views
         gm, c = self.gm, self.cfg
         self.itr += 1
@@ -296,10 +296,9 @@ class HotLoop:
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                         scale=True)
-            l1_value, ssim_value = fused_l1_dssim_grey(pkg["render"], self._gt_stack(mine))  # per view, [V]
-            loss = (((1.0 - c["lambda_dssim"]) * l1_value + c["lambda_dssim"] * ssim_value) * c["lambda_image"]).sum()
+            loss, per_view = fused_image_loss(pkg["render"], self._gt_stack(mine), c["lambda_dssim"], c["lambda_image"])
             if self.log_scalars:
-                self.last = dict(l1=l1_value[-1].item(), ssim=ssim_value[-1].item(), total=loss.item())
+                self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
             torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
         if gp is not None:
             main.wait_stream(self.side_stream)

@@ -14,7 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
-           "fnx_l1_ssim_backward", "fnx_l1_ssim_forward_batch", "fnx_l1_ssim_backward_batch")
+           "fnx_l1_ssim_backward", "fnx_l1_ssim_forward_batch", "fnx_l1_ssim_backward_batch",
+           "fnx_image_loss_forward", "fnx_image_loss_backward")
 
 
 def lib():
@@ -32,6 +33,9 @@ def lib():
         L.fnx_l1_ssim_backward.argtypes = [p, p, i, i, i, i, p, p, p, p, p]
         L.fnx_l1_ssim_forward_batch.argtypes = [p, p, i, i, i, i, i, p, p, p]
         L.fnx_l1_ssim_backward_batch.argtypes = [p, p, i, i, i, i, i, p, p, p, p, p]
+        f = C.c_float
+        L.fnx_image_loss_forward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p, p]
+        L.fnx_image_loss_backward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p]
         _LIB = L
     return _LIB
 
@@ -93,3 +97,51 @@ def fused_l1_dssim_grey(img, gt):
     give per-image [N] vectors (one launch for all views of a training batch)."""
     l1, s = _L1SSIM.apply(img, gt, True)
     return l1, 1.0 - s
+
+
+class _ImageLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, w_l1, w_dssim, grey):
+        L = lib()
+        if not img.is_cuda:
+            raise RuntimeError("fluidnexus_amd losses: tensors must be on a HIP device (no CPU path)")
+        img = img.float().contiguous()
+        gt = gt.float().contiguous()
+        if img.shape != gt.shape or img.dim() != 4:
+            raise RuntimeError(f"image {tuple(img.shape)} / target {tuple(gt.shape)}: expected equal [N,C,H,W] shapes")
+        N, Cn, H, W = img.shape
+        Ce = 1 if grey else Cn
+        nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
+        scratch = torch.empty(N * nt * 2 + N * 2 + 1, dtype=torch.float32, device=img.device)
+        partials, per_image, loss = scratch[:N * nt * 2], scratch[N * nt * 2:N * nt * 2 + 2 * N], scratch[-1:]
+        dmaps = torch.empty(N, 3, Ce, H, W, dtype=torch.float32, device=img.device)
+        _check(L.fnx_image_loss_forward(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
+                                        partials.data_ptr(), dmaps.data_ptr(), per_image.data_ptr(), loss.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(img, gt, dmaps)
+        ctx.consts = (float(w_l1), float(w_dssim), bool(grey))
+        per_image = per_image.view(N, 2)
+        ctx.mark_non_differentiable(per_image)
+        return loss.view(()), per_image
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_per_image):
+        L = lib()
+        img, gt, dmaps = ctx.saved_tensors
+        w_l1, w_dssim, grey = ctx.consts
+        N, Cn, H, W = img.shape
+        g = g_loss.float().contiguous()
+        out = torch.empty_like(img)
+        _check(L.fnx_image_loss_backward(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
+                                         dmaps.data_ptr(), g.data_ptr(), out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream))
+        return out, None, None, None, None
+
+
+def fused_image_loss(img, gt, lambda_dssim, lambda_image=1.0, grey=True):
+    """Image term of a whole training batch as one scalar:
+    sum_n ((1 - lambda_dssim) * L1_n + lambda_dssim * (1 - SSIM_n)) * lambda_image over the [N,3,H,W] batch
+    (train_physical_particle.py:356-366; grey: on the grey-mean images as the physical stage forms them).
+    Returns (loss, per_image) with per_image [N,2] = detached (L1_n, SSIM_n) for logging.  Three kernels."""
+    return _ImageLoss.apply(img, gt, (1.0 - float(lambda_dssim)) * float(lambda_image),
+                            float(lambda_dssim) * float(lambda_image), bool(grey))

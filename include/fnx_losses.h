@@ -37,6 +37,16 @@ int fnx_l1_ssim_forward_batch(const float *img, const float *gt, int N, int C, i
 int fnx_l1_ssim_backward_batch(const float *img, const float *gt, int N, int C, int H, int W, int grey,
                                const float *dmaps, const float *g_l1, const float *g_ssim, float *dL_dimg,
                                fnx_stream_t stream);
+/* The image term of a training batch as one scalar (train_physical_particle.py:356-366, summed over the
+ * views): loss = sum_n ( w_l1 * L1_n + w_dssim * (1 - SSIM_n) ) with w_l1 = (1 - lambda_dssim) * lambda_image,
+ * w_dssim = lambda_dssim * lambda_image.  forward also returns per_image [N,2] = (L1_n, SSIM_n);
+ * backward takes the upstream gradient of the scalar as a DEVICE scalar g_loss. */
+int fnx_image_loss_forward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                           float w_dssim, float *partials, float *dmaps, float *per_image, float *loss,
+                           fnx_stream_t stream);
+int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                            float w_dssim, const float *dmaps, const float *g_loss, float *dL_dimg,
+                            fnx_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

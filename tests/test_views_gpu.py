@@ -191,3 +191,30 @@ def test_fused_loss_batch_matches_per_image():
             (b1 * w1[n] + b2 * w2[n]).backward()
             assert torch.allclose(a1[n], b1, rtol=1e-6, atol=0) and torch.allclose(a2[n], b2, rtol=1e-6, atol=0)
             assert torch.allclose(xa.grad[n], xb.grad, rtol=1e-6, atol=1e-12)
+
+
+def test_fused_image_loss_scalar_matches_terms():
+    """fused_image_loss (one scalar for the batch) == the weighted sum of the per-image terms, value and gradient."""
+    from fluidnexus_amd.losses import fused_image_loss, fused_l1_dssim_grey, fused_l1_ssim
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    N, H, W = 4, 96, 80
+    x = torch.rand(N, 3, H, W, generator=gen).to(dev)
+    y = torch.rand(N, 3, H, W, generator=gen).to(dev)
+    lam, lam_img = 0.2, 1.5
+    for grey in (True, False):
+        xa = x.clone().requires_grad_(True)
+        loss, per = fused_image_loss(xa, y, lam, lam_img, grey=grey)
+        (loss * 0.7).backward()
+        xb = x.clone().requires_grad_(True)
+        if grey:
+            l1, dssim = fused_l1_dssim_grey(xb, y)
+        else:
+            l1, ss = fused_l1_ssim(xb, y)
+            dssim = 1.0 - ss
+        ref = (((1.0 - lam) * l1 + lam * dssim) * lam_img).sum()
+        (ref * 0.7).backward()
+        assert loss.shape == () and per.shape == (N, 2) and not per.requires_grad
+        assert torch.allclose(loss, ref, rtol=2e-6, atol=0)
+        assert torch.allclose(per[:, 0], l1, rtol=2e-6, atol=0) and torch.allclose(1.0 - per[:, 1], dssim, rtol=1e-5, atol=1e-7)
+        assert (xa.grad - xb.grad).abs().max().item() <= 1e-5 * xb.grad.abs().max().item()
