@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
-           "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward")
+           "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
+           "fnx_physical_stage")
 
 
 def physics():
@@ -35,6 +36,8 @@ def physics():
     lib.fnx_visual_interp_forward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p]
     lib.fnx_visual_interp_backward.restype = i
     lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
+    lib.fnx_physical_stage.restype = i
+    lib.fnx_physical_stage.argtypes = [p, i, f, p, p, p, p, p, f, f, f, f, f, f, f, p, i, p, p, p, p, p, p]
     _LIB = lib
     return lib
 

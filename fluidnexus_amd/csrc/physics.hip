@@ -195,14 +195,15 @@ density_forward_kernel(const float *__restrict__ xyz, int N, const float *__rest
 __global__ void __launch_bounds__(256)
 density_backward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                         float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
-                        const float4 *__restrict__ rec, const float *__restrict__ g, float *__restrict__ dL_dxyz) {
+                        const float4 *__restrict__ rec, const float *__restrict__ g, float gscale,
+                        float *__restrict__ dL_dxyz) {
     const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const int ii = min(i, N - 1);
-    const float Gi = g[ii] / imass[ii] / p0;
+    const float Gi = (g[ii] * gscale) / imass[ii] / p0;
     float ax = 0.f, ay = 0.f, az = 0.f;
     for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
                        [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
-                           const float Gj = g[j] / imass[j] / p0;
+                           const float Gj = (g[j] * gscale) / imass[j] / p0;
                            const float t = H2 - r2;
                            const float dW = -3.0f * term1 * (t * t);  // d poly6 / d r2
                            const float k = (Gi + Gj) * dW * 2.0f;
@@ -218,6 +219,122 @@ density_backward_kernel(const float *__restrict__ xyz, int N, const float *__res
         dL_dxyz[3 * i + 1] = ay;
         dL_dxyz[3 * i + 2] = az;
     }
+}
+
+// ---- physical-particle stage, fused (fnx_physical_stage) -------------------------------------------
+// x = x_nn * sf and the one-tick advected guess x' (gm_dynamics.py:1014-1030, same operation order as
+// the reference's tensor expression); also sum (x - x_est)^2 -> terms[0].
+__global__ void __launch_bounds__(256)
+stage_points_kernel(const float *__restrict__ x_nn, int N, float sf, const float *__restrict__ x_est,
+                    const float *__restrict__ x_prev, const float *__restrict__ buoyancy,
+                    const float *__restrict__ force, float bmax, float secs, float *__restrict__ x,
+                    float *__restrict__ xg, float *__restrict__ terms) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float e2 = 0.f;
+    if (i < N) {
+        const float yn = x_nn[3 * i + 1];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float xs = x_nn[3 * i + c] * sf;
+            float b = buoyancy[3 * i + c];
+            if (bmax > 0.0f) b = b * (1.0f - (yn / bmax));
+            const float tmp_v = (xs - x_prev[3 * i + c]) / secs;
+            const float ev = tmp_v + b * secs + secs * force[3 * i + c];
+            x[3 * i + c] = xs;
+            xg[3 * i + c] = xs + secs * ev;
+            const float d = xs - x_est[3 * i + c];
+            e2 += d * d;
+        }
+    }
+    // per-workgroup partial sums (deterministic; stage_combine_kernel adds them up)
+    __shared__ float s_w[4];
+    e2 = wave_sum63(e2);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = e2;
+    __syncthreads();
+    if (threadIdx.x == 0) terms[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// d_i = p_ratio_i - 1 and per-workgroup sums of d_i^2 -> term[blockIdx.x].  16 lanes per particle (as
+// density_forward_kernel).
+__global__ void __launch_bounds__(256)
+density_term_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
+                    float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
+                    const float4 *__restrict__ rec, float *__restrict__ d_out, float *__restrict__ term) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    float acc = 0.f;
+    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, uint32_t, float, float, float, float r2) {
+                           const float t = H2 - r2;
+                           acc += term1 * (t * t * t);
+                       });
+    acc = row_sum15(acc);
+    float d2 = 0.f;
+    if (sub == 15 && i < N) {
+        const float d = acc / imass[i] / p0 - 1.0f;
+        d_out[i] = d;
+        d2 = d * d;
+    }
+    __shared__ float s_w[4];
+    d2 = wave_sum63(d2);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) term[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// grad = d loss / d x_nn (physics.py _PhysicalStageLoss.backward, same association) and the weighted loss.
+__global__ void __launch_bounds__(256)
+stage_combine_kernel(int N, float sf, const float *__restrict__ x, const float *__restrict__ x_est,
+                     const float *__restrict__ dx_est, const float *__restrict__ dg, const float *__restrict__ buoyancy,
+                     float bmax, float secs, float lam_e, float lam_g, float lam_n, const float *__restrict__ partials,
+                     float *__restrict__ terms, float *__restrict__ loss, float *__restrict__ grad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) {  // add up the per-workgroup partial sums (fixed order), weighted loss
+        __shared__ float s_r[256];
+        const int nb_e = (N + 255) / 256, nb_d = (N + 15) / 16;
+        const float *part[3] = {partials, partials + nb_e, partials + nb_e + nb_d};
+        const int cnt[3] = {nb_e, (lam_g > 0.f) ? nb_d : 0, (lam_n > 0.f) ? nb_d : 0};
+        float tot[3];
+        for (int k = 0; k < 3; k++) {
+            float a = 0.f;
+            for (int j = threadIdx.x; j < cnt[k]; j += 256) a += part[k][j];
+            s_r[threadIdx.x] = a;
+            __syncthreads();
+            for (int off = 128; off >= 1; off >>= 1) {
+                if ((int)threadIdx.x < off) s_r[threadIdx.x] += s_r[threadIdx.x + off];
+                __syncthreads();
+            }
+            tot[k] = s_r[0];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            terms[0] = tot[0];
+            terms[1] = tot[1];
+            terms[2] = tot[2];
+            float L = 0.f;
+            if (lam_e > 0.f) L = L + lam_e * (tot[0] / (float)(3 * (size_t)N));
+            if (lam_g > 0.f) L = L + lam_g * (tot[1] / (float)N);
+            if (lam_n > 0.f) L = L + lam_n * (tot[2] / (float)N);
+            loss[0] = L;
+        }
+    }
+    if (i >= N) return;
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float gx = 0.f;
+        if (lam_e > 0.f) gx += (x[3 * i + c] - x_est[3 * i + c]) * (2.0f * lam_e / (float)(3 * (size_t)N));
+        if (lam_g > 0.f) gx += dx_est[3 * i + c];
+        o[c] = gx * sf;
+        if (lam_n > 0.f) o[c] = o[c] + dg[3 * i + c] * (2.0f * sf);
+    }
+    if (lam_n > 0.f && bmax > 0.0f) {
+        const float dot = (dg[3 * i] * buoyancy[3 * i] + dg[3 * i + 1] * buoyancy[3 * i + 1]) + dg[3 * i + 2] * buoyancy[3 * i + 2];
+        o[1] += dot * (-(secs * secs) / bmax);
+    }
+    grad[3 * i] = o[0];
+    grad[3 * i + 1] = o[1];
+    grad[3 * i + 2] = o[2];
 }
 
 // Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
@@ -391,8 +508,45 @@ int fnx_density_backward(const float *xyz, int N, const float *imass, float H, f
         return fail(FNX_ERR_INVALID_ARG, "density_backward: bad argument");
     GridView g = carve(const_cast<char *>(grid), N);
     hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N,
-                       imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, dL_dxyz);
+                       imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, 1.0f, dL_dxyz);
     return hip_check("density_backward");
+}
+
+int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float *x_est, const float *x_prev,
+                       const float *imass, const float *buoyancy, const float *force, float buoyancy_max_y, float H,
+                       float p0, float secs, float lam_e, float lam_g, float lam_n, char *est_grid, int build_est_grid,
+                       char *guess_grid, float *scratch, float *terms, float *loss, float *grad, fnx_stream_t stream) {
+    if (N <= 0 || !x_nn || !x_est || !x_prev || !imass || !buoyancy || !force || !est_grid || !guess_grid ||
+        !scratch || !terms || !loss || !grad || H <= 0.f || secs == 0.f)
+        return fail(FNX_ERR_INVALID_ARG, "physical_stage: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    float *x = scratch, *xg = scratch + 3 * (size_t)N, *d1 = scratch + 6 * (size_t)N, *d2 = d1 + N;
+    float *dx_est = d2 + N, *dg = dx_est + 3 * (size_t)N;
+    const int nb_e = (N + 255) / 256, nb_d = (N + 15) / 16;
+    float *part_e = dg + 3 * (size_t)N, *part_g = part_e + nb_e, *part_n = part_g + nb_d;  // total <= 15 N + 64 floats
+    hipLaunchKernelGGL(stage_points_kernel, dim3(nb_e), dim3(256), 0, s, x_nn, N, scale_factor, x_est, x_prev,
+                       buoyancy, force, buoyancy_max_y, secs, x, xg, part_e);
+    const float inv = 1.0f / H, H2 = H * H, t1 = poly6_term1(H);
+    if (lam_g > 0.f) {
+        if (build_est_grid)
+            if (int rc = fnx_grid_build(x, N, H, est_grid, stream)) return rc;
+        GridView g = carve(est_grid, N);
+        hipLaunchKernelGGL(density_term_kernel, dim3((N + 15) / 16), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+                           g.M - 1, g.start, g.rec, d1, part_g);
+        hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+                           g.M - 1, g.start, g.rec, d1, 2.0f * lam_g / (float)N, dx_est);
+    }
+    if (lam_n > 0.f) {
+        if (int rc = fnx_grid_build(xg, N, H, guess_grid, stream)) return rc;
+        GridView g = carve(guess_grid, N);
+        hipLaunchKernelGGL(density_term_kernel, dim3((N + 15) / 16), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+                           g.M - 1, g.start, g.rec, d2, part_n);
+        hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+                           g.M - 1, g.start, g.rec, d2, 2.0f * lam_n / (float)N, dg);
+    }
+    hipLaunchKernelGGL(stage_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, scale_factor, x, x_est, dx_est,
+                       dg, buoyancy, buoyancy_max_y, secs, lam_e, lam_g, lam_n, part_e, terms, loss, grad);
+    return hip_check("physical_stage");
 }
 
 int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,

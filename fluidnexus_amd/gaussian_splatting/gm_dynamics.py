@@ -116,6 +116,17 @@ class GaussianModel:
             self._grid_cache[slot] = hit
         return hit[1]
 
+    def _grid_slot(self, slot, xyz):
+        """(grid, needs_build) for fused entry points that build the grid themselves: the cached grid of
+        the current particle state, or fresh storage registered under the current state's key."""
+        key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version)
+        hit = self._grid_cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1], False
+        grid = physics.HashGrid(xyz.detach(), self.H, build=False)
+        self._grid_cache[slot] = (key, grid)
+        return grid, True
+
     def state_memo(self, slot):
         """A dict that lives as long as _estimate_xyz_nn keeps its current value (tensor version)."""
         key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version)

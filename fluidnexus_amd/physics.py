@@ -26,14 +26,15 @@ def _req(t: torch.Tensor) -> torch.Tensor:
 class HashGrid:
     """Opaque uniform hash grid over a point cloud (cell edge = H)."""
 
-    def __init__(self, xyz: torch.Tensor, cell: float):
+    def __init__(self, xyz: torch.Tensor, cell: float, build: bool = True):
         lib = PL.physics()
         xyz = _req(xyz.detach())
         self.N = xyz.shape[0]
         self.cell = float(cell)
         self.blob = torch.empty(lib.fnx_grid_bytes(self.N), dtype=torch.uint8, device=xyz.device)
-        PL.check(lib.fnx_grid_build(xyz.data_ptr() if self.N else None, self.N, self.cell, self.blob.data_ptr(),
-                                    _stream()))
+        if build:  # build=False: storage only, a fused entry point fills it (fnx_physical_stage)
+            PL.check(lib.fnx_grid_build(xyz.data_ptr() if self.N else None, self.N, self.cell, self.blob.data_ptr(),
+                                        _stream()))
 
 
 class _DensityRatio(torch.autograd.Function):
@@ -151,80 +152,44 @@ def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_gr
 
 class _PhysicalStageLoss(torch.autograd.Function):
     """lambda_exyz * l2(x_nn * sf, x_est) + lambda_gas * l2(p_ratio(x), 1) + lambda_next * l2(p_ratio(x'), 1)
-    (train_physical_particle.py:368-404) as ONE autograd node: the forward runs the reference's op
-    sequence without recording a graph, the backward is analytic (density kernel backward + the
-    affine Jacobian of the one-tick advection, gm_dynamics.py:1014-1030)."""
+    (train_physical_particle.py:368-404) as ONE autograd node on top of fnx_physical_stage: value and
+    analytic gradient (density kernel backward + the affine Jacobian of the one-tick advection,
+    gm_dynamics.py:1014-1030) come out of one launch sequence of ~12 kernels."""
 
     @staticmethod
-    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, grids, memo):
-        ctx.memo = memo
+    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, memo):
         if memo is not None and "loss" in memo:  # same particle state as an earlier call of this iteration
-            ctx.gm, ctx.lams, ctx.grids = gm, (lam_e, lam_g, lam_n), grids
-            ctx.save_for_backward(*memo["saved"])
+            ctx.grad = memo["grad"]
             return memo["loss"].clone()
-        with torch.no_grad():
-            sf, secs = gm.scale_factor, gm._secs
-            x = x_nn * sf
-            N = x.shape[0]
-            loss = x.new_zeros(())
-            e = d1 = d2 = xg = None
-            if lam_e > 0:
-                e = x - gm._estimate_xyz
-                loss = loss + lam_e * (e ** 2).mean()
-            if lam_g > 0:
-                d1 = _DensityRatio.apply(x, gm._imass, gm.H, gm.p0, grids("est", x)) - 1.0
-                loss = loss + lam_g * (d1 ** 2).mean()
-            if lam_n > 0:
-                xg = gm.get_guess_hidden_particles_from_nn()
-                d2 = _DensityRatio.apply(xg, gm._imass, gm.H, gm.p0, grids("guess", xg)) - 1.0
-                loss = loss + lam_n * (d2 ** 2).mean()
-        ctx.gm, ctx.lams, ctx.grids = gm, (lam_e, lam_g, lam_n), grids
-        saved = (x, e if e is not None else x.new_empty(0), d1 if d1 is not None else x.new_empty(0),
-                 d2 if d2 is not None else x.new_empty(0), xg if xg is not None else x.new_empty(0))
-        ctx.save_for_backward(*saved)
+        lib = PL.physics()
+        x = _req(x_nn.detach())
+        N = x.shape[0]
+        dev = x.device
+        est, build_est = gm._grid_slot("est", x)
+        guess, _ = gm._grid_slot("guess", x)
+        out = torch.empty(4 + 3 * N, dtype=torch.float32, device=dev)  # terms[3] | loss | grad[N,3]
+        scratch = torch.empty(15 * N + 64, dtype=torch.float32, device=dev)
+        base = out.data_ptr()
+        PL.check(lib.fnx_physical_stage(
+            x.data_ptr(), N, float(gm.scale_factor), _req(gm._estimate_xyz).data_ptr(), _req(gm._xyz).data_ptr(),
+            _req(gm._imass).data_ptr(), _req(gm._buoyancy).data_ptr(), _req(gm._force).data_ptr(),
+            float(gm.buoyancy_max_y), float(gm.H), float(gm.p0), float(gm._secs), lam_e, lam_g, lam_n,
+            est.blob.data_ptr(), int(build_est), guess.blob.data_ptr(), scratch.data_ptr(), base, base + 12, base + 16,
+            _stream()))
+        loss, grad = out[3].view(()), out[4:].view(N, 3)
+        ctx.grad = grad
         if memo is not None:
-            memo.update(loss=loss, saved=saved)
+            memo.update(loss=loss, grad=grad, terms=out[:3])
             return loss.clone()
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        lib = PL.physics()
-        gm, (lam_e, lam_g, lam_n), grids = ctx.gm, ctx.lams, ctx.grids
-        memo = ctx.memo
-        if memo is not None and "grad" in memo:
-            return memo["grad"] * g, None, None, None, None, None, None
-        x, e, d1, d2, xg = ctx.saved_tensors
-        N = x.shape[0]
-        sf, secs = gm.scale_factor, gm._secs
-        gx = torch.zeros_like(x)  # dL / d(x_nn * sf)
-        if lam_e > 0:
-            gx += e * (2.0 * lam_e / (3 * N))
-        if lam_g > 0:
-            up = (d1 * (2.0 * lam_g / N)).contiguous()
-            dx = torch.empty_like(x)
-            PL.check(lib.fnx_density_backward(x.data_ptr(), N, gm._imass.data_ptr(), gm.H, gm.p0,
-                                              grids("est", x).blob.data_ptr(), up.data_ptr(), dx.data_ptr(), _stream()))
-            gx += dx
-        out = gx * sf
-        if lam_n > 0:
-            up = (d2 * (2.0 * lam_n / N)).contiguous()
-            dg = torch.empty_like(x)
-            PL.check(lib.fnx_density_backward(xg.data_ptr(), N, gm._imass.data_ptr(), gm.H, gm.p0,
-                                              grids("guess", xg).blob.data_ptr(), up.data_ptr(), dg.data_ptr(),
-                                              _stream()))
-            # x' = x_nn sf + secs ((x_nn sf - x_prev) / secs + b secs + secs f)  =>  d x' / d x_nn = 2 sf I (+ buoyancy)
-            out = out + dg * (2.0 * sf)
-            if gm.buoyancy_max_y > 0.0:
-                out[:, 1] += (dg * gm._buoyancy).sum(dim=1) * (-(secs * secs) / gm.buoyancy_max_y)
-        if memo is not None:
-            memo["grad"] = out
-        return out * g, None, None, None, None, None, None
+        return ctx.grad * g, None, None, None, None, None
 
 
 def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
     """Weighted physics terms of the physical-particle stage for GaussianModel `gm` (one autograd node).
     `memo`: dict kept by the caller while the particle state is unchanged; the terms are view-independent,
     so the views of one iteration share one evaluation (value and gradient are reused bit for bit)."""
-    return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next),
-                                    gm._cached_grid, memo)
+    return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next), memo)

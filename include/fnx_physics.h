@@ -60,6 +60,21 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
                                float H, float secs, float eps, const char *visual_grid, const float *sum_w,
                                const float *wvel, const float *dL_dout, float *dL_dhidden, fnx_stream_t stream);
 
+/* The three physics terms of the physical-particle stage and their gradient in one call
+ * (entries_fluid_nexus/train_physical_particle.py:368-404 as one launch sequence of ~12 kernels):
+ *   x  = x_nn * scale_factor                                   (hidden particles, scaled units)
+ *   x' = x + secs * ((x - x_prev) / secs + b' secs + secs force), b' = buoyancy (1 - x_nn.y / buoyancy_max_y)
+ *        when buoyancy_max_y > 0, else buoyancy                  (gm_dynamics.py:1014-1030)
+ *   loss = lam_e mean((x - x_est)^2) + lam_g mean((p_ratio(x) - 1)^2) + lam_n mean((p_ratio(x') - 1)^2)
+ * terms[3] receive the three unweighted SUMS of squares, *loss the weighted loss, grad [N,3] = d loss / d x_nn.
+ * est_grid: hash grid over x with cell = H -- built here when build_est_grid != 0, otherwise it must already
+ * be up to date (callers that just ran fnx_visual_interp_forward on the same x own one); guess_grid: blob of
+ * fnx_grid_bytes(N), always rebuilt (over x'); scratch: 15 N + 64 floats.  A term with lambda <= 0 is skipped. */
+int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float *x_est, const float *x_prev,
+                       const float *imass, const float *buoyancy, const float *force, float buoyancy_max_y, float H,
+                       float p0, float secs, float lam_e, float lam_g, float lam_n, char *est_grid, int build_est_grid,
+                       char *guess_grid, float *scratch, float *terms, float *loss, float *grad, fnx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
