@@ -139,6 +139,45 @@ __device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ex, fl
            ((uint32_t)(cx1 && cy1) << 3);
 }
 
+// Minimum of the quadratic form q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 (conic of a splat, positive
+// definite) over the rectangle [X0, X1] x [Y0, Y1] of offsets from the splat centre: 0 if the centre is
+// inside, otherwise the smallest of the four edge minima (1-D quadratics, clamped minimisers).
+__device__ __forceinline__ float conic_min_over_rect(float a, float b, float c, float X0, float X1, float Y0,
+                                                     float Y1) {
+    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
+    const float nbc = -b / c, nba = -b / a;
+    float m = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float X = k ? X1 : X0;
+        const float dy = fminf(fmaxf(nbc * X, Y0), Y1);
+        m = fminf(m, a * X * X + 2.0f * b * X * dy + c * dy * dy);
+        const float Y = k ? Y1 : Y0;
+        const float dx = fminf(fmaxf(nba * Y, X0), X1);
+        m = fminf(m, a * dx * dx + 2.0f * b * dx * Y + c * Y * Y);
+    }
+    return m;
+}
+
+// quadrant_mask refined with the exact ellipse test: a pixel can contribute only where
+// power = -q/2 >= thr (thr = -(ln(255 o) with margins), see splat_footprint), so a quadrant whose
+// minimum of q exceeds -2 thr (plus a further 0.1 % + 0.01, far above the fp32 error of the evaluation
+// near the threshold) holds no contributing pixel.  Any NaN keeps the quadrant.
+__device__ __forceinline__ uint32_t quadrant_mask_exact(float x, float y, float a, float b, float c, float thr,
+                                                        float ex, float ey, float tile_x0, float tile_y0) {
+    uint32_t m = quadrant_mask(x, y, ex, ey, tile_x0, tile_y0);
+    if (m == 0u) return 0u;
+    const float lim = (-2.0f * thr) * 1.001f + 0.01f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if ((m >> q) & 1u) {
+            const float X0 = tile_x0 + (float)((q & 1) * 8) - x, Y0 = tile_y0 + (float)((q >> 1) * 8) - y;
+            if (conic_min_over_rect(a, b, c, X0, X0 + 7.0f, Y0, Y0 + 7.0f) > lim) m &= ~(1u << q);
+        }
+    }
+    return m;
+}
+
 // Real-SH basis constants (ch3 auxiliary.h:22-39).
 __device__ static const float kSH0 = 0.28209479177387814f;
 __device__ static const float kSH1 = 0.4886025119029199f;

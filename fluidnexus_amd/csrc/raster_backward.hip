@@ -171,7 +171,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             const uint32_t id = point_list[r0 + q];
             const float4 *rec = blend_rec + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-            qm = quadrant_mask(ra.x, ra.y, rc.x, rc.y, tile_x0, tile_y0);
+            qm = quadrant_mask_exact(ra.x, ra.y, ra.z, ra.w, rb.x, rb.z, rc.x, rc.y, tile_x0, tile_y0);
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);

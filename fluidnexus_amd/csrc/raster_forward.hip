@@ -295,7 +295,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
-            qm = quadrant_mask(pa.x, pa.y, pc.x, pc.y, tile_x0, tile_y0);
+            qm = quadrant_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
             s_ra[tid] = pa;
             s_rb[tid] = pb;
             s_col[0][tid] = pc.z;
