@@ -82,6 +82,7 @@ def main():
                     help="the views of an iteration: one view-batched launch sequence (default), one rasteriser call "
                          "per view on parallel streams / graph branches, or one call per view in series")
     ap.add_argument("--serial-views", action="store_true", help="same as --views serial")
+    ap.add_argument("--torch-adam", action="store_true", help="gradient mean + optimiser step with torch ops / torch.optim.Adam")
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
@@ -123,7 +124,8 @@ def main():
     loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
                    fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics,
                    capturable=not (a.no_graph or a.host_sync),
-                   parallel_views=view_mode == "branches", batched_views=view_mode == "batched")
+                   parallel_views=view_mode == "branches", batched_views=view_mode == "batched",
+                   fused_step=view_mode == "batched" and not (a.no_graph or a.host_sync) and not a.torch_adam)
     loop.make_targets()
     from fluidnexus_amd.harness import shard_views
     loop_views = shard_views(len(cams), rank, world)

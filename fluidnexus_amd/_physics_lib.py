@@ -9,7 +9,7 @@ _LIB = None
 
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
-           "fnx_physical_stage")
+           "fnx_physical_stage", "fnx_adam_step")
 
 
 def physics():
@@ -38,6 +38,8 @@ def physics():
     lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
     lib.fnx_physical_stage.restype = i
     lib.fnx_physical_stage.argtypes = [p, i, f, p, p, p, p, p, f, f, f, f, f, f, f, p, i, p, p, p, p, p, p]
+    lib.fnx_adam_step.restype = i
+    lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, f, f, f, p, p]
     _LIB = lib
     return lib
 

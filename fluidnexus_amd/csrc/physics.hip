@@ -337,6 +337,35 @@ stage_combine_kernel(int N, float sf, const float *__restrict__ x, const float *
     grad[3 * i + 2] = o[2];
 }
 
+// ---- optimiser step of the particle positions (fnx_adam_step) ---------------------------------------
+// g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch, then torch.optim.Adam's update (amsgrad off, no weight decay),
+// fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far and is advanced
+// by adam_step_inc_kernel afterwards (every workgroup of this kernel reads the old value).
+__global__ void __launch_bounds__(256)
+adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, float s0, const float *__restrict__ g1,
+                 float s1, const float *__restrict__ g2, float s2, float inv_batch, float *__restrict__ m,
+                 float *__restrict__ v, const float *__restrict__ step, float lr, float b1, float b2, float eps,
+                 float *__restrict__ grad_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = step[0] + 1.0f;
+    float g = 0.f;
+    if (g0) g = g + g0[i] * s0;
+    if (g1) g = g + g1[i] * s1;
+    if (g2) g = g + g2[i] * s2;
+    g = g * inv_batch;
+    if (grad_out) grad_out[i] = g;
+    const float mi = m[i] + (1.0f - b1) * (g - m[i]);        // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;          // exp_avg_sq
+    m[i] = mi;
+    v[i] = vi;
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float step_size = lr / bc1;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    x[i] = x[i] - step_size * (mi / denom);
+}
+__global__ void adam_step_inc_kernel(float *step) { step[0] = step[0] + 1.0f; }
+
 // Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
 __device__ __forceinline__ float oct_sum7(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
@@ -547,6 +576,19 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
     hipLaunchKernelGGL(stage_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, scale_factor, x, x_est, dx_est,
                        dg, buoyancy, buoyancy_max_y, secs, lam_e, lam_g, lam_n, part_e, terms, loss, grad);
     return hip_check("physical_stage");
+}
+
+int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
+                  float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
+                  float eps, float *grad_out, fnx_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !exp_avg || !exp_avg_sq)) || !step || !(g0 || g1 || g2))
+        return fail(FNX_ERR_INVALID_ARG, "adam_step: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0)
+        hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, g0, s0, g1, s1, g2, s2,
+                           inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_out);
+    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+    return hip_check("adam_step");
 }
 
 int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,

@@ -57,6 +57,7 @@ class GaussianModel:
         self._visual_grid = None
         self._grid_cache = {}
         self._visual_memo = (None, {})
+        self._grad_cache_used = False
         self._state_memos = {}
         self.defer_visual_backward = False  # opt-in: see flush_deferred_gradients
         self.fit_color = self.fit_opacity = self.fit_scales = self.fit_rotation = True
@@ -221,10 +222,17 @@ class GaussianModel:
 
     def zero_gradient_cache_current(self):
         self._estimate_xyz_nn_grad = torch.zeros_like(self._estimate_xyz_nn)
+        self._grad_cache_used = False
 
     def cache_gradient_current(self):
         if self._estimate_xyz_nn.grad is not None:
             self._estimate_xyz_nn_grad += self._estimate_xyz_nn.grad
+            self._grad_cache_used = True
+
+    def accumulate_gradient_current(self, grad, scale=1.0):
+        """cache += grad * scale (a gradient term computed outside autograd's .grad, e.g. the shared physics term)."""
+        self._estimate_xyz_nn_grad += grad * float(scale)
+        self._grad_cache_used = True
 
     def flush_deferred_gradients(self):
         """With defer_visual_backward the hidden->visual interpolation back-propagates once per
@@ -233,6 +241,18 @@ class GaussianModel:
         dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
         if dh is not None:
             self._estimate_xyz_nn_grad += dh * self.scale_factor  # hidden = x_nn * scale_factor
+            self._grad_cache_used = True
+
+    def fused_step_current(self, batch_size, extra_terms=()):
+        """set_batch_gradient_current + optimizer.step() + zero_grad as one kernel (physics.adam_step):
+        gradient = (cache + deferred hidden<-visual term + extra (tensor, scale) terms) / batch_size.
+        Same update rule as the torch optimiser, on its own state tensors."""
+        dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
+        terms = [(self._estimate_xyz_nn_grad, 1.0)] if self._grad_cache_used else []
+        terms += list(extra_terms) + ([(dh, self.scale_factor)] if dh is not None else [])
+        physics.adam_step(self._estimate_xyz_nn, self.optimizer, terms, batch_size)
+        self._estimate_xyz_nn.grad = None
+        self.invalidate_caches()
 
     def set_batch_gradient_current(self, batch_size):
         self.flush_deferred_gradients()

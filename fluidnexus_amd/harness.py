@@ -90,7 +90,8 @@ class HotLoop:
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
-                 force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False):
+                 force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False,
+                 fused_step=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.log_scalars = log_scalars
@@ -113,6 +114,9 @@ class HotLoop:
                 "batched_views needs render_dynamics, the fused image loss / physics node and the deferred visual backward"
         self._gt_cache = None
         self.side_stream = None
+        self.fused_step = bool(fused_step)  # gradient mean + Adam as one kernel (batched_views only)
+        if self.fused_step:
+            assert self.batched_views and capturable, "fused_step needs batched_views and capturable=True"
         self.view_streams = []
         gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
@@ -302,11 +306,18 @@ class HotLoop:
             torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
         if gp is not None:
             main.wait_stream(self.side_stream)
-            if n_phys:
-                gm._estimate_xyz_nn_grad += gp * float(n_phys)
+        multi = self.world > 1 or self.force_all_reduce
+        if self.fused_step and not multi:
+            gm.fused_step_current(batch, [(gp, float(n_phys))] if gp is not None and n_phys else [])
+            return
+        if gp is not None and n_phys:
+            gm.accumulate_gradient_current(gp, n_phys)
         gm.flush_deferred_gradients()
-        if self.world > 1 or self.force_all_reduce:
+        if multi:
             dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
+        if self.fused_step:
+            gm.fused_step_current(batch)
+            return
         gm.set_batch_gradient_current(batch)
         gm.optimizer.step()
         gm.optimizer.zero_grad()

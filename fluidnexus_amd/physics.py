@@ -193,3 +193,33 @@ def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
     `memo`: dict kept by the caller while the particle state is unchanged; the terms are view-independent,
     so the views of one iteration share one evaluation (value and gradient are reused bit for bit)."""
     return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next), memo)
+
+
+def adam_step(param, optimizer, terms, batch_size, grad_out=None):
+    """Gradient mean + Adam step of `param` in one kernel (fnx_adam_step), on the state of `optimizer`
+    (a torch.optim.Adam with amsgrad = False, weight_decay = 0 whose only parameter is `param`).
+    terms: up to three (tensor, scale) pairs; the gradient is sum(tensor * scale) / batch_size."""
+    lib = PL.physics()
+    group = optimizer.param_groups[0]
+    if group.get("amsgrad") or group.get("weight_decay") or group.get("maximize"):
+        raise RuntimeError("adam_step: amsgrad / weight_decay / maximize are not supported")
+    st = optimizer.state[param]
+    if len(st) == 0:  # same lazy initialisation as torch.optim.Adam._init_group (capturable layout)
+        st["step"] = torch.zeros((), dtype=torch.float32, device=param.device)
+        st["exp_avg"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+        st["exp_avg_sq"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+    if not st["step"].is_cuda:
+        raise RuntimeError("adam_step needs the optimiser state on the device (capturable=True)")
+    terms = [(t, float(sc)) for t, sc in terms if t is not None]
+    if not 1 <= len(terms) <= 3:
+        raise RuntimeError("adam_step takes one to three gradient terms")
+    ts = [_req(t.detach()) for t, _ in terms] + [None] * (3 - len(terms))
+    sc = [sc for _, sc in terms] + [0.0] * (3 - len(terms))
+    b1, b2 = group["betas"]
+    x = param.data
+    assert x.is_contiguous() and x.dtype == torch.float32
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    PL.check(lib.fnx_adam_step(x.data_ptr(), x.numel(), ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
+                               1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                               st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                               ptr(grad_out), _stream()))

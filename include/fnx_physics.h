@@ -75,6 +75,17 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
                        float p0, float secs, float lam_e, float lam_g, float lam_n, char *est_grid, int build_est_grid,
                        char *guess_grid, float *scratch, float *terms, float *loss, float *grad, fnx_stream_t stream);
 
+/* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
+ * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
+ *   g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch            (NULL terms are skipped; n = number of floats)
+ *   exp_avg += (1 - beta1)(g - exp_avg); exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g^2; t = *step + 1
+ *   x -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps);  *step = t
+ * exp_avg / exp_avg_sq / step are the optimiser's own state tensors (step: DEVICE fp32 scalar), so the state
+ * stays loadable by torch.  grad_out (optional) receives g. */
+int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
+                  float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
+                  float eps, float *grad_out, fnx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,33 @@ def test_hot_loop_runs_and_descends():
     for _ in range(20):
         loop.iteration()
     assert np.isfinite(loop.last["total"]) and loop.last["total"] < first
+
+
+def test_adam_step_matches_torch_adam():
+    """fnx_adam_step (gradient mean + Adam in one kernel) against torch.optim.Adam over several steps,
+    on the optimiser's own state tensors."""
+    import torch
+    from fluidnexus_amd.physics import adam_step
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    x0 = torch.randn(5000, 3, generator=gen).to(dev)
+    pa = torch.nn.Parameter(x0.clone())
+    pb = torch.nn.Parameter(x0.clone())
+    kw = dict(lr=0.0, eps=1e-15)
+    oa = torch.optim.Adam([{"params": [pa], "lr": 1.6e-4, "name": "a"}], capturable=True, **kw)
+    ob = torch.optim.Adam([{"params": [pb], "lr": 1.6e-4, "name": "b"}], capturable=True, **kw)
+    batch = 5
+    for it in range(8):
+        g1 = torch.randn(5000, 3, generator=gen).to(dev) * 10.0 ** (it % 3 - 1)
+        g2 = torch.randn(5000, 3, generator=gen).to(dev)
+        pa.grad = ((g1 * 5.0) + g2 * 100.0) * (1.0 / batch)
+        oa.step()
+        adam_step(pb, ob, [(g1, 5.0), (g2, 100.0)], batch)
+    torch.cuda.synchronize()
+    assert float(ob.state[pb]["step"]) == 8.0
+    moved = (pa.detach() - x0).abs().max().item()
+    assert moved > 5e-4
+    assert (pa.detach() - pb.detach()).abs().max().item() <= 1e-3 * moved  # ~2 ulp of |x| ~ 4; the step itself is ~1.6e-4
+    for k in ("exp_avg", "exp_avg_sq"):
+        a, b = oa.state[pa][k], ob.state[pb][k]
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
