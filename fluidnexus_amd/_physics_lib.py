@@ -39,7 +39,7 @@ def physics():
     lib.fnx_physical_stage.restype = i
     lib.fnx_physical_stage.argtypes = [p, i, f, p, p, p, p, p, f, f, f, f, f, f, f, p, i, p, p, p, p, p, p]
     lib.fnx_adam_step.restype = i
-    lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, f, f, f, p, p]
+    lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, C.c_double, C.c_double, f, p, p]
     _LIB = lib
     return lib
 

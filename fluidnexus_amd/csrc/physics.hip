@@ -344,8 +344,8 @@ stage_combine_kernel(int N, float sf, const float *__restrict__ x, const float *
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, float s0, const float *__restrict__ g1,
                  float s1, const float *__restrict__ g2, float s2, float inv_batch, float *__restrict__ m,
-                 float *__restrict__ v, const float *__restrict__ step, float lr, float b1, float b2, float eps,
-                 float *__restrict__ grad_out) {
+                 float *__restrict__ v, const float *__restrict__ step, float lr, float b1, float b2, float omb1,
+                 float omb2, float eps, float *__restrict__ grad_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float t = step[0] + 1.0f;
@@ -355,8 +355,8 @@ adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, flo
     if (g2) g = g + g2[i] * s2;
     g = g * inv_batch;
     if (grad_out) grad_out[i] = g;
-    const float mi = m[i] + (1.0f - b1) * (g - m[i]);        // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = b2 * v[i] + (1.0f - b2) * g * g;          // exp_avg_sq
+    const float mi = m[i] + omb1 * (g - m[i]);  // exp_avg.lerp_(grad, 1 - beta1); 1 - beta rounded from double like torch
+    const float vi = b2 * v[i] + omb2 * g * g;  // exp_avg_sq
     m[i] = mi;
     v[i] = vi;
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
@@ -579,14 +579,16 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
-                  float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
-                  float eps, float *grad_out, fnx_stream_t stream) {
+                  float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1_d,
+                  double beta2_d, float eps, float *grad_out, fnx_stream_t stream) {
+    const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     if (n < 0 || (n > 0 && (!x || !exp_avg || !exp_avg_sq)) || !step || !(g0 || g1 || g2))
         return fail(FNX_ERR_INVALID_ARG, "adam_step: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (n > 0)
         hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, g0, s0, g1, s1, g2, s2,
-                           inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_out);
+                           inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, (float)(1.0 - (double)beta1_d),
+                           (float)(1.0 - (double)beta2_d), eps, grad_out);
     hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step);
     return hip_check("adam_step");
 }
