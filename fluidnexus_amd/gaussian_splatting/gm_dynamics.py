@@ -221,8 +221,18 @@ class GaussianModel:
         self._visual_xyz.grad = self._visual_xyz_grad * (1.0 / batch_size)
 
     def zero_gradient_cache_current(self):
-        self._estimate_xyz_nn_grad = torch.zeros_like(self._estimate_xyz_nn)
+        self._estimate_xyz_nn_grad_store = None  # zero-filled on first use (the fused step may never touch it)
         self._grad_cache_used = False
+
+    @property
+    def _estimate_xyz_nn_grad(self):
+        if getattr(self, "_estimate_xyz_nn_grad_store", None) is None:
+            self._estimate_xyz_nn_grad_store = torch.zeros_like(self._estimate_xyz_nn)
+        return self._estimate_xyz_nn_grad_store
+
+    @_estimate_xyz_nn_grad.setter
+    def _estimate_xyz_nn_grad(self, value):
+        self._estimate_xyz_nn_grad_store = value
 
     def cache_gradient_current(self):
         if self._estimate_xyz_nn.grad is not None:

@@ -88,10 +88,14 @@ def _settings(GRsetting, cam, bg_color, scaling_modifier, sh_degree):
                      prefiltered=False)
 
 
-def _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales):
-    return {"render": image, "viewspace_points": screen, "visibility_filter": radii > 0, "radii": radii,
-            "opacity": opacity, "depth": depth, "render_xyz": render_xyz, "raw_render_xyz": raw_render_xyz,
-            "means3D": means3D, "means2D": screen, "rotations": rotations, "colors_precomp": colors, "scales": scales}
+def _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales,
+          visibility=True):
+    out = {"render": image, "viewspace_points": screen, "radii": radii,
+           "opacity": opacity, "depth": depth, "render_xyz": render_xyz, "raw_render_xyz": raw_render_xyz,
+           "means3D": means3D, "means2D": screen, "rotations": rotations, "colors_precomp": colors, "scales": scales}
+    if visibility:
+        out["visibility_filter"] = radii > 0
+    return out
 
 
 def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None,
@@ -121,6 +125,17 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
                                      colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
                                      rotations=rotations.float(), cov3D_precomp=None)
     return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
+
+
+class _LazyPackage(dict):
+    """Return dict of the view-batched pipe: "visibility_filter" (= radii > 0) is materialised on first access,
+    the hot loop never reads it."""
+
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            self[key] = self["radii"] > 0
+            return self[key]
+        raise KeyError(key)
 
 
 _VIEW_BATCH_CACHE: dict = {}
@@ -160,7 +175,9 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
         means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
         opacity, scales, rotations, colors = _static_attributes(gm, pos_type, False)
     V = len(viewpoint_cameras)
-    screen = torch.zeros((V,) + tuple(means3D.shape), dtype=means3D.dtype, device=means3D.device, requires_grad=True)
+    # zero "screen-space points" whose .grad receives the per-view 2D-mean gradients: a stride-0 view of one
+    # zero (the rasteriser never reads the values), instead of filling V*P*3 floats every iteration
+    screen = torch.zeros(1, dtype=means3D.dtype, device=means3D.device).expand((V,) + tuple(means3D.shape)).requires_grad_()
     rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
                                                      gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
     if not (gpf_only or gs_only) and not any(
@@ -169,7 +186,9 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
     image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
                                      opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
                                      cov3D_precomp=None)
-    return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
+    pkg = _LazyPackage(_pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors,
+                             scales, visibility=False))
+    return pkg
 
 
 def render_fluid(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None, GRsetting=None,
