@@ -24,7 +24,7 @@ FNX_ERR_CAPACITY = 4
 class GeomLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
                 ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "sort_key0",
-                 "sort_key1", "sort_val0", "sort_val1", "sort_hist", "blk_hist", "blk_rel", "blend_rec", "total")]
+                 "sort_key1", "sort_val0", "sort_val1", "rect", "rect_sorted", "sort_hist", "blk_hist", "blk_rel", "blend_rec", "total")]
 
 
 class ImageLayout(C.Structure):

@@ -39,6 +39,8 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     o->sort_key1 = off;     off = align_up(off + p * 4);
     o->sort_val0 = off;     off = align_up(off + p * 4);
     o->sort_val1 = off;     off = align_up(off + p * 4);
+    o->rect = off;          off = align_up(off + p * 8);
+    o->rect_sorted = off;   off = align_up(off + p * 8);
     o->sort_hist = off;     off = align_up(off + (2 * 256 * nsb + 256) * 4);
     o->blk_hist = off;      off = align_up(off + nb * t * 2);
     o->blk_rel = off;       off = align_up(off + nb * t * 4);

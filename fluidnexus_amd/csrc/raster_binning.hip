@@ -40,15 +40,29 @@ colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__r
     const int t = blockIdx.x * 64 + lane;
     const int per = (NB + 15) / 16;
     const int b0 = w * per, b1 = min(NB, b0 + per);
+    // the band is read once, eight rows at a time (independent loads in flight; the kernel is pure latency),
+    // and kept in registers for the second pass when it fits
+    constexpr int kKeep = 24;
+    uint32_t keep[kKeep];
     uint32_t sum = 0;
-    if (t < T)
-        for (int b = b0; b < b1; b++) sum += blk_hist[(size_t)b * T + t];
+    if (t < T) {
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) keep[k] = (b0 + k < b1) ? (uint32_t)blk_hist[(size_t)(b0 + k) * T + t] : 0u;
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) sum += keep[k];
+        for (int b = b0 + kKeep; b < b1; b++) sum += blk_hist[(size_t)b * T + t];
+    }
     s_band[w][lane] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int k = 0; k < w; k++) run += s_band[k][lane];
     if (t < T) {
-        for (int b = b0; b < b1; b++) {
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) {
+            if (b0 + k < b1) blk_rel[(size_t)(b0 + k) * T + t] = run;
+            run += keep[k];
+        }
+        for (int b = b0 + kKeep; b < b1; b++) {
             blk_rel[(size_t)b * T + t] = run;
             run += blk_hist[(size_t)b * T + t];
         }
@@ -88,7 +102,7 @@ __global__ void __launch_bounds__(256)
 sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift,
                     const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total, int first_pass,
-                    size_t geom_stride) {
+                    const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted, size_t geom_stride) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave running offsets
     {
         const int vw = blockIdx.y;
@@ -98,6 +112,10 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
         vals_out = view_at(vals_out, geom_stride, vw);
         hist_rel = view_at(hist_rel, geom_stride, vw);
         digit_total = view_at(digit_total, geom_stride, vw);
+        if (rect_sorted) {  // last pass: also bring the tile rectangles into rank order
+            rect = view_at(rect, geom_stride, vw);
+            rect_sorted = view_at(rect_sorted, geom_stride, vw);
+        }
     }
     __shared__ uint32_t s_wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -152,8 +170,10 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
             const uint32_t r = (uint32_t)__popcll(same & lt_mask);
             const uint32_t pos = run_off[d] + r;
             const int i = base + k * 64 + lane;
+            const uint32_t v = first_pass ? (uint32_t)i : vals_in[i];
             keys_out[pos] = key[k];
-            vals_out[pos] = first_pass ? (uint32_t)i : vals_in[i];
+            vals_out[pos] = v;
+            if (rect_sorted) rect_sorted[pos] = rect[v];
         }
         // the wave's LDS reads above are issued before this write (in-order per wave)
         if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
@@ -162,17 +182,18 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
 
 // ---------------------------------------------------------------------------------------------
 // Per-(rank block, tile) instance counts.  A 256-thread workgroup owns kSplatBlock = 1024
-// consecutive depth ranks (4 per thread); counts go through an LDS histogram over the tiles.
+// consecutive depth ranks (4 per thread).  The kernel is bound by LDS atomic throughput, so a splat
+// does not add 1 to every tile of its rectangle: per tile row it adds +1 at the first column and -1
+// just past the last one (2 atomics per row instead of one per tile), and the counts are the running
+// sums along each tile row, formed once per block.
 __global__ void __launch_bounds__(256)
-rank_hist_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 *__restrict__ means2D,
-                 const int *__restrict__ radii, int gx, int gy, uint16_t *__restrict__ blk_hist, const ViewBatch vb) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, int gy, uint16_t *__restrict__ blk_hist,
+                 const ViewBatch vb) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // T row-delta counters (mod 2^32)
     {
         const int vw = blockIdx.y;
-        sorted_ids = view_at(sorted_ids, vb.geom, vw);
-        means2D = view_at(means2D, vb.geom, vw);
+        rect_sorted = view_at(rect_sorted, vb.geom, vw);
         blk_hist = view_at(blk_hist, vb.geom, vw);
-        radii += (size_t)vw * P;
     }
     for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -180,14 +201,20 @@ rank_hist_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const fl
     for (int k = 0; k < kSplatBlock / 256; k++) {
         const int rank = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
         if (rank >= P) break;
-        const uint32_t id = sorted_ids[rank];
-        const int rad = radii[id];
-        if (rad > 0) {
-            const float2 p = means2D[id];
-            int x0, y0, x1, y1;
-            tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * gx + x], 1u);
+        const uint2 r = rect_sorted[rank];
+        const int x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
+        if (x1 > x0)
+            for (int y = y0; y < y1; y++) {
+                atomicAdd(&s_hist[y * gx + x0], 1u);
+                if (x1 < gx) atomicAdd(&s_hist[y * gx + x1], 0xFFFFFFFFu);  // -1
+            }
+    }
+    __syncthreads();
+    for (int y = threadIdx.x; y < gy; y += 256) {  // running sum along the row
+        uint32_t run = 0;
+        for (int x = 0; x < gx; x++) {
+            run += s_hist[y * gx + x];
+            s_hist[y * gx + x] = run;
         }
     }
     __syncthreads();
@@ -284,8 +311,8 @@ struct InstanceWalk {
 };
 
 __global__ void __launch_bounds__(kEmitThreads)
-emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 *__restrict__ means2D,
-            const int *__restrict__ radii, int gx, int gy, const uint32_t *__restrict__ ranges,
+emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect_sorted, int gx,
+            int gy, const uint32_t *__restrict__ ranges,
             const uint32_t *__restrict__ blk_rel, uint32_t *__restrict__ point_list, uint32_t *__restrict__ header,
             uint32_t capacity, int TW, int V, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_mask[TW][kEmitMaskWords] | s_cur[TW]
@@ -298,9 +325,8 @@ emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 
     const int vw = blockIdx.x % V, blk = blockIdx.x / V;
     {
         sorted_ids = view_at(sorted_ids, vb.geom, vw);
-        means2D = view_at(means2D, vb.geom, vw);
+        rect_sorted = view_at(rect_sorted, vb.geom, vw);
         blk_rel = view_at(blk_rel, vb.geom, vw);
-        radii += (size_t)vw * P;
         ranges = view_at(ranges, vb.img, vw);
         header = view_at(header, vb.img, vw);
         point_list = view_at(point_list, vb.bin, vw);
@@ -333,13 +359,7 @@ emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const float2 
         uint2 rect = make_uint2(0u, 0u);
         if (rank < P) {
             id = sorted_ids[rank];
-            const int rad = radii[id];
-            if (rad > 0) {
-                const float2 p = means2D[id];
-                int x0, y0, x1, y1;
-                tile_rect(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
-                rect = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-            }
+            rect = rect_sorted[rank];
         }
         s_id[l] = id;
         s_rect[l] = rect;
@@ -485,7 +505,8 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
 // keys0 holds the depth keys; after the call vals0 = ids in (depth bits, id) order.
 // hist: u32[NSB*256] chunk histograms, hist_rel: u32[NSB*256] their prefix over chunks, totals: u32[256].
 void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, int V, const ViewBatch &vb) {
+                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, const uint2 *rect, uint2 *rect_sorted,
+                       int V, const ViewBatch &vb) {
     const int NSB = sort_blocks(P);
     uint32_t *kin = keys0, *kout = keys1, *vin = vals0, *vout = vals1;
     for (int pass = 0; pass < 4; pass++) {
@@ -494,23 +515,23 @@ void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, u
         hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(4, V), dim3(1024), 0, s, 256, NSB, hist, hist_rel, totals,
                            vb.geom, vb.geom);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, vin, kout, vout, shift, hist_rel,
-                           totals, pass == 0 ? 1 : 0, vb.geom);
+                           totals, pass == 0 ? 1 : 0, rect, pass == 3 ? rect_sorted : (uint2 *)nullptr, vb.geom);
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
     // 4 passes: the result is back in (keys0, vals0)
 }
 
-void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
-                      const int *radii, uint16_t *blk_hist, int V, const ViewBatch &vb) {
+void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist, int V,
+                      const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
-    hipLaunchKernelGGL(rank_hist_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, sorted_ids,
-                       means2D, radii, gx, gy, blk_hist, vb);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, rect_sorted, gx,
+                       gy, blk_hist, vb);
 }
 
-void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const float2 *means2D,
-                 const int *radii, const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list,
-                 uint32_t *header, uint32_t capacity, int V, const ViewBatch &vb) {
+void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const uint2 *rect_sorted,
+                 const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
+                 uint32_t capacity, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     const int TW = T < kEmitTileWindow ? T : kEmitTileWindow;
     static bool attr_set = false;
@@ -521,7 +542,7 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids,
         attr_set = true;
     }
     hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P) * V), dim3(kEmitThreads), lds, s, P, T, sorted_ids,
-                       means2D, radii, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
+                       rect_sorted, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
 }
 
 }  // namespace fnx

@@ -97,8 +97,8 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
-                  uint32_t *__restrict__ sort_key, float4 *__restrict__ blend_rec, int prefiltered,
-                  const ViewBatch vb) {
+                  uint32_t *__restrict__ sort_key, uint2 *__restrict__ rect, float4 *__restrict__ blend_rec,
+                  int prefiltered, const ViewBatch vb) {
     const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
     view += 16 * vw;
     proj += 16 * vw;
@@ -112,6 +112,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     conic_opacity = view_at(conic_opacity, vb.geom, vw);
     tiles_touched = view_at(tiles_touched, vb.geom, vw);
     sort_key = view_at(sort_key, vb.geom, vw);
+    rect = view_at(rect, vb.geom, vw);
     blend_rec = view_at(blend_rec, vb.geom, vw);
     const float tan_fovx = vb.tan_fovx[vw], tan_fovy = vb.tan_fovy[vw];
     const float focal_x = vb.focal_x[vw], focal_y = vb.focal_y[vw];
@@ -180,6 +181,9 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             __builtin_trap();  // ch3 auxiliary.h:140-143
         }
         sort_key[idx] = key;
+        // tile rectangle for the binning kernels ((0, 0) = no instances)
+        rect[idx] = (key != 0xFFFFFFFFu) ? make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16))
+                                         : make_uint2(0u, 0u);
     }
 }
 
@@ -406,13 +410,13 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp,
                                 const float *view, const float *proj, const float *campos, int W, int H,
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
-                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
+                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key, uint2 *rect,
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3((P + 255) / 256, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, blend_rec, prefiltered, vb);
+                       sort_key, rect, blend_rec, prefiltered, vb);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -420,17 +424,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint32_t *sort_key, float4 *blend_rec,
+                       uint32_t *tiles_touched, uint32_t *sort_key, uint2 *rect, float4 *blend_rec,
                        int prefiltered, int V, const ViewBatch &vb) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, rect,
                                blend_rec, prefiltered, V, vb);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, rect,
                                blend_rec, prefiltered, V, vb);
 }
 

@@ -194,6 +194,8 @@ typedef struct {
     size_t sort_key1;     /* u32[P]   sort pong                                     */
     size_t sort_val0;     /* u32[P]   after the sort: ids in (depth bits, id) order */
     size_t sort_val1;     /* u32[P]                                                 */
+    size_t rect;          /* u32[2P]  tile rectangle of each splat: x0 | x1 << 16, y0 | y1 << 16 (0, 0 if invisible) */
+    size_t rect_sorted;   /* u32[2P]  the same in depth-rank order                  */
     size_t sort_hist;     /* u32[(2*ceil(P/1024)+1)*256] radix digit histograms + prefixes */
     size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of depth-rank block b touching tile t */
     size_t blk_rel;       /* u32[ceil(P/1024) * T] exclusive prefix over blocks     */

@@ -45,7 +45,7 @@ def test_scratch_layouts():
     lib = _lib.raster()
     g = _lib.geom_layout(300000, 512, 512)
     offs = [g.depths, g.clamped, g.radii, g.means2D, g.cov3D, g.conic_opacity, g.rgb, g.tiles_touched, g.sort_key0,
-            g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist, g.blk_hist, g.blk_rel, g.total]
+            g.sort_key1, g.sort_val0, g.sort_val1, g.rect, g.rect_sorted, g.sort_hist, g.blk_hist, g.blk_rel, g.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert lib.fnx_geom_bytes(300000, 512, 512) == g.total
     assert lib.fnx_geom_bytes(0, 512, 512) <= lib.fnx_geom_bytes(1000, 512, 512) < lib.fnx_geom_bytes(2000, 512, 512)
