@@ -160,9 +160,16 @@ __device__ __forceinline__ void for_neighbours(int sub, float px, float py, floa
                                                uint32_t mask, const uint32_t *__restrict__ start,
                                                const float4 *__restrict__ rec, F &&f) {
     const int3 c = cell_of(px, py, pz, inv_cell);
+    // fractional position inside the own cell: a neighbouring cell whose closest point is farther than H
+    // (0.1 % margin against the rounding of f) holds no neighbour
+    const float fx = px * inv_cell - (float)c.x, fy = py * inv_cell - (float)c.y, fz = pz * inv_cell - (float)c.z;
+    const float cell2 = (1.0f / inv_cell) * (1.0f / inv_cell);
     for (int dz = -1; dz <= 1; dz++)
         for (int dy = -1; dy <= 1; dy++)
             for (int dx = -1; dx <= 1; dx++) {
+                const float gx = dx < 0 ? fx : (dx > 0 ? 1.0f - fx : 0.0f), gy = dy < 0 ? fy : (dy > 0 ? 1.0f - fy : 0.0f),
+                            gz = dz < 0 ? fz : (dz > 0 ? 1.0f - fz : 0.0f);
+                if ((gx * gx + gy * gy + gz * gz) * cell2 > H2 * 1.001f) continue;
                 const int3 cc = make_int3(c.x + dx, c.y + dy, c.z + dz);
                 const uint32_t h = cell_hash(cc, mask);
                 const uint32_t s0 = start[h], s1 = start[h + 1];
@@ -427,52 +434,105 @@ visual_forward_kernel(const float *__restrict__ visual, int V, float inv_cell, f
     }
 }
 
-// per visual-grid slot: (g, S) and (wvel, -) of the visual particle stored there
+// per visual-grid slot, everything the hidden<-visual backward needs from the visual particle stored there,
+// with the divisions done once per visual particle instead of once per pair:
+//   G = g / Sc (Sc = max(S, eps)),  c2 = [S > eps] secs (g . wvel) / Sc^2
 __global__ void __launch_bounds__(256)
 slot_visual_payload_kernel(const float4 *__restrict__ rec, int V, const float *__restrict__ sum_w,
-                           const float *__restrict__ wvel, const float *__restrict__ g, float4 *__restrict__ a0,
-                           float4 *__restrict__ a1) {
+                           const float *__restrict__ wvel, const float *__restrict__ g, float secs, float eps,
+                           float4 *__restrict__ a0) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= V) return;
     const uint32_t v = __float_as_uint(rec[s].w);
-    a0[s] = make_float4(g[3 * v], g[3 * v + 1], g[3 * v + 2], sum_w[v]);
-    a1[s] = make_float4(wvel[3 * v], wvel[3 * v + 1], wvel[3 * v + 2], 0.f);
+    const float S = sum_w[v], Sc = fmaxf(S, eps);
+    const float gx = g[3 * v], gy = g[3 * v + 1], gz = g[3 * v + 2];
+    float c2 = 0.f;
+    if (S > eps) c2 = secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
+    a0[s] = make_float4(gx / Sc, gy / Sc, gz / Sc, c2);
 }
 
-// 32 lanes per hidden particle; the grid holds the VISUAL points (~80 per bucket) with their
-// per-slot payload, so the candidate loop streams 48 contiguous bytes per candidate.
+// squared distance from a point at fractional position f (in cell units, [0,1)) inside its cell to the
+// neighbouring cell at offset d along one axis
+__device__ __forceinline__ float axis_gap2(float f, int d, float cell) {
+    const float g = d < 0 ? f : (d > 0 ? 1.0f - f : 0.0f);
+    return (g * cell) * (g * cell);
+}
+
+// One wave per hidden particle; the grid holds the VISUAL points (~65 per bucket).  Candidates are tested
+// 64 at a time; the ~15 % that lie within H are compacted (ballot + popcount) into a per-wave LDS ring and
+// the gradient terms are evaluated on full waves of survivors, instead of running the heavy part of the
+// loop with most lanes masked off.  Cells of the 27-neighbourhood that lie entirely beyond H are skipped.
+//   d hidden_j = sum_v [ w G_v + (secs (G_v . u_j) - c2_v) dW/dr2 2 (hidden_j - visual_v) ]
 __global__ void __launch_bounds__(256)
 visual_backward_kernel(const float *__restrict__ hidden, const float *__restrict__ hidden_prev, int N, float inv_cell,
-                       float H2, float term1, float secs, float eps, uint32_t mask,
+                       float cell, float H2, float term1, float secs, uint32_t mask,
                        const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
-                       const float4 *__restrict__ a0, const float4 *__restrict__ a1, float *__restrict__ dL_dhidden) {
-    const int j = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
-    const int jj = min(j, N - 1);
-    const float hx = hidden[3 * jj], hy = hidden[3 * jj + 1], hz = hidden[3 * jj + 2];
-    const float ux = (hx - hidden_prev[3 * jj]) / secs, uy = (hy - hidden_prev[3 * jj + 1]) / secs,
-                uz = (hz - hidden_prev[3 * jj + 2]) / secs;
+                       const float4 *__restrict__ a0, float *__restrict__ dL_dhidden) {
+    __shared__ float4 s_e[4][128];   // (ex, ey, ez, r2) of the survivors
+    __shared__ uint32_t s_s[4][128];  // their grid slots
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= N) return;  // whole wave
+    const float hx = hidden[3 * j], hy = hidden[3 * j + 1], hz = hidden[3 * j + 2];
+    const float ux = (hx - hidden_prev[3 * j]) / secs, uy = (hy - hidden_prev[3 * j + 1]) / secs,
+                uz = (hz - hidden_prev[3 * j + 2]) / secs;
+    const int3 c = cell_of(hx, hy, hz, inv_cell);
+    const float fx = hx * inv_cell - (float)c.x, fy = hy * inv_cell - (float)c.y, fz = hz * inv_cell - (float)c.z;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours<32>(sub, hx, hy, hz, inv_cell, H2, mask, start, rec,
-                       [&](uint32_t s, uint32_t, float ex, float ey, float ez, float r2) {
-                           const float4 gs = a0[s];
-                           const float4 wv = a1[s];
-                           const float S = gs.w;
-                           const float Sc = fmaxf(S, eps);
-                           const float t = H2 - r2;
-                           const float w = term1 * (t * t * t);
-                           const float dW = -3.0f * term1 * (t * t);
-                           const float a = w / Sc;  // through u_j: (1/secs) * secs * w/S * g
-                           float dLdw = secs * (gs.x * ux + gs.y * uy + gs.z * uz) / Sc;
-                           if (S > eps) dLdw -= secs * (gs.x * wv.x + gs.y * wv.y + gs.z * wv.z) / (Sc * Sc);
-                           const float k = dLdw * dW * 2.0f;  // d r2 / d hidden_j = 2 (hidden_j - visual_v) = 2 e
-                           ax += a * gs.x + k * ex;
-                           ay += a * gs.y + k * ey;
-                           az += a * gs.z + k * ez;
-                       });
-    ax = half_sum31(ax);
-    ay = half_sum31(ay);
-    az = half_sum31(az);
-    if (sub == 31 && j < N) {
+    uint32_t head = 0, tail = 0;  // ring positions (wave-uniform)
+    auto drain = [&](uint32_t n) {  // evaluate n <= 64 survivors starting at head
+        if ((uint32_t)lane < n) {
+            const uint32_t q = (head + lane) & 127u;
+            const float4 e = s_e[w][q];
+            const float4 G = a0[s_s[w][q]];
+            const float t = H2 - e.w;
+            const float wgt = term1 * (t * t * t);
+            const float dW = -3.0f * term1 * (t * t);
+            const float dLdw = secs * (G.x * ux + G.y * uy + G.z * uz) - G.w;
+            const float k = dLdw * dW * 2.0f;
+            ax += wgt * G.x + k * e.x;
+            ay += wgt * G.y + k * e.y;
+            az += wgt * G.z + k * e.z;
+        }
+        head += n;
+    };
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                // the margin keeps every cell whose closest point could be within H despite fp32 rounding of f
+                if (axis_gap2(fx, dx, cell) + axis_gap2(fy, dy, cell) + axis_gap2(fz, dz, cell) > H2 * 1.001f) continue;
+                const uint32_t h = cell_hash(make_int3(c.x + dx, c.y + dy, c.z + dz), mask);
+                const uint32_t s0 = start[h], s1 = start[h + 1];
+                for (uint32_t base = s0; base < s1; base += 64) {
+                    const uint32_t sl = base + lane;
+                    bool pass = false;
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sl < s1) {
+                        const float4 q = rec[sl];
+                        e.x = hx - q.x;
+                        e.y = hy - q.y;
+                        e.z = hz - q.z;
+                        e.w = e.x * e.x + e.y * e.y + e.z * e.z;
+                        pass = e.w < H2;
+                    }
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) {
+                        const uint32_t q = (tail + (uint32_t)__popcll(m & lt_mask)) & 127u;
+                        s_e[w][q] = e;
+                        s_s[w][q] = sl;
+                    }
+                    tail += (uint32_t)__popcll(m);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's LDS writes before its reads
+                    if (tail - head >= 64u) drain(64u);
+                }
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    drain(tail - head);
+    ax = wave_sum63(ax);
+    ay = wave_sum63(ay);
+    az = wave_sum63(az);
+    if (lane == 63) {
         dL_dhidden[3 * j + 0] = ax;
         dL_dhidden[3 * j + 1] = ay;
         dL_dhidden[3 * j + 2] = az;
@@ -618,10 +678,10 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
     GridView g = carve(const_cast<char *>(visual_grid), V);
     if (V > 0)
         hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
-                           V, sum_w, wvel, dL_dout, g.aux0, g.aux1);
-    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, hidden,
-                       hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0,
-                       g.aux1, dL_dhidden);
+                           V, sum_w, wvel, dL_dout, secs, eps, g.aux0);
+    hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden,
+                       hidden_prev, N, 1.0f / H, H, H * H, poly6_term1(H), secs, g.M - 1, g.start, g.rec, g.aux0,
+                       dL_dhidden);
     return hip_check("visual_interp_backward");
 }
 
