@@ -19,7 +19,9 @@ LIBS = {
     "libfnx_physics.so": ["physics.hip"],
     "libfnx_losses.so": ["losses.hip"],
 }
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+# -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 arithmetic into v_pk_{mul,add,fma}_f32; on gfx950 the
+# VALU-bound blend kernels measured 19 % slower with them (issue stalls + register shuffling), DESIGN.md 4.2.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -38,6 +40,7 @@ def _stale(out: str, srcs: list[str]) -> bool:
     deps.append(os.path.join(_HERE, "..", "include", "fnx_raster.h"))
     deps.append(os.path.join(_HERE, "..", "include", "fnx_physics.h"))
     deps.append(os.path.join(_HERE, "..", "include", "fnx_losses.h"))
+    deps.append(os.path.abspath(__file__))  # the compiler flags live here
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
