@@ -222,7 +222,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     const float alpha = fminf(0.99f, rb.y * G);
                     active = !(alpha < 1.0f / 255.0f);
                     if (active) {
-                        Tr = Tr / (1.f - alpha);
+                        // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
+                        // the backward is compared within fp32 summation tolerance, not bit for bit
+                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        Tr = Tr * inv_1ma;
                         const float dchannel_dcolor = alpha * Tr;
                         float dL_dalpha = 0.0f;
 #pragma unroll
@@ -237,7 +240,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                         last_alpha = alpha;
                         if (wants) {
                             dL_dalpha *= Tr;
-                            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                            dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                             const float dL_dG = rb.y * dL_dalpha;
                             const float gdx = G * dx;
                             const float gdy = G * dy;
