@@ -230,7 +230,7 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
 // own: depth order without sorting and without ordered atomics.  Tiles are handled in windows of at
 // most kEmitTileWindow (the LDS arrays are per window).
 #ifndef FNX_EMIT_THREADS
-#define FNX_EMIT_THREADS 1024
+#define FNX_EMIT_THREADS 512
 #endif
 #ifndef FNX_EXP_EMIT
 #define FNX_EXP_EMIT 0  // timing experiments (tools/build_variant.py): 10 loads only, 11 no bitmask / output
@@ -243,7 +243,10 @@ extern "C" int fnx_debug_emit_clock(unsigned long long *host, int n) {
 #endif
 constexpr int kEmitThreads = FNX_EMIT_THREADS;          // many waves per workgroup: the passes are latency-bound
 constexpr int kEmitPer = kSplatBlock / kEmitThreads;   // splats loaded per thread
-constexpr int kEmitChunk = 8;                          // instances per thread and sub-batch (kept in registers)
+#ifndef FNX_EMIT_CHUNK
+#define FNX_EMIT_CHUNK 8
+#endif
+constexpr int kEmitChunk = FNX_EMIT_CHUNK;             // instances per thread and sub-batch (kept in registers)
 constexpr int kEmitStage = kEmitChunk * kEmitThreads;  // instances per sub-batch
 constexpr int kEmitMaskWords = 8;                      // per-tile bitmask: 8 x 32 ranks
 constexpr int kEmitSpan = 32 * kEmitMaskWords;         // ranks per sub-batch
