@@ -5,7 +5,10 @@ poly6 :188-191, get_guess_hidden_particles_from_nn :1014-1030, get_gas_constrain
 
 PARITY STATUS: pinned by tests/golden/physics.npz, which holds outputs and autograd gradients of
 the reference's own methods (imported with the missing third-party modules stubbed, see
-tests/golden/gen_reference_golden.py).  The edge list comes from torch_cluster.radius{,_graph}
+tests/golden/gen_reference_golden.py).  PbfOracle (the per-frame PBF predictor / solver, SURVEY 8(f)1:
+guess_hidden_particles :978-1012, remove_invalid_particles :1032-1060, project_gas_constraints :1075-1183,
+spiky_grad :193-199, confirm_guess_hidden_particles :1323-1337, update_visual_particles :1353-1398) is pinned
+by tests/golden/pbf.npz in the same way.  The edge list comes from torch_cluster.radius{,_graph}
 (1.6.3, not vendored): parity is unpinned at that boundary; here an edge is every ordered pair
 with distance < r (self-loop included), and clouds are kept below KNN_K neighbours per particle.
 """
@@ -65,3 +68,81 @@ class PhysicsOracle:
         vv = torch.zeros(V, 3, dtype=est.dtype).index_add_(0, row, vel[col] * p6.unsqueeze(-1))
         sp = torch.zeros(V, dtype=est.dtype).index_add_(0, row, p6).clamp_min(self.EPSILON)
         return visual_xyz + vv * self.secs / sp.unsqueeze(-1)
+
+
+
+class PbfOracle(PhysicsOracle):
+    """One frame step of the position-based-fluids predictor / solver on plain tensors (no in-place
+    mutation of the arguments; every method returns the new state)."""
+
+    def __init__(self, H=2.0, p0=1.5, secs=0.033, scale_factor=100.0, eps=1e-8, buoyancy_max_y=0.0, k=3,
+                 relaxation=0.01, K_P=0.2, E_P=4, DQ_P=0.25):
+        super().__init__(H, p0, secs, scale_factor, eps, buoyancy_max_y)
+        self.k, self.RELAXATION, self.K_P, self.E_P, self.DQ_P = k, relaxation, K_P, E_P, DQ_P
+        self.spiky_grad_term1 = 45.0 / (np.pi * H ** 6)                               # gm_dynamics.py:131
+        self.lamb_corr_denom = self.poly6(torch.tensor(DQ_P * DQ_P * H * H))            # :133
+
+    def spiky_grad(self, r, rlen):                                                     # :193-199
+        mask = (rlen < self.H) & (rlen > 0)
+        r_norm = r / (rlen.unsqueeze(-1) + self.EPSILON)
+        grad = -r_norm * self.spiky_grad_term1 * (self.H - rlen).unsqueeze(-1) ** 2
+        grad[~mask] = 0.0
+        return grad
+
+    def neighbor_counts(self, xyz):                                                    # :1040-1045 (no self loops)
+        row, col = self._edges(xyz, xyz, self.H)
+        return torch.bincount(row[row != col], minlength=xyz.shape[0])
+
+    def guess_hidden_particles(self, xyz, velocity, force, buoyancy, gravity, alpha, decay_rate, stable=False):
+        """:978-1012 without the wind term -> (velocity, buoyancy, force, estimate_xyz)"""
+        secs, a = (0.01, -1.0) if stable else (self.secs, alpha)
+        buoyancy = torch.ones_like(buoyancy) * (gravity * a)
+        cur = buoyancy
+        if self.buoyancy_max_y > 0.0:
+            cur = buoyancy * (1.0 - (xyz[:, 1:2] / (self.buoyancy_max_y * self.scale_factor)))
+        velocity = velocity + (cur * secs + secs * force)
+        if decay_rate > 0.0:
+            buoyancy = buoyancy * decay_rate
+        return velocity, buoyancy, torch.zeros_like(force), xyz + secs * velocity
+
+    def project_gas_constraints(self, exyz, velocity, force, imass, counts):
+        """:1075-1160 -> (estimate_xyz, force, p_ratio, lambdas)"""
+        N = exyz.shape[0]
+        row, col = self._edges(exyz, exyz, self.H)          # includes self loops
+        diff = exyz[row] - exyz[col]
+        dist2 = torch.sum(diff ** 2, dim=1)
+        p6 = self.poly6(dist2)
+        pi = torch.zeros(N).index_add_(0, row, p6).unsqueeze(1) / imass
+        neighbors_len = torch.bincount(row, minlength=N).unsqueeze(1).float()
+        ns = row != col
+        row_ns, col_ns, diff_ns, dist2_ns = row[ns], col[ns], diff[ns], dist2[ns]
+        rlen = torch.sqrt(dist2_ns + self.EPSILON)
+        sg = self.spiky_grad(diff_ns, rlen)
+        gr = torch.zeros(N, 3).index_add_(0, row_ns, sg) / self.p0
+        gr_dot = torch.sum(gr ** 2, dim=1)
+        grad_dot = torch.zeros(N).index_add_(0, row_ns, torch.sum((sg / self.p0) ** 2, dim=1))
+        denom = (grad_dot + gr_dot).unsqueeze(1)
+        p_ratio = pi / self.p0
+        force = force + velocity * (1.0 - p_ratio) * -self.k
+        lambdas = -(p_ratio - 1.0) / (denom + self.RELAXATION)
+        lamb_corr = -self.K_P * (p6[ns] / self.lamb_corr_denom) ** self.E_P
+        lam_sum = lambdas[row_ns].squeeze(1) + lambdas[col_ns].squeeze(1)
+        deltas = (lam_sum + lamb_corr).unsqueeze(-1) * sg
+        deltas_sum = torch.zeros(N, 3).index_add_(0, row_ns, deltas) / self.p0
+        return exyz + deltas_sum / (neighbors_len + counts), force, p_ratio, lambdas
+
+    def confirm_guess_hidden_particles(self, xyz, exyz):
+        """:1323-1337 -> (xyz, velocity)"""
+        velocity = (exyz - xyz) / self.secs
+        mask = torch.norm(exyz - xyz, dim=1) < self.EPSILON
+        velocity = torch.where(mask.unsqueeze(1), torch.zeros_like(velocity), velocity)
+        return torch.where(mask.unsqueeze(1), xyz, exyz), velocity
+
+    def update_visual_particles(self, visual, exyz, velocity):
+        """:1353-1398 -> visual_xyz"""
+        V = visual.shape[0]
+        row, col = self._edges(visual, exyz, self.H)
+        p6 = self.poly6(torch.sum((visual[row] - exyz[col]) ** 2, dim=1))
+        vv = torch.zeros(V, 3).index_add_(0, row, velocity[col] * p6.unsqueeze(-1))
+        s = torch.zeros(V).index_add_(0, row, p6).clamp_min(self.EPSILON)
+        return visual + vv * self.secs / s.unsqueeze(-1)

@@ -211,6 +211,90 @@ def gen_physics():
     np.savez(os.path.join(OUT, "physics.npz"), **out)
 
 
+def gen_pbf():
+    """PBF predictor / solver of one frame step: guess_hidden_particles -> solver_iterations x
+    project_gas_constraints -> confirm_guess_hidden_particles -> update_visual_particles, plus the neighbour
+    counts of remove_invalid_particles, run by the reference's own gm_dynamics.py on the CPU.  The reference
+    hard-codes device="cuda" in a few tensor constructors (gm_dynamics.py:986-1010,1337); those keyword
+    arguments / .cuda() calls are redirected to the CPU here, nothing else is touched."""
+    import gaussian_splatting.gm_dynamics as gmd
+
+    def to_cpu(fn):
+        def wrapped(*a, **k):
+            if k.get("device") == "cuda":
+                k = dict(k, device="cpu")
+            return fn(*a, **k)
+        return wrapped
+
+    saved = (torch.ones_like, torch.zeros_like, torch.Tensor.cuda)
+    torch.ones_like, torch.zeros_like = to_cpu(torch.ones_like), to_cpu(torch.zeros_like)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        rng = np.random.RandomState(11)
+        out = {}
+        for tag, (n_side, V, alpha, buoy_max_y, decay, iters) in dict(a=(6, 400, -1.0, 0.0, 0.0, 3),
+                                                                       b=(7, 600, 0.5, 0.6, 0.98, 4)).items():
+            gm = gmd.GaussianModel.__new__(gmd.GaussianModel)
+            gm.H, gm.KNN_K, gm.p0, gm._secs, gm.scale_factor, gm.EPSILON = 2.0, 100, 1.5, 0.033, 100.0, 1e-8
+            gm.H2, gm.H6, gm.H9 = gm.H ** 2, gm.H ** 6, gm.H ** 9
+            gm.poly6_term1 = 315.0 / (64.0 * np.pi * gm.H9)
+            gm.spiky_grad_term1 = 45.0 / (np.pi * gm.H6)
+            gm.k, gm.RELAXATION, gm.K_P, gm.E_P, gm.DQ_P = 3, 0.01, 0.2, 4, 0.25       # gm_dynamics.py:100-111
+            gm.lamb_corr_denom = gm.poly6(torch.tensor(gm.DQ_P * gm.DQ_P * gm.H * gm.H))   # :133
+            gm.alpha, gm.buoyancy_max_y, gm.buoyancy_decay_rate, gm.min_neighbors = alpha, buoy_max_y, decay, 1
+            gm._gravity = torch.tensor([0.0, -9.8, 0.0]).reshape(1, 3)
+            N = n_side ** 3
+            grid = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3)
+            x = (grid * 0.9 + rng.uniform(-0.2, 0.2, size=(N, 3)) + np.array([0.0, 3.0, 0.0])).astype(np.float32)
+            x[-1] += 40.0  # two stragglers without neighbours (remove_invalid_particles) ...
+            x[-2] += np.array([-50.0, 0.0, 30.0], np.float32)
+            x[-3] = x[-4] + np.array([0.3, 0.0, 0.0], np.float32) + 25.0  # ... and a far pair
+            x[-4] += 25.0
+            gm._xyz = torch.tensor(x)
+            gm._estimate_xyz = torch.tensor(x.copy())
+            gm._velocity = torch.tensor((rng.normal(size=(N, 3)) * 2.0 + np.array([0.0, 20.0, 0.0])).astype(np.float32))
+            gm._force = torch.tensor((rng.normal(size=(N, 3)) * 0.5).astype(np.float32))
+            gm._buoyancy = torch.tensor(rng.uniform(0.5, 1.5, size=(N, 3)).astype(np.float32))
+            gm._imass = torch.tensor(rng.uniform(0.8, 1.2, size=(N, 1)).astype(np.float32))
+            gm._counts = torch.tensor(rng.randint(0, 3, size=(N, 1)).astype(np.float32))
+            gm._visual_xyz = torch.tensor((rng.uniform(-1.0, n_side * 0.9 + 1.0, size=(V, 3))
+                                           + np.array([0.0, 3.0, 0.0])).astype(np.float32))
+            o = dict(xyz0=x, velocity0=gm._velocity.numpy().copy(), force0=gm._force.numpy().copy(),
+                     buoyancy0=gm._buoyancy.numpy().copy(), imass=gm._imass.numpy().copy(),
+                     counts0=gm._counts.numpy().copy(), visual0=gm._visual_xyz.numpy().copy(),
+                     consts=np.array([gm.H, gm.p0, gm._secs, gm.scale_factor, gm.EPSILON, gm.k, gm.RELAXATION, gm.K_P,
+                                      gm.E_P, gm.DQ_P, alpha, buoy_max_y, decay, iters], np.float64),
+                     gravity=gm._gravity.numpy().copy())
+            # neighbour counts of remove_invalid_particles (:1032-1049; edges without self loops).  The reference
+            # calls radius_graph with torch_cluster's default max_num_neighbors = 32 there; only
+            # `count >= min_neighbors` (= 1) is used, which truncation cannot change, so the fixture stores the
+            # untruncated counts and the keep-mask.
+            ei = gmd.radius_graph(x=gm._xyz, r=gm.H, loop=False, max_num_neighbors=10 ** 9)
+            o["neighbor_counts"] = torch.bincount(ei[0], minlength=N).numpy().astype(np.int32)
+            o["keep_mask"] = (o["neighbor_counts"] >= gm.min_neighbors)
+            gm.guess_hidden_particles(stable=False, use_wind=False)
+            o.update(velocity1=gm._velocity.numpy().copy(), buoyancy1=gm._buoyancy.numpy().copy(),
+                     force1=gm._force.numpy().copy(), estimate1=gm._estimate_xyz.numpy().copy(),
+                     counts1=gm._counts.numpy().copy())
+            for _ in range(iters):
+                gm.update_solver_counts()
+            o["counts2"] = gm._counts.numpy().copy()
+            for it in range(iters):
+                ret = gm.project_gas_constraints()
+                o[f"estimate_it{it}"] = gm._estimate_xyz.numpy().copy()
+                o[f"force_it{it}"] = gm._force.numpy().copy()
+                o[f"p_ratio_mean_it{it}"] = np.float64(ret["p_ratio"])
+                o[f"lambdas_mean_it{it}"] = np.float64(ret["lambdas"])
+            gm.confirm_guess_hidden_particles()
+            o.update(xyz3=gm._xyz.numpy().copy(), velocity3=gm._velocity.numpy().copy())
+            gm.update_visual_particles()
+            o["visual3"] = gm._visual_xyz.numpy().copy()
+            out.update({f"{k}_{tag}": v for k, v in o.items()})
+        np.savez(os.path.join(OUT, "pbf.npz"), **out)
+    finally:
+        torch.ones_like, torch.zeros_like, torch.Tensor.cuda = saved
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
@@ -218,6 +302,7 @@ if __name__ == "__main__":
     gen_losses()
     gen_general()
     gen_physics()
+    gen_pbf()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
