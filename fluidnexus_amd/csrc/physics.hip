@@ -344,6 +344,164 @@ stage_combine_kernel(int N, float sf, const float *__restrict__ x, const float *
     grad[3 * i + 2] = o[2];
 }
 
+// ---- PBF predictor / solver of the per-frame step ---------------------------------------
+// guess_hidden_particles (gm_dynamics.py:978-1012, no wind): new buoyancy = gravity * alpha for every particle,
+// optionally attenuated with height for the velocity update and decayed for storage.
+__global__ void __launch_bounds__(256)
+pbf_predict_kernel(const float *__restrict__ xyz, float *__restrict__ velocity, float *__restrict__ buoyancy,
+                   float *__restrict__ force, float *__restrict__ estimate, float *__restrict__ counts, int N, float gx,
+                   float gy, float gz, float alpha, float secs, float scale_max_y, float decay) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float b[3] = {1.0f * (gx * alpha), 1.0f * (gy * alpha), 1.0f * (gz * alpha)};
+    float coeff = 1.0f;
+    if (scale_max_y > 0.0f) coeff = 1.0f - (xyz[3 * i + 1] / scale_max_y);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float cur = (scale_max_y > 0.0f) ? b[c] * coeff : b[c];
+        const float v = velocity[3 * i + c] + (cur * secs + secs * force[3 * i + c]);
+        velocity[3 * i + c] = v;
+        buoyancy[3 * i + c] = (decay > 0.0f) ? b[c] * decay : b[c];
+        force[3 * i + c] = 0.0f;
+        estimate[3 * i + c] = xyz[3 * i + c] + secs * v;
+    }
+    counts[i] = 0.0f;
+}
+
+// number of other particles within H (remove_invalid_particles :1040-1045)
+__global__ void __launch_bounds__(256)
+pbf_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, float H2, uint32_t mask,
+                 const uint32_t *__restrict__ start, const float4 *__restrict__ rec, int *__restrict__ out) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    float n = 0.f;
+    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, uint32_t j, float, float, float, float) { n += (j != (uint32_t)ii) ? 1.f : 0.f; });
+    n = row_sum15(n);
+    if (sub == 15 && i < N) out[i] = (int)n;
+}
+
+// spiky kernel gradient (:193-199) of the offset e = x_i - x_j with r2 = |e|^2
+__device__ __forceinline__ bool spiky_grad(float ex, float ey, float ez, float r2, float H, float eps, float term1,
+                                           float &gx, float &gy, float &gz) {
+    const float rlen = sqrtf(r2 + eps);
+    if (!(rlen < H) || !(rlen > 0.f)) return false;
+    const float inv = 1.0f / (rlen + eps);
+    const float t = H - rlen;
+    const float s = term1 * (t * t);
+    gx = -(ex * inv) * s;
+    gy = -(ey * inv) * s;
+    gz = -(ez * inv) * s;
+    return true;
+}
+
+// project_gas_constraints, node pass (:1086-1133): density ratio, lambda, neighbour count, force correction
+__global__ void __launch_bounds__(256)
+pbf_lambda_kernel(const float *__restrict__ x, const float *__restrict__ velocity, float *__restrict__ force,
+                  const float *__restrict__ imass, int N, float inv_cell, float H, float H2, float poly6_t1,
+                  float spiky_t1, float p0, float kk, float relax, float eps, uint32_t mask,
+                  const uint32_t *__restrict__ start, const float4 *__restrict__ rec, float *__restrict__ lambdas,
+                  float *__restrict__ nlen) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    float pi = 0.f, cnt = 0.f, grx = 0.f, gry = 0.f, grz = 0.f, gd = 0.f;
+    for_neighbours<16>(sub, x[3 * ii], x[3 * ii + 1], x[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
+                           const float t = H2 - r2;
+                           pi += poly6_t1 * (t * t * t);
+                           cnt += 1.f;
+                           float gx, gy, gz;
+                           if (j != (uint32_t)ii && spiky_grad(ex, ey, ez, r2, H, eps, spiky_t1, gx, gy, gz)) {
+                               grx += gx;
+                               gry += gy;
+                               grz += gz;
+                               const float a = gx / p0, b = gy / p0, c = gz / p0;
+                               gd += a * a + b * b + c * c;
+                           }
+                       });
+    pi = row_sum15(pi);
+    cnt = row_sum15(cnt);
+    grx = row_sum15(grx);
+    gry = row_sum15(gry);
+    grz = row_sum15(grz);
+    gd = row_sum15(gd);
+    if (sub == 15 && i < N) {
+        const float p_ratio = pi / imass[i] / p0;
+        const float a = grx / p0, b = gry / p0, c = grz / p0;
+        const float denom = gd + (a * a + b * b + c * c);
+        lambdas[i] = -(p_ratio - 1.0f) / (denom + relax);
+        nlen[i] = cnt;
+        const float f = (1.0f - p_ratio) * -kk;
+#pragma unroll
+        for (int d = 0; d < 3; d++) force[3 * i + d] += velocity[3 * i + d] * f;
+    }
+}
+
+// project_gas_constraints, position pass (:1135-1160): Jacobi update from the OLD positions into x_new
+__global__ void __launch_bounds__(256)
+pbf_delta_kernel(const float *__restrict__ x, int N, float inv_cell, float H, float H2, float poly6_t1, float spiky_t1,
+                 float p0, float K_P, float E_P, float corr_denom, float eps, uint32_t mask,
+                 const uint32_t *__restrict__ start, const float4 *__restrict__ rec, const float *__restrict__ lambdas,
+                 const float *__restrict__ nlen, const float *__restrict__ counts, float *__restrict__ x_new) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    const float li = lambdas[ii];
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    for_neighbours<16>(sub, x[3 * ii], x[3 * ii + 1], x[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
+                           float gx, gy, gz;
+                           if (j != (uint32_t)ii && spiky_grad(ex, ey, ez, r2, H, eps, spiky_t1, gx, gy, gz)) {
+                               const float t = H2 - r2;
+                               const float p6 = poly6_t1 * (t * t * t);
+                               const float q = p6 / corr_denom;
+                               // the reference's exponent is 4 (gm_dynamics.py:110): two squarings instead of powf
+                               const float corr = -K_P * ((E_P == 4.0f) ? (q * q) * (q * q) : powf(q, E_P));
+                               const float w = (li + lambdas[j]) + corr;
+                               dx += w * gx;
+                               dy += w * gy;
+                               dz += w * gz;
+                           }
+                       });
+    dx = row_sum15(dx);
+    dy = row_sum15(dy);
+    dz = row_sum15(dz);
+    if (sub == 15 && i < N) {
+        const float den = nlen[i] + counts[i];
+        x_new[3 * i + 0] = x[3 * i + 0] + (dx / p0) / den;
+        x_new[3 * i + 1] = x[3 * i + 1] + (dy / p0) / den;
+        x_new[3 * i + 2] = x[3 * i + 2] + (dz / p0) / den;
+    }
+}
+
+// confirm_guess_hidden_particles (:1323-1337)
+__global__ void __launch_bounds__(256)
+pbf_confirm_kernel(float *__restrict__ xyz, const float *__restrict__ estimate, float *__restrict__ velocity, int N,
+                   float secs, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float dx = estimate[3 * i] - xyz[3 * i], dy = estimate[3 * i + 1] - xyz[3 * i + 1],
+                dz = estimate[3 * i + 2] - xyz[3 * i + 2];
+    const bool still = sqrtf(dx * dx + dy * dy + dz * dz) < eps;
+    velocity[3 * i + 0] = still ? 0.f : dx / secs;
+    velocity[3 * i + 1] = still ? 0.f : dy / secs;
+    velocity[3 * i + 2] = still ? 0.f : dz / secs;
+    if (!still) {
+        xyz[3 * i + 0] = estimate[3 * i + 0];
+        xyz[3 * i + 1] = estimate[3 * i + 1];
+        xyz[3 * i + 2] = estimate[3 * i + 2];
+    }
+}
+
+// per grid slot: the given velocity of the hidden particle stored there (update_visual_particles)
+__global__ void __launch_bounds__(256)
+slot_given_velocity_kernel(const float4 *__restrict__ rec, int N, const float *__restrict__ velocity,
+                           float4 *__restrict__ u) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= N) return;
+    const uint32_t j = __float_as_uint(rec[s].w);
+    u[s] = make_float4(velocity[3 * j], velocity[3 * j + 1], velocity[3 * j + 2], 0.f);
+}
+
 // ---- optimiser step of the particle positions (fnx_adam_step) ---------------------------------------
 // g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch, then torch.optim.Adam's update (amsgrad off, no weight decay),
 // fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far and is advanced
@@ -636,6 +794,75 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
     hipLaunchKernelGGL(stage_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, scale_factor, x, x_est, dx_est,
                        dg, buoyancy, buoyancy_max_y, secs, lam_e, lam_g, lam_n, part_e, terms, loss, grad);
     return hip_check("physical_stage");
+}
+
+int fnx_pbf_predict(const float *xyz, float *velocity, float *buoyancy, float *force, float *estimate_xyz, float *counts,
+                    int N, const float *gravity, float alpha, float secs, float scale_max_y, float decay_rate,
+                    fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !velocity || !buoyancy || !force || !estimate_xyz || !counts || !gravity)
+        return fail(FNX_ERR_INVALID_ARG, "pbf_predict: bad argument");
+    hipLaunchKernelGGL(pbf_predict_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, velocity,
+                       buoyancy, force, estimate_xyz, counts, N, gravity[0], gravity[1], gravity[2], alpha, secs,
+                       scale_max_y, decay_rate);
+    return hip_check("pbf_predict");
+}
+
+int fnx_pbf_neighbor_counts(const float *xyz, int N, float H, char *grid, int *counts, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !grid || !counts || H <= 0.f) return fail(FNX_ERR_INVALID_ARG, "pbf_neighbor_counts: bad argument");
+    if (int rc = fnx_grid_build(xyz, N, H, grid, stream)) return rc;
+    GridView g = carve(grid, N);
+    hipLaunchKernelGGL(pbf_count_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N, 1.0f / H, H * H,
+                       g.M - 1, g.start, g.rec, counts);
+    return hip_check("pbf_neighbor_counts");
+}
+
+int fnx_pbf_project(float *estimate_xyz, const float *velocity, float *force, const float *imass, const float *counts,
+                    int N, float H, float p0, float k, float relaxation, float K_P, float E_P, float DQ_P, float eps,
+                    char *grid, float *scratch, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !estimate_xyz || !velocity || !force || !imass || !counts || !grid || !scratch || H <= 0.f)
+        return fail(FNX_ERR_INVALID_ARG, "pbf_project: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = fnx_grid_build(estimate_xyz, N, H, grid, stream)) return rc;
+    GridView g = carve(grid, N);
+    float *lambdas = scratch, *nlen = scratch + N, *x_new = scratch + 2 * (size_t)N;
+    const float H2 = H * H, p6t = poly6_term1(H);
+    const float spt = (float)(45.0 / (M_PI * std::pow((double)H, 6.0)));  // gm_dynamics.py:131
+    // lamb_corr_denom = poly6(DQ_P^2 H^2) (:133), evaluated like the reference's fp32 tensor expression
+    const float r2q = DQ_P * DQ_P * H * H, tq = H2 - r2q;
+    const float corr_denom = (r2q < H2) ? p6t * (tq * tq * tq) : 0.0f;
+    hipLaunchKernelGGL(pbf_lambda_kernel, dim3((N + 15) / 16), dim3(256), 0, s, estimate_xyz, velocity, force, imass, N,
+                       1.0f / H, H, H2, p6t, spt, p0, k, relaxation, eps, g.M - 1, g.start, g.rec, lambdas, nlen);
+    hipLaunchKernelGGL(pbf_delta_kernel, dim3((N + 15) / 16), dim3(256), 0, s, estimate_xyz, N, 1.0f / H, H, H2, p6t, spt,
+                       p0, K_P, E_P, corr_denom, eps, g.M - 1, g.start, g.rec, lambdas, nlen, counts, x_new);
+    (void)hipMemcpyAsync(estimate_xyz, x_new, (size_t)N * 12, hipMemcpyDeviceToDevice, s);
+    return hip_check("pbf_project");
+}
+
+int fnx_pbf_confirm(float *xyz, const float *estimate_xyz, float *velocity, int N, float secs, float eps,
+                    fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !estimate_xyz || !velocity || secs == 0.f) return fail(FNX_ERR_INVALID_ARG, "pbf_confirm: bad argument");
+    hipLaunchKernelGGL(pbf_confirm_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, estimate_xyz,
+                       velocity, N, secs, eps);
+    return hip_check("pbf_confirm");
+}
+
+int fnx_visual_advect(float *visual, int V, const float *hidden, const float *velocity, int N, float H, float secs,
+                      float eps, char *hidden_grid, float *scratch, fnx_stream_t stream) {
+    if (V == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !visual || !hidden_grid || !scratch || (N > 0 && (!hidden || !velocity)) || H <= 0.f)
+        return fail(FNX_ERR_INVALID_ARG, "visual_advect: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = fnx_grid_build(hidden, N, H, hidden_grid, stream)) return rc;
+    GridView g = carve(hidden_grid, N);
+    if (N > 0)
+        hipLaunchKernelGGL(slot_given_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, s, g.rec, N, velocity, g.aux0);
+    hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 31) / 32), dim3(256), 0, s, visual, V, 1.0f / H, H * H,
+                       poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, visual, scratch, scratch + V);
+    return hip_check("visual_advect");
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,

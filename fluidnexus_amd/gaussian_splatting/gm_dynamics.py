@@ -41,6 +41,7 @@ class GaussianModel:
         self.active_sh_degree = 0
         # hidden (physics) particles
         self._xyz = self._estimate_xyz = self._force = self._velocity = self._imass = self._buoyancy = e
+        self._counts = self._particle_id = None
         self._estimate_xyz_nn = e
         # visual particles + constant Gaussian attributes, static background Gaussians, other groups
         for g in _GROUPS:
@@ -71,6 +72,132 @@ class GaussianModel:
         self.buoyancy_max_y = float(buoyancy_max_y)
         self.poly6_term1 = 315.0 / (64.0 * np.pi * self.H9)
         self.spiky_grad_term1 = 45.0 / (np.pi * self.H6)
+
+    def setup_solver_constants(self, alpha=0.0, buoyancy_decay_rate=0.0, min_neighbors=-1, gravity=(0.0, -9.8, 0.0)):
+        """The PBF solver constants of setup_constants (gm_dynamics.py:84,100-111,133)."""
+        self.alpha, self.buoyancy_decay_rate, self.min_neighbors = float(alpha), float(buoyancy_decay_rate), int(min_neighbors)
+        self.RELAXATION, self.K_P, self.E_P, self.DQ_P = 0.01, 0.2, 4, 0.25
+        self._gravity = torch.tensor(gravity, dtype=torch.float32).reshape(1, 3)
+        self.lamb_corr_denom = float(self.poly6_term1 * (self.H2 - self.DQ_P * self.DQ_P * self.H * self.H) ** 3)
+
+    # -- PBF predictor / solver of the per-frame step (gm_dynamics.py:978-1183, 1323-1398) on fused kernels --
+    def _pbf_scratch(self, n_floats, slot="pbf"):
+        buf = self._grid_cache.get(("scratch", slot))
+        if buf is None or buf.numel() < n_floats or buf.device != self._xyz.device:
+            buf = torch.empty(n_floats, dtype=torch.float32, device=self._xyz.device)
+            self._grid_cache[("scratch", slot)] = buf
+        return buf
+
+    def _own(self, name):
+        """The attribute as a contiguous fp32 device tensor the kernels may update in place."""
+        t = getattr(self, name)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+            setattr(self, name, t)
+        if not t.is_cuda:
+            raise RuntimeError("fluidnexus_amd physics: tensors must be on a HIP device (no CPU path)")
+        return t
+
+    @torch.no_grad()
+    def guess_hidden_particles(self, stable=False, use_wind=False):
+        """:978-1012.  During stable iterations a smaller step and unit downward buoyancy are used."""
+        if use_wind:
+            raise NotImplementedError("wind force (gm_dynamics.py:1001-1005) is not part of this build")
+        import ctypes as C
+        lib = physics.PL.physics()
+        secs, alpha = (0.01, -1.0) if stable else (self._secs, self.alpha)
+        N = self._xyz.shape[0]
+        xyz, vel, buo, force = self._own("_xyz"), self._own("_velocity"), self._own("_buoyancy"), self._own("_force")
+        if self._estimate_xyz.shape != xyz.shape or self._estimate_xyz.data_ptr() == xyz.data_ptr():
+            self._estimate_xyz = torch.empty_like(xyz)
+        est = self._own("_estimate_xyz")
+        if getattr(self, "_counts", None) is None or self._counts.shape[0] != N:
+            self._counts = torch.zeros(N, 1, dtype=torch.float32, device=xyz.device)
+        g = (C.c_float * 3)(*[float(v) for v in self._gravity.reshape(3).tolist()])
+        physics.PL.check(lib.fnx_pbf_predict(xyz.data_ptr(), vel.data_ptr(), buo.data_ptr(), force.data_ptr(), est.data_ptr(),
+                                             self._own("_counts").data_ptr(), N, g, float(alpha), float(secs),
+                                             float(self.buoyancy_max_y * self.scale_factor), float(self.buoyancy_decay_rate),
+                                             physics._stream()))
+        self.invalidate_caches()
+
+    def update_solver_counts(self):
+        self._counts += 1.0
+
+    @torch.no_grad()
+    def project_gas_constraints(self):
+        """:1075-1183 (one solver iteration).  The reference returns ~20 host-synchronising `.item()` means for
+        TensorBoard; they are not computed here (empty dict)."""
+        lib = physics.PL.physics()
+        N = self._estimate_xyz.shape[0]
+        grid = physics.HashGrid(self._estimate_xyz, self.H, build=False) if self._grid_cache.get("pbf_grid") is None or \
+            self._grid_cache["pbf_grid"].N != N else self._grid_cache["pbf_grid"]
+        self._grid_cache["pbf_grid"] = grid
+        physics.PL.check(lib.fnx_pbf_project(
+            self._own("_estimate_xyz").data_ptr(), self._own("_velocity").data_ptr(), self._own("_force").data_ptr(),
+            self._own("_imass").data_ptr(), self._own("_counts").data_ptr(), N, float(self.H), float(self.p0), float(self.k),
+            float(self.RELAXATION), float(self.K_P), float(self.E_P), float(self.DQ_P), float(self.EPSILON),
+            grid.blob.data_ptr(), self._pbf_scratch(5 * N).data_ptr(), physics._stream()))
+        return {}
+
+    @torch.no_grad()
+    def confirm_guess_hidden_particles(self):
+        """:1323-1337: velocity from the displacement, positions accepted (both left alone below EPSILON)."""
+        lib = physics.PL.physics()
+        physics.PL.check(lib.fnx_pbf_confirm(self._own("_xyz").data_ptr(), self._own("_estimate_xyz").data_ptr(),
+                                             self._own("_velocity").data_ptr(), self._xyz.shape[0], float(self._secs),
+                                             float(self.EPSILON), physics._stream()))
+        self.invalidate_caches()
+
+    confirm_guess_hidden_particles_wo_velocity = confirm_guess_hidden_particles  # identical bodies, :1339-1350
+
+    @torch.no_grad()
+    def confirm_guess_hidden_particles_from_nn(self):
+        """:1352-1355"""
+        self._estimate_xyz = self._estimate_xyz_nn.detach().clone().requires_grad_(False) * self.scale_factor
+        self.invalidate_caches()
+
+    @torch.no_grad()
+    def update_visual_particles(self):
+        """:1353-1398: advect the visual particles with the poly6-weighted velocity of the hidden ones."""
+        V = self._visual_xyz.shape[0]
+        if V == 0:
+            return
+        lib = physics.PL.physics()
+        N = self._estimate_xyz.shape[0]
+        vis = self._own("_visual_xyz")
+        grid = physics.HashGrid(self._estimate_xyz, self.H, build=False)
+        physics.PL.check(lib.fnx_visual_advect(vis.data_ptr(), V, self._own("_estimate_xyz").data_ptr(),
+                                               self._own("_velocity").data_ptr(), N, float(self.H), float(self._secs),
+                                               float(self.EPSILON), grid.blob.data_ptr(),
+                                               self._pbf_scratch(4 * V, "advect").data_ptr(), physics._stream()))
+        self._visual_grid = None
+        self.invalidate_caches()
+
+    @torch.no_grad()
+    def neighbor_counts(self):
+        """Number of other hidden particles within H of each one (the statistic of remove_invalid_particles)."""
+        lib = physics.PL.physics()
+        xyz = self._own("_xyz")
+        N = xyz.shape[0]
+        out = torch.empty(N, dtype=torch.int32, device=xyz.device)
+        grid = physics.HashGrid(xyz, self.H, build=False)
+        physics.PL.check(lib.fnx_pbf_neighbor_counts(xyz.data_ptr(), N, float(self.H), grid.blob.data_ptr(), out.data_ptr(),
+                                                     physics._stream()))
+        return out
+
+    @torch.no_grad()
+    def remove_invalid_particles(self):
+        """:1032-1060: drop hidden particles with fewer than min_neighbors neighbours (one host sync, like the
+        reference's `mask.all()`)."""
+        if self.min_neighbors < 0:
+            return
+        mask = self.neighbor_counts() >= self.min_neighbors
+        if not bool(mask.all()):
+            for name in ("_xyz", "_estimate_xyz", "_buoyancy", "_force", "_velocity", "_imass", "_counts", "_particle_id"):
+                t = getattr(self, name, None)
+                if t is not None and t.shape[:1] == mask.shape:
+                    setattr(self, name, t[mask])
+            self.invalidate_caches()
 
     # -- getters ------------------------------------------------------------------------------------
     get_xyz = property(lambda s: s._xyz)

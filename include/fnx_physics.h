@@ -75,6 +75,37 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
                        float p0, float secs, float lam_e, float lam_g, float lam_n, char *est_grid, int build_est_grid,
                        char *guess_grid, float *scratch, float *terms, float *loss, float *grad, fnx_stream_t stream);
 
+/*
+ * Position-based-fluids predictor / solver of the per-frame step.  Each call is the fused,
+ * GPU-resident form of one method of the reference's GaussianModel (gm_dynamics.py); all arrays are [N,3] / [N]
+ * fp32 device arrays updated in place as the reference updates its attributes.
+ *   fnx_pbf_predict          guess_hidden_particles :978-1012 (no wind): buoyancy <- gravity * alpha [* decay],
+ *                            velocity += (buoyancy (1 - y / scale_max_y)) secs + secs force, force <- 0,
+ *                            estimate <- xyz + secs velocity, counts <- 0.  gravity: HOST float[3];
+ *                            scale_max_y = buoyancy_max_y * scale_factor, <= 0 disables the height term;
+ *                            alpha / secs are the caller's (stable: -1.0 / 0.01).
+ *   fnx_pbf_neighbor_counts  remove_invalid_particles :1040-1045: number of OTHER particles within H (builds `grid`).
+ *   fnx_pbf_project          project_gas_constraints :1075-1160: rebuilds `grid` over estimate_xyz, node pass
+ *                            (density ratio, lambda, neighbour count, force += velocity (1 - p_ratio)(-k)), then the
+ *                            Jacobi position pass (lambda_i + lambda_j + lamb_corr) spiky_grad / p0 /
+ *                            (neighbours + counts).  scratch: 5 N floats.
+ *   fnx_pbf_confirm          confirm_guess_hidden_particles(_wo_velocity) :1323-1350.
+ *   fnx_visual_advect        update_visual_particles :1353-1398: visual += secs sum_j w_vj velocity_j /
+ *                            max(sum_j w_vj, eps), in place (builds `hidden_grid` over `hidden`); scratch: 4 V floats.
+ * Neighbour rule as above (r^2 < H^2, no max_num_neighbors truncation).
+ */
+int fnx_pbf_predict(const float *xyz, float *velocity, float *buoyancy, float *force, float *estimate_xyz, float *counts,
+                    int N, const float *gravity, float alpha, float secs, float scale_max_y, float decay_rate,
+                    fnx_stream_t stream);
+int fnx_pbf_neighbor_counts(const float *xyz, int N, float H, char *grid, int *counts, fnx_stream_t stream);
+int fnx_pbf_project(float *estimate_xyz, const float *velocity, float *force, const float *imass, const float *counts,
+                    int N, float H, float p0, float k, float relaxation, float K_P, float E_P, float DQ_P, float eps,
+                    char *grid, float *scratch, fnx_stream_t stream);
+int fnx_pbf_confirm(float *xyz, const float *estimate_xyz, float *velocity, int N, float secs, float eps,
+                    fnx_stream_t stream);
+int fnx_visual_advect(float *visual, int V, const float *hidden, const float *velocity, int N, float H, float secs,
+                      float eps, char *hidden_grid, float *scratch, fnx_stream_t stream);
+
 /* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
  * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
  *   g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch            (NULL terms are skipped; n = number of floats)
