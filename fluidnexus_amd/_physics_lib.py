@@ -10,7 +10,7 @@ _LIB = None
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
-           "fnx_pbf_confirm", "fnx_visual_advect")
+           "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2")
 
 
 def physics():
@@ -50,6 +50,8 @@ def physics():
     lib.fnx_pbf_confirm.argtypes = [p, p, p, i, f, f, p]
     lib.fnx_visual_advect.restype = i
     lib.fnx_visual_advect.argtypes = [p, i, p, p, i, f, f, f, p, p, p]
+    lib.fnx_knn_mean_dist2.restype = i
+    lib.fnx_knn_mean_dist2.argtypes = [p, i, f, p, p, p]
     lib.fnx_adam_step.restype = i
     lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, C.c_double, C.c_double, f, p, p]
     _LIB = lib

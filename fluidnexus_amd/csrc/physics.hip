@@ -502,6 +502,63 @@ slot_given_velocity_kernel(const float4 *__restrict__ rec, int N, const float *_
     u[s] = make_float4(velocity[3 * j], velocity[3 * j + 1], velocity[3 * j + 2], 0.f);
 }
 
+// ---- mean squared distance to the 3 nearest neighbours (simple-knn distCUDA2) -----------
+// The reference (submodules/simple-knn/simple_knn.cu:134-166) finds the exact 3 nearest other points with a
+// Morton sort + box pruning and returns (d1 + d2 + d3) / 3 of the squared distances.  Here: the uniform hash
+// grid of this file, searched ring by ring (cube shells of cells around the query's cell); after ring r every
+// unexamined point is at least r * cell away, so the search stops once the third best squared distance is
+// <= (r cell)^2.  Candidates are accepted only if their own integer cell is the visited cell (hash collisions
+// must not be counted twice).  Queries that run past kKnnMaxRing rings (isolated points) scan all points.
+constexpr int kKnnMaxRing = 6;
+__device__ __forceinline__ void knn_update3(float d, float *best) {  // updateKBest<3>, simple_knn.cu:120-131
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (best[j] > d) {
+            const float t = best[j];
+            best[j] = d;
+            d = t;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+knn_mean_dist2_kernel(const float *__restrict__ xyz, int N, float inv_cell, float cell, uint32_t mask,
+                      const uint32_t *__restrict__ start, const float4 *__restrict__ rec, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+    const int3 c = cell_of(px, py, pz, inv_cell);
+    float best[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    bool done = false;
+    for (int r = 0; r <= kKnnMaxRing && !done; r++) {
+        for (int dz = -r; dz <= r; dz++)
+            for (int dy = -r; dy <= r; dy++)
+                for (int dx = -r; dx <= r; dx++) {
+                    if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;  // shell of ring r only
+                    const int3 cc = make_int3(c.x + dx, c.y + dy, c.z + dz);
+                    const uint32_t h = cell_hash(cc, mask);
+                    for (uint32_t s = start[h]; s < start[h + 1]; s++) {
+                        const float4 q = rec[s];
+                        if (__float_as_uint(q.w) == (uint32_t)i) continue;
+                        const int3 qc = cell_of(q.x, q.y, q.z, inv_cell);
+                        if (qc.x != cc.x || qc.y != cc.y || qc.z != cc.z) continue;
+                        const float ex = q.x - px, ey = q.y - py, ez = q.z - pz;
+                        knn_update3(ex * ex + ey * ey + ez * ez, best);
+                    }
+                }
+        const float reach = (float)r * cell;
+        done = best[2] <= reach * reach;
+    }
+    if (!done) {  // isolated query: exact scan
+        best[0] = best[1] = best[2] = 3.402823466e38f;
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            const float ex = xyz[3 * j] - px, ey = xyz[3 * j + 1] - py, ez = xyz[3 * j + 2] - pz;
+            knn_update3(ex * ex + ey * ey + ez * ez, best);
+        }
+    }
+    out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
 // ---- optimiser step of the particle positions (fnx_adam_step) ---------------------------------------
 // g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch, then torch.optim.Adam's update (amsgrad off, no weight decay),
 // fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far and is advanced
@@ -863,6 +920,16 @@ int fnx_visual_advect(float *visual, int V, const float *hidden, const float *ve
     hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 31) / 32), dim3(256), 0, s, visual, V, 1.0f / H, H * H,
                        poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, visual, scratch, scratch + V);
     return hip_check("visual_advect");
+}
+
+int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *mean_dist2, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !grid || !mean_dist2 || !(cell > 0.f)) return fail(FNX_ERR_INVALID_ARG, "knn_mean_dist2: bad argument");
+    if (int rc = fnx_grid_build(xyz, N, cell, grid, stream)) return rc;
+    GridView g = carve(grid, N);
+    hipLaunchKernelGGL(knn_mean_dist2_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N, 1.0f / cell,
+                       cell, g.M - 1, g.start, g.rec, mean_dist2);
+    return hip_check("knn_mean_dist2");
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,

@@ -223,3 +223,23 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None):
                                1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                ptr(grad_out), _stream()))
+
+
+def knn_mean_dist2(points):
+    """simple_knn._C.distCUDA2 (submodules/simple-knn/simple_knn.cu): mean squared distance of every point of
+    `points` [N,3] to its 3 nearest other points, fp32 [N].  One host sync to size the search grid from the
+    bounding box (the reference copies min / max to the host as well, simple_knn.cu:175-180)."""
+    lib = PL.physics()
+    pts = _req(points.detach())
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise RuntimeError("points must have dimensions (num_points, 3)")
+    N = pts.shape[0]
+    out = torch.empty(N, dtype=torch.float32, device=pts.device)
+    if N == 0:
+        return out
+    ext = (pts.max(dim=0).values - pts.min(dim=0).values).clamp_min(1e-12).double().cpu()
+    vol = float(ext[0] * ext[1] * ext[2])
+    cell = max((vol / N) ** (1.0 / 3.0) * 1.5, 1e-6 * float(ext.max()), 1e-30)
+    grid = HashGrid(pts, cell, build=False)
+    PL.check(lib.fnx_knn_mean_dist2(pts.data_ptr(), N, float(cell), grid.blob.data_ptr(), out.data_ptr(), _stream()))
+    return out

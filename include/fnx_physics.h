@@ -106,6 +106,12 @@ int fnx_pbf_confirm(float *xyz, const float *estimate_xyz, float *velocity, int 
 int fnx_visual_advect(float *visual, int V, const float *hidden, const float *velocity, int N, float H, float secs,
                       float eps, char *hidden_grid, float *scratch, fnx_stream_t stream);
 
+/* simple-knn's distCUDA2 (submodules/simple-knn/simple_knn.cu:134-203): mean_dist2[i] = mean of the
+ * squared distances from point i to its 3 nearest OTHER points (exact; FLT_MAX terms when N < 4, as the reference).
+ * `cell` is the edge of the search grid built here in `grid` (fnx_grid_bytes(N)): any positive value is correct,
+ * ~(volume / N)^(1/3) is fast. */
+int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *mean_dist2, fnx_stream_t stream);
+
 /* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
  * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
  *   g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch            (NULL terms are skipped; n = number of floats)
