@@ -42,6 +42,11 @@ class GaussianModel:
         # hidden (physics) particles
         self._xyz = self._estimate_xyz = self._force = self._velocity = self._imass = self._buoyancy = e
         self._counts = self._particle_id = None
+        self.alpha, self.buoyancy_decay_rate, self.buoyancy_max_y, self.min_neighbors = 0.0, 0.0, 0.0, -1
+        self.remove_out_boundary = False
+        self.emit_ratio_hidden = self.emit_ratio_visual = 1.0
+        self.emit_counter = self.total_sim_iterations = self.total_tb_log_iterations = 0
+        self._particle_id_max = self.particle_id_max = 0
         self._estimate_xyz_nn = e
         # visual particles + constant Gaussian attributes, static background Gaussians, other groups
         for g in _GROUPS:
@@ -198,6 +203,141 @@ class GaussianModel:
                 if t is not None and t.shape[:1] == mask.shape:
                     setattr(self, name, t[mask])
             self.invalidate_caches()
+
+    # -- checkpoints and scene files (gm_dynamics.py:1690-1735, 1834-2090; gm_background.py:184-225) ------
+    _HIDDEN_FILES = (("xyz", "_xyz", True), ("estimate_xyz", "_estimate_xyz", True), ("buoyancy", "_buoyancy", False),
+                     ("force", "_force", False), ("velocity", "_velocity", False), ("imass", "_imass", False),
+                     ("counts", "_counts", False), ("gravity", "_gravity", False))
+    _VISUAL_FILES = (("visual_color", "_visual_color"), ("visual_scales", "_visual_scales"),
+                     ("visual_rotation", "_visual_rotation"), ("visual_opacity", "_visual_opacity"))
+    _SCALARS = ("alpha", "k", "p0", "buoyancy_decay_rate", "buoyancy_max_y", "min_neighbors", "remove_out_boundary")
+
+    @torch.no_grad()
+    def save_hidden(self, checkpoint_path, frame_idx):
+        """:1834-1898: frame_XXX_<name>.npy per array (positions divided by scale_factor) + scalar_values.json."""
+        import json
+        import os
+        os.makedirs(checkpoint_path, exist_ok=True)
+        stem = os.path.join(checkpoint_path, f"frame_{frame_idx:03d}_")
+        for name, attr, scaled in self._HIDDEN_FILES:
+            a = getattr(self, attr).detach().clone().cpu().numpy()
+            np.save(stem + name + ".npy", a / self.scale_factor if scaled else a)
+        np.save(stem + "particle_id.npy", self._particle_id.detach().clone().cpu().numpy())
+        scalars = {"scale_factor": self.scale_factor, "secs": self._secs}
+        scalars.update({k: getattr(self, k) for k in self._SCALARS})
+        scalars.update(emit_ratio_hidden=self.emit_ratio_hidden, emit_ratio_visual=self.emit_ratio_visual,
+                       emit_counter=self.emit_counter, total_iterations=self.total_iterations,
+                       total_sim_iterations=self.total_sim_iterations,
+                       total_tb_log_iterations=self.total_tb_log_iterations, particle_id_max=self._particle_id_max)
+        with open(stem + "scalar_values.json", "w") as f:
+            json.dump(scalars, f)
+
+    @torch.no_grad()
+    def save_visual(self, checkpoint_path, frame_idx, scale=True):
+        """:1900-1923"""
+        import os
+        os.makedirs(checkpoint_path, exist_ok=True)
+        stem = os.path.join(checkpoint_path, f"frame_{frame_idx:03d}_")
+        v = self._visual_xyz.detach().clone().cpu().numpy()
+        np.save(stem + "visual_xyz.npy", v / self.scale_factor if scale else v)
+        for name, attr in self._VISUAL_FILES:
+            np.save(stem + name + ".npy", getattr(self, attr).detach().clone().cpu().numpy())
+
+    def save_all(self, checkpoint_path, frame_idx, re_sim=False):
+        """:1987-1991"""
+        self.save_hidden(checkpoint_path, frame_idx)
+        if self._visual_xyz.shape[0] > 0:
+            self.save_visual(checkpoint_path, frame_idx)
+
+    @torch.no_grad()
+    def load_hidden(self, checkpoint_path, frame_idx, device="cuda"):
+        """:1993-2062 (the reference always loads onto "cuda"; `device` exists for host-side tools and tests)."""
+        import json
+        import os
+        stem = os.path.join(checkpoint_path, f"frame_{frame_idx:03d}_")
+
+        def arr(name, dtype=torch.float):
+            path = stem + name + ".npy"
+            assert os.path.exists(path), f"File not found: {path}"
+            return torch.tensor(np.load(path), dtype=dtype, device=device)
+
+        with open(stem + "scalar_values.json", "r") as f:
+            sv = json.load(f)
+        # the reference multiplies by the scale_factor the model held BEFORE the json is read (:1996-2000,2039)
+        for name, attr, scaled in self._HIDDEN_FILES:
+            t = arr(name)
+            setattr(self, attr, t * self.scale_factor if scaled else t)
+        pid = stem + "particle_id.npy"
+        self._particle_id = (torch.tensor(np.load(pid), dtype=torch.int, device=device) if os.path.exists(pid)
+                             else torch.arange(self._xyz.shape[0], device=device))
+        self.scale_factor, self._secs = sv["scale_factor"], sv["secs"]
+        for k in self._SCALARS:
+            setattr(self, k, sv[k])
+        for k in ("emit_ratio_hidden", "emit_ratio_visual", "emit_counter"):
+            setattr(self, k, sv.get(k, getattr(self, k)))
+        for k in ("total_iterations", "total_sim_iterations", "total_tb_log_iterations"):
+            setattr(self, k, sv.get(k, 0))
+        self.particle_id_max = sv.get("particle_id_max", 0)
+        self.invalidate_caches()
+        return True
+
+    @torch.no_grad()
+    def load_visual(self, checkpoint_path, frame_idx, scale=True, color_3ch=False, device="cuda"):
+        """:2064-2090 -> number of visual particles"""
+        import os
+        stem = os.path.join(checkpoint_path, f"frame_{frame_idx:03d}_")
+
+        def arr(name):
+            path = stem + name + ".npy"
+            assert os.path.exists(path), f"File not found: {path}"
+            return torch.tensor(np.load(path), dtype=torch.float, device=device)
+
+        self._visual_xyz = arr("visual_xyz")
+        if scale:
+            self._visual_xyz = self._visual_xyz * self.scale_factor
+        for name, attr in self._VISUAL_FILES:
+            setattr(self, attr, arr(name))
+        if color_3ch and self._visual_color.shape[1] == 1:
+            self._visual_color = torch.cat((self._visual_color, self._visual_color, self._visual_color), dim=1)
+        self._visual_grid = None
+        self.invalidate_caches()
+        return self._visual_xyz.shape[0]
+
+    def load_ply(self, path, device="cuda"):
+        """:1700-1735: the static background Gaussians of a trained background stage -> _gs_*.  x and y are
+        stored negated (gm_background.py:206-210); colour comes from the color_i properties."""
+        from ..utils.ply_io import read_vertex_ply
+        names, col = read_vertex_ply(path)
+        xyz = np.stack((col["x"] * -1.0, col["y"] * -1.0, col["z"]), axis=1)
+
+        def group(prefix):
+            ks = sorted((n for n in names if n.startswith(prefix)), key=lambda n: int(n.split("_")[-1]))
+            return np.stack([col[k] for k in ks], axis=1) if ks else np.zeros((xyz.shape[0], 0))
+
+        t = lambda a: torch.tensor(a, dtype=torch.float, device=device, requires_grad=False)  # noqa: E731
+        self._gs_xyz, self._gs_color, self._gs_opacity = t(xyz), t(group("color_")), t(col["opacity"][..., np.newaxis])
+        self._gs_scales, self._gs_rotation = t(group("scale_")), t(group("rot"))
+
+    def save_background_ply(self, path):
+        """gm_background.py:184-225 for the background Gaussians held in _gs_*: properties x y z (x, y negated)
+        nx ny nz (zeros) f_dc_i = (colour - 0.5) / C0, f_rest_i (zeros), opacity (logit), scale_i (log),
+        rot_i (raw), color_i -- all float32, binary little-endian."""
+        import os
+        from ..utils.ply_io import write_vertex_ply
+        from ..utils.sh_utils import rgb2sh
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        xyz = self._gs_xyz.detach().cpu().numpy().copy()
+        xyz[:, 0] *= -1.0
+        xyz[:, 1] *= -1.0
+        color = self._gs_color.detach().cpu().numpy()
+        C = color.shape[1]
+        names = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(C)] + [f"f_rest_{i}" for i in range(C)]
+                 + ["opacity"] + [f"scale_{i}" for i in range(self._gs_scales.shape[1])]
+                 + [f"rot_{i}" for i in range(self._gs_rotation.shape[1])] + [f"color_{i}" for i in range(C)])
+        cols = np.concatenate((xyz, np.zeros_like(xyz), rgb2sh(color), np.zeros_like(color),
+                               self._gs_opacity.detach().cpu().numpy(), self._gs_scales.detach().cpu().numpy(),
+                               self._gs_rotation.detach().cpu().numpy(), color), axis=1)
+        write_vertex_ply(path, names, cols)
 
     # -- getters ------------------------------------------------------------------------------------
     get_xyz = property(lambda s: s._xyz)

@@ -295,6 +295,36 @@ def gen_pbf():
         torch.ones_like, torch.zeros_like, torch.Tensor.cuda = saved
 
 
+def gen_checkpoint():
+    """A per-frame checkpoint written by the reference's own save_hidden / save_visual (gm_dynamics.py:1834-1923)
+    from a small seeded state, plus the state itself for the loader test."""
+    import shutil
+    import gaussian_splatting.gm_dynamics as gmd
+    rng = np.random.RandomState(21)
+    gm = gmd.GaussianModel.__new__(gmd.GaussianModel)
+    N, V = 12, 9
+    f = lambda *s: torch.tensor(rng.normal(size=s).astype(np.float32))  # noqa: E731
+    gm.scale_factor, gm._secs, gm.alpha, gm.k, gm.p0 = 100.0, 0.033, 0.0, 3, 1.5
+    gm.buoyancy_decay_rate, gm.buoyancy_max_y, gm.min_neighbors, gm.remove_out_boundary = 0.98, 0.6, 1, False
+    gm.emit_ratio_hidden, gm.emit_ratio_visual, gm.emit_counter = 0.5, 2.0, 7
+    gm.total_iterations, gm.total_sim_iterations, gm.total_tb_log_iterations, gm._particle_id_max = 1234, 56, 78, 40
+    gm._xyz, gm._estimate_xyz, gm._buoyancy, gm._force, gm._velocity = f(N, 3) * 30, f(N, 3) * 30, f(N, 3), f(N, 3), f(N, 3)
+    gm._imass, gm._counts = torch.tensor(rng.uniform(0.8, 1.2, size=(N, 1)).astype(np.float32)), torch.tensor(
+        rng.randint(0, 10, size=(N, 1)).astype(np.float32))
+    gm._gravity = torch.tensor([[0.0, -9.8, 0.0]])
+    gm._particle_id = torch.tensor(rng.permutation(40)[:N].astype(np.int32))
+    gm._visual_xyz, gm._visual_color, gm._visual_scales = f(V, 3) * 30, torch.tensor(rng.uniform(size=(V, 1)).astype(np.float32)), f(V, 3)
+    gm._visual_rotation, gm._visual_opacity = f(V, 4), f(V, 1)
+    d = os.path.join(OUT, "checkpoint")
+    shutil.rmtree(d, ignore_errors=True)
+    gm.save_hidden(d, 7)
+    gm.save_visual(d, 7)
+    state = {k: getattr(gm, k).numpy() for k in ("_xyz", "_estimate_xyz", "_buoyancy", "_force", "_velocity", "_imass",
+                                                  "_counts", "_gravity", "_particle_id", "_visual_xyz", "_visual_color",
+                                                  "_visual_scales", "_visual_rotation", "_visual_opacity")}
+    np.savez(os.path.join(OUT, "checkpoint_state.npz"), **state)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
@@ -303,6 +333,7 @@ if __name__ == "__main__":
     gen_general()
     gen_physics()
     gen_pbf()
+    gen_checkpoint()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
