@@ -98,6 +98,8 @@ def main():
     if use_dist:
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"  # keep stdout to the one JSON line (the banner goes to stdout)
+        # RCCL writes its warnings to stdout; send them to a file so that stdout stays the one JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fnx_rccl_debug_%h_%p.log")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -78,6 +78,14 @@ __device__ __forceinline__ uint32_t cell_hash(int3 c, uint32_t mask) {
     return (lo | (hi << 9)) & mask;
 }
 
+// zero-fill as a kernel: hipMemsetAsync nodes inside a captured hipGraph were found to make replays fault after an
+// unrelated device-to-host copy on this ROCm, and a kernel costs the same launch
+__global__ void __launch_bounds__(256)
+zero_u32_kernel(uint32_t *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 __global__ void __launch_bounds__(256)
 grid_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask, uint32_t *__restrict__ count) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -784,7 +792,7 @@ int fnx_grid_build(const float *xyz, int N, float cell, char *grid, fnx_stream_t
     if (N < 0 || !grid || cell <= 0.f || (N > 0 && !xyz)) return fail(FNX_ERR_INVALID_ARG, "grid_build: bad argument");
     hipStream_t s = (hipStream_t)stream;
     GridView g = carve(grid, N);
-    (void)hipMemsetAsync(g.count, 0, (size_t)g.M * 4, s);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((g.M + 255) / 256), dim3(256), 0, s, g.count, (size_t)g.M);
     const float inv = 1.0f / cell;
     if (N > 0)
         hipLaunchKernelGGL(grid_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xyz, N, inv, g.M - 1, g.count);

@@ -122,6 +122,8 @@ class HotLoop:
         self.itr = 0
         self.last = {}
         self.graph = None
+        self.graph_finish = None
+        self._reduce_buf = None
         self._replay = False
         # Graph mode keeps every iteration (eager or captured) on one dedicated stream: autograd's gradient
         # accumulation is bound to the stream a leaf was first used on, and a leaf first used on the
@@ -191,8 +193,23 @@ class HotLoop:
         self.gm.invalidate_caches()
         rasterizer._pending_status.clear()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self.stream):
-            self._iteration_body()
+        self.graph_finish = None
+        if self.batched_views and (self.world > 1 or self.force_all_reduce):
+            # Multi-GPU: the RCCL all-reduce stays OUTSIDE the captured graphs (local gradient | all-reduce |
+            # batch mean + optimiser step) and works on a buffer allocated OUTSIDE the graphs' memory pool:
+            # RCCL touching pool memory (as a host read does) makes later replays fault with
+            # "write access to a read-only page".  A 0.3 MB all-reduce costs one launch either way.
+            self._reduce_buf = torch.zeros_like(self.gm._estimate_xyz_nn.detach())
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=self.stream):
+                self._iteration_body_batched(phase="local")
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
+                self._finish_step(len(self.cams), grad=self._reduce_buf)
+            self.graph_finish = g2
+        else:
+            with torch.cuda.graph(g, stream=self.stream):
+                self._iteration_body()
         self.graph = g
         self._replay = True
         return g
@@ -213,6 +230,9 @@ class HotLoop:
                 self.itr += 1
                 self.gm.total_iterations += 1
                 self.graph.replay()
+                if self.graph_finish is not None:
+                    dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
+                    self.graph_finish.replay()
             else:
                 self._iteration_body()
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -267,7 +287,7 @@ class HotLoop:
             self._gt_cache = (key, torch.stack([self.cams[v].original_image for v in mine]).contiguous())
         return self._gt_cache[1]
 
-    def _iteration_body_batched(self):
+    def _iteration_body_batched(self, phase="all"):
         """Same iteration with this rank's views rendered, compared and back-propagated by ONE launch
         sequence (rasteriser / loss kernels take the view as a grid dimension).  Mathematically the sum
         over the views of the per-view losses of `_iteration_body`; the physics gradient, identical for
@@ -314,8 +334,20 @@ class HotLoop:
             gm.accumulate_gradient_current(gp, n_phys)
         gm.flush_deferred_gradients()
         if multi:
+            if phase == "local":
+                # the caller all-reduces self._reduce_buf outside the captured graph, then runs _finish_step
+                self._reduce_buf.copy_(gm._estimate_xyz_nn_grad)
+                return
             dist.all_reduce(gm._estimate_xyz_nn_grad, op=dist.ReduceOp.SUM)
+        self._finish_step(batch)
+
+    def _finish_step(self, batch, grad=None):
+        """Batch mean of the (reduced) gradient cache + optimiser step."""
+        gm = self.gm
+        if grad is not None:
+            gm._estimate_xyz_nn_grad = grad
         if self.fused_step:
+            gm._grad_cache_used = True
             gm.fused_step_current(batch)
             return
         gm.set_batch_gradient_current(batch)

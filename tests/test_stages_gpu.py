@@ -86,8 +86,12 @@ def test_graph_replay_matches_eager(parallel):
             start = gm._estimate_xyz_nn.detach().clone()
             if use_graph:
                 loop.capture(warmup=1)
-            for _ in range(6 if not use_graph else 5):
+            for k in range(6 if not use_graph else 5):
                 loop.iteration()
+                if k == 1:
+                    # a device-to-host read between replays must not disturb later replays (hipMemsetAsync nodes
+                    # inside a captured graph used to make the next replay fault after any D2H copy)
+                    assert np.isfinite(gm._estimate_xyz_nn.detach().sum().item())
             rasterizer.check_status()
             torch.cuda.synchronize()
             results.append((start.cpu(), gm._estimate_xyz_nn.detach().cpu().clone()))
