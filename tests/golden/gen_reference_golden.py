@@ -325,6 +325,91 @@ def gen_checkpoint():
     np.savez(os.path.join(OUT, "checkpoint_state.npz"), **state)
 
 
+def gen_background():
+    """Background-stage model (gaussian_splatting/gm_background.py:150-476): optimiser surgery of
+    densify / clone / split / prune, densification statistics, opacity reset and the pruning helpers, run by the
+    reference's own class on the CPU (device="cuda" keywords / .cuda() redirected as in gen_pbf)."""
+    from types import SimpleNamespace
+    import gaussian_splatting.gm_background as gmb
+
+    def to_cpu(fn):
+        def wrapped(*a, **k):
+            if k.get("device") == "cuda":
+                k = dict(k, device="cpu")
+            return fn(*a, **k)
+        return wrapped
+
+    saved = (torch.zeros, torch.ones, torch.Tensor.cuda, torch.cuda.empty_cache)
+    torch.zeros, torch.ones = to_cpu(torch.zeros), to_cpu(torch.ones)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    try:
+        rng = np.random.RandomState(31)
+        N = 300
+        init = dict(xyz=rng.uniform(-1, 1, size=(N, 3)), color=rng.uniform(0, 1, size=(N, 3)),
+                    opacity=rng.normal(size=(N, 1)) * 2.0, scaling=rng.uniform(-6.0, -2.0, size=(N, 3)),
+                    rotation=rng.normal(size=(N, 4)))
+        init = {k: v.astype(np.float32) for k, v in init.items()}
+        args = SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
+                               position_lr_delay_mult=0.01, position_lr_max_steps=30000, color_lr=0.0025,
+                               opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+        gm = gmb.GaussianModel()
+        gm.spatial_lr_scale = 1.3
+        for k, attr in (("xyz", "_xyz"), ("color", "_color"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                        ("rotation", "_rotation")):
+            setattr(gm, attr, torch.nn.Parameter(torch.tensor(init[k]).requires_grad_(True)))
+        gm.max_radii2D = torch.zeros(N)
+        gm.training_setup(args)
+        out = {f"init_{k}": v for k, v in init.items()}
+        out["lr_xyz_1000"] = np.float64(gm.update_learning_rate(1000))
+        g1 = {k: rng.normal(size=v.shape).astype(np.float32) for k, v in init.items()}
+        for k, attr in (("xyz", "_xyz"), ("color", "_color"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                        ("rotation", "_rotation")):
+            getattr(gm, attr).grad = torch.tensor(g1[k])
+            out[f"grad_{k}"] = g1[k]
+        gm.optimizer.step()
+        gm.optimizer.zero_grad(set_to_none=True)
+        for it in range(2):
+            vs = torch.zeros(N, 3, requires_grad=True)
+            vs.grad = torch.tensor((rng.normal(size=(N, 3)) * 0.0004).astype(np.float32))
+            filt = torch.tensor(rng.uniform(size=N) < 0.7)
+            out[f"vs_grad{it}"], out[f"filter{it}"] = vs.grad.numpy().copy(), filt.numpy().copy()
+            gm.add_densification_stats(vs, filt)
+        out["accum"], out["denom"] = gm.xyz_gradient_accum.numpy().copy(), gm.denom.numpy().copy()
+        radii = rng.uniform(0, 30, size=N).astype(np.float32)
+        gm.max_radii2D = torch.tensor(radii)
+        out["max_radii2D"] = radii
+        torch.manual_seed(123)
+        gm.densify_and_prune(0.0002, 0.005, 2.0, 20)
+        out["n_after_densify"] = np.int64(gm.get_xyz.shape[0])
+        for k, attr in (("xyz", "_xyz"), ("color", "_color"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                        ("rotation", "_rotation")):
+            out[f"dp_{k}"] = getattr(gm, attr).detach().numpy().copy()
+        for grp in gm.optimizer.param_groups:
+            st = gm.optimizer.state[grp["params"][0]]
+            out[f"dp_exp_avg_{grp['name']}"] = st["exp_avg"].numpy().copy()
+            out[f"dp_exp_avg_sq_{grp['name']}"] = st["exp_avg_sq"].numpy().copy()
+        out["dp_stats_shapes"] = np.array([gm.xyz_gradient_accum.shape[0], gm.denom.shape[0], gm.max_radii2D.shape[0]])
+        gm.reset_opacity()
+        out["reset_opacity"] = gm._opacity.detach().numpy().copy()
+        out["reset_exp_avg_opacity_absmax"] = np.float64(gm.optimizer.state[gm._opacity]["exp_avg"].abs().max())
+        gm.prune_large_points()
+        out["n_after_large"] = np.int64(gm.get_xyz.shape[0])
+        gm._valid_min_y, gm._valid_max_z = -0.2, 0.1
+        gm.prune_near_points()
+        out["n_after_near"] = np.int64(gm.get_xyz.shape[0])
+        cams = rng.uniform(-1.5, 1.5, size=(4, 3)).astype(np.float32)
+        out["cams"] = cams
+        gm.set_cam_locations(cams)
+        out["smoke_to_cams_dist"] = gm.smoke_to_cams_dist.numpy().copy()
+        gm.prune_near_cam_points()
+        out["n_after_cam"] = np.int64(gm.get_xyz.shape[0])
+        out["final_xyz"] = gm._xyz.detach().numpy().copy()
+        np.savez(os.path.join(OUT, "background.npz"), **out)
+    finally:
+        torch.zeros, torch.ones, torch.Tensor.cuda, torch.cuda.empty_cache = saved
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
@@ -334,6 +419,7 @@ if __name__ == "__main__":
     gen_physics()
     gen_pbf()
     gen_checkpoint()
+    gen_background()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
