@@ -101,6 +101,25 @@ __device__ __forceinline__ float exp_fixed(float x) {
     return (x < -87.0f) ? 0.0f : v;
 }
 
+// The same sequence without the two range guards, for callers that only USE the result when -87 <= x <= 0 (the blend
+// kernels discard every lane whose power is positive or below the splat's threshold >= -ln(255) - margin): on that
+// range it returns exactly exp_fixed(x); outside it returns garbage that must not be consumed.
+__device__ __forceinline__ float exp_fixed_in_range(float x) {
+    const float t = x * 1.44269504088896341f;
+    const float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    return y * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
 // Footprint of a splat for culling, computed once per splat in preprocess.  A pixel can receive a
 // contribution (alpha >= 1/255) only if power >= -ln(255 o); that ellipse's axis-aligned bounding
 // box has half extents sqrt(2 tau c / det), sqrt(2 tau a / det) (conic (a, b, c), det = ac - b^2).
@@ -110,7 +129,7 @@ __device__ __forceinline__ float exp_fixed(float x) {
 // evaluated; (ex, ey) half extents, ex < 0 meaning "never contributes" (o < 1/255: alpha = min(.99,
 // o G) with G <= 1 stays below 1/255), +huge meaning "cannot be culled".
 __device__ __forceinline__ void splat_footprint(float a, float b, float c, float o, float &thr, float &ex, float &ey) {
-    thr = -3.0e38f;
+    thr = -87.0f;  // below -87 the fixed exp is exactly 0, i.e. alpha < 1/255: never a contribution
     ex = ey = 3.0e38f;
     if (o < 1.0f / 255.0f) {
         ex = ey = -1.0f;
@@ -118,7 +137,7 @@ __device__ __forceinline__ void splat_footprint(float a, float b, float c, float
     }
     const float tau = __logf(255.0f * o) * 1.0001f + 1.0e-3f;
     if (!(tau > 0.0f)) return;
-    thr = -tau;
+    thr = fmaxf(-tau, -87.0f);
     const float det = a * c - b * b;
     if (!(det > 0.0f)) return;
     const float k = 2.0f * tau / det;

@@ -218,7 +218,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
                 active = !(power > 0.0f) && !(power < rb.z);
                 if (active) {
-                    const float G = exp_fixed(power);
+                    const float G = exp_fixed_in_range(power);  // here thr <= power <= 0
                     const float alpha = fminf(0.99f, rb.y * G);
                     active = !(alpha < 1.0f / 255.0f);
                     if (active) {

@@ -356,7 +356,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
                 const float dx = ra.x - pxf, dy = ra.y - pyf;
                 const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
                 const bool ok = !(power > 0.0f) && !(power < rb.z) && (i0 + k < n_w);
-                alpha[k] = fminf(0.99f, rb.y * exp_fixed(power));
+                alpha[k] = fminf(0.99f, rb.y * exp_fixed_in_range(power));  // consumed only where ok (thr <= power <= 0)
                 hit[k] = ok && !(alpha[k] < 1.0f / 255.0f);
                 depth[k] = rb.w;
             }
