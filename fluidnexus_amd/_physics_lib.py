@@ -10,7 +10,8 @@ _LIB = None
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
-           "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2")
+           "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
+           "fnx_grid_cell_items")
 
 
 def physics():
@@ -35,6 +36,12 @@ def physics():
     lib.fnx_density_backward.argtypes = [p, i, p, f, f, p, p, p, p]
     lib.fnx_visual_interp_forward.restype = i
     lib.fnx_visual_interp_forward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p]
+    lib.fnx_visual_interp_forward_cells.restype = i
+    lib.fnx_visual_interp_forward_cells.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p]
+    lib.fnx_grid_cell_items_bytes.restype = C.c_size_t
+    lib.fnx_grid_cell_items_bytes.argtypes = [i]
+    lib.fnx_grid_cell_items.restype = i
+    lib.fnx_grid_cell_items.argtypes = [p, i, p, p]
     lib.fnx_visual_interp_backward.restype = i
     lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
     lib.fnx_physical_stage.restype = i

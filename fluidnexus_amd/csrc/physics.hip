@@ -657,6 +657,114 @@ visual_forward_kernel(const float *__restrict__ visual, int V, float inv_cell, f
     }
 }
 
+// Cell-centric form of the same interpolation.  The visual particles are static within a frame, so their own
+// hash grid (built once) lists them cell by cell; one wave takes 64 consecutive slots of that list -- particles
+// of one or two cells -- stages the hidden particles of the cell's 27-neighbourhood (position + velocity, ~200
+// candidates) in LDS ONCE and every lane walks them with broadcast LDS reads.  The particle-centric kernel above
+// re-reads start / records from L2 for every particle in arbitrary order; this one reads them once per cell.
+constexpr int kCellCand = 256;  // staged candidates per round (2 x 4 KiB of LDS per one-wave workgroup)
+// Work items of a grid for cell-by-cell kernels: every non-empty bucket becomes ceil(count / 64) items
+// (first slot, slots), so that one wave handles particles of ONE cell (up to hash collisions) -- a wave that
+// takes 64 consecutive slots instead spans up to dozens of sparse cells at the rim of the plume and becomes the
+// tail of the launch.  Item order is arbitrary (atomic append); nothing depends on it.
+__global__ void __launch_bounds__(256)
+grid_cell_items_kernel(uint32_t M, const uint32_t *__restrict__ start, uint2 *__restrict__ items,
+                       uint32_t *__restrict__ n_items) {
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= M) return;
+    const uint32_t s0 = start[h], cnt = start[h + 1] - s0;
+    if (cnt == 0) return;
+    const uint32_t k = (cnt + 63) / 64, each = (cnt + k - 1) / k;
+    const uint32_t at = atomicAdd(n_items, k);
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t b = j * each;
+        items[at + j] = make_uint2(s0 + b, min(each, cnt - b));
+    }
+}
+
+__global__ void __launch_bounds__(64)
+visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float secs, float eps,
+                            const float4 *__restrict__ vrec, const uint2 *__restrict__ items,
+                            const uint32_t *__restrict__ n_items, uint32_t hmask,
+                            const uint32_t *__restrict__ hstart, const float4 *__restrict__ hrec,
+                            const float4 *__restrict__ u, float *__restrict__ out, float *__restrict__ sum_w,
+                            float *__restrict__ wvel) {
+    __shared__ float4 s_pos[kCellCand];
+    __shared__ float4 s_vel[kCellCand];
+    const int lane = threadIdx.x;
+    const uint32_t n_work = *n_items;
+    for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
+        const uint2 it = items[item];
+        const bool valid = (uint32_t)lane < it.y;
+        const float4 me = vrec[valid ? it.x + lane : it.x];
+        const int3 c = cell_of(me.x, me.y, me.z, inv_cell);
+        float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {  // one round per distinct cell among the lanes: one, unless cells collide in the bucket
+            const int lead = __ffsll((long long)todo) - 1;
+            const int3 c0 = make_int3(__shfl(c.x, lead), __shfl(c.y, lead), __shfl(c.z, lead));
+            const bool mine = valid && c.x == c0.x && c.y == c0.y && c.z == c0.z;
+            // lanes 0..26 and 32..58 own one neighbour bucket each (two lanes per bucket: even / odd records)
+            const int bl = lane & 31, par = lane >> 5;
+            uint32_t s0 = 0, cnt = 0;
+            if (bl < 27) {
+                const int dx = bl % 3 - 1, dy = (bl / 3) % 3 - 1, dz = bl / 9 - 1;
+                const uint32_t h = cell_hash(make_int3(c0.x + dx, c0.y + dy, c0.z + dz), hmask);
+                s0 = hstart[h];
+                cnt = hstart[h + 1] - s0;
+            }
+            uint32_t inc = cnt;  // prefix over the 27 sizes, within each half of the wave
+            for (int off = 1; off < 32; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 32);
+                if (bl >= off) inc += t;
+            }
+            const uint32_t first = inc - cnt;  // position of this bucket's first record
+            const uint32_t total = (uint32_t)__shfl((int)inc, 26);
+            for (uint32_t base = 0; base < total; base += kCellCand) {
+                const uint32_t n = min((uint32_t)kCellCand, total - base);
+                for (uint32_t j = par; j < cnt; j += 4) {  // stage the part of this bucket that falls into the round
+                    const uint32_t i0 = first + j, i1 = i0 + 2;
+                    const bool in0 = i0 >= base && i0 < base + n, in1 = j + 2 < cnt && i1 >= base && i1 < base + n;
+                    float4 p0, v0, p1, v1;
+                    if (in0) { p0 = hrec[s0 + j]; v0 = u[s0 + j]; }
+                    if (in1) { p1 = hrec[s0 + j + 2]; v1 = u[s0 + j + 2]; }
+                    if (in0) { s_pos[i0 - base] = p0; s_vel[i0 - base] = v0; }
+                    if (in1) { s_pos[i1 - base] = p1; s_vel[i1 - base] = v1; }
+                }
+                __syncthreads();  // one wave per workgroup: orders the LDS writes before the reads
+                if (mine) {
+#pragma unroll 4
+                    for (uint32_t i = 0; i < n; i++) {
+                        const float4 q = s_pos[i];
+                        const float4 uj = s_vel[i];
+                        const float ex = me.x - q.x, ey = me.y - q.y, ez = me.z - q.z;
+                        const float r2 = ex * ex + ey * ey + ez * ez;
+                        const float t = H2 - r2;
+                        const float w = r2 < H2 ? term1 * (t * t * t) : 0.0f;  // +0 terms leave the sums unchanged
+                        S += w;
+                        ax += uj.x * w;
+                        ay += uj.y * w;
+                        az += uj.z * w;
+                    }
+                }
+                __syncthreads();
+            }
+            todo &= ~__ballot(mine);
+        }
+        if (valid) {
+            const uint32_t v = __float_as_uint(me.w);
+            sum_w[v] = S;
+            wvel[3 * v + 0] = ax;
+            wvel[3 * v + 1] = ay;
+            wvel[3 * v + 2] = az;
+            const float Sc = fmaxf(S, eps);
+            out[3 * v + 0] = me.x + ax * secs / Sc;
+            out[3 * v + 1] = me.y + ay * secs / Sc;
+            out[3 * v + 2] = me.z + az * secs / Sc;
+        }
+    }
+}
+
 // per visual-grid slot, everything the hidden<-visual backward needs from the visual particle stored there,
 // with the divisions done once per visual particle instead of once per pair:
 //   G = g / Sc (Sc = max(S, eps)),  c2 = [S > eps] secs (g . wvel) / Sc^2
@@ -968,6 +1076,41 @@ int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, c
     hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 31) / 32), dim3(256), 0, (hipStream_t)stream, visual, V,
                        1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel);
     return hip_check("visual_interp_forward");
+}
+
+size_t fnx_grid_cell_items_bytes(int N) { return 64 + ((size_t)(N > 0 ? N : 0) + (size_t)(N > 0 ? N : 0) / 64 + 1) * 8; }
+
+int fnx_grid_cell_items(const char *grid, int N, char *items, fnx_stream_t stream) {
+    if (N < 0 || !grid || !items) return fail(FNX_ERR_INVALID_ARG, "grid_cell_items: bad argument");
+    GridView g = carve(const_cast<char *>(grid), N);
+    uint32_t *n_items = (uint32_t *)items;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_items, (size_t)16);
+    if (N > 0)
+        hipLaunchKernelGGL(grid_cell_items_kernel, dim3((g.M + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.M,
+                           g.start, (uint2 *)(items + 64), n_items);
+    return hip_check("grid_cell_items");
+}
+
+int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                    float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                    const char *visual_items, float *out, float *sum_w, float *wvel,
+                                    fnx_stream_t stream) {
+    if (V == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !visual || !hidden_grid || !visual_grid || !visual_items || !out || !sum_w || !wvel ||
+        (N > 0 && (!hidden || !hidden_prev)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward_cells: bad argument");
+    GridView g = carve(const_cast<char *>(hidden_grid), N);
+    GridView gv = carve(const_cast<char *>(visual_grid), V);
+    if (N > 0)
+        hipLaunchKernelGGL(slot_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec, N,
+                           hidden_prev, secs, g.aux0);
+    // one-wave workgroups that stride over the items; 20 of them fit a CU (8 KiB of LDS each)
+    const size_t bound = (size_t)V + (size_t)V / 64 + 1;
+    const unsigned wgs = (unsigned)(bound < 5120 ? bound : 5120);
+    hipLaunchKernelGGL(visual_forward_cells_kernel, dim3(wgs), dim3(64), 0, (hipStream_t)stream, V, 1.0f / H, H * H,
+                       poly6_term1(H), secs, eps, gv.rec, (const uint2 *)(visual_items + 64),
+                       (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel);
+    return hip_check("visual_interp_forward_cells");
 }
 
 int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,

@@ -35,6 +35,15 @@ class HashGrid:
         if build:  # build=False: storage only, a fused entry point fills it (fnx_physical_stage)
             PL.check(lib.fnx_grid_build(xyz.data_ptr() if self.N else None, self.N, self.cell, self.blob.data_ptr(),
                                         _stream()))
+        self._items = None
+
+    def cell_items(self) -> torch.Tensor:
+        """Per-cell work items of the (built) grid for the cell-by-cell kernels; made on first use."""
+        if self._items is None:
+            lib = PL.physics()
+            self._items = torch.empty(lib.fnx_grid_cell_items_bytes(self.N), dtype=torch.uint8, device=self.blob.device)
+            PL.check(lib.fnx_grid_cell_items(self.blob.data_ptr(), self.N, self._items.data_ptr(), _stream()))
+        return self._items
 
 
 class _DensityRatio(torch.autograd.Function):
@@ -86,9 +95,12 @@ class _VisualFromHidden(torch.autograd.Function):
             out = torch.empty_like(visual)
             sum_w = torch.empty(V, dtype=torch.float32, device=visual.device)
             wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
-            PL.check(lib.fnx_visual_interp_forward(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N,
-                                                   H, secs, eps, hgrid.blob.data_ptr(), out.data_ptr(),
-                                                   sum_w.data_ptr(), wvel.data_ptr(), _stream()))
+            if visual_grid is None:
+                visual_grid = HashGrid(visual, H)
+            PL.check(lib.fnx_visual_interp_forward_cells(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N,
+                                                         H, secs, eps, hgrid.blob.data_ptr(), visual_grid.blob.data_ptr(),
+                                                         visual_grid.cell_items().data_ptr(), out.data_ptr(),
+                                                         sum_w.data_ptr(), wvel.data_ptr(), _stream()))
             if memo is not None:
                 memo.update(out=out, sum_w=sum_w, wvel=wvel)
         if visual_grid is None:

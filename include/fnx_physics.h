@@ -53,6 +53,19 @@ int fnx_density_backward(const float *xyz, int N, const float *imass, float H, f
 int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
                               float H, float secs, float eps, const char *hidden_grid, float *out, float *sum_w,
                               float *wvel, fnx_stream_t stream);
+/* Work items of a built grid for the cell-by-cell kernels: `items` (fnx_grid_cell_items_bytes(N) bytes, device)
+ * receives a count word and, per non-empty bucket, ceil(count/64) (first slot, slots) pairs in arbitrary order.
+ * Built once per grid. */
+size_t fnx_grid_cell_items_bytes(int N);
+int fnx_grid_cell_items(const char *grid, int N, char *items, fnx_stream_t stream);
+/* fnx_visual_interp_forward with the visual particles walked cell by cell: `visual_grid` is a grid built over
+ * `visual` with cell = H and `visual_items` its work items (both static within a frame, so built once); the hidden
+ * neighbourhood of a cell is staged in LDS once per cell instead of being re-read per particle.  Same results up
+ * to fp32 summation order. */
+int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                    float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                    const char *visual_items, float *out, float *sum_w, float *wvel,
+                                    fnx_stream_t stream);
 /* dL_dhidden[j] = sum_v [ w_vj/S_v * g_v + dL/dw_vj * dW/dr2 * 2 (hidden_j - visual_v) ], S_v = max(sum_w, eps),
  * dL/dw_vj = secs * (g_v . u_j)/S_v - [sum_w_v > eps] * secs * (g_v . wvel_v)/S_v^2.
  * `visual_grid` is built over `visual` with cell = H. */
