@@ -19,6 +19,28 @@ inline int tiles_y(int H) { return (H + 15) / 16; }
 constexpr int kSplatBlock = 1024;
 constexpr int kSortChunk = 1024;
 constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB
+// Depth sort digits: 9 bits.  Keys are sorted relative to the smallest visible key, so three passes order any
+// view whose depths span less than 2^27 ulps (a far/near ratio of ~2^16); the fourth pass runs only beyond that.
+constexpr int kSortBits = 9;
+constexpr int kSortRadix = 1 << kSortBits;
+constexpr int kKeyBlock = 256;  // splats per preprocess workgroup = per entry of the block-minimum array
+// u32 words inside the geometry blob's sort_hist region
+struct SortScratch {
+    size_t hist, hist_rel, totals, ctl, kmin_blk, kmax_blk, words;
+};
+enum { SORT_CTL_KMIN = 0, SORT_CTL_WIDE = 1 };  // smallest visible key; 1 if the fourth pass is needed
+inline SortScratch sort_scratch(int P) {
+    const size_t p = (size_t)(P > 0 ? P : 0), nsb = (p + kSortChunk - 1) / kSortChunk;
+    SortScratch o;
+    o.hist = 0;
+    o.hist_rel = o.hist + nsb * kSortRadix;
+    o.totals = o.hist_rel + nsb * kSortRadix;
+    o.ctl = o.totals + kSortRadix;
+    o.kmin_blk = o.ctl + 16;
+    o.kmax_blk = o.kmin_blk + (p + kKeyBlock - 1) / kKeyBlock;
+    o.words = o.kmax_blk + nsb;
+    return o;
+}
 inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
 inline int sort_blocks(int P) { return (P + kSortChunk - 1) / kSortChunk; }
 
@@ -26,7 +48,7 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     size_t off = 0;
     size_t p = (size_t)(P > 0 ? P : 0);
     size_t t = (size_t)tiles_x(W) * tiles_y(H);
-    size_t nb = (size_t)splat_blocks(P > 0 ? P : 0), nsb = (size_t)sort_blocks(P > 0 ? P : 0);
+    size_t nb = (size_t)splat_blocks(P > 0 ? P : 0);
     o->depths = off;        off = align_up(off + p * 4);
     o->clamped = off;       off = align_up(off + p * 3);
     o->radii = off;         off = align_up(off + p * 4);
@@ -35,13 +57,15 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     o->conic_opacity = off; off = align_up(off + p * 16);
     o->rgb = off;           off = align_up(off + p * 12);
     o->tiles_touched = off; off = align_up(off + p * 4);
+    // sort_key0|sort_key1 and sort_val0|sort_val1 are used as two P-entry (key, id) pair buffers: keep each
+    // couple adjacent (the raw depth keys of the preprocess occupy the first P words of the first couple)
     o->sort_key0 = off;     off = align_up(off + p * 4);
     o->sort_key1 = off;     off = align_up(off + p * 4);
     o->sort_val0 = off;     off = align_up(off + p * 4);
     o->sort_val1 = off;     off = align_up(off + p * 4);
     o->rect = off;          off = align_up(off + p * 8);
     o->rect_sorted = off;   off = align_up(off + p * 8);
-    o->sort_hist = off;     off = align_up(off + (2 * 256 * nsb + 256) * 4);
+    o->sort_hist = off;     off = align_up(off + sort_scratch(P).words * 4);
     o->blk_hist = off;      off = align_up(off + nb * t * 2);
     o->blk_rel = off;       off = align_up(off + nb * t * 4);
     o->blend_rec = off;     off = align_up(off + p * 64);

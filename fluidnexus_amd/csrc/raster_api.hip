@@ -19,18 +19,18 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
-                       uint32_t *sort_key, uint2 *rect, float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb);
+                       uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
+                       const ViewBatch &vb);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
                       const ViewBatch &vb);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
-void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, const uint2 *rect, uint2 *rect_sorted,
-                       int V, const ViewBatch &vb);
+void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb);
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist, int V,
                       const ViewBatch &vb);
-void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const uint2 *rect_sorted,
-                 const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
+void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
                  uint32_t capacity, int V, const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
@@ -259,13 +259,13 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
-                           g.rect, g.blend_rec, prefiltered, V, vb);
+                           g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb);
     }
     {
     ProfScope ps(2, s);
-    const size_t nsb256 = (size_t)fnx::sort_blocks(P) * 256;
-    fnx::launch_depth_sort(s, P, g.sort_key0, g.sort_key1, g.sort_val0, g.sort_val1, g.sort_hist,
-                           g.sort_hist + nsb256, g.sort_hist + 2 * nsb256, g.rect, g.rect_sorted, V, vb);
+    // (key, id) pair buffers: sort_key0|sort_key1 and sort_val0|sort_val1 are adjacent P-word arrays
+    fnx::launch_depth_sort(s, P, g.sort_key0, (uint2 *)g.sort_key0, (uint2 *)g.sort_val0, g.sort_hist, g.rect,
+                           g.rect_sorted, V, vb);
     fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, V, vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, V, vb);
@@ -328,7 +328,8 @@ int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binni
     const uint32_t cap = (uint32_t)binning_capacity;
     {
     ProfScope ps(4, s);
-    fnx::launch_emit(s, P, width, height, g.sort_val0, g.rect_sorted, img.ranges, g.blk_rel, bin.point_list, img.header,
+    fnx::launch_emit(s, P, width, height, (const uint2 *)g.sort_val0, (const uint2 *)g.sort_key0, g.sort_hist + fnx::sort_scratch(P).ctl,
+                     g.rect_sorted, img.ranges, g.blk_rel, bin.point_list, img.header,
                      cap, V, vb);
     }
     {

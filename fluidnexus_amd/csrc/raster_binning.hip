@@ -5,8 +5,10 @@
 // The reference sorts R = sum(tiles touched) 64-bit (tile | depth) keys.  Here only the P splats
 // are sorted, once, by depth; the R instances are never sorted globally:
 //
-//   depth sort      stable LSD radix sort of (depth bits -> id), 4 x 8-bit passes, wave64 ballot
-//                   ranking: sorted_ids[rank] = splat id in (depth bits, id) order
+//   depth sort      stable LSD radix sort of (depth bits -> id), 9-bit digits, wave64 ballot ranking:
+//                   sorted_ids[rank] = splat id in (depth bits, id) order.  Keys are taken relative to
+//                   the smallest visible key, so 3 passes suffice unless the depths span >= 2^27 ulps
+//                   (then a 4th runs; its kernels return at once otherwise)
 //   rank_hist       splats in RANK order, blocks of 1024 consecutive ranks: how many splats of the
 //                   block touch each tile -> blk_hist[block][tile]               (LDS atomics only)
 //   tile_colscan    column prefix of that matrix -> blk_rel[block][tile], tile totals
@@ -31,8 +33,22 @@ namespace fnx {
 template <typename CountT>
 __global__ void __launch_bounds__(1024)
 colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__restrict__ blk_rel,
-               uint32_t *__restrict__ tile_count, size_t hist_stride, size_t count_stride) {
+               uint32_t *__restrict__ tile_count, size_t hist_stride, size_t count_stride,
+               const uint32_t *__restrict__ kmax_blk, uint32_t *__restrict__ ctl, int only_if_wide) {
     __shared__ uint32_t s_band[16][64];
+    if (ctl) {  // depth-sort passes
+        ctl = view_at(ctl, hist_stride, blockIdx.y);
+        if (only_if_wide && ctl[SORT_CTL_WIDE] == 0u) return;
+        if (kmax_blk && blockIdx.x == 0 && threadIdx.x < 64) {
+            // first pass: largest relative key of the view -> is the fourth pass needed?
+            kmax_blk = view_at(kmax_blk, hist_stride, blockIdx.y);
+            uint32_t m = 0;
+            for (int b = threadIdx.x; b < NB; b += 64) m = max(m, kmax_blk[b]);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+            if (threadIdx.x == 0) ctl[SORT_CTL_WIDE] = (m >> (3 * kSortBits)) ? 1u : 0u;
+        }
+    }
     blk_hist = view_at(blk_hist, hist_stride, blockIdx.y);
     blk_rel = view_at(blk_rel, hist_stride, blockIdx.y);
     tile_count = view_at(tile_count, count_stride, blockIdx.y);
@@ -76,67 +92,130 @@ colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// Depth sort: LSD radix, 8-bit digits, stable.  Workgroup = 256 threads = 4 waves over a chunk of
+// Depth sort: LSD radix, kSortBits-bit digits, stable.  Workgroup = 256 threads = 4 waves over a chunk of
 // kSortChunk = 1024 keys; wave w owns keys [256 w, 256 w + 256) of the chunk in 4 steps of 64.
+// Pass 0 reads the raw keys and sorts key' = key - kmin (culled splats: 0; their rank is irrelevant, they emit
+// nothing), where kmin is the smallest visible key of the view; the later passes read key' as scattered.
+enum { SORT_FIRST = 0, SORT_MIDDLE = 1, SORT_THIRD = 2, SORT_FOURTH = 3 };
+
+__device__ __forceinline__ uint32_t relative_key(uint32_t key, uint32_t kmin) {
+    return key == 0xFFFFFFFFu ? 0u : key - kmin;
+}
+
 __global__ void __launch_bounds__(256)
-sort_hist_kernel(int P, const uint32_t *__restrict__ keys, int shift, int NSB, uint32_t *__restrict__ hist,
-                 size_t geom_stride) {
-    __shared__ uint32_t s_h[256];
-    keys = view_at(keys, geom_stride, blockIdx.y);
+sort_hist_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *__restrict__ pairs, int pass,
+                 uint32_t *__restrict__ hist, const uint32_t *__restrict__ kmin_blk, uint32_t *__restrict__ kmax_blk,
+                 uint32_t *__restrict__ ctl, size_t geom_stride) {
+    __shared__ uint32_t s_h[kSortRadix];
+    __shared__ uint32_t s_red[4];
+    raw_keys = view_at(raw_keys, geom_stride, blockIdx.y);
+    pairs = view_at(pairs, geom_stride, blockIdx.y);
     hist = view_at(hist, geom_stride, blockIdx.y);
-    s_h[threadIdx.x] = 0;
+    ctl = view_at(ctl, geom_stride, blockIdx.y);
+    if (pass == SORT_FOURTH && ctl[SORT_CTL_WIDE] == 0u) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int shift = pass * kSortBits;
+    uint32_t kmin = 0;
+    if (pass == SORT_FIRST) {
+        // every workgroup reduces the preprocess workgroups' minima (a few KiB from L2); workgroup 0 publishes it
+        kmin_blk = view_at(kmin_blk, geom_stride, blockIdx.y);
+        const int nkb = (P + kKeyBlock - 1) / kKeyBlock;
+        uint32_t m = 0xFFFFFFFFu;
+        for (int b = tid; b < nkb; b += 256) m = min(m, kmin_blk[b]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+        if (lane == 0) s_red[w] = m;
+        __syncthreads();
+        kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        if (blockIdx.x == 0 && tid == 0) ctl[SORT_CTL_KMIN] = kmin;
+        __syncthreads();
+    }
+    for (int d = tid; d < kSortRadix; d += 256) s_h[d] = 0;
     __syncthreads();
     const int base = blockIdx.x * kSortChunk;
+    uint32_t kmax = 0;
 #pragma unroll
     for (int k = 0; k < kSortChunk / 256; k++) {
-        const int i = base + k * 256 + threadIdx.x;
-        if (i < P) atomicAdd(&s_h[(keys[i] >> shift) & 255u], 1u);
+        const int i = base + k * 256 + tid;
+        if (i < P) {
+            uint32_t key;
+            if (pass == SORT_FIRST) {
+                key = relative_key(raw_keys[i], kmin);
+                kmax = max(kmax, key);
+            } else {
+                key = pairs[i].x;
+            }
+            atomicAdd(&s_h[(key >> shift) & (kSortRadix - 1)], 1u);
+        }
+    }
+    if (pass == SORT_FIRST) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+        if (lane == 0) s_red[w] = kmax;
     }
     __syncthreads();
-    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = s_h[threadIdx.x];  // block-major rows of 256 digits
+    for (int d = tid; d < kSortRadix; d += 256)
+        hist[(size_t)blockIdx.x * kSortRadix + d] = s_h[d];  // block-major rows of kSortRadix digits
+    if (pass == SORT_FIRST && tid == 0) {
+        kmax_blk = view_at(kmax_blk, geom_stride, blockIdx.y);
+        kmax_blk[blockIdx.x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    }
 }
 
 // Stable scatter of one pass.  Rank of a key inside its 64-key step: lanes holding the same digit
-// are found with 8 ballots; the rank is the number of lower lanes in that set.
+// are found with kSortBits ballots; the rank is the number of lower lanes in that set.
+// The tile rectangles are brought into rank order by the last pass that runs (the third, or the fourth).
 __global__ void __launch_bounds__(256)
-sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift,
-                    const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total, int first_pass,
-                    const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted, size_t geom_stride) {
-    __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave running offsets
+sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *__restrict__ pairs_in,
+                    uint2 *__restrict__ pairs_out, int pass,
+                    const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total,
+                    const uint32_t *__restrict__ ctl, const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted,
+                    size_t geom_stride) {
+    __shared__ uint32_t s_cnt[4][kSortRadix];   // per-wave digit counts, then per-wave running offsets
+    __shared__ uint32_t s_wtot[4];
+    bool with_rect = false;
+    uint32_t kmin = 0;
     {
         const int vw = blockIdx.y;
-        keys_in = view_at(keys_in, geom_stride, vw);
-        vals_in = view_at(vals_in, geom_stride, vw);
-        keys_out = view_at(keys_out, geom_stride, vw);
-        vals_out = view_at(vals_out, geom_stride, vw);
+        ctl = view_at(ctl, geom_stride, vw);
+        const bool wide = ctl[SORT_CTL_WIDE] != 0u;
+        if (pass == SORT_FOURTH && !wide) return;
+        if (pass == SORT_FIRST) kmin = ctl[SORT_CTL_KMIN];
+        with_rect = (pass == SORT_THIRD && !wide) || pass == SORT_FOURTH;
+        raw_keys = view_at(raw_keys, geom_stride, vw);
+        pairs_in = view_at(pairs_in, geom_stride, vw);
+        pairs_out = view_at(pairs_out, geom_stride, vw);
         hist_rel = view_at(hist_rel, geom_stride, vw);
         digit_total = view_at(digit_total, geom_stride, vw);
-        if (rect_sorted) {  // last pass: also bring the tile rectangles into rank order
-            rect = view_at(rect, geom_stride, vw);
-            rect_sorted = view_at(rect_sorted, geom_stride, vw);
-        }
+        rect = view_at(rect, geom_stride, vw);
+        rect_sorted = view_at(rect_sorted, geom_stride, vw);
     }
-    __shared__ uint32_t s_wtot[4];
+    const int shift = pass * kSortBits;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int base = blockIdx.x * kSortChunk + w * 256;
 #pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[k][tid] = 0;
+    for (int k = 0; k < 4; k++)
+        for (int d = tid; d < kSortRadix; d += 256) s_cnt[k][d] = 0;
     __syncthreads();
-    uint32_t key[4];
+    uint2 kv[4];  // (relative key, splat id)
     bool valid[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = base + k * 64 + lane;
         valid[k] = i < P;
-        key[k] = valid[k] ? keys_in[i] : 0xFFFFFFFFu;
-        if (valid[k]) atomicAdd(&s_cnt[w][(key[k] >> shift) & 255u], 1u);
+        kv[k] = make_uint2(0u, 0u);
+        if (valid[k]) {
+            kv[k] = pass == SORT_FIRST ? make_uint2(relative_key(raw_keys[i], kmin), (uint32_t)i) : pairs_in[i];
+            atomicAdd(&s_cnt[w][(kv[k].x >> shift) & (kSortRadix - 1)], 1u);
+        }
     }
     __syncthreads();
-    // thread = digit: global base of the digit (exclusive scan of the 256 digit totals) + keys of
-    // this digit in earlier chunks + earlier waves of this chunk
+    // thread = digit pair (2 tid, 2 tid + 1): global base of the digit (exclusive scan of the digit totals) +
+    // keys of this digit in earlier chunks + earlier waves of this chunk
     {
-        const uint32_t tot = digit_total[tid];
+        static_assert(kSortRadix == 512, "two digits per thread");
+        const uint32_t t0 = digit_total[2 * tid], t1 = digit_total[2 * tid + 1];
+        const uint32_t tot = t0 + t1;
         uint32_t inc = tot;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
@@ -146,12 +225,14 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
         __syncthreads();
         uint32_t dbase = inc - tot;
         for (int k = 0; k < w; k++) dbase += s_wtot[k];
-        uint32_t run = dbase + hist_rel[(size_t)blockIdx.x * 256 + tid];
+        const uint2 rel = *reinterpret_cast<const uint2 *>(hist_rel + (size_t)blockIdx.x * kSortRadix + 2 * tid);
+        uint32_t run0 = dbase + rel.x, run1 = dbase + t0 + rel.y;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t c = s_cnt[k][tid];
-            s_cnt[k][tid] = run;
-            run += c;
+            const uint2 c = *reinterpret_cast<const uint2 *>(&s_cnt[k][2 * tid]);
+            *reinterpret_cast<uint2 *>(&s_cnt[k][2 * tid]) = make_uint2(run0, run1);
+            run0 += c.x;
+            run1 += c.y;
         }
     }
     __syncthreads();
@@ -159,21 +240,18 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ keys_in, const uint32_t 
     volatile uint32_t *run_off = s_cnt[w];  // updated by one lane, read by the others: keep it out of registers
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t d = (key[k] >> shift) & 255u;
+        const uint32_t d = (kv[k].x >> shift) & (kSortRadix - 1);
         unsigned long long same = __ballot(valid[k]);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < kSortBits; b++) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             same &= ((d >> b) & 1u) ? m : ~m;
         }
         if (valid[k]) {
             const uint32_t r = (uint32_t)__popcll(same & lt_mask);
             const uint32_t pos = run_off[d] + r;
-            const int i = base + k * 64 + lane;
-            const uint32_t v = first_pass ? (uint32_t)i : vals_in[i];
-            keys_out[pos] = key[k];
-            vals_out[pos] = v;
-            if (rect_sorted) rect_sorted[pos] = rect[v];
+            pairs_out[pos] = kv[k];
+            if (with_rect) rect_sorted[pos] = rect[kv[k].y];
         }
         // the wave's LDS reads above are issued before this write (in-order per wave)
         if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
@@ -314,8 +392,9 @@ struct InstanceWalk {
 };
 
 __global__ void __launch_bounds__(kEmitThreads)
-emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect_sorted, int gx,
-            int gy, const uint32_t *__restrict__ ranges,
+emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__restrict__ sorted4,
+            const uint32_t *__restrict__ sort_ctl, const uint2 *__restrict__ rect_sorted, int gx, int gy,
+            const uint32_t *__restrict__ ranges,
             const uint32_t *__restrict__ blk_rel, uint32_t *__restrict__ point_list, uint32_t *__restrict__ header,
             uint32_t capacity, int TW, int V, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_mask[TW][kEmitMaskWords] | s_cur[TW]
@@ -327,13 +406,15 @@ emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const uint2 *
     // are dispatched first, so the long workgroups do not end up in the tail of the launch
     const int vw = blockIdx.x % V, blk = blockIdx.x / V;
     {
-        sorted_ids = view_at(sorted_ids, vb.geom, vw);
         rect_sorted = view_at(rect_sorted, vb.geom, vw);
         blk_rel = view_at(blk_rel, vb.geom, vw);
         ranges = view_at(ranges, vb.img, vw);
         header = view_at(header, vb.img, vw);
         point_list = view_at(point_list, vb.bin, vw);
     }
+    // ids in depth order: where the third sort pass left them, or the fourth if it had to run
+    const uint2 *__restrict__ sorted_ids =  // (relative key, id) pairs
+        view_at(view_at(sort_ctl, vb.geom, vw)[SORT_CTL_WIDE] ? sorted4 : sorted3, vb.geom, vw);
     if (header[HDR_NUM_RENDERED] > capacity) {
         if (blk == 0 && threadIdx.x == 0) {
             header[HDR_STATUS] = FNX_ERR_CAPACITY;
@@ -361,7 +442,7 @@ emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const uint2 *
         uint32_t id = 0;
         uint2 rect = make_uint2(0u, 0u);
         if (rank < P) {
-            id = sorted_ids[rank];
+            id = sorted_ids[rank].y;
             rect = rect_sorted[rank];
         }
         s_id[l] = id;
@@ -502,27 +583,31 @@ emit_kernel(int P, int T, const uint32_t *__restrict__ sorted_ids, const uint2 *
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb) {
     hipLaunchKernelGGL((colscan_kernel<uint16_t>), dim3((T + 63) / 64, V), dim3(1024), 0, s, T, splat_blocks(P),
-                       blk_hist, blk_rel, tile_count, vb.geom, vb.img);
+                       blk_hist, blk_rel, tile_count, vb.geom, vb.img, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                       0);
 }
 
-// keys0 holds the depth keys; after the call vals0 = ids in (depth bits, id) order.
-// hist: u32[NSB*256] chunk histograms, hist_rel: u32[NSB*256] their prefix over chunks, totals: u32[256].
-void launch_depth_sort(hipStream_t s, int P, uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1,
-                       uint32_t *hist, uint32_t *hist_rel, uint32_t *totals, const uint2 *rect, uint2 *rect_sorted,
-                       int V, const ViewBatch &vb) {
+// `raw_keys` holds the depth keys (preprocess), `scratch` the geometry blob's sort_hist region; pairs_a / pairs_b
+// are two P-entry (relative key, id) buffers (pairs_a may alias raw_keys: it is first written by the second pass).
+// After the call the pairs in (depth bits, id) order are in pairs_b (three passes) or pairs_a (four: scratch ctl
+// word SORT_CTL_WIDE is 1).
+void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb) {
     const int NSB = sort_blocks(P);
-    uint32_t *kin = keys0, *kout = keys1, *vin = vals0, *vout = vals1;
+    const SortScratch L = sort_scratch(P);
+    uint32_t *hist = scratch + L.hist, *hist_rel = scratch + L.hist_rel, *totals = scratch + L.totals,
+             *ctl = scratch + L.ctl, *kmin_blk = scratch + L.kmin_blk, *kmax_blk = scratch + L.kmax_blk;
+    uint2 *pin = pairs_a, *pout = pairs_b;
     for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, shift, NSB, hist, vb.geom);
-        hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(4, V), dim3(1024), 0, s, 256, NSB, hist, hist_rel, totals,
-                           vb.geom, vb.geom);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, kin, vin, kout, vout, shift, hist_rel,
-                           totals, pass == 0 ? 1 : 0, rect, pass == 3 ? rect_sorted : (uint2 *)nullptr, vb.geom);
-        uint32_t *t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(NSB, V), dim3(256), 0, s, P, raw_keys, pin, pass, hist, kmin_blk,
+                           kmax_blk, ctl, vb.geom);
+        hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(kSortRadix / 64, V), dim3(1024), 0, s, kSortRadix, NSB, hist,
+                           hist_rel, totals, vb.geom, vb.geom, pass == SORT_FIRST ? kmax_blk : (const uint32_t *)nullptr,
+                           ctl, pass == SORT_FOURTH ? 1 : 0);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, raw_keys, pin, pout, pass, hist_rel,
+                           totals, ctl, rect, rect_sorted, vb.geom);
+        uint2 *t = pin; pin = pout; pout = t;
     }
-    // 4 passes: the result is back in (keys0, vals0)
 }
 
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist, int V,
@@ -532,7 +617,8 @@ void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sort
                        gy, blk_hist, vb);
 }
 
-void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids, const uint2 *rect_sorted,
+void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted,
                  const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
                  uint32_t capacity, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
@@ -544,8 +630,8 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint32_t *sorted_ids,
                                   kEmitTileWindow * 4 * (kEmitMaskWords + 1));
         attr_set = true;
     }
-    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P) * V), dim3(kEmitThreads), lds, s, P, T, sorted_ids,
-                       rect_sorted, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
+    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P) * V), dim3(kEmitThreads), lds, s, P, T, sorted3, sorted4,
+                       sort_ctl, rect_sorted, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
 }
 
 }  // namespace fnx

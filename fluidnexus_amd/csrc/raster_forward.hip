@@ -86,7 +86,8 @@ __device__ inline float3 cov2d_ewa(const float3 mean, float focal_x, float focal
 // ---------------------------------------------------------------------------------------------
 // K1: per-Gaussian preprocess (ch3 forward.cu:148-244), one thread per splat.  Besides the
 // reference's per-splat state it writes the packed 64-byte record the blend kernels read and
-//   sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones (raster_binning.hip).
+//   sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones (raster_binning.hip),
+//   key_min_blk[block]: the smallest key of the workgroup's splats (the sort works relative to the minimum).
 template <int C>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -97,8 +98,9 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   int *__restrict__ radii, float2 *__restrict__ means2D,
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
-                  uint32_t *__restrict__ sort_key, uint2 *__restrict__ rect, float4 *__restrict__ blend_rec,
-                  int prefiltered, const ViewBatch vb) {
+                  uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
+                  float4 *__restrict__ blend_rec, int prefiltered, const ViewBatch vb) {
+    __shared__ uint32_t s_min[4];
     const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
     view += 16 * vw;
     proj += 16 * vw;
@@ -112,17 +114,17 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     conic_opacity = view_at(conic_opacity, vb.geom, vw);
     tiles_touched = view_at(tiles_touched, vb.geom, vw);
     sort_key = view_at(sort_key, vb.geom, vw);
+    key_min_blk = view_at(key_min_blk, vb.geom, vw);
     rect = view_at(rect, vb.geom, vw);
     blend_rec = view_at(blend_rec, vb.geom, vw);
     const float tan_fovx = vb.tan_fovx[vw], tan_fovy = vb.tan_fovy[vw];
     const float focal_x = vb.focal_x[vw], focal_y = vb.focal_y[vw];
-    {
-        const int idx = blockIdx.x * 256 + threadIdx.x;
-        if (idx >= P) return;
+    uint32_t key = 0xFFFFFFFFu;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < P) {
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         radii[idx] = 0;
         tiles_touched[idx] = 0;
-        uint32_t key = 0xFFFFFFFFu;
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         const float3 p_view = xform4x3(p_orig, view);
         // near cull: only view-space z <= 0.2 (ch3 auxiliary.h:138)
@@ -185,6 +187,13 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
         rect[idx] = (key != 0xFFFFFFFFu) ? make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16))
                                          : make_uint2(0u, 0u);
     }
+    // smallest key of the workgroup (0xFFFFFFFF if it holds no visible splat)
+    uint32_t m = key;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) key_min_blk[blockIdx.x] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
 }
 
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
@@ -410,13 +419,14 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp,
                                 const float *view, const float *proj, const float *campos, int W, int H,
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
-                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key, uint2 *rect,
+                                float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
+                                uint32_t *key_min_blk, uint2 *rect,
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3((P + 255) / 256, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, rect, blend_rec, prefiltered, vb);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, vb);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -424,17 +434,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint8_t *clamped, const float *cov3D_precomp, const float *colors_precomp, const float *view,
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
-                       uint32_t *tiles_touched, uint32_t *sort_key, uint2 *rect, float4 *blend_rec,
-                       int prefiltered, int V, const ViewBatch &vb) {
+                       uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
+                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, rect,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
                                blend_rec, prefiltered, V, vb);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
-                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, rect,
+                               means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
                                blend_rec, prefiltered, V, vb);
 }
 

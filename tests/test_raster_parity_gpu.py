@@ -159,6 +159,33 @@ def test_edge_cases(oracle):
     _assert_grads_close(oracle.backward(f, dL), h.backward(dL), rtol=5e-4)
 
 
+@pytest.mark.parametrize("far,wide", [(3.0, False), (9000.0, False), (40000.0, True), (1.0e7, True)])
+def test_depth_span(oracle, far, wide):
+    """The depth sort works on keys relative to the nearest visible splat and runs its fourth radix pass only
+    when they span >= 2^27 ulps: both regimes, with tied depths (id order must decide)."""
+    W, H = 64, 64
+    rng = np.random.RandomState(7)
+    P = 6000
+    dist = np.exp(rng.uniform(math.log(0.25), math.log(far), size=P))
+    dist[:200] = dist[200:400]  # exact ties
+    dist[-1], dist[-2] = 0.25, far
+    lateral = rng.uniform(-0.25, 0.25, size=(P, 2)) * dist[:, None]
+    xyz = np.stack([lateral[:, 0], lateral[:, 1], 2.0 - dist], axis=1).astype(np.float32)  # camera at z = +2, looking down -z
+    xyz[:200, :2] = xyz[200:400, :2]
+    g = dict(means3D=xyz, scales=(np.exp(rng.uniform(-4.5, -3.5, size=(P, 3))) * dist[:, None]).astype(np.float32),
+             rotations=np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1)),
+             opacities=rng.uniform(0.05, 0.6, size=(P, 1)).astype(np.float32),
+             colors=rng.uniform(0, 1, size=(P, 3)).astype(np.float32))
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.zeros(3, np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg)
+    keys = f["depths"][f["radii"] > 0].view(np.uint32).astype(np.int64)
+    assert ((keys.max() - keys.min()) >> 27 != 0) == wide
+    _assert_forward_exact(f, h)
+    dL = rng.normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL), rtol=5e-4)
+
+
 def test_empty_and_capacity(oracle):
     from tests.hip_harness import HipRun, scene_kwargs
     from fluidnexus_amd import _lib
