@@ -26,9 +26,23 @@ constexpr int kSortRadix = 1 << kSortBits;
 constexpr int kKeyBlock = 256;  // splats per preprocess workgroup = per entry of the block-minimum array
 // u32 words inside the geometry blob's sort_hist region
 struct SortScratch {
-    size_t hist, hist_rel, totals, ctl, kmin_blk, kmax_blk, words;
+    size_t hist, hist_rel, totals, ctl, kmin_blk, kmax_blk, blk_total, emit_ctl, emit_items, words;
 };
 enum { SORT_CTL_KMIN = 0, SORT_CTL_WIDE = 1 };  // smallest visible key; 1 if the fourth pass is needed
+// Emission work items: a rank block with many instances (the nearest, largest splats) is split into up to
+// kEmitBands items, each a band of tile rows (a rectangle clipped to a band of rows is still a rectangle).
+#ifndef FNX_EMIT_BANDS
+#define FNX_EMIT_BANDS 8
+#endif
+#ifndef FNX_EMIT_BAND_TARGET
+#define FNX_EMIT_BAND_TARGET 8192
+#endif
+constexpr int kEmitBands = FNX_EMIT_BANDS;
+constexpr uint32_t kEmitBandTarget = FNX_EMIT_BAND_TARGET;  // instances per item aimed at
+enum { EMIT_CTL_ITEMS = 0, EMIT_CTL_TICKET = 1 };  // items of this view; next ticket (view 0's word, all views)
+__host__ __device__ inline uint32_t emit_item_pack(uint32_t blk, uint32_t band, uint32_t nbands) {
+    return (blk << 8) | (band << 4) | nbands;  // nbands <= 8, band < 8, blk < 2^24
+}
 inline SortScratch sort_scratch(int P) {
     const size_t p = (size_t)(P > 0 ? P : 0), nsb = (p + kSortChunk - 1) / kSortChunk;
     SortScratch o;
@@ -38,7 +52,10 @@ inline SortScratch sort_scratch(int P) {
     o.ctl = o.totals + kSortRadix;
     o.kmin_blk = o.ctl + 16;
     o.kmax_blk = o.kmin_blk + (p + kKeyBlock - 1) / kKeyBlock;
-    o.words = o.kmax_blk + nsb;
+    o.blk_total = o.kmax_blk + nsb;  // instances per rank block (rank_hist -> emit)
+    o.emit_ctl = o.blk_total + (p + kSplatBlock - 1) / kSplatBlock;
+    o.emit_items = o.emit_ctl + 4;
+    o.words = o.emit_items + (p + kSplatBlock - 1) / kSplatBlock * kEmitBands;
     return o;
 }
 inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }

@@ -21,16 +21,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
                        const ViewBatch &vb);
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
-                      const ViewBatch &vb);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int P, int H,
+                      uint32_t *sort_scratch_words, int V, const ViewBatch &vb);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
                        uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb);
-void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist, int V,
-                      const ViewBatch &vb);
+void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
+                      uint32_t *blk_total, int V, const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
-                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel,
+                 uint32_t *emit_ctl, const uint32_t *emit_items, uint32_t *point_list, uint32_t *header,
                  uint32_t capacity, int V, const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
@@ -266,9 +267,10 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     // (key, id) pair buffers: sort_key0|sort_key1 and sort_val0|sort_val1 are adjacent P-word arrays
     fnx::launch_depth_sort(s, P, g.sort_key0, (uint2 *)g.sort_key0, (uint2 *)g.sort_val0, g.sort_hist, g.rect,
                            g.rect_sorted, V, vb);
-    fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, V, vb);
+    fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
+                          vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
-    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, V, vb);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, P, height, g.sort_hist, V, vb);
     }
     return hip_check("stage1");
 }
@@ -328,9 +330,10 @@ int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binni
     const uint32_t cap = (uint32_t)binning_capacity;
     {
     ProfScope ps(4, s);
-    fnx::launch_emit(s, P, width, height, (const uint2 *)g.sort_val0, (const uint2 *)g.sort_key0, g.sort_hist + fnx::sort_scratch(P).ctl,
-                     g.rect_sorted, img.ranges, g.blk_rel, bin.point_list, img.header,
-                     cap, V, vb);
+    const fnx::SortScratch L = fnx::sort_scratch(P);
+    fnx::launch_emit(s, P, width, height, (const uint2 *)g.sort_val0, (const uint2 *)g.sort_key0, g.sort_hist + L.ctl,
+                     g.rect_sorted, img.ranges, g.blk_rel, g.sort_hist + L.emit_ctl, g.sort_hist + L.emit_items,
+                     bin.point_list, img.header, cap, V, vb);
     }
     {
         ProfScope ps(0, s);

@@ -266,13 +266,16 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
 // sums along each tile row, formed once per block.
 __global__ void __launch_bounds__(256)
 rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, int gy, uint16_t *__restrict__ blk_hist,
-                 const ViewBatch vb) {
+                 uint32_t *__restrict__ blk_total, const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // T row-delta counters (mod 2^32)
+    __shared__ uint32_t s_total;
     {
         const int vw = blockIdx.y;
         rect_sorted = view_at(rect_sorted, vb.geom, vw);
         blk_hist = view_at(blk_hist, vb.geom, vw);
+        blk_total = view_at(blk_total, vb.geom, vw);
     }
+    if (threadIdx.x == 0) s_total = 0;
     for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
     __syncthreads();
 #pragma unroll
@@ -297,7 +300,17 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
     }
     __syncthreads();
     uint16_t *row = blk_hist + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += 256) row[i] = (uint16_t)s_hist[i];
+    uint32_t sum = 0;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        row[i] = (uint16_t)s_hist[i];
+        sum += s_hist[i];
+    }
+    // instances of the whole block: emit splits heavy blocks over several workgroups
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_total, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_total[blockIdx.x] = s_total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,7 +324,7 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
 #define FNX_EMIT_THREADS 512
 #endif
 #ifndef FNX_EXP_EMIT
-#define FNX_EXP_EMIT 0  // timing experiments (tools/build_variant.py): 10 loads only, 11 no bitmask / output
+#define FNX_EXP_EMIT 0  // timing experiments (tools/build_variant.py): 10 loads only, 11 no bitmask / output, 12 no store, 13 lane-contiguous store
 #endif
 #ifdef FNX_EXP_CLOCK  // developer timing: per-workgroup [start, end, sub-batches, instances] of the last emit launch
 __device__ unsigned long long g_emit_clock[4 * 16384];
@@ -391,39 +404,57 @@ struct InstanceWalk {
     }
 };
 
+// Persistent workgroups: each takes tickets from one counter; ticket t is item t / V of view t % V, so the
+// items come in block order across all views -- the front blocks (nearest, largest splats, most instances) first,
+// and the long items do not end up in the tail.  (Launching one workgroup per possible item and returning early
+// from the unused ones costs ~45 ns of dispatch per workgroup.)
 __global__ void __launch_bounds__(kEmitThreads)
-emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__restrict__ sorted4,
-            const uint32_t *__restrict__ sort_ctl, const uint2 *__restrict__ rect_sorted, int gx, int gy,
-            const uint32_t *__restrict__ ranges,
-            const uint32_t *__restrict__ blk_rel, uint32_t *__restrict__ point_list, uint32_t *__restrict__ header,
-            uint32_t capacity, int TW, int V, const ViewBatch vb) {
+emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__restrict__ sorted4_all,
+            const uint32_t *__restrict__ sort_ctl, const uint2 *__restrict__ rect_sorted_all, int gx, int gy,
+            const uint32_t *__restrict__ ranges_all, const uint32_t *__restrict__ blk_rel_all,
+            uint32_t *__restrict__ emit_ctl, const uint32_t *__restrict__ emit_items,
+            uint32_t *__restrict__ point_list_all, uint32_t *__restrict__ header_all, uint32_t capacity, int TW, int V,
+            const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_mask[TW][kEmitMaskWords] | s_cur[TW]
     __shared__ uint32_t s_id[kSplatBlock];
     __shared__ uint2 s_rect[kSplatBlock];    // (x0 | x1 << 16, y0 | y1 << 16), tile coordinates
     __shared__ uint32_t s_pre[kSplatBlock];  // inclusive prefix of the per-splat instance counts (current window)
     __shared__ uint32_t s_wsum[kEmitThreads / 64];
-    // 1-D grid, block-major: the front blocks (nearest, largest splats, most instances) of ALL views
-    // are dispatched first, so the long workgroups do not end up in the tail of the launch
-    const int vw = blockIdx.x % V, blk = blockIdx.x / V;
-    {
-        rect_sorted = view_at(rect_sorted, vb.geom, vw);
-        blk_rel = view_at(blk_rel, vb.geom, vw);
-        ranges = view_at(ranges, vb.img, vw);
-        header = view_at(header, vb.img, vw);
-        point_list = view_at(point_list, vb.bin, vw);
-    }
+    __shared__ uint32_t s_items[kMaxViews];
+    __shared__ uint32_t s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < V) s_items[tid] = view_at(emit_ctl, vb.geom, tid)[EMIT_CTL_ITEMS];
+    lds_barrier();
+    uint32_t most = 0;
+    for (int v = 0; v < V; v++) most = max(most, s_items[v]);
+  for (;;) {
+    lds_barrier();  // the previous item is done with the LDS arrays (and s_ticket has been read)
+    if (tid == 0) s_ticket = atomicAdd(&emit_ctl[EMIT_CTL_TICKET], 1u);
+    lds_barrier();
+    const uint32_t ticket = s_ticket;
+    const int vw = (int)(ticket % (uint32_t)V);
+    const uint32_t item_no = ticket / (uint32_t)V;
+    if (item_no >= most) break;
+    if (item_no >= s_items[vw]) continue;
+    const uint32_t item = view_at(emit_items, vb.geom, vw)[item_no];
+    const int blk = (int)(item >> 8), band = (int)((item >> 4) & 15u), nbands = (int)(item & 15u);
+    const int ry0 = (int)((long long)band * gy / nbands), ry1 = (int)((long long)(band + 1) * gy / nbands);
+    const uint2 *__restrict__ rect_sorted = view_at(rect_sorted_all, vb.geom, vw);
+    const uint32_t *__restrict__ blk_rel = view_at(blk_rel_all, vb.geom, vw);
+    const uint32_t *__restrict__ ranges = view_at(ranges_all, vb.img, vw);
+    uint32_t *__restrict__ header = view_at(header_all, vb.img, vw);
+    uint32_t *__restrict__ point_list = view_at(point_list_all, vb.bin, vw);
     // ids in depth order: where the third sort pass left them, or the fourth if it had to run
     const uint2 *__restrict__ sorted_ids =  // (relative key, id) pairs
-        view_at(view_at(sort_ctl, vb.geom, vw)[SORT_CTL_WIDE] ? sorted4 : sorted3, vb.geom, vw);
+        view_at(view_at(sort_ctl, vb.geom, vw)[SORT_CTL_WIDE] ? sorted4_all : sorted3_all, vb.geom, vw);
     if (header[HDR_NUM_RENDERED] > capacity) {
-        if (blk == 0 && threadIdx.x == 0) {
+        if (item_no == 0 && tid == 0) {
             header[HDR_STATUS] = FNX_ERR_CAPACITY;
             header[HDR_CAPACITY] = capacity;
         }
-        return;
+        continue;
     }
     uint32_t *s_mask = s_dyn, *s_cur = s_dyn + (size_t)TW * kEmitMaskWords;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t *rel = blk_rel + (size_t)blk * T;
 #ifdef FNX_EXP_CLOCK
     const unsigned long long clk0 = wall_clock64();
@@ -433,26 +464,57 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__rest
 #else
 #define FNX_PH(i)
 #endif
-    // the block's splats: local index l = kEmitPer tid + k (consecutive ranks per thread, so the
-    // workgroup-wide prefix over l is a per-thread running sum on top of a prefix over threads)
+    // the block's splats that touch the band, compacted in rank order: local index l (consecutive entries per
+    // thread, so the workgroup-wide prefix over l is a per-thread running sum on top of a prefix over threads).
+    // Positions in the compacted list order the instances exactly like the ranks do.
+    {
+        uint32_t id[kEmitPer];
+        uint2 rc[kEmitPer];
+        uint32_t have = 0;
 #pragma unroll
-    for (int k = 0; k < kEmitPer; k++) {
-        const int l = kEmitPer * tid + k;
-        const int rank = blk * kSplatBlock + l;
-        uint32_t id = 0;
-        uint2 rect = make_uint2(0u, 0u);
-        if (rank < P) {
-            id = sorted_ids[rank].y;
-            rect = rect_sorted[rank];
+        for (int k = 0; k < kEmitPer; k++) {
+            const int rank = blk * kSplatBlock + kEmitPer * tid + k;
+            id[k] = 0;
+            rc[k] = make_uint2(0u, 0u);
+            if (rank < P) {
+                id[k] = sorted_ids[rank].y;
+                const uint2 rect = rect_sorted[rank];
+                // clip the tile rows to the band
+                const uint32_t y0 = max(rect.y & 0xFFFFu, (uint32_t)ry0), y1 = min(rect.y >> 16, (uint32_t)ry1);
+                if (y1 > y0 && (rect.x >> 16) > (rect.x & 0xFFFFu)) {
+                    rc[k] = make_uint2(rect.x, y0 | (y1 << 16));
+                    have++;
+                }
+            }
         }
-        s_id[l] = id;
-        s_rect[l] = rect;
+        uint32_t inc = have;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) s_wsum[w] = inc;
+        lds_barrier();
+        uint32_t pos = inc - have, n_c = 0;
+        for (int k = 0; k < kEmitThreads / 64; k++) {
+            if (k < w) pos += s_wsum[k];
+            n_c += s_wsum[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kEmitPer; k++)
+            if (rc[k].x | rc[k].y) {
+                s_id[pos] = id[k];
+                s_rect[pos] = rc[k];
+                pos++;
+            }
+        for (int l = tid; l < kSplatBlock; l += kEmitThreads)
+            if ((uint32_t)l >= n_c) s_rect[l] = make_uint2(0u, 0u);
     }
-    if (FNX_EXP_EMIT == 10) return;
+    if (FNX_EXP_EMIT == 10) continue;
     FNX_PH(0)
-    for (int tw0 = 0; tw0 < T; tw0 += TW) {
-        const int tw1 = min(T, tw0 + TW);
-        const bool whole = (tw0 == 0 && tw1 == T);
+    const int band_t0 = ry0 * gx, band_t1 = ry1 * gx;
+    for (int tw0 = band_t0; tw0 < band_t1; tw0 += TW) {
+        const int tw1 = min(band_t1, tw0 + TW);
+        const bool whole = (tw0 == band_t0 && tw1 == band_t1);
         lds_barrier();
         for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
             s_cur[i] = ranges[2 * (tw0 + i)] + rel[tw0 + i];
@@ -541,7 +603,13 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__rest
                         const uint32_t bw = b >> 5;
                         uint32_t r = __popc(s_mask[bw * TW + t] & ((1u << (b & 31u)) - 1u));
                         for (uint32_t q = 0; q < bw; q++) r += __popc(s_mask[q * TW + t]);
-                        point_list[s_cur[t] + r] = s_id[l];
+                        if (FNX_EXP_EMIT == 12) {  // no scattered store
+                            if (r == 0x7FFFFFFFu) point_list[0] = s_id[l];
+                        } else if (FNX_EXP_EMIT == 13) {  // store, but lane-contiguous
+                            point_list[(size_t)blk * 8192 + (size_t)k * kEmitThreads + tid + (r >> 30)] = s_id[l];
+                        } else {
+                            point_list[s_cur[t] + r] = s_id[l];
+                        }
                     }
                 lds_barrier();
                 FNX_PH(5)
@@ -566,7 +634,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__rest
     }
 #ifdef FNX_EXP_CLOCK
     if (tid == 0) {
-        const int wg = vw * (gridDim.x / V) + blk;
+        const int wg = (int)ticket;
         if (wg < 16000) {
             g_emit_clock[4 * wg] = clk0;
             g_emit_clock[4 * wg + 1] = wall_clock64();
@@ -577,6 +645,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3, const uint2 *__rest
             for (int i = 0; i < 8; i++) g_emit_clock[4 * 16000 + (wg ? 8 : 0) + i] = ph[i];
     }
 #endif
+  }  // tickets
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,28 +679,47 @@ void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pa
     }
 }
 
-void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist, int V,
-                      const ViewBatch &vb) {
+void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
+                      uint32_t *blk_total, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     hipLaunchKernelGGL(rank_hist_kernel, dim3(splat_blocks(P), V), dim3(256), (size_t)T * 4, s, P, T, rect_sorted, gx,
-                       gy, blk_hist, vb);
+                       gy, blk_hist, blk_total, vb);
 }
 
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
-                 const uint32_t *sort_ctl, const uint2 *rect_sorted,
-                 const uint32_t *ranges, const uint32_t *blk_rel, uint32_t *point_list, uint32_t *header,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel,
+                 uint32_t *emit_ctl, const uint32_t *emit_items, uint32_t *point_list, uint32_t *header,
                  uint32_t capacity, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     const int TW = T < kEmitTileWindow ? T : kEmitTileWindow;
-    static bool attr_set = false;
     const size_t lds = (size_t)TW * 4 * (kEmitMaskWords + 1);
-    if (!attr_set && TW > 1024) {  // large images: static + dynamic LDS exceeds the default 64 KiB limit
-        (void)hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kEmitTileWindow * 4 * (kEmitMaskWords + 1));
-        attr_set = true;
+    // resident workgroups for this LDS size (host-side queries, cached)
+    static int n_cu = 0, wgs_small = 0, wgs_large = 0;
+    const bool large = TW > 1024;  // large images: static + dynamic LDS exceeds the default 64 KiB limit
+    int &wgs = large ? wgs_large : wgs_small;
+    if (wgs == 0) {
+        if (large)
+            (void)hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kEmitTileWindow * 4 * (kEmitMaskWords + 1));
+        if (n_cu == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        int per_cu = 0;
+        const size_t lds_max = (size_t)kEmitTileWindow * 4 * (kEmitMaskWords + 1);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)emit_kernel, kEmitThreads,
+                                                         large ? lds_max : (size_t)1024 * 4 * (kEmitMaskWords + 1)) !=
+                hipSuccess || per_cu <= 0)
+            per_cu = 1;
+        (void)hipGetLastError();
+        wgs = n_cu * per_cu;
     }
-    hipLaunchKernelGGL(emit_kernel, dim3(splat_blocks(P) * V), dim3(kEmitThreads), lds, s, P, T, sorted3, sorted4,
-                       sort_ctl, rect_sorted, gx, gy, ranges, blk_rel, point_list, header, capacity, TW, V, vb);
+    const int items_bound = splat_blocks(P) * V * kEmitBands;  // never more workgroups than items
+    hipLaunchKernelGGL(emit_kernel, dim3(wgs < items_bound ? wgs : items_bound), dim3(kEmitThreads), lds, s, P, T, sorted3,
+                       sorted4, sort_ctl, rect_sorted, gx, gy, ranges, blk_rel, emit_ctl, emit_items, point_list, header,
+                       capacity, TW, V, vb);
 }
 
 }  // namespace fnx

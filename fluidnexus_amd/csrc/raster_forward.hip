@@ -197,11 +197,17 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
 }
 
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
-// rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.
+// rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.  It also lays out the
+// emission work items of the view (raster_binning.hip): per rank block, 1..kEmitBands bands of tile rows
+// depending on the block's instance count, in block order (nearest = heaviest first).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ ranges,
-                 uint32_t *__restrict__ header, size_t img_stride) {
+                 uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
+                 const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
+                 uint32_t *__restrict__ emit_items, size_t geom_stride) {
     __shared__ uint32_t s_part[1024];
+    blk_total = view_at(blk_total, geom_stride, blockIdx.y);
+    emit_items = view_at(emit_items, geom_stride, blockIdx.y);
     tile_count = view_at(tile_count, img_stride, blockIdx.y);
     ranges = view_at(ranges, img_stride, blockIdx.y);
     header = view_at(header, img_stride, blockIdx.y);
@@ -230,6 +236,34 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         header[HDR_NUM_RENDERED] = s_part[1023];
         header[HDR_STATUS] = 0u;
         header[HDR_CAPACITY] = 0u;
+    }
+    // emission work items: exclusive prefix of the per-block band counts
+    __syncthreads();
+    const int bper = (NB + 1023) / 1024;
+    const int bb = tid * bper, be = min(NB, bb + bper);
+    uint32_t items = 0;
+    for (int i = bb; i < be; i++) {
+        const uint32_t inst = blk_total[i];
+        if (inst) items += (uint32_t)max(1, min(min(kEmitBands, gy), (int)((inst + kEmitBandTarget - 1u) / kEmitBandTarget)));
+    }
+    s_part[tid] = items;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t at = s_part[tid] - items;
+    for (int i = bb; i < be; i++) {
+        const uint32_t inst = blk_total[i];
+        if (!inst) continue;  // a block without instances emits nothing
+        const uint32_t nbands = (uint32_t)max(1, min(min(kEmitBands, gy), (int)((inst + kEmitBandTarget - 1u) / kEmitBandTarget)));
+        for (uint32_t j = 0; j < nbands; j++) emit_items[at++] = emit_item_pack((uint32_t)i, j, nbands);
+    }
+    if (tid == 1023) {
+        view_at(emit_ctl, geom_stride, blockIdx.y)[EMIT_CTL_ITEMS] = s_part[1023];
+        if (blockIdx.y == 0) emit_ctl[EMIT_CTL_TICKET] = 0u;  // one ticket counter for all views (view 0's word)
     }
 }
 
@@ -448,9 +482,12 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                                blend_rec, prefiltered, V, vb);
 }
 
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int V,
-                      const ViewBatch &vb) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, header, vb.img);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int P, int H,
+                      uint32_t *sort_scratch_words, int V, const ViewBatch &vb) {
+    const SortScratch L = sort_scratch(P);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, header, vb.img,
+                       splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
+                       sort_scratch_words + L.emit_items, vb.geom);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
