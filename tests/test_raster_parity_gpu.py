@@ -186,6 +186,22 @@ def test_depth_span(oracle, far, wide):
     _assert_grads_close(oracle.backward(f, dL), h.backward(dL), rtol=5e-4)
 
 
+def test_large_image_tile_windows(oracle):
+    """More than 2048 tiles: the emission walks the tiles in windows (light rank blocks) and in bands of tile
+    rows (heavy ones); a few screen-filling splats make the first rank block heavy."""
+    P, W, H = 5000, 1040, 800
+    g = S.random_gaussians(P, seed=11, box=0.7, log_scale=(-5.0, -3.0))
+    g["scales"][:40] *= 12.0
+    g["means3D"][:40, 2] += 0.4  # large and near the camera
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.array([0.0, 0.2, 0.1], np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg)
+    assert ((W + 15) // 16) * ((H + 15) // 16) > 2048 and f["num_rendered"] > 50000
+    _assert_forward_exact(f, h)
+    dL = np.random.RandomState(11).normal(size=(3, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL), rtol=5e-4)
+
+
 def test_empty_and_capacity(oracle):
     from tests.hip_harness import HipRun, scene_kwargs
     from fluidnexus_amd import _lib
