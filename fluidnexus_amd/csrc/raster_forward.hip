@@ -405,17 +405,16 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
             }
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
+                const bool live = hit[k] && !done;
                 const uint32_t j = (j4 >> (8 * k)) & 255u;
                 const float test_T = Tr * (1 - alpha[k]);
-                const bool live = hit[k] && !done;
                 const bool stop = live && (test_T < 0.0001f);
                 const bool take = live && !stop;
                 done = done || stop;
+                // a pixel that does not take the entry adds col * 0 * T = 0: one select instead of one per channel
+                const float a_eff = take ? alpha[k] : 0.0f;
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) {
-                    const float a_new = acc[ch] + col[k][ch] * alpha[k] * Tr;
-                    acc[ch] = take ? a_new : acc[ch];
-                }
+                for (int ch = 0; ch < C; ch++) acc[ch] = acc[ch] + col[k][ch] * a_eff * Tr;
                 Dm = (take && Tr > 0.5f && test_T < 0.5f) ? depth[k] : Dm;
                 Tr = take ? test_T : Tr;
                 last_contributor = take ? pos0 + j : last_contributor;
