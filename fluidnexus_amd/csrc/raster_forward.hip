@@ -309,6 +309,11 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
     const int tile = xcd_tile(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // The blend loop multiplies the colour of an entry it does NOT take by alpha = 0 instead of selecting per
+    // channel, and the last group of a list reads up to three slots past its end: every colour slot must hold a
+    // finite value from the start (0 * garbage could be NaN).  Colours are assumed finite, like everywhere else.
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
     const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;

@@ -425,7 +425,8 @@ class GaussianModel:
             self.flush_deferred_gradients()
             self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
         return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
-                                          self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1])
+                                          self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1],
+                                          share_output=getattr(self, "share_visual_output", False))
 
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):

@@ -112,6 +112,8 @@ class HotLoop:
         if self.batched_views:
             assert fused_physics and defer_visual_backward and image_loss == "fused" and rd_pipe == "render_dynamics", \
                 "batched_views needs render_dynamics, the fused image loss / physics node and the deferred visual backward"
+        # one visual forward per iteration, consumed once: hand the memoised tensor out without a copy
+        gm.share_visual_output = self.batched_views
         self._gt_cache = None
         self.side_stream = None
         self.fused_step = bool(fused_step)  # gradient mean + Adam as one kernel (batched_views only)
@@ -292,7 +294,7 @@ class HotLoop:
         sequence (rasteriser / loss kernels take the view as a grid dimension).  Mathematically the sum
         over the views of the per-view losses of `_iteration_body`; the physics gradient, identical for
         every view, is evaluated once and added once per local view."""
-        from .losses import fused_image_loss
+        from .losses import image_loss_value_and_grad
         from .renderer.pipes import render_dynamics_views
         gm, c = self.gm, self.cfg
         self.itr += 1
@@ -314,16 +316,26 @@ class HotLoop:
             fork.record(main)
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
-                gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
+                if self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
+                    from .physics import physical_stage_value_and_grad
+                    _, gp = physical_stage_value_and_grad(gm, c["lambda_exyz"], c["lambda_gas_constraints"],
+                                                          c["lambda_next_gas_constraints"],
+                                                          gm.state_memo("physics_loss"))
+                else:
+                    gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
         if mine:
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                         scale=True)
-            loss, per_view = fused_image_loss(pkg["render"], self._gt_stack(mine), c["lambda_dssim"], c["lambda_image"])
+            # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
+            # that saves the ones seed and its copies), then back through the rasteriser
+            loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                                                             c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
-            torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
+            torch.autograd.grad([pkg["render"]], [gm._estimate_xyz_nn], grad_outputs=[dimg],
+                                allow_unused=True)  # -> deferred visual backward
         if gp is not None:
             main.wait_stream(self.side_stream)
         multi = self.world > 1 or self.force_all_reduce

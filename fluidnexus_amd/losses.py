@@ -138,6 +138,28 @@ class _ImageLoss(torch.autograd.Function):
         return out, None, None, None, None
 
 
+_ONE = {}
+
+
+def image_loss_value_and_grad(img, gt, lambda_dssim, lambda_image=1.0, grey=True):
+    """(loss, per_image [N,2], d loss / d img) of fused_image_loss without an autograd node: forward and
+    backward kernels back to back, seeded with a resident 1.0."""
+    class _Ctx:
+        def save_for_backward(self, *t):
+            self.saved_tensors = t
+
+        def mark_non_differentiable(self, *t):
+            pass
+    ctx = _Ctx()
+    loss, per_image = _ImageLoss.forward(ctx, img, gt, (1.0 - float(lambda_dssim)) * float(lambda_image),
+                                         float(lambda_dssim) * float(lambda_image), bool(grey))
+    one = _ONE.get(img.device)
+    if one is None:
+        one = _ONE[img.device] = torch.ones((), dtype=torch.float32, device=img.device)
+    dimg = _ImageLoss.backward(ctx, one, None)[0]
+    return loss, per_image, dimg
+
+
 def fused_image_loss(img, gt, lambda_dssim, lambda_image=1.0, grey=True):
     """Image term of a whole training batch as one scalar:
     sum_n ((1 - lambda_dssim) * L1_n + lambda_dssim * (1 - SSIM_n)) * lambda_image over the [N,3,H,W] batch

@@ -150,7 +150,7 @@ def flush_deferred_visual_backward(memo):
 
 
 def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,
-                       memo=None):
+                       memo=None, share_output=False):
     """visual [V,3] (constant), hidden [N,3] (differentiable), hidden_prev [N,3] -> advected visual [V,3].
     `visual_grid`: a HashGrid over `visual` to reuse across iterations (visual is fixed within a frame);
     `hidden_grid`: an up-to-date HashGrid over `hidden`; `memo`: a dict the caller keeps for as long as
@@ -158,7 +158,8 @@ def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_gr
     node (the views of one iteration all see the same particle state)."""
     out = _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
                                   hidden_grid, memo)
-    return out.clone() if memo is not None else out
+    # memoised results are handed out as copies unless the caller promises not to modify them in place
+    return out.clone() if memo is not None and not share_output else out
 
 
 
@@ -169,10 +170,8 @@ class _PhysicalStageLoss(torch.autograd.Function):
     gm_dynamics.py:1014-1030) come out of one launch sequence of ~12 kernels."""
 
     @staticmethod
-    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, memo):
-        if memo is not None and "loss" in memo:  # same particle state as an earlier call of this iteration
-            ctx.grad = memo["grad"]
-            return memo["loss"].clone()
+    def run(x_nn, gm, lam_e, lam_g, lam_n):
+        """The launch sequence: returns (terms [3], loss [], grad [N,3]) -- views of one device buffer."""
         lib = PL.physics()
         x = _req(x_nn.detach())
         N = x.shape[0]
@@ -188,16 +187,34 @@ class _PhysicalStageLoss(torch.autograd.Function):
             float(gm.buoyancy_max_y), float(gm.H), float(gm.p0), float(gm._secs), lam_e, lam_g, lam_n,
             est.blob.data_ptr(), int(build_est), guess.blob.data_ptr(), scratch.data_ptr(), base, base + 12, base + 16,
             _stream()))
-        loss, grad = out[3].view(()), out[4:].view(N, 3)
+        return out[:3], out[3].view(()), out[4:].view(N, 3)
+
+    @staticmethod
+    def forward(ctx, x_nn, gm, lam_e, lam_g, lam_n, memo):
+        if memo is not None and "loss" in memo:  # same particle state as an earlier call of this iteration
+            ctx.grad = memo["grad"]
+            return memo["loss"].clone()
+        terms, loss, grad = _PhysicalStageLoss.run(x_nn, gm, lam_e, lam_g, lam_n)
         ctx.grad = grad
         if memo is not None:
-            memo.update(loss=loss, grad=grad, terms=out[:3])
+            memo.update(loss=loss, grad=grad, terms=terms)
             return loss.clone()
         return loss
 
     @staticmethod
     def backward(ctx, g):
         return ctx.grad * g, None, None, None, None, None
+
+
+def physical_stage_value_and_grad(gm, lam_exyz, lam_gas, lam_next, memo=None):
+    """(loss, d loss / d x_nn [N,3]) of physical_stage_loss without going through autograd: the hot loop adds the
+    gradient to its batch gradient itself, which saves the scalar clone, the ones seed and the grad * 1 kernels."""
+    if memo is not None and "loss" in memo:
+        return memo["loss"], memo["grad"]
+    terms, loss, grad = _PhysicalStageLoss.run(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next))
+    if memo is not None:
+        memo.update(loss=loss, grad=grad, terms=terms)
+    return loss, grad
 
 
 def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):

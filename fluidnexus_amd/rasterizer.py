@@ -164,10 +164,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.aux = (bg, view, proj, campos)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)  # the reference ignores their grads (__init__.py:83)
+        ctx.set_materialize_grads(False)  # no zero-filled stand-ins for the unused grads of radii / depth
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        if grad_out_color is None:
+            return (None,) * 11
         lib = _lib.raster()
         rs = ctx.raster_settings
         Cn = ctx.channels
@@ -321,10 +324,13 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         ctx.grad_splat_limit = -1 if grad_splat_limit is None else int(grad_splat_limit)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)
+        ctx.set_materialize_grads(False)  # no zero-filled stand-ins for the unused grads of radii / depth
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        if grad_out_color is None:
+            return (None,) * 11
         lib = _lib.raster()
         vbatch, Cn = ctx.vbatch, ctx.channels
         rs = vbatch.settings[0]
