@@ -419,8 +419,11 @@ class GaussianModel:
         visual = self._visual_xyz.detach()
         if self._visual_grid is None or self._visual_grid[0] is not self._visual_xyz:
             self._visual_grid = (self._visual_xyz, physics.HashGrid(visual, self.H))
-        x = self._estimate_xyz_nn * self.scale_factor
         key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version, id(self._visual_xyz))
+        if (self._visual_memo[0] == key and "out" in self._visual_memo[1] and not torch.is_grad_enabled()
+                and getattr(self, "share_visual_output", False)):
+            return self._visual_memo[1]["out"]  # already evaluated for this particle state
+        x = self._estimate_xyz_nn * self.scale_factor
         if self._visual_memo[0] != key:
             self.flush_deferred_gradients()
             self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
@@ -512,22 +515,52 @@ class GaussianModel:
         self._estimate_xyz_nn_grad += grad * float(scale)
         self._grad_cache_used = True
 
+    # -- explicit chain of the view-batched hot loop (harness.HotLoop, batched_views) -------------------------
+    def render_means_from_nn(self):
+        """Rasteriser positions of the physical-particle stage, [visual particles advected by the hidden ones /
+        scale_factor | static background Gaussians], as a LEAF tensor in a resident buffer: the background rows are
+        written once, the fluid rows by one division per call.  The caller differentiates the render with respect to
+        this leaf and hands the fluid rows of the gradient to defer_render_means_gradient -- the same chain as
+        render_dynamics(pos_type="guess_visual_nn", scale=True) without the per-iteration cat / mul / div nodes."""
+        with torch.no_grad():
+            raw = self.get_visual_xyz_from_nn()
+        V, G = raw.shape[0], self._gs_xyz.shape[0]
+        key = (id(self._gs_xyz), self._gs_xyz._version, V, G, raw.device)
+        if getattr(self, "_render_means", None) is None or self._render_means[0] != key:
+            buf = torch.empty(V + G, 3, dtype=torch.float32, device=raw.device)
+            buf[V:] = self._gs_xyz.detach()
+            self._render_means = (key, buf.requires_grad_(True))
+        buf = self._render_means[1]
+        with torch.no_grad():
+            torch.div(raw, self.scale_factor, out=buf[:V])
+        return buf
+
+    def defer_render_means_gradient(self, g_means):
+        """g_means: gradient with respect to render_means_from_nn()'s tensor.  Queues its fluid rows for the one
+        hidden<-visual backward of the iteration; the 1 / scale_factor of the division is applied to the result."""
+        memo = self._visual_memo[1]
+        assert memo.get("defer") and "saved" in memo, "render_means_from_nn() first (deferred visual backward)"
+        memo.setdefault("g_list", []).append(g_means[:self._visual_xyz.shape[0]])
+        memo["g_scale"] = 1.0 / self.scale_factor
+
     def flush_deferred_gradients(self):
         """With defer_visual_backward the hidden->visual interpolation back-propagates once per
         iteration on the summed per-view gradients (the map is linear); add that term to the cache.
         Called by set_batch_gradient_current, and by the multi-GPU loop before its all-reduce."""
+        g_scale = self._visual_memo[1].get("g_scale", 1.0)
         dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
         if dh is not None:
-            self._estimate_xyz_nn_grad += dh * self.scale_factor  # hidden = x_nn * scale_factor
+            self._estimate_xyz_nn_grad += dh * (self.scale_factor * g_scale)  # hidden = x_nn * scale_factor
             self._grad_cache_used = True
 
     def fused_step_current(self, batch_size, extra_terms=()):
         """set_batch_gradient_current + optimizer.step() + zero_grad as one kernel (physics.adam_step):
         gradient = (cache + deferred hidden<-visual term + extra (tensor, scale) terms) / batch_size.
         Same update rule as the torch optimiser, on its own state tensors."""
+        g_scale = self._visual_memo[1].get("g_scale", 1.0)
         dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
         terms = [(self._estimate_xyz_nn_grad, 1.0)] if self._grad_cache_used else []
-        terms += list(extra_terms) + ([(dh, self.scale_factor)] if dh is not None else [])
+        terms += list(extra_terms) + ([(dh, self.scale_factor * g_scale)] if dh is not None else [])
         physics.adam_step(self._estimate_xyz_nn, self.optimizer, terms, batch_size)
         self._estimate_xyz_nn.grad = None
         self.invalidate_caches()

@@ -325,17 +325,18 @@ class HotLoop:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
         if mine:
+            means3D = gm.render_means_from_nn()  # leaf: [advected visual / scale_factor | background]
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
-                                        scale=True)
+                                        scale=True, means3D=means3D)
             # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
             # that saves the ones seed and its copies), then back through the rasteriser
             loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
                                                              c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
-            torch.autograd.grad([pkg["render"]], [gm._estimate_xyz_nn], grad_outputs=[dimg],
-                                allow_unused=True)  # -> deferred visual backward
+            g_means, = torch.autograd.grad([pkg["render"]], [means3D], grad_outputs=[dimg])
+            gm.defer_render_means_gradient(g_means)  # -> the one hidden<-visual backward of the iteration
         if gp is not None:
             main.wait_stream(self.side_stream)
         multi = self.world > 1 or self.force_all_reduce

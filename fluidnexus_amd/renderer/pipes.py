@@ -154,16 +154,38 @@ def _view_batch(GRsetting, cameras, bg_color, scaling_modifier, sh_degree):
     return hit
 
 
+_ZERO = {}
+
+
+def _zero_scalar(like):
+    """A resident zero (the stride-0 screen-space tensor expands it; no fill kernel per iteration)."""
+    key = (like.device, like.dtype)
+    z = _ZERO.get(key)
+    if z is None:
+        z = _ZERO[key] = torch.zeros(1, dtype=like.dtype, device=like.device)
+    return z
+
+
 def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                           GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
-                          gpf_only=False, gs_only=False, debug=False, **kwargs):
+                          gpf_only=False, gs_only=False, debug=False, means3D=None, **kwargs):
     """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
     reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
     per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
-    [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3]); render[v] equals render_dynamics(camera v)."""
+    [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3]); render[v] equals render_dynamics(camera v).
+    `means3D`: positions [fluid | background] prepared by the caller (gm.render_means_from_nn()) instead of
+    the pos_type lookup + scaling + concatenation done here."""
     from ..rasterizer import GaussianRasterizerViews
-    raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
-    if gpf_only:
+    if means3D is not None:
+        assert not (gpf_only or gs_only)
+        n_fluid = means3D.shape[0] - gm.get_gs_xyz.shape[0]
+        raw_render_xyz = render_xyz = means3D[:n_fluid]
+        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, False)
+    else:
+        raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    if means3D is not None:
+        pass
+    elif gpf_only:
         means3D = render_xyz
         opacity, scales, rotations, colors = _attributes(gm, pos_type)
         if colors.shape[1] == 1:
@@ -177,7 +199,7 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
     V = len(viewpoint_cameras)
     # zero "screen-space points" whose .grad receives the per-view 2D-mean gradients: a stride-0 view of one
     # zero (the rasteriser never reads the values), instead of filling V*P*3 floats every iteration
-    screen = torch.zeros(1, dtype=means3D.dtype, device=means3D.device).expand((V,) + tuple(means3D.shape)).requires_grad_()
+    screen = _zero_scalar(means3D).expand((V,) + tuple(means3D.shape)).requires_grad_()
     rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
                                                      gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
     if not (gpf_only or gs_only) and not any(
