@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--physics-once", action="store_true",
                     help="evaluate the view-independent physics terms once per iteration instead of once per view")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph-iters", type=int, default=5,
+                    help="iterations recorded per hipGraph (reduced to a divisor of --steps; 1 in multi-GPU runs)")
     ap.add_argument("--views", default="batched", choices=["batched", "branches", "serial"],
                     help="the views of an iteration: one view-batched launch sequence (default), one rasteriser call "
                          "per view on parallel streams / graph branches, or one call per view in series")
@@ -141,7 +143,11 @@ def main():
     graph_mode = False
     if loop.capturable:
         try:
-            loop.capture(warmup=1)
+            # several iterations per graph: one launch gap per replay; the timed region still runs exactly --steps
+            gi = max(1, int(a.graph_iters))
+            while a.steps % gi:
+                gi -= 1
+            loop.capture(warmup=1, iterations=gi)
             for _ in range(2):
                 loop.iteration()
             rasterizer.check_status()
@@ -157,8 +163,11 @@ def main():
         _lib.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    steps_done = 0
+    while steps_done < a.steps:
+        steps_done += loop.iterations_per_call
         loop.iteration()
+    assert steps_done == a.steps
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -233,7 +242,8 @@ def main():
                    "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
                    "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
                    "host_sync": bool(a.host_sync), "image_loss": image_loss,
-                   "launch": "hipGraph replay of one whole iteration" if graph_mode else "eager",
+                   "launch": (f"hipGraph replay, {loop.graph_iterations} whole iteration(s) per graph" if graph_mode
+                              else "eager"),
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
                              "branches": "one rasteriser call per view, views as parallel graph branches",
                              "serial": "one rasteriser call per view, in series"}[view_mode],

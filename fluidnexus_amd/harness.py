@@ -115,6 +115,7 @@ class HotLoop:
         # one visual forward per iteration, consumed once: hand the memoised tensor out without a copy
         gm.share_visual_output = self.batched_views
         self._gt_cache = None
+        self.graph_iterations = 1
         self.side_stream = None
         self.fused_step = bool(fused_step)  # gradient mean + Adam as one kernel (batched_views only)
         if self.fused_step:
@@ -180,12 +181,15 @@ class HotLoop:
             loss = loss + c["lambda_next_gas_constraints"] * l2_loss(pn, torch.ones_like(pn))
         return loss
 
-    def capture(self, warmup=3):
+    def capture(self, warmup=3, iterations=1):
         """Record one whole iteration (all views forward + losses + backward + gradient mean + Adam) as a
         hipGraph; later iteration() calls replay it.  Needs the sync-free rasteriser mode with a seeded
         binning capacity (run a few eager iterations first) and capturable=True.  The launch sequence is
         frozen: the binning capacity and every cache decision are those of the recorded iteration;
-        rasterizer.check_status() after replays still reports a capacity overflow."""
+        rasterizer.check_status() after replays still reports a capacity overflow.
+        `iterations` > 1 records that many consecutive iterations in one graph (one launch gap per replay instead
+        of one per iteration; the learning rate is constant in this stage, gm.update_learning_rate_current): every
+        iteration() call then advances the optimisation by `iterations` steps (self.iterations_per_call)."""
         assert self.capturable, "HotLoop(capturable=True) is required for graph capture"
         from . import rasterizer
         assert not rasterizer._HOST_SYNC, "graph capture needs rasterizer.set_host_sync(False)"
@@ -209,12 +213,22 @@ class HotLoop:
             with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
                 self._finish_step(len(self.cams), grad=self._reduce_buf)
             self.graph_finish = g2
+            iterations = 1
         else:
+            itr0, tot0 = self.itr, self.gm.total_iterations
             with torch.cuda.graph(g, stream=self.stream):
-                self._iteration_body()
+                for _ in range(int(iterations)):
+                    self._iteration_body()
+            self.itr, self.gm.total_iterations = itr0, tot0  # recording is not running
         self.graph = g
+        self.graph_iterations = int(iterations)
         self._replay = True
         return g
+
+    @property
+    def iterations_per_call(self):
+        """Optimisation steps one iteration() call performs (> 1 only while replaying a multi-iteration graph)."""
+        return self.graph_iterations if (self.graph is not None and self._replay) else 1
 
     def use_graph(self, enabled: bool):
         """Switch between replaying the captured graph and eager launches.  The graph (and the memory
@@ -229,8 +243,8 @@ class HotLoop:
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             if self.graph is not None and self._replay:
-                self.itr += 1
-                self.gm.total_iterations += 1
+                self.itr += self.graph_iterations
+                self.gm.total_iterations += self.graph_iterations
                 self.graph.replay()
                 if self.graph_finish is not None:
                     dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)

@@ -63,11 +63,12 @@ def test_render_fluid_ch1_pipe_matches_oracle(oracle):
     assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
 
 
-@pytest.mark.parametrize("parallel", [False, True, "batched"])
+@pytest.mark.parametrize("parallel", [False, True, "batched", "batched_x5"])
 def test_graph_replay_matches_eager(parallel):
     """A captured iteration replayed K times moves the particles like K eager iterations -- also with the
     views forked onto parallel streams / graph branches, and with the view-batched launch sequence
-    (graph) against the per-view calls (eager)."""
+    (graph) against the per-view calls (eager); "batched_x5": five iterations recorded in one graph, fused
+    gradient-mean + Adam step."""
     from fluidnexus_amd import rasterizer
     from fluidnexus_amd.harness import HotLoop, build_smoke_frame
     results = []
@@ -78,15 +79,17 @@ def test_graph_replay_matches_eager(parallel):
             gm, cams = build_smoke_frame(P_fluid=20000, P_background=5000, hidden_dims=(8, 20, 8), n_views=2, size=128)
             loop = HotLoop(gm, cams, fused_physics=True, defer_visual_backward=True, image_loss="fused",
                            capturable=True, parallel_views=parallel is True and use_graph,
-                           batched_views=parallel == "batched" and use_graph)
+                           batched_views=str(parallel).startswith("batched") and use_graph,
+                           fused_step=parallel == "batched_x5" and use_graph)
             loop.make_targets()
             for _ in range(2):
                 loop.iteration()
             rasterizer.check_status()
             start = gm._estimate_xyz_nn.detach().clone()
             if use_graph:
-                loop.capture(warmup=1)
-            for k in range(6 if not use_graph else 5):
+                loop.capture(warmup=1, iterations=5 if parallel == "batched_x5" else 1)
+                assert loop.iterations_per_call == (5 if parallel == "batched_x5" else 1)
+            for k in range(6 if not use_graph else 5 // loop.iterations_per_call):
                 loop.iteration()
                 if k == 1:
                     # a device-to-host read between replays must not disturb later replays (hipMemsetAsync nodes
