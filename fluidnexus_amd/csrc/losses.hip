@@ -192,38 +192,39 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
 }
 
 // per_image[n] = (mean |x - y|, mean ssim_map) of image n; loss = sum_n (w_l1 * l1_n + w_dssim * (1 - ssim_n)).
-// One workgroup; fixed summation order (tile index ascending per thread, then a tree) -> deterministic.
-__global__ void __launch_bounds__(256)
+// One workgroup of 16 waves, a wave per image (images n = w, w + 16, ...): fixed summation order (tile index
+// ascending per lane, a butterfly over the lanes, images in order) -> deterministic.
+__global__ void __launch_bounds__(1024)
 image_loss_combine_kernel(const float *__restrict__ partials, int N, int nt, float inv_count, float w_l1, float w_dssim,
                           float *__restrict__ per_image, float *__restrict__ loss) {
-    __shared__ float s_a[256], s_b[256];
-    const int tid = threadIdx.x;
-    float total = 0.f;
-    for (int n = 0; n < N; n++) {
+    extern __shared__ float s_term[];  // N per-image loss terms
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int n = w; n < N; n += 16) {
+        const float2 *p = reinterpret_cast<const float2 *>(partials) + (size_t)n * nt;
         float a = 0.f, b = 0.f;
-        for (int i = tid; i < nt; i += 256) {
-            a += partials[2 * ((size_t)n * nt + i)];
-            b += partials[2 * ((size_t)n * nt + i) + 1];
+        for (int i = lane; i < nt; i += 64) {
+            const float2 v = p[i];
+            a += v.x;
+            b += v.y;
         }
-        s_a[tid] = a;
-        s_b[tid] = b;
-        __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if (tid < off) {
-                s_a[tid] += s_a[tid + off];
-                s_b[tid] += s_b[tid + off];
-            }
-            __syncthreads();
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
         }
-        const float l1 = s_a[0] * inv_count, ss = s_b[0] * inv_count;
-        if (tid == 0) {
+        const float l1 = a * inv_count, ss = b * inv_count;
+        if (lane == 0) {
             per_image[2 * n] = l1;
             per_image[2 * n + 1] = ss;
+            s_term[n] = w_l1 * l1 + w_dssim * (1.0f - ss);
         }
-        total += w_l1 * l1 + w_dssim * (1.0f - ss);
-        __syncthreads();
     }
-    if (tid == 0) loss[0] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int n = 0; n < N; n++) total += s_term[n];
+        loss[0] = total;
+    }
 }
 
 thread_local char g_err[512] = "";
@@ -278,8 +279,8 @@ int fnx_image_loss_forward(const float *img, const float *gt, int N, int C, int 
     if (rc) return rc;
     const int nt = fnx_l1_ssim_tiles(C, H, W, grey);
     const float inv = 1.0f / (float)((size_t)(grey ? 1 : C) * H * W);
-    hipLaunchKernelGGL(image_loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, N, nt, inv, w_l1,
-                       w_dssim, per_image, loss);
+    hipLaunchKernelGGL(image_loss_combine_kernel, dim3(1), dim3(1024), (size_t)N * sizeof(float), (hipStream_t)stream,
+                       partials, N, nt, inv, w_l1, w_dssim, per_image, loss);
     return hip_check("image_loss_forward");
 }
 int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,

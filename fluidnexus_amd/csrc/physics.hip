@@ -94,40 +94,64 @@ grid_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t
     atomicAdd(&count[cell_hash(c, mask)], 1u);
 }
 
-// Exclusive scan of the bucket counts: one 1024-thread workgroup walks the array in chunks of 4096
-// (uint4 per thread, coalesced), wave-scans with shuffles and carries the running total.
+// Exclusive scan of the bucket counts by one 1024-thread workgroup.  The kernel is pure latency (it sits on the
+// critical path of every iteration, before the first neighbour search): up to eight 4096-bucket chunks (coalesced
+// uint4 per thread) are loaded at once and scanned side by side, so the workgroup synchronises twice per 32768
+// buckets instead of twice per 4096, and the 16 wave totals are scanned with shuffles.
 __global__ void __launch_bounds__(1024)
 grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
                  uint32_t *__restrict__ cursor) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+    constexpr int K = 8;
+    __shared__ uint32_t s_wave[K][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < M; base += 4096) {  // M is a power of two >= 4096
-        const uint4 c = *reinterpret_cast<const uint4 *>(count + base + tid * 4);
-        const uint32_t sum = c.x + c.y + c.z + c.w;
-        uint32_t inc = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
-            if (lane >= (uint32_t)off) inc += v;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < M; base += K * 4096u) {  // M is a power of two >= 4096
+        uint4 c[K];
+        uint32_t sum[K], inc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t at = base + (uint32_t)k * 4096u + tid * 4u;
+            c[k] = at < M ? *reinterpret_cast<const uint4 *>(count + at) : make_uint4(0, 0, 0, 0);
+            sum[k] = c[k].x + c[k].y + c[k].z + c[k].w;
+            inc[k] = sum[k];
         }
-        if (lane == 63) s_wave[w] = inc;
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t v = (uint32_t)__shfl_up((int)inc[k], off);
+                if (lane >= (uint32_t)off) inc[k] += v;
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < K; k++) s_wave[k][w] = inc[k];
+        }
         __syncthreads();
-        uint32_t pre = s_carry + inc - sum;
-        for (uint32_t k = 0; k < w; k++) pre += s_wave[k];
-        uint4 o;
-        o.x = pre;
-        o.y = pre + c.x;
-        o.z = o.y + c.y;
-        o.w = o.z + c.z;
-        *reinterpret_cast<uint4 *>(start + base + tid * 4) = o;
-        *reinterpret_cast<uint4 *>(cursor + base + tid * 4) = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        if (tid == 1023) s_carry = pre + sum;
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            // every wave scans the 16 wave totals of chunk k itself (lanes 0..15)
+            uint32_t winc = lane < 16 ? s_wave[k][lane] : 0u;
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)winc, off);
+                if (lane >= (uint32_t)off) winc += v;
+            }
+            const uint32_t before = w ? (uint32_t)__shfl((int)winc, (int)w - 1) : 0u;
+            const uint32_t total = (uint32_t)__shfl((int)winc, 15);
+            const uint32_t at = base + (uint32_t)k * 4096u + tid * 4u;
+            if (at < M) {
+                uint4 o;
+                o.x = carry + before + inc[k] - sum[k];
+                o.y = o.x + c[k].x;
+                o.z = o.y + c[k].y;
+                o.w = o.z + c[k].z;
+                *reinterpret_cast<uint4 *>(start + at) = o;
+                *reinterpret_cast<uint4 *>(cursor + at) = make_uint4(0, 0, 0, 0);
+            }
+            carry += total;
+        }
+        __syncthreads();  // s_wave is rewritten by the next round
     }
-    if (tid == 0) start[M] = s_carry;
+    if (tid == 0) start[M] = carry;
 }
 
 __global__ void __launch_bounds__(256)
@@ -569,32 +593,45 @@ knn_mean_dist2_kernel(const float *__restrict__ xyz, int N, float inv_cell, floa
 
 // ---- optimiser step of the particle positions (fnx_adam_step) ---------------------------------------
 // g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch, then torch.optim.Adam's update (amsgrad off, no weight decay),
-// fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far and is advanced
-// by adam_step_inc_kernel afterwards (every workgroup of this kernel reads the old value).
+// fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far; every workgroup
+// reads the old value, and the workgroup that finishes LAST (a self-resetting arrival counter) advances it, so
+// the step costs one launch.  One adam_step at a time per device (the counter is a module global).
+// scaled_out (optional) receives the updated x * scale -- the positions in simulation units the next
+// iteration's neighbour search starts from.
+__device__ unsigned int g_adam_arrived = 0;
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, float s0, const float *__restrict__ g1,
                  float s1, const float *__restrict__ g2, float s2, float inv_batch, float *__restrict__ m,
-                 float *__restrict__ v, const float *__restrict__ step, float lr, float b1, float b2, float omb1,
-                 float omb2, float eps, float *__restrict__ grad_out) {
+                 float *__restrict__ v, float *__restrict__ step, float lr, float b1, float b2, float omb1,
+                 float omb2, float eps, float *__restrict__ grad_out, float *__restrict__ scaled_out, float scale) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const float t = step[0] + 1.0f;
-    float g = 0.f;
-    if (g0) g = g + g0[i] * s0;
-    if (g1) g = g + g1[i] * s1;
-    if (g2) g = g + g2[i] * s2;
-    g = g * inv_batch;
-    if (grad_out) grad_out[i] = g;
-    const float mi = m[i] + omb1 * (g - m[i]);  // exp_avg.lerp_(grad, 1 - beta1); 1 - beta rounded from double like torch
-    const float vi = b2 * v[i] + omb2 * g * g;  // exp_avg_sq
-    m[i] = mi;
-    v[i] = vi;
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float step_size = lr / bc1;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    x[i] = x[i] - step_size * (mi / denom);
+    if (i < n) {
+        float g = 0.f;
+        if (g0) g = g + g0[i] * s0;
+        if (g1) g = g + g1[i] * s1;
+        if (g2) g = g + g2[i] * s2;
+        g = g * inv_batch;
+        if (grad_out) grad_out[i] = g;
+        const float mi = m[i] + omb1 * (g - m[i]);  // exp_avg.lerp_(grad, 1 - beta1); 1 - beta rounded from double like torch
+        const float vi = b2 * v[i] + omb2 * g * g;  // exp_avg_sq
+        m[i] = mi;
+        v[i] = vi;
+        const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+        const float step_size = lr / bc1;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        const float xn = x[i] - step_size * (mi / denom);
+        x[i] = xn;
+        if (scaled_out) scaled_out[i] = xn * scale;
+    }
+    __syncthreads();  // every thread of the workgroup has read step[0]
+    if (threadIdx.x == 0 && !(t < 0.5f)) {  // (always true: t >= 1) the comparison makes the read complete first
+        if (atomicAdd(&g_adam_arrived, 1u) == gridDim.x - 1) {  // all workgroups have read the old value
+            step[0] = t;
+            g_adam_arrived = 0;
+        }
+    }
 }
-__global__ void adam_step_inc_kernel(float *step) { step[0] = step[0] + 1.0f; }
 
 // Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
 __device__ __forceinline__ float oct_sum7(float v) {
@@ -1050,16 +1087,15 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
                   float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1_d,
-                  double beta2_d, float eps, float *grad_out, fnx_stream_t stream) {
+                  double beta2_d, float eps, float *grad_out, float *scaled_out, float scale, fnx_stream_t stream) {
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     if (n < 0 || (n > 0 && (!x || !exp_avg || !exp_avg_sq)) || !step || !(g0 || g1 || g2))
         return fail(FNX_ERR_INVALID_ARG, "adam_step: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    if (n > 0)
-        hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, g0, s0, g1, s1, g2, s2,
-                           inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, (float)(1.0 - (double)beta1_d),
-                           (float)(1.0 - (double)beta2_d), eps, grad_out);
-    hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+    // n == 0 still advances the step count: one (empty) workgroup
+    hipLaunchKernelGGL(adam_step_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, x, n, g0, s0, g1, s1, g2, s2,
+                       inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, (float)(1.0 - (double)beta1_d),
+                       (float)(1.0 - (double)beta2_d), eps, grad_out, scaled_out, scale);
     return hip_check("adam_step");
 }
 

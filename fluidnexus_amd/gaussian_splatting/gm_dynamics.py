@@ -414,6 +414,14 @@ class GaussianModel:
         x = self.get_guess_hidden_particles_from_nn()
         return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("guess", x))
 
+    def _scaled_estimate(self):
+        """_estimate_xyz_nn * scale_factor; after a fused step (fused_step_current) the product is already resident."""
+        est = self._estimate_xyz_nn
+        hit = getattr(self, "_est_scaled", None)
+        if hit is not None and hit[0] == (id(est), est._version) and not torch.is_grad_enabled():
+            return hit[1]
+        return est * self.scale_factor
+
     def get_visual_xyz_from_nn(self):
         """Visual particles advected by the poly6-weighted velocity of their hidden neighbours."""
         visual = self._visual_xyz.detach()
@@ -423,7 +431,7 @@ class GaussianModel:
         if (self._visual_memo[0] == key and "out" in self._visual_memo[1] and not torch.is_grad_enabled()
                 and getattr(self, "share_visual_output", False)):
             return self._visual_memo[1]["out"]  # already evaluated for this particle state
-        x = self._estimate_xyz_nn * self.scale_factor
+        x = self._scaled_estimate()
         if self._visual_memo[0] != key:
             self.flush_deferred_gradients()
             self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
@@ -561,9 +569,15 @@ class GaussianModel:
         dh = physics.flush_deferred_visual_backward(self._visual_memo[1])
         terms = [(self._estimate_xyz_nn_grad, 1.0)] if self._grad_cache_used else []
         terms += list(extra_terms) + ([(dh, self.scale_factor * g_scale)] if dh is not None else [])
-        physics.adam_step(self._estimate_xyz_nn, self.optimizer, terms, batch_size)
-        self._estimate_xyz_nn.grad = None
+        # the step also leaves x_nn * scale_factor (the next iteration's simulation-unit positions) in a resident buffer
+        est = self._estimate_xyz_nn
+        buf = getattr(self, "_est_scaled", None)
+        if buf is None or buf[1].shape != est.shape or buf[1].device != est.device:
+            buf = (None, torch.empty_like(est.detach()))
+        physics.adam_step(est, self.optimizer, terms, batch_size, scaled_out=buf[1], scale=self.scale_factor)
+        est.grad = None
         self.invalidate_caches()
+        self._est_scaled = ((id(est), est._version), buf[1])
 
     def set_batch_gradient_current(self, batch_size):
         self.flush_deferred_gradients()

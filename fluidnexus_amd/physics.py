@@ -224,10 +224,11 @@ def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
     return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next), memo)
 
 
-def adam_step(param, optimizer, terms, batch_size, grad_out=None):
+def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=None, scale=1.0):
     """Gradient mean + Adam step of `param` in one kernel (fnx_adam_step), on the state of `optimizer`
     (a torch.optim.Adam with amsgrad = False, weight_decay = 0 whose only parameter is `param`).
-    terms: up to three (tensor, scale) pairs; the gradient is sum(tensor * scale) / batch_size."""
+    terms: up to three (tensor, scale) pairs; the gradient is sum(tensor * scale) / batch_size.
+    scaled_out: optional tensor like `param` that receives the updated param * scale."""
     lib = PL.physics()
     group = optimizer.param_groups[0]
     if group.get("amsgrad") or group.get("weight_decay") or group.get("maximize"):
@@ -251,7 +252,7 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None):
     PL.check(lib.fnx_adam_step(x.data_ptr(), x.numel(), ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
                                1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                               ptr(grad_out), _stream()))
+                               ptr(grad_out), ptr(scaled_out), float(scale), _stream()))
 
 
 def knn_mean_dist2(points):

@@ -132,10 +132,12 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
  *   x -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps);  *step = t
  * exp_avg / exp_avg_sq / step are the optimiser's own state tensors (step: DEVICE fp32 scalar), so the state
  * stays loadable by torch.  The betas are doubles so that 1 - beta is rounded from the double difference like
- * torch's (1 - 0.999f differs from float(0.001) by 1.3e-5 relative).  grad_out (optional) receives g. */
+ * torch's (1 - 0.999f differs from float(0.001) by 1.3e-5 relative).  grad_out (optional) receives g; scaled_out
+ * (optional) receives the updated x * scale (the positions in simulation units, gm_dynamics.py:1256).
+ * Not reentrant per device: one adam step at a time (a device-global arrival counter advances *step). */
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
                   float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1, double beta2,
-                  float eps, float *grad_out, fnx_stream_t stream);
+                  float eps, float *grad_out, float *scaled_out, float scale, fnx_stream_t stream);
 
 #ifdef __cplusplus
 }
