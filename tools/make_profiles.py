@@ -79,11 +79,13 @@ with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
     f.write(f"# SQ counters per launch ({TAG}): rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES "
             "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -- python bench.py --no-cpu-baseline --no-graph "
             "--steps 5 --warmup 2\n\n"
-            "`valu %` = SQ_ACTIVE_INST_VALU (quad-cycles) / (duration x 2.4 GHz / 4 x 1024 SIMDs): share of the SIMD issue capacity "
-            "spent on VALU instructions (a wave64 VALU op occupies its SIMD16 for 4 cycles); `wait %` = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
+            "`valu %` = SQ_INSTS_VALU / (duration x 933 G wave-instructions/s): share of the chip's MEASURED fp32 VALU issue rate "
+            "(tools/micro/pk_rate.hip: dependent-free v_fma_f32 streams, 8 waves per SIMD, reach 933 G wave64 instructions/s = "
+            "one per 2.63 cycles per SIMD at 2.4 GHz; v_pk_fma_f32 reaches 433 G/s, i.e. no more fp32 work per second); "
+            "`busy %` = SQ_ACTIVE_INST_VALU x 4 / (duration x 2.4 GHz x 1024 SIMDs); `wait %` = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
             "(waves parked in s_waitcnt / barriers); `stall %` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.  Durations are from the counter "
             "run (slower than the plain trace); averages over all launches (rasteriser forward kernels include single-view launches).\n\n")
-    f.write("| kernel | us | VALU M | SALU M | LDS M | waves | valu % | stall % | wait % |\n|---|---|---|---|---|---|---|---|---|\n")
+    f.write("| kernel | us | VALU M | SALU M | LDS M | waves | valu % | busy % | stall % | wait % |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for k, c in sorted(sq.items(), key=lambda kv: -sum(dur[kv[0]]) / max(len(dur[kv[0]]), 1)):
         us = sum(dur[k]) / len(dur[k])
         if us < 8 or "at::" in k or "rocclr" in k:
@@ -91,6 +93,7 @@ with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
         cap = us * 2400 / 4 * 1024
         wc = max(c.get("SQ_WAVE_CYCLES", 1), 1)
         f.write(f"| `{k[:60]}` | {us:.1f} | {c.get('SQ_INSTS_VALU', 0) / 1e6:.2f} | {c.get('SQ_INSTS_SALU', 0) / 1e6:.2f} | "
-                f"{c.get('SQ_INSTS_LDS', 0) / 1e6:.2f} | {c.get('SQ_WAVES', 0):.0f} | {100 * c.get('SQ_ACTIVE_INST_VALU', 0) / cap:.0f} | "
+                f"{c.get('SQ_INSTS_LDS', 0) / 1e6:.2f} | {c.get('SQ_WAVES', 0):.0f} | "
+                f"{100 * c.get('SQ_INSTS_VALU', 0) / (us * 1e-6 * 933e9):.0f} | {100 * c.get('SQ_ACTIVE_INST_VALU', 0) / cap:.0f} | "
                 f"{100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} | {100 * c.get('SQ_WAIT_ANY', 0) / wc:.0f} |\n")
 print("wrote", sorted(os.listdir(DST)))
