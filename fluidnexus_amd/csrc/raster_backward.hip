@@ -201,10 +201,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             }
         }
         __syncthreads();
-        const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
+        // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
+        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
 
         for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
-            const uint32_t j = s_list[w][i];
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[w][i]);
             const uint32_t q = top - 1 - j;
             const bool wants = s_id[j] < grad_limit;  // wave-uniform
             float val[NV];

@@ -379,7 +379,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
             }
         }
         __syncthreads();
-        const uint32_t n_w = s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w];
+        // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
+        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
         // The only state carried from entry to entry is (T, colour, depth, done); power / exp / alpha
         // of an entry do not depend on it.  A lone wave runs ~500 cycles per entry when everything is
@@ -391,7 +393,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
         constexpr int kGroup = 4;
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(done)) break;
-            const uint32_t j4 = *reinterpret_cast<const uint32_t *>(&s_list[w][i0]);
+            const uint32_t j4 = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0]));
             float alpha[kGroup], depth[kGroup], col[kGroup][C];
             bool hit[kGroup];
 #pragma unroll
