@@ -167,3 +167,74 @@ def test_adam_step_matches_torch_adam():
     for k in ("exp_avg", "exp_avg_sq"):
         a, b = oa.state[pa][k], ob.state[pb][k]
         assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
+def test_adam_step_scaled_output_and_step_count():
+    """fnx_adam_step advances the step count exactly once per call (last-arriving workgroup) and can leave
+    x * scale resident; also n smaller than one workgroup and a large n."""
+    from fluidnexus_amd.physics import adam_step
+    dev = torch.device("cuda")
+    for n in (7, 100_000):
+        p = torch.nn.Parameter(torch.linspace(-1, 1, 3 * n, device=dev).view(n, 3).clone())
+        opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": "p"}], capturable=True, lr=0.0, eps=1e-15)
+        scaled = torch.full_like(p.detach(), float("nan"))
+        for k in range(5):
+            g = torch.full_like(p.detach(), 0.5 + k)
+            adam_step(p, opt, [(g, 1.0)], 2, scaled_out=scaled, scale=100.0)
+            torch.cuda.synchronize()
+            assert float(opt.state[p]["step"]) == k + 1
+            assert torch.equal(scaled, p.detach() * 100.0)
+
+
+def test_visual_forward_cells_equals_particle_walk():
+    """The cell-by-cell visual interpolation (work items of the visual grid, hidden neighbourhood staged in LDS)
+    against the particle-centric kernel: same neighbour sets, sums equal up to fp32 order.  Sparse rim cells,
+    dense cells split into several items, empty neighbourhoods and hash-bucket collisions (far-apart clusters)."""
+    import ctypes as C
+    from fluidnexus_amd import physics
+    from fluidnexus_amd import _physics_lib as PL
+    lib = PL.physics()
+    rng = np.random.RandomState(3)
+    H, secs, eps = 2.0, 1.0 / 30.0, 1e-8
+    hid = np.concatenate([rng.uniform(0, 24, size=(6000, 3)), rng.uniform(0, 24, size=(3000, 3)) + [4096.0, 0, 0]])
+    hid = hid.astype(np.float32)
+    prev = (hid - rng.normal(size=hid.shape) * 0.2).astype(np.float32)
+    vis = np.concatenate([rng.uniform(-3, 27, size=(20000, 3)),            # rim cells without neighbours
+                          rng.uniform(10, 12, size=(3000, 3)),             # one very dense cell region
+                          rng.uniform(0, 24, size=(2000, 3)) + [4096.0, 0, 0]]).astype(np.float32)
+    d = "cuda"
+    hid_t, prev_t, vis_t = (torch.tensor(a, device=d) for a in (hid, prev, vis))
+    V, N = vis.shape[0], hid.shape[0]
+    hg = physics.HashGrid(hid_t, H)
+    vg = physics.HashGrid(vis_t, H)
+    outs = []
+    for cells in (False, True):
+        out = torch.empty(V, 3, device=d)
+        sw = torch.empty(V, device=d)
+        wv = torch.empty(V, 3, device=d)
+        s = torch.cuda.current_stream().cuda_stream
+        if cells:
+            PL.check(lib.fnx_visual_interp_forward_cells(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs,
+                                                         eps, hg.blob.data_ptr(), vg.blob.data_ptr(),
+                                                         vg.cell_items().data_ptr(), out.data_ptr(), sw.data_ptr(),
+                                                         wv.data_ptr(), s))
+        else:
+            PL.check(lib.fnx_visual_interp_forward(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs, eps,
+                                                   hg.blob.data_ptr(), out.data_ptr(), sw.data_ptr(), wv.data_ptr(), s))
+        torch.cuda.synchronize()
+        outs.append((out.cpu().numpy(), sw.cpu().numpy(), wv.cpu().numpy()))
+    (o0, s0, w0), (o1, s1, w1) = outs
+    assert (s0 > 0).sum() > 5000 and (s0 == 0).sum() > 1000
+    assert ((s0 == 0) == (s1 == 0)).all()  # same neighbour sets
+    for a, b, what in ((s0, s1, "sum_w"), (w0, w1, "wvel"), (o0, o1, "out")):
+        scale = np.abs(a).max()
+        assert np.abs(a - b).max() <= 2e-6 * scale, what
+    # the items cover every visual particle exactly once
+    items = vg.cell_items().cpu().numpy()
+    n_items = int(items[:4].view(np.uint32)[0])
+    it = items[64:64 + 8 * n_items].view(np.uint32).reshape(-1, 2)
+    assert it[:, 1].sum() == V and it[:, 1].max() <= 64
+    cover = np.zeros(V, np.int32)
+    for s0_, c_ in it:
+        cover[s0_:s0_ + c_] += 1
+    assert (cover == 1).all()
