@@ -209,10 +209,15 @@ class HotLoop:
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=self.stream):
                 self._iteration_body_batched(phase="local")
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
-                self._finish_step(len(self.cams), grad=self._reduce_buf)
-            self.graph_finish = g2
+            if self.fused_step:
+                # batch mean + Adam step is ONE kernel (fnx_adam_step): launched eagerly behind the all-reduce, it
+                # costs a kernel launch instead of the ~27 us start-up gap of a second graph
+                self.graph_finish = "eager"
+            else:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
+                    self._finish_step(len(self.cams), grad=self._reduce_buf)
+                self.graph_finish = g2
             iterations = 1
         else:
             itr0, tot0 = self.itr, self.gm.total_iterations
@@ -248,7 +253,10 @@ class HotLoop:
                 self.graph.replay()
                 if self.graph_finish is not None:
                     dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
-                    self.graph_finish.replay()
+                    if self.graph_finish == "eager":
+                        self._finish_step(len(self.cams), grad=self._reduce_buf)
+                    else:
+                        self.graph_finish.replay()
             else:
                 self._iteration_body()
         torch.cuda.current_stream().wait_stream(self.stream)

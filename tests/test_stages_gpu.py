@@ -1,5 +1,6 @@
 """-m gpu: the two optimisation stages and the 1-channel pipe end to end on small synthetic frames."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -163,3 +164,48 @@ def test_background_stage_trains_and_densifies_on_gpu():
     assert gm.xyz_gradient_accum.shape[0] == gm.get_xyz.shape[0] == gm.max_radii2D.shape[0]
     assert all(gm.optimizer.state[getattr(gm, a)]["exp_avg"].shape == getattr(gm, a).shape
                for a in ("_xyz", "_color", "_opacity", "_scaling", "_rotation"))
+
+
+def test_distributed_graph_loop_matches_single_process():
+    """The multi-GPU loop (captured local pass | RCCL all-reduce of the leaf gradient | eager fused batch-mean +
+    Adam kernel) with a 1-rank process group moves the particles like the single-process multi-iteration graph."""
+    import torch.distributed as dist
+    from fluidnexus_amd import rasterizer
+    from fluidnexus_amd.harness import HotLoop, build_smoke_frame
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fnx_rccl_test_%h_%p.log")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    results = []
+    try:
+        for use_dist in (False, True):
+            rasterizer.set_host_sync(False)
+            rasterizer._capacity_hwm.clear()
+            gm, cams = build_smoke_frame(P_fluid=20000, P_background=5000, hidden_dims=(8, 20, 8), n_views=2, size=128)
+            loop = HotLoop(gm, cams, fused_physics=True, defer_visual_backward=True, image_loss="fused", capturable=True,
+                           batched_views=True, fused_step=True, force_all_reduce=use_dist)
+            loop.make_targets()
+            for _ in range(2):
+                loop.iteration()
+            rasterizer.check_status()
+            start = gm._estimate_xyz_nn.detach().clone()
+            loop.capture(warmup=1, iterations=1 if use_dist else 3)
+            assert (loop.graph_finish == "eager") == use_dist
+            for k in range(6 // loop.iterations_per_call):
+                loop.iteration()
+                if k == 0:
+                    assert np.isfinite(gm._estimate_xyz_nn.detach().sum().item())  # D2H between replays
+            rasterizer.check_status()
+            torch.cuda.synchronize()
+            results.append((start.cpu(), gm._estimate_xyz_nn.detach().cpu().clone()))
+    finally:
+        rasterizer.set_host_sync(True)
+        if created:
+            dist.destroy_process_group()
+    (s0, e0), (s1, e1) = results
+    moved = (e0 - s0).abs().max().item()
+    assert moved > 0
+    assert (s0 - s1).abs().max().item() <= 0.02 * moved
+    assert (e0 - e1).abs().max().item() <= 0.05 * moved + 1e-7
