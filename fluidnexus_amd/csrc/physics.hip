@@ -907,6 +907,148 @@ visual_backward_kernel(const float *__restrict__ hidden, const float *__restrict
     }
 }
 
+// Cell-centric form of the same backward.  The hidden particles of one cell (a work item of the HIDDEN grid,
+// fnx_grid_cell_items) see the same 27 visual buckets, so a 4-wave workgroup takes an item: lanes = candidates
+// (~1 750 visual slots of the neighbourhood, flattened; position + payload loaded once per CELL instead of once per
+// hidden particle, with no start -> record -> payload dependent chain per bucket), and every candidate is tested
+// against up to kBwdGroup hidden particles whose positions / velocities sit in scalar registers.  Per-lane sums
+// for each hidden particle are reduced across the wave once at the end, the four waves' partials through LDS.
+constexpr int kBwdGroup = 8;
+__global__ void __launch_bounds__(256)
+visual_backward_cells_kernel(float inv_cell, float H2, float term1, float secs, const float4 *__restrict__ hrec,
+                             const uint2 *__restrict__ hitems, const uint32_t *__restrict__ n_hitems,
+                             const float *__restrict__ hidden_prev, uint32_t vmask,
+                             const uint32_t *__restrict__ vstart, const float4 *__restrict__ vrec,
+                             const float4 *__restrict__ a0, float *__restrict__ dL_dhidden) {
+    __shared__ uint32_t s_first[28], s_s0[28];
+    __shared__ float s_part[4][kBwdGroup][3];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_work = *n_hitems;
+    for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
+        const uint2 it = hitems[item];
+        const bool valid = (uint32_t)lane < it.y;
+        // every wave holds the item's hidden particles (lane = particle): position, velocity, id
+        const float4 me = hrec[valid ? it.x + lane : it.x];
+        const uint32_t jid = __float_as_uint(me.w);
+        const float ux = (me.x - hidden_prev[3 * jid]) / secs, uy = (me.y - hidden_prev[3 * jid + 1]) / secs,
+                    uz = (me.z - hidden_prev[3 * jid + 2]) / secs;
+        const int3 c = cell_of(me.x, me.y, me.z, inv_cell);
+        unsigned long long todo = __ballot(valid);
+        while (todo) {  // one round per distinct cell among the lanes: one, unless cells collide in the bucket
+            const int lead = __ffsll((long long)todo) - 1;
+            const int3 c0 = make_int3(__shfl(c.x, lead), __shfl(c.y, lead), __shfl(c.z, lead));
+            const bool mine = valid && c.x == c0.x && c.y == c0.y && c.z == c0.z;
+            // the 27 visual buckets of the neighbourhood: ranges by lanes 0..26 of wave 0, prefix, into LDS
+            __syncthreads();  // the previous round / item is done with s_first / s_s0 / s_part
+            if (w == 0) {
+                uint32_t s0 = 0, cnt = 0;
+                if (lane < 27) {
+                    const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+                    const uint32_t h = cell_hash(make_int3(c0.x + dx, c0.y + dy, c0.z + dz), vmask);
+                    s0 = vstart[h];
+                    cnt = vstart[h + 1] - s0;
+                }
+                uint32_t inc = cnt;
+                for (int off = 1; off < 32; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+                    if (lane >= off) inc += t;
+                }
+                if (lane < 27) {
+                    s_first[lane] = inc - cnt;
+                    s_s0[lane] = s0;
+                }
+                if (lane == 26) s_first[27] = inc;
+            }
+            __syncthreads();
+            const uint32_t total = s_first[27];
+            unsigned long long left = __ballot(mine);
+            while (left) {  // groups of kBwdGroup hidden particles of this cell
+                float hx[kBwdGroup], hy[kBwdGroup], hz[kBwdGroup], vx[kBwdGroup], vy[kBwdGroup], vz[kBwdGroup];
+                uint32_t hj[kBwdGroup];
+                int ng = 0;
+#pragma unroll
+                for (int k = 0; k < kBwdGroup; k++) {
+                    const bool have = left != 0ull;  // wave-uniform
+                    const int src = have ? __ffsll((long long)left) - 1 : 0;
+                    if (have) {
+                        left &= left - 1ull;
+                        ng = k + 1;
+                    }
+                    // wave-uniform values (scalar registers): particle k of the group
+                    hx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.x), src));
+                    hy[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.y), src));
+                    hz[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.z), src));
+                    vx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ux), src));
+                    vy[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uy), src));
+                    vz[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uz), src));
+                    hj[k] = (uint32_t)__builtin_amdgcn_readlane((int)jid, src);
+                }
+                float ax[kBwdGroup], ay[kBwdGroup], az[kBwdGroup];
+#pragma unroll
+                for (int k = 0; k < kBwdGroup; k++) ax[k] = ay[k] = az[k] = 0.f;
+                // wave w takes every fourth 64-candidate chunk, two chunks per step (their loads in flight together)
+                for (uint32_t base = (uint32_t)w * 64u; base < total; base += 512u) {
+                    float4 q[2], G[2];
+                    bool in[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t i = base + (uint32_t)u * 256u + lane;
+                        in[u] = i < total;
+                        uint32_t b = 0;  // bucket of flat index i: last b with s_first[b] <= i
+#pragma unroll
+                        for (int step = 16; step >= 1; step >>= 1)
+                            if (b + step < 27u && s_first[b + step] <= i) b += step;
+                        const uint32_t slot = in[u] ? s_s0[b] + (i - s_first[b]) : 0u;
+                        q[u] = vrec[slot];
+                        G[u] = a0[slot];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+#pragma unroll
+                        for (int k = 0; k < kBwdGroup; k++) {
+                            if (k < ng) {  // wave-uniform
+                                const float ex = hx[k] - q[u].x, ey = hy[k] - q[u].y, ez = hz[k] - q[u].z;
+                                const float r2 = ex * ex + ey * ey + ez * ez;
+                                if (in[u] && r2 < H2) {
+                                    const float t = H2 - r2;
+                                    const float wgt = term1 * (t * t * t);
+                                    const float dW = -3.0f * term1 * (t * t);
+                                    const float dLdw = secs * (G[u].x * vx[k] + G[u].y * vy[k] + G[u].z * vz[k]) - G[u].w;
+                                    const float kk = dLdw * dW * 2.0f;
+                                    ax[k] += wgt * G[u].x + kk * ex;
+                                    ay[k] += wgt * G[u].y + kk * ey;
+                                    az[k] += wgt * G[u].z + kk * ez;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kBwdGroup; k++) {
+                    if (k < ng) {
+                        const float sx = wave_sum63(ax[k]), sy = wave_sum63(ay[k]), sz = wave_sum63(az[k]);
+                        if (lane == 63) {
+                            s_part[w][k][0] = sx;
+                            s_part[w][k][1] = sy;
+                            s_part[w][k][2] = sz;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (w == 0 && lane < 3 * ng) {
+                    const int k = lane / 3, d = lane - 3 * k;
+                    uint32_t j = hj[0];
+#pragma unroll
+                    for (int q = 1; q < kBwdGroup; q++) j = (k == q) ? hj[q] : j;
+                    dL_dhidden[3 * j + d] = (s_part[0][k][d] + s_part[1][k][d]) + (s_part[2][k][d] + s_part[3][k][d]);
+                }
+                __syncthreads();  // s_part is rewritten by the next group
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
+}
+
 thread_local char g_err[512] = "";
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -1164,6 +1306,28 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
                        hidden_prev, N, 1.0f / H, H, H * H, poly6_term1(H), secs, g.M - 1, g.start, g.rec, g.aux0,
                        dL_dhidden);
     return hip_check("visual_interp_backward");
+}
+
+int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                     float H, float secs, float eps, const char *visual_grid, const char *hidden_grid,
+                                     const char *hidden_items, const float *sum_w, const float *wvel,
+                                     const float *dL_dout, float *dL_dhidden, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !hidden || !hidden_prev || !visual_grid || !hidden_grid || !hidden_items || !dL_dhidden ||
+        (V > 0 && (!visual || !sum_w || !wvel || !dL_dout)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_backward_cells: bad argument");
+    GridView g = carve(const_cast<char *>(visual_grid), V);
+    GridView gh = carve(const_cast<char *>(hidden_grid), N);
+    if (V > 0)
+        hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
+                           V, sum_w, wvel, dL_dout, secs, eps, g.aux0);
+    // workgroups stride over the items (their number is only known on the device)
+    const size_t bound = (size_t)N + (size_t)N / 64 + 1;
+    const unsigned wgs = (unsigned)(bound < 4096 ? bound : 4096);
+    hipLaunchKernelGGL(visual_backward_cells_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, 1.0f / H, H * H,
+                       poly6_term1(H), secs, gh.rec, (const uint2 *)(hidden_items + 64), (const uint32_t *)hidden_items,
+                       hidden_prev, g.M - 1, g.start, g.rec, g.aux0, dL_dhidden);
+    return hip_check("visual_interp_backward_cells");
 }
 
 }  // extern "C"

@@ -338,6 +338,11 @@ class HotLoop:
             fork.record(main)
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
+                # work items of the hidden-particle grid for the cell-by-cell hidden<-visual backward at the end
+                # of the iteration: two tiny kernels, off the critical path on this branch
+                vmemo = gm._visual_memo[1]
+                if "hgrid" in vmemo:
+                    vmemo["hitems"] = vmemo["hgrid"].cell_items(refresh=True)
                 if self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
                     from .physics import physical_stage_value_and_grad
                     _, gp = physical_stage_value_and_grad(gm, c["lambda_exyz"], c["lambda_gas_constraints"],

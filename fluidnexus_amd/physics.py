@@ -37,11 +37,13 @@ class HashGrid:
                                         _stream()))
         self._items = None
 
-    def cell_items(self) -> torch.Tensor:
-        """Per-cell work items of the (built) grid for the cell-by-cell kernels; made on first use."""
-        if self._items is None:
+    def cell_items(self, refresh: bool = False) -> torch.Tensor:
+        """Per-cell work items of the (built) grid for the cell-by-cell kernels; made on first use, and again with
+        `refresh` (a grid object that is rebuilt in place over moved points keeps its buffers)."""
+        if self._items is None or refresh:
             lib = PL.physics()
-            self._items = torch.empty(lib.fnx_grid_cell_items_bytes(self.N), dtype=torch.uint8, device=self.blob.device)
+            if self._items is None:
+                self._items = torch.empty(lib.fnx_grid_cell_items_bytes(self.N), dtype=torch.uint8, device=self.blob.device)
             PL.check(lib.fnx_grid_cell_items(self.blob.data_ptr(), self.N, self._items.data_ptr(), _stream()))
         return self._items
 
@@ -108,8 +110,12 @@ class _VisualFromHidden(torch.autograd.Function):
         ctx.save_for_backward(visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob)
         ctx.consts = (H, secs, eps)
         ctx.memo = memo
-        if memo is not None and memo.get("defer"):
-            memo["saved"] = (visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob, (H, secs, eps))
+        if memo is not None:
+            if hgrid is not None:
+                memo["hgrid"] = hgrid  # the backward walks the hidden particles cell by cell over this grid
+            if memo.get("defer"):
+                memo["saved"] = (visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob, (H, secs, eps))
+        ctx.hgrid = memo.get("hgrid") if memo is not None else hgrid
         return out
 
     @staticmethod
@@ -125,12 +131,28 @@ class _VisualFromHidden(torch.autograd.Function):
             # (kept as a list: the views may run on different streams; they are summed after the join)
             memo.setdefault("g_list", []).append(g)
             return None, None, None, None, None, None, None, None, None
-        dh = torch.empty_like(hidden)
-        PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
-                                                hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
-                                                vblob.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
-                                                dh.data_ptr(), _stream()))
+        dh = _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, ctx.hgrid, None, sum_w, wvel, g)
         return None, dh, None, None, None, None, None, None, None
+
+
+def _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, hgrid, hitems, sum_w, wvel, g):
+    """dL/dhidden [N,3]: cell by cell over the hidden grid when one is at hand (`hitems`: its work items, built here
+    when None), else a wave per hidden particle."""
+    lib = PL.physics()
+    dh = torch.empty_like(hidden)
+    if hgrid is not None and hgrid.N == hidden.shape[0]:
+        if hitems is None:
+            hitems = hgrid.cell_items(refresh=True)
+        PL.check(lib.fnx_visual_interp_backward_cells(
+            visual.data_ptr(), visual.shape[0], hidden.data_ptr(), hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
+            vblob.data_ptr(), hgrid.blob.data_ptr(), hitems.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
+            dh.data_ptr(), _stream()))
+    else:
+        PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
+                                                hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
+                                                sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(), dh.data_ptr(),
+                                                _stream()))
+    return dh
 
 
 def flush_deferred_visual_backward(memo):
@@ -142,11 +164,8 @@ def flush_deferred_visual_backward(memo):
     gl = memo.pop("g_list")
     g = gl[0] if len(gl) == 1 else torch.stack(gl).sum(dim=0)
     g = g.contiguous()
-    dh = torch.empty_like(hidden)
-    PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
-                                            hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
-                                            sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(), dh.data_ptr(), _stream()))
-    return dh
+    return _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, memo.get("hgrid"), memo.get("hitems"),
+                            sum_w, wvel, g)
 
 
 def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,

@@ -72,6 +72,14 @@ int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hid
 int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
                                float H, float secs, float eps, const char *visual_grid, const float *sum_w,
                                const float *wvel, const float *dL_dout, float *dL_dhidden, fnx_stream_t stream);
+/* The same with the hidden particles walked cell by cell: `hidden_grid` is the grid built over `hidden` (cell = H)
+ * and `hidden_items` its work items (fnx_grid_cell_items, rebuilt whenever the grid is); the visual neighbourhood of
+ * a cell is read once per cell instead of once per hidden particle.  Same results up to fp32 summation order.
+ * `hidden` itself is only checked for NULL: positions come from the grid records (bit-identical copies). */
+int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                     float H, float secs, float eps, const char *visual_grid, const char *hidden_grid,
+                                     const char *hidden_items, const float *sum_w, const float *wvel,
+                                     const float *dL_dout, float *dL_dhidden, fnx_stream_t stream);
 
 /* The three physics terms of the physical-particle stage and their gradient in one call
  * (entries_fluid_nexus/train_physical_particle.py:368-404 as one launch sequence of ~12 kernels):

@@ -238,3 +238,47 @@ def test_visual_forward_cells_equals_particle_walk():
     for s0_, c_ in it:
         cover[s0_:s0_ + c_] += 1
     assert (cover == 1).all()
+
+
+def test_visual_backward_cells_equals_particle_walk():
+    """The cell-by-cell hidden<-visual backward (work items of the HIDDEN grid, 4 waves per cell, candidates read once
+    per cell) against the wave-per-hidden-particle kernel on the scene of the forward test: dense and sparse cells,
+    cells with more than 8 hidden particles, hidden particles without any visual neighbour, bucket collisions."""
+    from fluidnexus_amd import physics
+    from fluidnexus_amd import _physics_lib as PL
+    lib = PL.physics()
+    rng = np.random.RandomState(5)
+    H, secs, eps = 2.0, 1.0 / 30.0, 1e-8
+    hid = np.concatenate([rng.uniform(0, 24, size=(6000, 3)), rng.uniform(11, 12, size=(300, 3)),
+                          rng.uniform(0, 24, size=(3000, 3)) + [4096.0, 0, 0], rng.uniform(200, 210, size=(50, 3))])
+    hid = hid.astype(np.float32)
+    prev = (hid - rng.normal(size=hid.shape) * 0.2).astype(np.float32)
+    vis = np.concatenate([rng.uniform(-3, 27, size=(30000, 3)), rng.uniform(10, 12, size=(3000, 3)),
+                          rng.uniform(0, 24, size=(2000, 3)) + [4096.0, 0, 0]]).astype(np.float32)
+    d = "cuda"
+    hid_t, prev_t, vis_t = (torch.tensor(a, device=d) for a in (hid, prev, vis))
+    V, N = vis.shape[0], hid.shape[0]
+    hg, vg = physics.HashGrid(hid_t, H), physics.HashGrid(vis_t, H)
+    s = torch.cuda.current_stream().cuda_stream
+    out, sw, wv = torch.empty(V, 3, device=d), torch.empty(V, device=d), torch.empty(V, 3, device=d)
+    PL.check(lib.fnx_visual_interp_forward(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs, eps,
+                                           hg.blob.data_ptr(), out.data_ptr(), sw.data_ptr(), wv.data_ptr(), s))
+    g = torch.tensor(rng.normal(size=(V, 3)).astype(np.float32), device=d)
+    res = []
+    for cells in (False, True):
+        dh = torch.full((N, 3), float("nan"), device=d)
+        if cells:
+            PL.check(lib.fnx_visual_interp_backward_cells(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs,
+                                                          eps, vg.blob.data_ptr(), hg.blob.data_ptr(),
+                                                          hg.cell_items().data_ptr(), sw.data_ptr(), wv.data_ptr(),
+                                                          g.data_ptr(), dh.data_ptr(), s))
+        else:
+            PL.check(lib.fnx_visual_interp_backward(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs, eps,
+                                                    vg.blob.data_ptr(), sw.data_ptr(), wv.data_ptr(), g.data_ptr(),
+                                                    dh.data_ptr(), s))
+        torch.cuda.synchronize()
+        res.append(dh.cpu().numpy())
+    a, b = res
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert (np.abs(a).sum(1) == 0).sum() >= 50 and ((np.abs(a).sum(1) == 0) == (np.abs(b).sum(1) == 0)).all()
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
