@@ -18,7 +18,7 @@ def physics():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "libfnx_physics.so")
+    path = os.environ.get("FNX_PHYSICS_LIB") or os.path.join(_HERE, "libfnx_physics.so")  # env: developer variants
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
                            "fluidnexus_amd has no CPU fallback.")

@@ -914,14 +914,18 @@ visual_backward_kernel(const float *__restrict__ hidden, const float *__restrict
 // against up to kBwdGroup hidden particles whose positions / velocities sit in scalar registers.  Per-lane sums
 // for each hidden particle are reduced across the wave once at the end, the four waves' partials through LDS.
 constexpr int kBwdGroup = 8;
-__global__ void __launch_bounds__(256)
+#ifndef FNX_BWD_WAVES
+#define FNX_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = FNX_BWD_WAVES;  // waves per cell item
+__global__ void __launch_bounds__(64 * kBwdWaves)
 visual_backward_cells_kernel(float inv_cell, float H2, float term1, float secs, const float4 *__restrict__ hrec,
                              const uint2 *__restrict__ hitems, const uint32_t *__restrict__ n_hitems,
                              const float *__restrict__ hidden_prev, uint32_t vmask,
                              const uint32_t *__restrict__ vstart, const float4 *__restrict__ vrec,
                              const float4 *__restrict__ a0, float *__restrict__ dL_dhidden) {
     __shared__ uint32_t s_first[28], s_s0[28];
-    __shared__ float s_part[4][kBwdGroup][3];
+    __shared__ float s_part[kBwdWaves][kBwdGroup][3];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_work = *n_hitems;
     for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
@@ -986,13 +990,13 @@ visual_backward_cells_kernel(float inv_cell, float H2, float term1, float secs, 
                 float ax[kBwdGroup], ay[kBwdGroup], az[kBwdGroup];
 #pragma unroll
                 for (int k = 0; k < kBwdGroup; k++) ax[k] = ay[k] = az[k] = 0.f;
-                // wave w takes every fourth 64-candidate chunk, two chunks per step (their loads in flight together)
-                for (uint32_t base = (uint32_t)w * 64u; base < total; base += 512u) {
+                // wave w takes every kBwdWaves-th 64-candidate chunk, two chunks per step (their loads in flight together)
+                for (uint32_t base = (uint32_t)w * 64u; base < total; base += 128u * kBwdWaves) {
                     float4 q[2], G[2];
                     bool in[2];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const uint32_t i = base + (uint32_t)u * 256u + lane;
+                        const uint32_t i = base + (uint32_t)u * (64u * kBwdWaves) + lane;
                         in[u] = i < total;
                         uint32_t b = 0;  // bucket of flat index i: last b with s_first[b] <= i
 #pragma unroll
@@ -1040,7 +1044,10 @@ visual_backward_cells_kernel(float inv_cell, float H2, float term1, float secs, 
                     uint32_t j = hj[0];
 #pragma unroll
                     for (int q = 1; q < kBwdGroup; q++) j = (k == q) ? hj[q] : j;
-                    dL_dhidden[3 * j + d] = (s_part[0][k][d] + s_part[1][k][d]) + (s_part[2][k][d] + s_part[3][k][d]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < kBwdWaves; ww++) sum += s_part[ww][k][d];
+                    dL_dhidden[3 * j + d] = sum;
                 }
                 __syncthreads();  // s_part is rewritten by the next group
             }
@@ -1324,7 +1331,7 @@ int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hi
     // workgroups stride over the items (their number is only known on the device)
     const size_t bound = (size_t)N + (size_t)N / 64 + 1;
     const unsigned wgs = (unsigned)(bound < 4096 ? bound : 4096);
-    hipLaunchKernelGGL(visual_backward_cells_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, 1.0f / H, H * H,
+    hipLaunchKernelGGL(visual_backward_cells_kernel, dim3(wgs), dim3(64 * kBwdWaves), 0, (hipStream_t)stream, 1.0f / H, H * H,
                        poly6_term1(H), secs, gh.rec, (const uint2 *)(hidden_items + 64), (const uint32_t *)hidden_items,
                        hidden_prev, g.M - 1, g.start, g.rec, g.aux0, dL_dhidden);
     return hip_check("visual_interp_backward_cells");
