@@ -44,7 +44,8 @@ SYMBOLS = (
     "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",
     "fnx_rasterize_backward", "fnx_rasterize_backward_ex", "fnx_mark_visible", "fnx_geom_layout", "fnx_image_layout", "fnx_binning_layout",
     "fnx_profile_enable", "fnx_profile_read",
-    "fnx_forward_stage1_views", "fnx_forward_stage2_views", "fnx_rasterize_backward_views",
+    "fnx_forward_stage1_views", "fnx_forward_stage2_views", "fnx_forward_stage2_views_status",
+    "fnx_rasterize_backward_views",
 )
 
 
@@ -94,6 +95,8 @@ def raster():
     lib.fnx_forward_stage1_views.argtypes = [i, i, p, p, i, i, i, i, i, p, p, p, p, p, f, p, p, p, p, p, fp, fp, i, p, p]
     lib.fnx_forward_stage2_views.restype = i
     lib.fnx_forward_stage2_views.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p]
+    lib.fnx_forward_stage2_views_status.restype = i
+    lib.fnx_forward_stage2_views_status.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p, p]
     lib.fnx_rasterize_backward_views.restype = i
     lib.fnx_rasterize_backward_views.argtypes = [i, i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, fp, fp, p,
                                                  p, p, c_int64, p, p, p, p, p, p, p, p, p, p, p, p, p, i, i, p]

@@ -35,8 +35,8 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
                  uint32_t capacity, int V, const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity, int V,
-                          const ViewBatch &vb);
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
+                          uint32_t *status_out, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -309,9 +309,10 @@ int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_
     return FNX_OK;
 }
 
-int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
-                             char *image_buffer, int P, int width, int height, const float *background,
-                             const int *radii, float *out_color, float *out_depth, fnx_stream_t stream) {
+int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffer, char *binning_buffer,
+                                    int64_t binning_capacity, char *image_buffer, int P, int width, int height,
+                                    const float *background, const int *radii, float *out_color, float *out_depth,
+                                    uint32_t *status_out, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
     if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
@@ -338,9 +339,16 @@ int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binni
     {
         ProfScope ps(0, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
-                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, V, vb);
+                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out, V, vb);
     }
     return hip_check("stage2");
+}
+
+int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
+                             char *image_buffer, int P, int width, int height, const float *background,
+                             const int *radii, float *out_color, float *out_depth, fnx_stream_t stream) {
+    return fnx_forward_stage2_views_status(channels, V, geom_buffer, binning_buffer, binning_capacity, image_buffer, P,
+                                           width, height, background, radii, out_color, out_depth, nullptr, stream);
 }
 
 int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,

@@ -288,7 +288,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
-                     uint32_t capacity, const ViewBatch vb) {
+                     uint32_t capacity, uint32_t *__restrict__ status_out, const ViewBatch vb) {
     {
         const int vw = blockIdx.y;
         ranges = view_at(ranges, vb.img, vw);
@@ -305,6 +305,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
     __shared__ float s_col[C][256];
     __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 4];
     __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
+    // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
+    // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
+    if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity) return;
     const int tile = xcd_tile(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
@@ -498,15 +501,15 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity, int V,
-                          const ViewBatch &vb) {
+                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
+                          uint32_t *status_out, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     if (C == 3)
         hipLaunchKernelGGL((blend_forward_kernel<3>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, vb);
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out, vb);
     else
         hipLaunchKernelGGL((blend_forward_kernel<1>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, vb);
+                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out, vb);
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

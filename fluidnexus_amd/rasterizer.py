@@ -302,18 +302,19 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                 _capacity_hwm[key] = cap
             bbytes = lib.fnx_binning_bytes(cap)
             binning = torch.empty(V * bbytes, **u8)
-            _lib.check(lib.fnx_forward_stage2_views(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P,
-                                                    W, H, vbatch.bg.data_ptr(), radii.data_ptr(), color.data_ptr(),
-                                                    depth.data_ptr(), stream))
-            if not synced:
+            status_ptr = None
+            if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 global _ring_next
                 ring = _ring(dev)
                 if _ring_next % _RING + V > _RING:  # keep the V slots contiguous
                     _ring_next += _RING - _ring_next % _RING
                 slot = _ring_next % _RING
                 _ring_next += V
-                al = (-img.data_ptr()) % 256  # each view's header sits at the first 256-byte boundary of its blob
-                ring[slot:slot + V].copy_(img.view(V, ibytes)[:, al:al + 32].view(torch.int32))
+                status_ptr = ring[slot:slot + V].data_ptr()
+            _lib.check(lib.fnx_forward_stage2_views_status(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                                           P, W, H, vbatch.bg.data_ptr(), radii.data_ptr(),
+                                                           color.data_ptr(), depth.data_ptr(), status_ptr, stream))
+            if not synced:
                 for v in range(V):
                     _pending_status.append((dev.index, slot + v, key))
                 while len(_pending_status) > _RING:

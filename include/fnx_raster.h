@@ -152,6 +152,13 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffers, char *imag
 int fnx_forward_stage2_views(int channels, int V, char *geom_buffers, char *binning_buffers, int64_t binning_capacity,
                              char *image_buffers, int P, int width, int height, const float *background,
                              const int *radii, float *out_color, float *out_depth, fnx_stream_t stream);
+/* The same; additionally the last kernel copies the 8 header words of every view (instance count, status, needed
+ * capacity, ...) to status_out[8 v ..] (device memory, may be NULL) for a deferred fnx_read_status-like check
+ * without a copy per call. */
+int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffers, char *binning_buffers,
+                                    int64_t binning_capacity, char *image_buffers, int P, int width, int height,
+                                    const float *background, const int *radii, float *out_color, float *out_depth,
+                                    uint32_t *status_out, fnx_stream_t stream);
 int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
                                  int height, const float *means3D, const float *shs, const float *colors_precomp,
                                  const float *scales, float scale_modifier, const float *rotations,
