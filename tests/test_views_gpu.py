@@ -218,3 +218,40 @@ def test_fused_image_loss_scalar_matches_terms():
         assert torch.allclose(loss, ref, rtol=2e-6, atol=0)
         assert torch.allclose(per[:, 0], l1, rtol=2e-6, atol=0) and torch.allclose(1.0 - per[:, 1], dssim, rtol=1e-5, atol=1e-7)
         assert (xa.grad - xb.grad).abs().max().item() <= 1e-5 * xb.grad.abs().max().item()
+
+
+def test_views_sync_free_capacity_overflow_is_reported():
+    """Sync-free mode sizes the binning buffer from a high-water mark; when a later batch needs more, nothing is
+    rendered for the overflowing view and check_status() raises (the status words are written by the forward's
+    last kernel into the persistent ring), after which the mark has grown and the same call succeeds."""
+    from fluidnexus_amd import _lib, rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews, ViewBatch
+    dev = torch.device("cuda")
+    W = H = 64
+    g = S.random_gaussians(3000, seed=2, box=0.5, log_scale=(-4.5, -3.0))
+    cams = S.arc_cameras(2, W, H, target=(0.0, 0.0, 0.0), distance=2.0, height=0.1, device=dev)
+    bg = torch.zeros(3, device=dev)
+    vb = ViewBatch(_settings(cams, W, H, bg, [0.8, 0.8]))
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+
+    def run():
+        return GaussianRasterizerViews(vb)(means3D=t["means3D"], means2D=torch.zeros(2, 3000, 3, device=dev),
+                                           shs=None, colors_precomp=t["colors"], opacities=t["opacities"],
+                                           scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    try:
+        rasterizer.set_host_sync(False)
+        rasterizer._capacity_hwm.clear()
+        ref = run()[0].clone()          # first call sizes the buffer with a host read
+        rasterizer.check_status()
+        key = (t["means3D"].device.index, W, H, 3, 3000)
+        assert rasterizer._capacity_hwm[key] > 1024
+        rasterizer._capacity_hwm[key] = 64   # pretend the mark came from a much lighter batch
+        run()
+        with pytest.raises(_lib.FnxError):
+            rasterizer.check_status()
+        assert rasterizer._capacity_hwm[key] > 1024  # grown from the reported instance count
+        again = run()[0]
+        rasterizer.check_status()
+        assert torch.equal(again, ref)
+    finally:
+        rasterizer.set_host_sync(True)
