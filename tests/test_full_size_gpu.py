@@ -1,0 +1,142 @@
+"""-m gpu: BASELINE config 3 at FULL size (200k fluid + 100k background Gaussians, 5 views at 512 x 512) through the
+C ABI, checked with size-independent properties instead of the CPU oracle (which needs minutes at this size):
+
+  binning   every tile list is ordered by (depth bits, id) -- the unique order the reference's stable radix sort of
+            (tile | depth) keys emitted in id order produces; every listed splat's rectangle contains the tile; the
+            instance counts add up (sum of tiles_touched = num_rendered = sum of range lengths: a checksum of
+            checksums); the listed multiset is exactly {(tile, id) : tile in rect(id)}
+  blend     deterministic (two runs bit-identical); affine in the colours and the background within fp32 rounding
+            (C(a c1 + b c2, a bg1 + b bg2) = a C(c1, bg1) + b C(c2, bg2)); final_T in [0, 1], n_contrib <= list length
+  batching  a view of the 5-view launch sequence equals the single-view call bit for bit
+  backward  linear in dL/dpixel; the colour gradient equals the directional derivative of the (affine) forward
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fluidnexus_amd import synthetic as S  # noqa: E402
+
+P_FLUID, P_BG, SIZE, VIEWS = 200_000, 100_000, 512, 5
+
+
+@pytest.fixture(scope="module")
+def scene():
+    g = S.smoke_scene(P_FLUID, P_BG, seed=0, channels=3)
+    cams = S.arc_cameras(VIEWS, SIZE, SIZE, device="cpu")
+    return g, cams
+
+
+def _run(g, cam, bg, colors=None):
+    from tests.hip_harness import HipRun, scene_kwargs
+    kw = scene_kwargs(g, cam, SIZE, SIZE, 0.8)
+    return HipRun(bg=bg, colors_precomp=g["colors"] if colors is None else colors, scales=g["scales"],
+                  rotations=g["rotations"], **kw)
+
+
+def _rects(means2D, radii, gx, gy):
+    """ch3 auxiliary.h:46-57 (getRect) on the library's own means2D / radii."""
+    r = radii.astype(np.int64)
+    x0 = np.clip(((means2D[:, 0] - r) / 16).astype(np.int64), 0, gx)
+    y0 = np.clip(((means2D[:, 1] - r) / 16).astype(np.int64), 0, gy)
+    x1 = np.clip(((means2D[:, 0] + r + 15) / 16).astype(np.int64), 0, gx)
+    y1 = np.clip(((means2D[:, 1] + r + 15) / 16).astype(np.int64), 0, gy)
+    return x0, y0, x1, y1
+
+
+@pytest.mark.parametrize("view", [0, 2, 4])
+def test_full_size_binning_properties(scene, view):
+    g, cams = scene
+    h = _run(g, cams[view], np.zeros(3, np.float32))
+    it = h.intermediates()
+    gx = gy = SIZE // 16
+    T = gx * gy
+    ranges, plist = it["ranges"].astype(np.int64), it["point_list"].astype(np.int64)
+    radii, touched = it["radii"], it["tiles_touched"].astype(np.int64)
+    vis = radii > 0
+    assert vis.sum() > 0.9 * (P_FLUID + P_BG) and h.R > 2_000_000
+    # checksum of checksums
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert touched[vis].sum() == h.R == lens.sum() and touched[~vis].sum() == 0
+    nonempty = lens > 0
+    starts = ranges[nonempty, 0]
+    assert (np.sort(starts) == starts).all() and (ranges[nonempty, 1][:-1] == starts[1:]).all() and starts[0] == 0
+    # order inside every tile: (depth bits, id) strictly increasing
+    tile_of = np.repeat(np.arange(T), lens)
+    keys = it["depths"].view(np.uint32).astype(np.int64)[plist]
+    same_tile = tile_of[1:] == tile_of[:-1]
+    dk, di = np.diff(keys), np.diff(plist)
+    assert ((dk > 0) | ((dk == 0) & (di > 0)))[same_tile].all()
+    assert vis[plist].all()
+    # membership: tile inside the splat's rectangle, and every (tile, id) of every rectangle is listed exactly once
+    x0, y0, x1, y1 = _rects(it["means2D"], radii, gx, gy)
+    tx, ty = tile_of % gx, tile_of // gx
+    assert ((tx >= x0[plist]) & (tx < x1[plist]) & (ty >= y0[plist]) & (ty < y1[plist])).all()
+    assert (((x1 - x0) * (y1 - y0))[vis] == touched[vis]).all()
+    assert np.unique(tile_of * (P_FLUID + P_BG) + plist).size == h.R
+    # per-pixel state
+    assert (it["final_T"] >= 0).all() and (it["final_T"] <= 1).all()
+    ncon = it["n_contrib"].astype(np.int64).reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(T, 256)
+    assert (ncon.max(1) <= lens).all()
+
+
+def test_full_size_blend_deterministic_and_affine(scene):
+    g, cams = scene
+    rng = np.random.RandomState(1)
+    c1, c2 = g["colors"], rng.uniform(0, 1, size=g["colors"].shape).astype(np.float32)
+    bg1, bg2 = np.array([0.1, 0.2, 0.3], np.float32), np.array([0.9, 0.0, 0.4], np.float32)
+    a, b = np.float32(0.75), np.float32(0.25)
+    A = _run(g, cams[1], bg1, c1)
+    A2 = _run(g, cams[1], bg1, c1)
+    assert torch.equal(A.color, A2.color) and torch.equal(A.depth, A2.depth)
+    B = _run(g, cams[1], bg2, c2)
+    M = _run(g, cams[1], a * bg1 + b * bg2, a * c1 + b * c2)
+    want = a * A.color.double() + b * B.color.double()
+    assert (M.color.double() - want).abs().max().item() < 5e-6  # the blend is affine in (colours, background)
+    assert torch.equal(M.depth, A.depth)  # geometry only
+
+
+def test_full_size_view_batch_equals_single_view(scene):
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews
+    g, cams = scene
+    dev = torch.device("cuda")
+    bg = torch.tensor([0.0, 0.1, 0.2], device=dev)
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    tan = math.tan(0.4)
+    gcams = S.arc_cameras(VIEWS, SIZE, SIZE, device=dev)
+    settings = [GaussianRasterizationSettings(image_height=SIZE, image_width=SIZE, tan_fov_x=tan, tan_fov_y=tan, bg=bg,
+                                              scale_modifier=1.0, view_matrix=c.world_view_transform,
+                                              proj_matrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+                                              prefiltered=False) for c in gcams]
+    from fluidnexus_amd.rasterizer import ViewBatch
+    with torch.no_grad():
+        color, radii, depth = GaussianRasterizerViews(ViewBatch(settings))(
+            means3D=t["means3D"], means2D=torch.zeros(VIEWS, P_FLUID + P_BG, 3, device=dev), shs=None,
+            colors_precomp=t["colors"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+            cov3D_precomp=None)
+    for v in (0, 3):
+        h = _run(g, cams[v], bg.cpu().numpy())
+        assert torch.equal(color[v], h.color) and torch.equal(depth[v], h.depth) and torch.equal(radii[v], h.radii)
+
+
+def test_full_size_backward_linear_and_consistent_with_forward(scene):
+    g, cams = scene
+    rng = np.random.RandomState(2)
+    bg = np.array([0.2, 0.2, 0.2], np.float32)
+    h = _run(g, cams[2], bg)
+    d1 = rng.normal(size=(3, SIZE, SIZE)).astype(np.float32)
+    d2 = rng.normal(size=(3, SIZE, SIZE)).astype(np.float32)
+    g1, g2, g12 = h.backward(d1), h.backward(d2), h.backward(d1 + 2.0 * d2)
+    for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        want = g1[k].astype(np.float64) + 2.0 * g2[k].astype(np.float64)
+        scale = np.abs(want).max() + 1e-30
+        assert np.abs(g12[k] - want).max() / scale < 2e-4, k  # linear in dL/dpixel (fp32 atomics order)
+    # the forward is affine in the colours: <dL/dcolours, dc> = <dL/dpixels, C(c + dc) - C(c)>
+    dc = rng.normal(size=g["colors"].shape).astype(np.float32) * 0.1
+    h2 = _run(g, cams[2], bg, g["colors"] + dc)
+    lhs = float((g1["dL_dcolors"].astype(np.float64) * dc).sum())
+    rhs = float(((h2.color.double() - h.color.double()).cpu().numpy() * d1).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0)
