@@ -124,13 +124,55 @@ l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
     }
 }
 
+// Optional tail of the backward kernel (workgroup 0 only): the per-image means and the scalar loss from the forward's
+// tile partials.  Only logging consumes them, so the reduction rides inside the backward launch instead of being a
+// launch of its own between the forward and the backward.  A wave per image, fixed summation order.
+struct CombineArgs {
+    const float *partials;  // NULL: no combine
+    int N, nt;
+    float inv_count, w_l1, w_dssim;
+    float *per_image, *loss;
+};
+constexpr int kCombineMaxImages = 64;
+__device__ void combine_in_workgroup(const CombineArgs &a, float *s_term /* [kCombineMaxImages] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int n = w; n < a.N; n += 4) {
+        const float2 *p = reinterpret_cast<const float2 *>(a.partials) + (size_t)n * a.nt;
+        float x = 0.f, y = 0.f;
+        for (int i = lane; i < a.nt; i += 64) {
+            const float2 v = p[i];
+            x += v.x;
+            y += v.y;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            x += __shfl_xor(x, off);
+            y += __shfl_xor(y, off);
+        }
+        const float l1 = x * a.inv_count, ss = y * a.inv_count;
+        if (lane == 0) {
+            a.per_image[2 * n] = l1;
+            a.per_image[2 * n + 1] = ss;
+            s_term[n] = a.w_l1 * l1 + a.w_dssim * (1.0f - ss);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int n = 0; n < a.N; n++) total += s_term[n];
+        a.loss[0] = total;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, int grey,
                         Win win, const float *__restrict__ dmaps, const float *__restrict__ g_l1,
                         const float *__restrict__ g_ssim, int g_stride, float scale_l1, float scale_ssim,
-                        float *__restrict__ dL_dimg) {
+                        float *__restrict__ dL_dimg, const CombineArgs comb) {
     __shared__ float s_d[3][HS][HS + 1];
     __shared__ float s_h[3][HS][TS + 1];
+    __shared__ float s_term[kCombineMaxImages];
+    if (comb.partials && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) combine_in_workgroup(comb, s_term);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int Ce = grey ? 1 : C;
     const int n = blockIdx.z / Ce, c = blockIdx.z - n * Ce, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
@@ -268,7 +310,7 @@ int fnx_l1_ssim_backward_batch(const float *img, const float *gt, int N, int C, 
     static const Win win = make_window();
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
-                       dmaps, g_l1, g_ssim, 1, 1.0f, 1.0f, dL_dimg);
+                       dmaps, g_l1, g_ssim, 1, 1.0f, 1.0f, dL_dimg, CombineArgs{nullptr, 0, 0, 0.f, 0.f, 0.f, nullptr, nullptr});
     return hip_check("l1_ssim_backward");
 }
 int fnx_image_loss_forward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
@@ -292,8 +334,25 @@ int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
     // d loss / d l1_n = w_l1, d loss / d ssim_n = -w_dssim; the upstream scalar multiplies both
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
-                       dmaps, g_loss, g_loss, 0, w_l1, -w_dssim, dL_dimg);
+                       dmaps, g_loss, g_loss, 0, w_l1, -w_dssim, dL_dimg,
+                       CombineArgs{nullptr, 0, 0, 0.f, 0.f, 0.f, nullptr, nullptr});
     return hip_check("image_loss_backward");
+}
+int fnx_image_loss_value_and_grad(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                                  float w_dssim, float *partials, float *dmaps, float *per_image, float *loss,
+                                  const float *g_loss, float *dL_dimg, fnx_stream_t stream) {
+    if (N < 1 || N > kCombineMaxImages || !per_image || !loss || !g_loss || !dL_dimg)
+        return fail(FNX_ERR_INVALID_ARG, "image_loss_value_and_grad: bad argument (1 <= N <= %d)", kCombineMaxImages);
+    int rc = fnx_l1_ssim_forward_batch(img, gt, N, C, H, W, grey, partials, dmaps, stream);
+    if (rc) return rc;
+    static const Win win = make_window();
+    const int nt = fnx_l1_ssim_tiles(C, H, W, grey);
+    const float inv = 1.0f / (float)((size_t)(grey ? 1 : C) * H * W);
+    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, grey, win,
+                       dmaps, g_loss, g_loss, 0, w_l1, -w_dssim, dL_dimg,
+                       CombineArgs{partials, N, nt, inv, w_l1, w_dssim, per_image, loss});
+    return hip_check("image_loss_value_and_grad");
 }
 int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
                         float *dmaps, fnx_stream_t stream) {

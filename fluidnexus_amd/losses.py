@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
            "fnx_l1_ssim_backward", "fnx_l1_ssim_forward_batch", "fnx_l1_ssim_backward_batch",
-           "fnx_image_loss_forward", "fnx_image_loss_backward")
+           "fnx_image_loss_forward", "fnx_image_loss_backward", "fnx_image_loss_value_and_grad")
 
 
 def lib():
@@ -36,6 +36,7 @@ def lib():
         f = C.c_float
         L.fnx_image_loss_forward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p, p]
         L.fnx_image_loss_backward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p]
+        L.fnx_image_loss_value_and_grad.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p, p, p, p]
         _LIB = L
     return _LIB
 
@@ -142,22 +143,31 @@ _ONE = {}
 
 
 def image_loss_value_and_grad(img, gt, lambda_dssim, lambda_image=1.0, grey=True):
-    """(loss, per_image [N,2], d loss / d img) of fused_image_loss without an autograd node: forward and
-    backward kernels back to back, seeded with a resident 1.0."""
-    class _Ctx:
-        def save_for_backward(self, *t):
-            self.saved_tensors = t
-
-        def mark_non_differentiable(self, *t):
-            pass
-    ctx = _Ctx()
-    loss, per_image = _ImageLoss.forward(ctx, img, gt, (1.0 - float(lambda_dssim)) * float(lambda_image),
-                                         float(lambda_dssim) * float(lambda_image), bool(grey))
+    """(loss, per_image [N,2], d loss / d img) of fused_image_loss without an autograd node: forward and backward
+    kernels back to back (fnx_image_loss_value_and_grad: the reduction to the scalars rides inside the backward
+    launch), seeded with a resident 1.0."""
+    L = lib()
+    if not img.is_cuda:
+        raise RuntimeError("fluidnexus_amd losses: tensors must be on a HIP device (no CPU path)")
+    img = img.float().contiguous()
+    gt = gt.float().contiguous()
+    if img.shape != gt.shape or img.dim() != 4:
+        raise RuntimeError(f"image {tuple(img.shape)} / target {tuple(gt.shape)}: expected equal [N,C,H,W] shapes")
+    N, Cn, H, W = img.shape
+    Ce = 1 if grey else Cn
+    nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
+    scratch = torch.empty(N * nt * 2 + N * 2 + 1, dtype=torch.float32, device=img.device)
+    partials, per_image, loss = scratch[:N * nt * 2], scratch[N * nt * 2:N * nt * 2 + 2 * N], scratch[-1:]
+    dmaps = torch.empty(N, 3, Ce, H, W, dtype=torch.float32, device=img.device)
     one = _ONE.get(img.device)
     if one is None:
         one = _ONE[img.device] = torch.ones((), dtype=torch.float32, device=img.device)
-    dimg = _ImageLoss.backward(ctx, one, None)[0]
-    return loss, per_image, dimg
+    dimg = torch.empty_like(img)
+    w_l1, w_dssim = (1.0 - float(lambda_dssim)) * float(lambda_image), float(lambda_dssim) * float(lambda_image)
+    _check(L.fnx_image_loss_value_and_grad(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
+                                           partials.data_ptr(), dmaps.data_ptr(), per_image.data_ptr(), loss.data_ptr(),
+                                           one.data_ptr(), dimg.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return loss.view(()), per_image.view(N, 2), dimg
 
 
 def fused_image_loss(img, gt, lambda_dssim, lambda_image=1.0, grey=True):

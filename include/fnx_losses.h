@@ -47,6 +47,11 @@ int fnx_image_loss_forward(const float *img, const float *gt, int N, int C, int 
 int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
                             float w_dssim, const float *dmaps, const float *g_loss, float *dL_dimg,
                             fnx_stream_t stream);
+/* fnx_image_loss_forward + fnx_image_loss_backward as two launches: the reduction to per_image / loss (consumed by
+ * logging only) rides inside the backward launch.  g_loss: device scalar (upstream gradient, usually 1).  N <= 64. */
+int fnx_image_loss_value_and_grad(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
+                                  float w_dssim, float *partials, float *dmaps, float *per_image, float *loss,
+                                  const float *g_loss, float *dL_dimg, fnx_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

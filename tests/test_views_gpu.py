@@ -255,3 +255,21 @@ def test_views_sync_free_capacity_overflow_is_reported():
         assert torch.equal(again, ref)
     finally:
         rasterizer.set_host_sync(True)
+
+
+def test_image_loss_value_and_grad_matches_autograd_node():
+    """The hot loop's two-launch image term (scalar reduction inside the backward launch) against the autograd
+    node fused_image_loss: loss, per-image terms and the gradient with respect to the rendered batch."""
+    from fluidnexus_amd.losses import fused_image_loss, image_loss_value_and_grad
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    img = torch.rand(5, 3, 70, 90, generator=gen).to(dev)
+    gt = torch.rand(5, 3, 70, 90, generator=gen).to(dev)
+    x = img.clone().requires_grad_(True)
+    loss_a, per_a = fused_image_loss(x, gt, 0.2, 0.8)
+    loss_a.backward()
+    loss_b, per_b, g_b = image_loss_value_and_grad(img, gt, 0.2, 0.8)
+    torch.cuda.synchronize()
+    assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * abs(loss_a.item())
+    assert (per_a - per_b).abs().max().item() <= 2e-6
+    assert torch.equal(x.grad, g_b)
