@@ -197,13 +197,17 @@ typedef struct {
     size_t conic_opacity; /* f32[4P]                                                */
     size_t rgb;           /* f32[3P]  SH colours                                    */
     size_t tiles_touched; /* u32[P]                                                 */
-    size_t sort_key0;     /* u32[P]   depth bits (0xFFFFFFFF if culled); sort ping  */
-    size_t sort_key1;     /* u32[P]   sort pong                                     */
-    size_t sort_val0;     /* u32[P]   after the sort: ids in (depth bits, id) order */
+    size_t sort_key0;     /* u32[P]   depth bits (0xFFFFFFFF if culled) as written by the preprocess; with
+                             sort_key1 one (key - nearest key, id) pair buffer uint2[P] of the depth sort */
+    size_t sort_key1;     /* u32[P]   second half of that pair buffer                */
+    size_t sort_val0;     /* u32[P]   with sort_val1 the other pair buffer uint2[P]; it holds the pairs in
+                             (depth bits, id) order after three passes, the first one after four        */
     size_t sort_val1;     /* u32[P]                                                 */
     size_t rect;          /* u32[2P]  tile rectangle of each splat: x0 | x1 << 16, y0 | y1 << 16 (0, 0 if invisible) */
     size_t rect_sorted;   /* u32[2P]  the same in depth-rank order                  */
-    size_t sort_hist;     /* u32[(2*ceil(P/1024)+1)*256] radix digit histograms + prefixes */
+    size_t sort_hist;     /* u32[...] sort scratch: 512-digit chunk histograms + prefixes, digit totals, control
+                             words (nearest key, fourth-pass flag), key minima / maxima per block, instances per
+                             rank block, emission work items (csrc/fnx_state.h: sort_scratch)                  */
     size_t blk_hist;      /* u16[ceil(P/1024) * T] splats of depth-rank block b touching tile t */
     size_t blk_rel;       /* u32[ceil(P/1024) * T] exclusive prefix over blocks     */
     size_t blend_rec;     /* f32[16P] packed per-splat record read by the blend kernels:
