@@ -15,10 +15,11 @@
 //   tile_scan       (raster_forward.hip) tile totals -> [start,end) ranges, num_rendered
 //   emit            each rank block owns the slice [start + blk_rel, +blk_hist) of every tile's
 //                   segment.  Slices of consecutive blocks are consecutive in depth, so a tile's list
-//                   is ordered as soon as every slice is: the block bucket-sorts its instances by
-//                   tile in LDS (counting sort, LDS atomics), orders each (block, tile) slice -- ~10
-//                   entries on average -- by counting smaller ranks, and writes splat ids straight to
-//                   their final position.  No global atomics, no per-tile sort pass.
+//                   is ordered as soon as every slice is.  Work items (tile_scan): a rank block, or a band
+//                   of tile rows of a heavy one; persistent workgroups take them by ticket.  Per sub-batch
+//                   of <= 256 ranks every tile gets an LDS bitmask of the ranks touching it (atomicOr);
+//                   an instance's position in its slice is the number of set bits below its own, and the
+//                   splat id goes straight to its final position.  No global atomics, no per-tile sort.
 //
 // (depth bits, id) is a total order and the reference's radix sort is stable over keys emitted in
 // id order, so the resulting lists are bit-identical to the reference's point_list.
