@@ -63,19 +63,3 @@ if hasattr(lib, "fnx_debug_emit_clock"):
     for off, label in ((0, "wg 0 (heavy)"), (8, "wg 200")):
         ph = [big[4 * 16000 + off + i] for i in range(8)]
         print(" ", label, "phase cycles:", {n: int(v) for n, v in zip(names, ph)}, "total", sum(ph))
-
-if hasattr(lib, "fnx_debug_blend_clock"):
-    n = 1024 * a.views
-    buf = (C.c_ulonglong * (4 * n))()
-    lib.fnx_debug_blend_clock(buf, 4 * n)
-    arr = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).astype(np.int64)
-    t0 = arr[:, 0].min()
-    st, en = (arr[:, 0] - t0) / 100.0, (arr[:, 1] - t0) / 100.0
-    dur = en - st
-    print("blend fwd WGs", n, "span us", en.max(), "dur mean", dur.mean(), "median", np.median(dur), "p90", np.percentile(dur, 90),
-          "max", dur.max(), "start max", st.max(), "sum/span (avg concurrency)", dur.sum() / en.max())
-    ts = np.linspace(0, en.max(), 21)
-    print("  resident WGs over time:", [int(((st <= t) & (en > t)).sum()) for t in ts])
-    A = np.stack([np.ones(n), arr[:, 2]], 1).astype(np.float64)
-    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
-    print("  fit dur = %.2f + %.5f * entries (us); entries mean %.0f max %d" % (coef[0], coef[1], arr[:, 2].mean(), arr[:, 2].max()))
