@@ -62,7 +62,7 @@ def physics():
     lib.fnx_knn_mean_dist2.restype = i
     lib.fnx_knn_mean_dist2.argtypes = [p, i, f, p, p, p]
     lib.fnx_adam_step.restype = i
-    lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, C.c_double, C.c_double, f, p, p, f, p]
+    lib.fnx_adam_step.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, C.c_double, C.c_double, f, p, p, f, p, p]
     _LIB = lib
     return lib
 

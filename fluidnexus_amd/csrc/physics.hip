@@ -595,15 +595,16 @@ knn_mean_dist2_kernel(const float *__restrict__ xyz, int N, float inv_cell, floa
 // g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch, then torch.optim.Adam's update (amsgrad off, no weight decay),
 // fp32 throughout like torch's fused kernel.  `step` holds the number of steps taken so far; every workgroup
 // reads the old value, and the workgroup that finishes LAST (a self-resetting arrival counter) advances it, so
-// the step costs one launch.  One adam_step at a time per device (the counter is a module global).
+// the step costs one launch.  The counter is caller-provided per-optimiser state (`arrived`, one zero-initialised
+// word next to `step`), so steps of different optimisers may be in flight on different streams.
 // scaled_out (optional) receives the updated x * scale -- the positions in simulation units the next
 // iteration's neighbour search starts from.
-__device__ unsigned int g_adam_arrived = 0;
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, float s0, const float *__restrict__ g1,
                  float s1, const float *__restrict__ g2, float s2, float inv_batch, float *__restrict__ m,
                  float *__restrict__ v, float *__restrict__ step, float lr, float b1, float b2, float omb1,
-                 float omb2, float eps, float *__restrict__ grad_out, float *__restrict__ scaled_out, float scale) {
+                 float omb2, float eps, float *__restrict__ grad_out, float *__restrict__ scaled_out, float scale,
+                 unsigned int *__restrict__ arrived) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float t = step[0] + 1.0f;
     if (i < n) {
@@ -626,9 +627,9 @@ adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, flo
     }
     __syncthreads();  // every thread of the workgroup has read step[0]
     if (threadIdx.x == 0 && !(t < 0.5f)) {  // (always true: t >= 1) the comparison makes the read complete first
-        if (atomicAdd(&g_adam_arrived, 1u) == gridDim.x - 1) {  // all workgroups have read the old value
+        if (atomicAdd(arrived, 1u) == gridDim.x - 1) {  // all workgroups have read the old value
             step[0] = t;
-            g_adam_arrived = 0;
+            *arrived = 0;
         }
     }
 }
@@ -1236,15 +1237,16 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
                   float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1_d,
-                  double beta2_d, float eps, float *grad_out, float *scaled_out, float scale, fnx_stream_t stream) {
+                  double beta2_d, float eps, float *grad_out, float *scaled_out, float scale, unsigned int *arrived,
+                  fnx_stream_t stream) {
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
-    if (n < 0 || (n > 0 && (!x || !exp_avg || !exp_avg_sq)) || !step || !(g0 || g1 || g2))
+    if (n < 0 || (n > 0 && (!x || !exp_avg || !exp_avg_sq)) || !step || !arrived || !(g0 || g1 || g2))
         return fail(FNX_ERR_INVALID_ARG, "adam_step: bad argument");
     hipStream_t s = (hipStream_t)stream;
     // n == 0 still advances the step count: one (empty) workgroup
     hipLaunchKernelGGL(adam_step_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, x, n, g0, s0, g1, s1, g2, s2,
                        inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, (float)(1.0 - (double)beta1_d),
-                       (float)(1.0 - (double)beta2_d), eps, grad_out, scaled_out, scale);
+                       (float)(1.0 - (double)beta2_d), eps, grad_out, scaled_out, scale, arrived);
     return hip_check("adam_step");
 }
 

@@ -118,12 +118,19 @@ class GaussianModel:
         est = self._own("_estimate_xyz")
         if getattr(self, "_counts", None) is None or self._counts.shape[0] != N:
             self._counts = torch.zeros(N, 1, dtype=torch.float32, device=xyz.device)
-        g = (C.c_float * 3)(*[float(v) for v in self._gravity.reshape(3).tolist()])
+        g = (C.c_float * 3)(*self._host_gravity())
         physics.PL.check(lib.fnx_pbf_predict(xyz.data_ptr(), vel.data_ptr(), buo.data_ptr(), force.data_ptr(), est.data_ptr(),
                                              self._own("_counts").data_ptr(), N, g, float(alpha), float(secs),
                                              float(self.buoyancy_max_y * self.scale_factor), float(self.buoyancy_decay_rate),
                                              physics._stream()))
         self.invalidate_caches()
+
+    def _host_gravity(self):
+        """Gravity as host floats; refreshed only when the tensor object changes (load_hidden), never per step."""
+        hit = getattr(self, "_gravity_host_of", None)
+        if hit is None or hit[0] is not self._gravity:
+            hit = self._gravity_host_of = (self._gravity, tuple(float(v) for v in self._gravity.reshape(3).tolist()))
+        return hit[1]
 
     def update_solver_counts(self):
         self._counts += 1.0
@@ -369,8 +376,11 @@ class GaussianModel:
         return self._estimate_xyz_nn * self.scale_factor + self._secs * estimate_velocity
 
     def invalidate_caches(self):
-        """Forget everything derived from the current particle state (grids, memoised forwards)."""
+        """Forget everything derived from the current particle state (grids, memoised forwards).  Storage that
+        depends on the particle COUNT only (solver scratch, the solver's grid buffers) is kept."""
+        keep = {k: v for k, v in self._grid_cache.items() if k == "pbf_grid" or (isinstance(k, tuple) and k[0] == "scratch")}
         self._grid_cache.clear()
+        self._grid_cache.update(keep)
         self._state_memos.clear()
         self._visual_memo = (None, {})
 
@@ -438,6 +448,29 @@ class GaussianModel:
         return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
                                           self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1],
                                           share_output=getattr(self, "share_visual_output", False))
+
+    @torch.no_grad()
+    def update_visual_xyz_from_nn(self):
+        """:1500-1502"""
+        self._visual_xyz = self.get_visual_xyz_from_nn().detach().clone().requires_grad_(False)
+        self._visual_grid = None
+        self.invalidate_caches()
+
+    def get_visual_xyz_from_hidden_guess(self):
+        """:1504-1547: the visual particles advected by the poly6-weighted solver velocities (_velocity) of the
+        hidden particles at their guessed positions (_estimate_xyz) -- update_visual_particles without the
+        in-place update.  Not differentiable here (no entry script back-propagates through it)."""
+        out = self._visual_xyz.detach().float().contiguous().clone()
+        V, N = out.shape[0], self._estimate_xyz.shape[0]
+        if V == 0 or N == 0:
+            return out
+        lib = physics.PL.physics()
+        grid = physics.HashGrid(self._estimate_xyz, self.H, build=False)
+        physics.PL.check(lib.fnx_visual_advect(out.data_ptr(), V, self._own("_estimate_xyz").data_ptr(),
+                                               self._own("_velocity").data_ptr(), N, float(self.H), float(self._secs),
+                                               float(self.EPSILON), grid.blob.data_ptr(),
+                                               self._pbf_scratch(4 * V, "advect").data_ptr(), physics._stream()))
+        return out
 
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):

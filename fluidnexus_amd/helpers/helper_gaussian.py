@@ -1,8 +1,18 @@
-"""FluidDynamics/helpers/helper_gaussian.py:4-26: model name -> class."""
+"""FluidDynamics/helpers/helper_gaussian.py:4-26: model name -> class (same names, same default, same error)."""
 
 
-def get_model(model="gm_dynamics"):
-    if model == "gm_dynamics":
+def get_model(model="gm_gs"):
+    if model == "gm_fluid":
+        # the fluid model of the ScalarReal scenes: fluid and background are not separated
+        from ..gaussian_splatting.gm_fluid import GaussianModel
+    elif model == "gm_background":
+        from ..gaussian_splatting.gm_background import GaussianModel
+    elif model == "gm_dynamics":
         from ..gaussian_splatting.gm_dynamics import GaussianModel
-        return GaussianModel
-    raise NotImplementedError(f"model {model} is outside this round's hot-path scope (SURVEY 8(f))")
+    elif model == "gm_gs":
+        # vanilla 3DGS with SH colour (gaussian_splatting/gaussian_model.py): not on any fluid pipe (SURVEY finding 3)
+        raise NotImplementedError("gm_gs (vanilla SH Gaussian model) is outside the hot-path scope; "
+                                  "use gm_dynamics / gm_fluid / gm_background")
+    else:
+        raise ValueError(f"Model {model} not found")
+    return GaussianModel

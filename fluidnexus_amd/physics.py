@@ -259,6 +259,8 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=Non
         st["exp_avg_sq"] = torch.zeros_like(param, memory_format=torch.preserve_format)
     if not st["step"].is_cuda:
         raise RuntimeError("adam_step needs the optimiser state on the device (capturable=True)")
+    if "fnx_arrived" not in st:  # arrival counter of the kernel's "last workgroup advances the step count" protocol
+        st["fnx_arrived"] = torch.zeros(1, dtype=torch.int32, device=param.device)
     terms = [(t, float(sc)) for t, sc in terms if t is not None]
     if not 1 <= len(terms) <= 3:
         raise RuntimeError("adam_step takes one to three gradient terms")
@@ -271,7 +273,8 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=Non
     PL.check(lib.fnx_adam_step(x.data_ptr(), x.numel(), ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
                                1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                               ptr(grad_out), ptr(scaled_out), float(scale), _stream()))
+                               ptr(grad_out), ptr(scaled_out), float(scale), st["fnx_arrived"].data_ptr(),
+                               _stream()))
 
 
 def knn_mean_dist2(points):

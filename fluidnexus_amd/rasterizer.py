@@ -28,9 +28,12 @@ _HOST_SYNC = True          # True = reference behaviour (exact-size binning buff
 _CAP_SLACK = 1.3           # head-room over the high-water mark when host sync is off
 _capacity_hwm: dict = {}   # (device, W, H, channels) -> capacity in instances
 _pending_status: list = []  # (ring slot, key) of sync-free forwards whose status has not been read yet
-_status_ring: dict = {}     # device index -> persistent int32[_RING, 8] copy of each forward's header words
-_RING = 256
+_captured_status: list = []  # (device, slot, key) of forwards recorded into a hipGraph: re-read on every check_status()
+_status_ring: dict = {}     # device index -> persistent int32[_RING + _CAPTURED, 8] copy of each forward's header words
+_RING = 256                 # rotating slots of eager forwards
+_CAPTURED = 8192            # slots owned by captured forwards (rows _RING ... of the same tensor), never recycled
 _ring_next = 0
+_captured_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
@@ -50,21 +53,55 @@ def _ring(dev: torch.device) -> torch.Tensor:
     if r is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("run one sync-free forward eagerly before capturing a graph")
-        r = torch.zeros(_RING, 8, dtype=torch.int32, device=dev)
+        r = torch.zeros(_RING + _CAPTURED, 8, dtype=torch.int32, device=dev)
         _status_ring[dev.index] = r
     return r
+
+
+def _status_slots(dev: torch.device, n: int, key):
+    """n consecutive ring rows for the header words of one sync-free forward (one per view), registered for
+    check_status().  An eager forward takes rotating rows and is checked once; a forward that is being recorded into
+    a hipGraph takes rows of its own that every replay rewrites, and check_status() re-reads them on every call --
+    replays run no Python, so a popped entry would never be looked at again."""
+    global _ring_next, _captured_next
+    ring = _ring(dev)
+    if torch.cuda.is_current_stream_capturing():
+        if _captured_next + n > _CAPTURED:
+            raise RuntimeError("status slots of captured forwards exhausted: rasterizer.release_captured_status()")
+        slot = _RING + _captured_next
+        _captured_next += n
+        for v in range(n):
+            _captured_status.append((dev.index, slot + v, key))
+        return ring, slot
+    if _ring_next % _RING + n > _RING:  # keep the n rows contiguous
+        _ring_next += _RING - _ring_next % _RING
+    slot = _ring_next % _RING
+    _ring_next += n
+    for v in range(n):
+        _pending_status.append((dev.index, slot + v, key))
+    while len(_pending_status) > _RING:
+        del _pending_status[0]
+    return ring, slot
+
+
+def release_captured_status():
+    """Forget the status rows of captured forwards (call when the graphs that own them are gone)."""
+    global _captured_next
+    _captured_status.clear()
+    _captured_next = 0
 
 
 def check_status():
     """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity;
     also refreshes the binning high-water marks and `last_num_rendered`."""
     global last_num_rendered
-    if not _pending_status:
+    if not _pending_status and not _captured_status:
         return
     host = {d: r.cpu() for d, r in _status_ring.items()}  # one small D2H copy per device, synchronising
     first, err = True, None
-    while _pending_status:
-        dev_index, slot, key = _pending_status.pop()
+    entries = list(reversed(_pending_status)) + list(_captured_status)
+    _pending_status.clear()
+    for dev_index, slot, key in entries:
         n, status, cap = (int(x) for x in host[dev_index][slot][:3])
         _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n * _CAP_SLACK) + 1024)
         if first:
@@ -148,15 +185,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                                               bg.data_ptr(), _ptr(colors_precomp), radii.data_ptr(),
                                               color.data_ptr(), depth.data_ptr(), stream))
             if num_rendered < 0:
-                global _ring_next
-                ring = _ring(dev)
-                slot = _ring_next % _RING
-                _ring_next += 1
+                ring, slot = _status_slots(dev, 1, key)
                 al = (-img.data_ptr()) % 256  # the header sits at the first 256-byte boundary of the blob
                 ring[slot].copy_(img[al:al + 32].view(torch.int32))
-                _pending_status.append((dev.index, slot, key))
-                if len(_pending_status) > _RING:
-                    del _pending_status[0]
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.channels = Cn
@@ -304,21 +335,11 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             binning = torch.empty(V * bbytes, **u8)
             status_ptr = None
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
-                global _ring_next
-                ring = _ring(dev)
-                if _ring_next % _RING + V > _RING:  # keep the V slots contiguous
-                    _ring_next += _RING - _ring_next % _RING
-                slot = _ring_next % _RING
-                _ring_next += V
+                ring, slot = _status_slots(dev, V, key)
                 status_ptr = ring[slot:slot + V].data_ptr()
             _lib.check(lib.fnx_forward_stage2_views_status(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
                                                            P, W, H, vbatch.bg.data_ptr(), radii.data_ptr(),
                                                            color.data_ptr(), depth.data_ptr(), status_ptr, stream))
-            if not synced:
-                for v in range(V):
-                    _pending_status.append((dev.index, slot + v, key))
-                while len(_pending_status) > _RING:
-                    del _pending_status[0]
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn

@@ -52,10 +52,12 @@ def _static_attributes(gm, pos_type, gs_only):
     names += [f"_gs_{n}" for n in ("opacity", "scales", "rotation", "color")]
     raws = [getattr(gm, n) for n in names]
     cacheable = not any(t.requires_grad for t in raws)
-    key = (id(gm), pos_type, gs_only) + tuple((id(t), t._version) for t in raws)
+    # the entry keeps the raw tensors alive and compares them by identity: ids of freed tensors are recycled
+    key = (pos_type, gs_only) + tuple(t._version for t in raws)
     if cacheable:
         hit = _STATIC_CACHE.get(id(gm))
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and hit[2] is gm and len(hit[3]) == len(raws) and all(
+                a is b for a, b in zip(hit[3], raws)):
             return hit[1]
     if gs_only:
         out = (gm.get_gs_opacity, gm.get_gs_scaling, gm.get_gs_rotation, gm.get_gs_color)
@@ -66,7 +68,7 @@ def _static_attributes(gm, pos_type, gs_only):
         out = (torch.cat([opacity, gm.get_gs_opacity], dim=0).float(), torch.cat([scales, gm.get_gs_scaling], dim=0).float(),
                torch.cat([rotations, gm.get_gs_rotation], dim=0).float(), torch.cat([colors, gm.get_gs_color], dim=0).float())
     if cacheable:
-        _STATIC_CACHE[id(gm)] = (key, out)
+        _STATIC_CACHE[id(gm)] = (key, out, gm, raws)
     return out
 
 
@@ -146,12 +148,14 @@ def _view_batch(GRsetting, cameras, bg_color, scaling_modifier, sh_degree):
     from ..rasterizer import ViewBatch
     key = (tuple(id(c) for c in cameras), id(bg_color), bg_color._version, float(scaling_modifier), int(sh_degree))
     hit = _VIEW_BATCH_CACHE.get(key)
-    if hit is None:
+    # the entry holds the cameras and the background tensor, so their ids cannot be recycled while it lives
+    if hit is None or hit[2] is not bg_color or any(a is not b for a, b in zip(hit[1], cameras)):
         if len(_VIEW_BATCH_CACHE) > 64:
             _VIEW_BATCH_CACHE.clear()
-        hit = ViewBatch([_settings(GRsetting, cam, bg_color, scaling_modifier, sh_degree) for cam in cameras])
+        hit = (ViewBatch([_settings(GRsetting, cam, bg_color, scaling_modifier, sh_degree) for cam in cameras]),
+               tuple(cameras), bg_color)
         _VIEW_BATCH_CACHE[key] = hit
-    return hit
+    return hit[0]
 
 
 _ZERO = {}

@@ -142,10 +142,12 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
  * stays loadable by torch.  The betas are doubles so that 1 - beta is rounded from the double difference like
  * torch's (1 - 0.999f differs from float(0.001) by 1.3e-5 relative).  grad_out (optional) receives g; scaled_out
  * (optional) receives the updated x * scale (the positions in simulation units, gm_dynamics.py:1256).
- * Not reentrant per device: one adam step at a time (a device-global arrival counter advances *step). */
+ * `arrived`: one zero-initialised device word owned by this optimiser (the last workgroup to arrive advances *step
+ * and resets the word); steps of different optimisers may overlap, two steps of the same one may not. */
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
                   float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1, double beta2,
-                  float eps, float *grad_out, float *scaled_out, float scale, fnx_stream_t stream);
+                  float eps, float *grad_out, float *scaled_out, float scale, unsigned int *arrived,
+                  fnx_stream_t stream);
 
 #ifdef __cplusplus
 }
