@@ -29,11 +29,15 @@ class GeomLayout(C.Structure):
 
 class ImageLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("header", "final_T", "n_contrib", "ranges", "tile_count", "total")]
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "total")]
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, c_size_t) for n in ("point_list", "total")]
+    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "total")]
+
+
+class StaticLayout(C.Structure):
+    _fields_ = [(n, c_size_t) for n in ("header", "starts", "radii", "blend_rec", "pairs", "total")]
 
 
 ALLOC_FN = C.CFUNCTYPE(c_void_p, c_size_t, c_void_p)
@@ -46,6 +50,8 @@ SYMBOLS = (
     "fnx_profile_enable", "fnx_profile_read",
     "fnx_forward_stage1_views", "fnx_forward_stage2_views", "fnx_forward_stage2_views_status",
     "fnx_rasterize_backward_views",
+    "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
+    "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
 )
 
 
@@ -100,6 +106,21 @@ def raster():
     lib.fnx_rasterize_backward_views.restype = i
     lib.fnx_rasterize_backward_views.argtypes = [i, i, i, i, i, p, i, i, p, p, p, p, f, p, p, p, p, p, fp, fp, p,
                                                  p, p, c_int64, p, p, p, p, p, p, p, p, p, p, p, p, p, i, i, p]
+    # static-split extension
+    lib.fnx_static_bytes.restype = c_size_t
+    lib.fnx_static_bytes.argtypes = [i, i, i, c_int64]
+    lib.fnx_binning_bytes_split.restype = c_size_t
+    lib.fnx_binning_bytes_split.argtypes = [c_int64, c_int64]
+    lib.fnx_static_finalize_views.restype = i
+    lib.fnx_static_finalize_views.argtypes = [i, p, p, p, i, i, i, i, c_int64, p, p, p]
+    lib.fnx_forward_stage1_views_split.restype = i
+    lib.fnx_forward_stage1_views_split.argtypes = lib.fnx_forward_stage1_views.argtypes[:-1] + [p, i, c_int64, p]
+    lib.fnx_forward_stage2_views_split.restype = i
+    lib.fnx_forward_stage2_views_split.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p, i, c_int64, i, p]
+    lib.fnx_rasterize_backward_views_split.restype = i
+    lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]
+    lib.fnx_binning_layout_split.argtypes = [c_int64, c_int64, C.POINTER(BinningLayout)]
+    lib.fnx_static_layout.argtypes = [i, i, i, c_int64, C.POINTER(StaticLayout)]
     lib.fnx_mark_visible.restype = i
     lib.fnx_mark_visible.argtypes = [i, p, p, p, p, p]
     lib.fnx_profile_enable.restype = i
@@ -148,7 +169,17 @@ def image_layout(W: int, H: int) -> ImageLayout:
     return L
 
 
-def binning_layout(R: int) -> BinningLayout:
+def binning_layout(R: int, R_static: int | None = None) -> BinningLayout:
+    """Layout of a binning blob; `R_static` (not None) selects the static-split layout."""
     L = BinningLayout()
-    raster().fnx_binning_layout(R, C.byref(L))
+    if R_static is None:
+        raster().fnx_binning_layout(R, C.byref(L))
+    else:
+        raster().fnx_binning_layout_split(R, R_static, C.byref(L))
+    return L
+
+
+def static_layout(P_static: int, W: int, H: int, R_static: int) -> StaticLayout:
+    L = StaticLayout()
+    raster().fnx_static_layout(P_static, W, H, R_static, C.byref(L))
     return L

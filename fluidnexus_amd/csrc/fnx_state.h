@@ -97,13 +97,30 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     o->n_contrib = off;   off = align_up(off + n * 4);
     o->ranges = off;      off = align_up(off + t * 8);
     o->tile_count = off;  off = align_up(off + t * 4);
+    o->dyn_start = off;   off = align_up(off + t * 4);
     o->total = off + kAlign;
 }
 
-inline void binning_layout(int64_t R, fnx_binning_layout_t *o) {
-    size_t r = (size_t)(R > 0 ? R : 0);
+// R = capacity of the per-call (dynamic) instances; R_static > 0: static-split layout (the merged point_list holds
+// R + R_static ids, the dynamic instances are emitted as (depth bits, id) pairs).
+inline void binning_layout(int64_t R, int64_t R_static, bool split, fnx_binning_layout_t *o) {
+    size_t r = (size_t)(R > 0 ? R : 0), rs = (size_t)(split && R_static > 0 ? R_static : 0);
     size_t off = 0;
-    o->point_list = off; off = align_up(off + r * 4);
+    o->point_list = off; off = align_up(off + (r + rs) * 4);
+    o->pairs = off;      off = align_up(off + (split ? r * 8 : 0));
+    o->total = off + kAlign;
+}
+
+// Static splat set binned once (fnx_static_finalize_views): everything the per-iteration kernels need from it.
+inline void static_layout(int P_static, int W, int H, int64_t R_static, fnx_static_layout_t *o) {
+    size_t p = (size_t)(P_static > 0 ? P_static : 0), r = (size_t)(R_static > 0 ? R_static : 0);
+    size_t t = (size_t)tiles_x(W) * tiles_y(H);
+    size_t off = 0;
+    o->header = off;    off = align_up(off + 32);
+    o->starts = off;    off = align_up(off + (t + 1) * 4);
+    o->radii = off;     off = align_up(off + p * 4);
+    o->blend_rec = off; off = align_up(off + p * 64);
+    o->pairs = off;     off = align_up(off + r * 8);
     o->total = off + kAlign;
 }
 
@@ -113,10 +130,23 @@ inline void binning_layout(int64_t R, fnx_binning_layout_t *o) {
 constexpr int kMaxViews = FNX_MAX_VIEWS;
 struct ViewBatch {
     size_t geom, img, bin;  // bytes between consecutive views' blobs (0 for a single view)
+    size_t bin_pairs;       // byte offset of the (key, id) pair array inside a binning blob (static-split mode)
+    size_t radii_stride;    // elements between consecutive views' radii (= total splat count)
     float tan_fovx[kMaxViews], tan_fovy[kMaxViews], focal_x[kMaxViews], focal_y[kMaxViews];
 };
 
+// Reference to the static blobs of a view batch (base == nullptr: no static set).  Static splats carry the ids
+// [id0, id0 + P) of the caller's arrays; the per-call (dynamic) splats the ids [0, id0).
+struct StaticRef {
+    const char *base;  // aligned start of view 0's blob
+    size_t stride;     // bytes between consecutive views' blobs
+    uint32_t id0;
+    int P;
+    size_t starts, radii, rec, pairs;  // byte offsets inside a blob
+};
+enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
+
 // header words inside the image blob
-enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2 };
+enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3 };
 
 }  // namespace fnx

@@ -20,9 +20,10 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb);
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int P, int H,
-                      uint32_t *sort_scratch_words, int V, const ViewBatch &vb);
+                       const ViewBatch &vb, const StaticRef &st);
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
+                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, int V, const ViewBatch &vb,
+                      const StaticRef &st);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
@@ -30,19 +31,24 @@ void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pa
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
                       uint32_t *blk_total, int V, const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
-                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *starts, const uint32_t *blk_rel,
                  uint32_t *emit_ctl, const uint32_t *emit_items, uint32_t *point_list, uint32_t *header,
-                 uint32_t capacity, int V, const ViewBatch &vb);
-void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
+                 uint32_t capacity, int pairs, int V, const ViewBatch &vb);
+void launch_static_pack(hipStream_t s, int P, int W, int H, const uint32_t *point_list, const uint32_t *dyn_start,
+                        const uint32_t *header, const int *radii, const float4 *blend_rec, char *blob,
+                        size_t blob_stride, const fnx_static_layout_t &L, uint32_t id0, uint32_t r_capacity, int V,
+                        const ViewBatch &vb);
+void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
-                          uint32_t *status_out, int V, const ViewBatch &vb);
+                          uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit, int V, const ViewBatch &vb);
+                           uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -119,6 +125,7 @@ struct Img {
     uint32_t *n_contrib;
     uint32_t *ranges;
     uint32_t *tile_count;
+    uint32_t *dyn_start;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -130,6 +137,7 @@ Img carve_img(char *blob, int W, int H) {
     i.n_contrib = (uint32_t *)(b + L.n_contrib);
     i.ranges = (uint32_t *)(b + L.ranges);
     i.tile_count = (uint32_t *)(b + L.tile_count);
+    i.dyn_start = (uint32_t *)(b + L.dyn_start);
     return i;
 }
 struct Bin {
@@ -137,7 +145,7 @@ struct Bin {
 };
 Bin carve_bin(char *blob, int64_t R) {
     fnx_binning_layout_t L;
-    fnx::binning_layout(R, &L);
+    fnx::binning_layout(R, 0, false, &L);
     char *b = aligned(blob);
     Bin o;
     o.point_list = (uint32_t *)(b + L.point_list);
@@ -147,20 +155,44 @@ Bin carve_bin(char *blob, int64_t R) {
 bool channels_ok(int c) { return c == 1 || c == 3; }
 
 // Strides and intrinsics of a batch of V views (focal lengths as rasterizer_impl.cu:207-208).
+// P = splats this call preprocesses; with a static set (P_static > 0 and `split`) the binning blobs use the split layout
 int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *tan_fovx, const float *tan_fovy,
-                    fnx::ViewBatch *vb) {
+                    fnx::ViewBatch *vb, bool split = false, int P_static = 0, int64_t R_static = 0) {
     if (V < 1 || V > fnx::kMaxViews) return fail(FNX_ERR_INVALID_ARG, "V must be in [1, %d] (got %d)", fnx::kMaxViews, V);
     if (!tan_fovx || !tan_fovy) return fail(FNX_ERR_INVALID_ARG, "tan_fovx / tan_fovy is NULL");
     memset(vb, 0, sizeof(*vb));
     vb->geom = fnx_geom_bytes(P, W, H);
     vb->img = fnx_image_bytes(W, H);
-    vb->bin = fnx_binning_bytes(capacity);
+    fnx_binning_layout_t BL;
+    fnx::binning_layout(capacity, R_static, split, &BL);
+    vb->bin = BL.total;
+    vb->bin_pairs = BL.pairs;
+    vb->radii_stride = (size_t)P + (size_t)(split ? P_static : 0);
     for (int v = 0; v < V; v++) {
         vb->tan_fovx[v] = tan_fovx[v];
         vb->tan_fovy[v] = tan_fovy[v];
         vb->focal_y[v] = H / (2.0f * tan_fovy[v]);
         vb->focal_x[v] = W / (2.0f * tan_fovx[v]);
     }
+    return FNX_OK;
+}
+
+// static_blobs == NULL: no static set (every field zero)
+int make_static_ref(const char *static_blobs, int P_dyn, int P_static, int W, int H, int64_t R_static,
+                    fnx::StaticRef *st) {
+    memset(st, 0, sizeof(*st));
+    if (!static_blobs) return FNX_OK;
+    if (P_static < 0 || R_static < 0 || R_static > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad static set size");
+    fnx_static_layout_t L;
+    fnx::static_layout(P_static, W, H, R_static, &L);
+    st->base = aligned(static_blobs);
+    st->stride = L.total;
+    st->id0 = (uint32_t)P_dyn;
+    st->P = P_static;
+    st->starts = L.starts;
+    st->radii = L.radii;
+    st->rec = L.blend_rec;
+    st->pairs = L.pairs;
     return FNX_OK;
 }
 
@@ -214,24 +246,47 @@ size_t fnx_image_bytes(int W, int H) {
 }
 size_t fnx_binning_bytes(int64_t R) {
     fnx_binning_layout_t L;
-    fnx::binning_layout(R, &L);
+    fnx::binning_layout(R, 0, false, &L);
+    return L.total;
+}
+size_t fnx_binning_bytes_split(int64_t capacity, int64_t R_static_capacity) {
+    fnx_binning_layout_t L;
+    fnx::binning_layout(capacity, R_static_capacity, true, &L);
+    return L.total;
+}
+size_t fnx_static_bytes(int P_static, int W, int H, int64_t R_static_capacity) {
+    fnx_static_layout_t L;
+    fnx::static_layout(P_static, W, H, R_static_capacity, &L);
     return L.total;
 }
 void fnx_geom_layout(int P, int W, int H, fnx_geom_layout_t *out) { fnx::geom_layout(P, W, H, out); }
 void fnx_image_layout(int W, int H, fnx_image_layout_t *out) { fnx::image_layout(W, H, out); }
-void fnx_binning_layout(int64_t R, fnx_binning_layout_t *out) { fnx::binning_layout(R, out); }
+void fnx_binning_layout(int64_t R, fnx_binning_layout_t *out) { fnx::binning_layout(R, 0, false, out); }
+void fnx_binning_layout_split(int64_t capacity, int64_t R_static_capacity, fnx_binning_layout_t *out) {
+    fnx::binning_layout(capacity, R_static_capacity, true, out);
+}
+void fnx_static_layout(int P_static, int W, int H, int64_t R_static_capacity, fnx_static_layout_t *out) {
+    fnx::static_layout(P_static, W, H, R_static_capacity, out);
+}
 
-int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M, int width,
-                             int height, const float *means3D, const float *shs, const float *colors_precomp,
-                             const float *opacities, const float *scales, float scale_modifier, const float *rotations,
-                             const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
-                             const float *cam_pos, const float *tan_fovx, const float *tan_fovy, int prefiltered,
-                             int *radii, fnx_stream_t stream) {
+int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M,
+                                   int width, int height, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *opacities, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                   const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                                   const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
     if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
     fnx::ViewBatch vb;
-    if (int rc = make_view_batch(V, P, width, height, 0, tan_fovx, tan_fovy, &vb)) return rc;
+    fnx::StaticRef st;
+    if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
+    if (int rc = make_view_batch(V, P, width, height, 0, tan_fovx, tan_fovy, &vb, st.base != nullptr, P_static,
+                                 R_static_capacity))
+        return rc;
+    if (st.base && (P == 0 || !radii)) return fail(FNX_ERR_INVALID_ARG, "static split needs P_dyn > 0 and radii [V, P_dyn + P_static]");
     if (V > 1 && P > 0 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
     hipStream_t s = (hipStream_t)stream;
     Img img = carve_img(image_buffer, width, height);
@@ -260,7 +315,7 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
-                           g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb);
+                           g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st);
     }
     {
     ProfScope ps(2, s);
@@ -270,9 +325,21 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
-    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.header, P, height, g.sort_hist, V, vb);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, V, vb, st);
     }
     return hip_check("stage1");
+}
+
+int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M, int width,
+                             int height, const float *means3D, const float *shs, const float *colors_precomp,
+                             const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                             const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                             const float *cam_pos, const float *tan_fovx, const float *tan_fovy, int prefiltered,
+                             int *radii, fnx_stream_t stream) {
+    return fnx_forward_stage1_views_split(channels, V, geom_buffer, image_buffer, P, D, M, width, height, means3D, shs,
+                                          colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                          viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, radii,
+                                          nullptr, 0, 0, stream);
 }
 
 int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
@@ -309,39 +376,82 @@ int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_
     return FNX_OK;
 }
 
-int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffer, char *binning_buffer,
-                                    int64_t binning_capacity, char *image_buffer, int P, int width, int height,
-                                    const float *background, const int *radii, float *out_color, float *out_depth,
-                                    uint32_t *status_out, fnx_stream_t stream) {
+int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char *binning_buffer,
+                                   int64_t binning_capacity, char *image_buffer, int P, int width, int height,
+                                   const float *background, float *out_color, float *out_depth, uint32_t *status_out,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   int materialize_all, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
     if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
         return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
     if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
-    if (binning_capacity > 0 && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
+    if ((binning_capacity > 0 || static_blobs) && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
     fnx::ViewBatch vb;
+    fnx::StaticRef st;
+    if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
     const float unused[fnx::kMaxViews] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (int rc = make_view_batch(V, P, width, height, binning_capacity, unused, unused, &vb)) return rc;
-    if (V > 1 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
+    if (int rc = make_view_batch(V, P, width, height, binning_capacity, unused, unused, &vb, st.base != nullptr, P_static,
+                                 R_static_capacity))
+        return rc;
     hipStream_t s = (hipStream_t)stream;
     Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
-    Bin bin = carve_bin(binning_buffer, binning_capacity);
-    (void)radii;  // the tile rectangles travel in the geometry blob since stage 1
+    Bin bin = carve_bin(binning_buffer, binning_capacity);  // point_list sits at offset 0 in both layouts
     const uint32_t cap = (uint32_t)binning_capacity;
     {
     ProfScope ps(4, s);
     const fnx::SortScratch L = fnx::sort_scratch(P);
     fnx::launch_emit(s, P, width, height, (const uint2 *)g.sort_val0, (const uint2 *)g.sort_key0, g.sort_hist + L.ctl,
-                     g.rect_sorted, img.ranges, g.blk_rel, g.sort_hist + L.emit_ctl, g.sort_hist + L.emit_items,
-                     bin.point_list, img.header, cap, V, vb);
+                     g.rect_sorted, img.dyn_start, g.blk_rel, g.sort_hist + L.emit_ctl, g.sort_hist + L.emit_items,
+                     bin.point_list, img.header, cap, st.base ? 1 : 0, V, vb);
     }
     {
         ProfScope ps(0, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
-                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out, V, vb);
+                                  img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
+                                  img.tile_count, img.dyn_start, st, materialize_all, V, vb);
     }
     return hip_check("stage2");
+}
+
+int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffer, char *binning_buffer,
+                                    int64_t binning_capacity, char *image_buffer, int P, int width, int height,
+                                    const float *background, const int *radii, float *out_color, float *out_depth,
+                                    uint32_t *status_out, fnx_stream_t stream) {
+    if (V > 1 && P > 0 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
+    return fnx_forward_stage2_views_split(channels, V, geom_buffer, binning_buffer, binning_capacity, image_buffer, P,
+                                          width, height, background, out_color, out_depth, status_out, nullptr, 0, 0, 0,
+                                          stream);
+}
+
+// Once per frame: instances of the static subset (already through fnx_forward_stage1_views as a splat set of its own)
+// -> the views' static blobs.
+int fnx_static_finalize_views(int V, char *geom_buffer, char *binning_scratch, char *image_buffer, int P_static,
+                              int width, int height, int id_offset, int64_t R_static_capacity, const int *radii,
+                              char *static_blobs, fnx_stream_t stream) {
+    if (P_static <= 0 || width <= 0 || height <= 0 || id_offset < 0)
+        return fail(FNX_ERR_INVALID_ARG, "bad P_static/width/height/id_offset");
+    if (!geom_buffer || !image_buffer || !static_blobs || !radii) return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (R_static_capacity < 0 || R_static_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
+    if (R_static_capacity > 0 && !binning_scratch) return fail(FNX_ERR_INVALID_ARG, "binning_scratch is NULL");
+    fnx::ViewBatch vb;
+    const float unused[fnx::kMaxViews] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (int rc = make_view_batch(V, P_static, width, height, R_static_capacity, unused, unused, &vb)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = carve_geom(geom_buffer, P_static, width, height);
+    Img img = carve_img(image_buffer, width, height);
+    Bin bin = carve_bin(binning_scratch, R_static_capacity);
+    const uint32_t cap = (uint32_t)R_static_capacity;
+    const fnx::SortScratch L = fnx::sort_scratch(P_static);
+    fnx::launch_emit(s, P_static, width, height, (const uint2 *)g.sort_val0, (const uint2 *)g.sort_key0, g.sort_hist + L.ctl,
+                     g.rect_sorted, img.dyn_start, g.blk_rel, g.sort_hist + L.emit_ctl, g.sort_hist + L.emit_items,
+                     bin.point_list, img.header, cap, 0, V, vb);
+    fnx_static_layout_t SL;
+    fnx::static_layout(P_static, width, height, R_static_capacity, &SL);
+    fnx::launch_static_pack(s, P_static, width, height, bin.point_list, img.dyn_start, img.header, radii, g.blend_rec,
+                            aligned(static_blobs), SL.total, SL, (uint32_t)id_offset, cap, V, vb);
+    return hip_check("static_finalize");
 }
 
 int fnx_forward_stage2_views(int channels, int V, char *geom_buffer, char *binning_buffer, int64_t binning_capacity,
@@ -385,16 +495,19 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
                               out_color, out_depth, stream);
 }
 
-int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
-                                 int height, const float *means3D, const float *shs, const float *colors_precomp,
-                                 const float *scales, float scale_modifier, const float *rotations,
-                                 const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
-                                 const float *campos, const float *tan_fovx, const float *tan_fovy, const int *radii,
-                                 char *geom_buffer, char *binning_buffer, int64_t binning_capacity, char *image_buffer,
-                                 const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity_views,
-                                 float *dL_dcolor_views, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D,
-                                 float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
-                                 int grad_splat_limit, int geometry_only, fnx_stream_t stream) {
+int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M, const float *background, int width,
+                                       int height, const float *means3D, const float *shs,
+                                       const float *colors_precomp, const float *scales, float scale_modifier,
+                                       const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                       const float *projmatrix, const float *campos, const float *tan_fovx,
+                                       const float *tan_fovy, const int *radii, char *geom_buffer,
+                                       char *binning_buffer, int64_t binning_capacity, char *image_buffer,
+                                       const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                                       float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
+                                       float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                       float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                                       const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                       fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // rasterize_points.cu:160
     if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix ||
@@ -407,9 +520,15 @@ int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const
     if (geometry_only && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
     if (binning_capacity < 0) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     fnx::ViewBatch vb;
-    if (int rc = make_view_batch(V, P, width, height, binning_capacity, tan_fovx, tan_fovy, &vb)) return rc;
-    if (V > 1 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
+    fnx::StaticRef st;
+    if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
+    if (int rc = make_view_batch(V, P, width, height, binning_capacity, tan_fovx, tan_fovy, &vb, st.base != nullptr,
+                                 P_static, R_static_capacity))
+        return rc;
+    if ((V > 1 || st.base) && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
+    // static splats take no gradients: the limit stays within the per-call splats; the gradient arrays span all splats
     const int limit = (grad_splat_limit < 0 || grad_splat_limit > P) ? P : grad_splat_limit;
+    const int P_all = P + (st.base ? P_static : 0);
     hipStream_t s = (hipStream_t)stream;
     Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
@@ -420,17 +539,36 @@ int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const
     const size_t cov3D_stride = cov3D_precomp ? 0 : vb.geom;
     {
         ProfScope ps(1, s);
-        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P, width, height, img.ranges, bin.point_list,
+        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P_all, width, height, img.ranges, bin.point_list,
                                    background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
                                    dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
-                                   (uint32_t)limit, V, vb);
+                                   (uint32_t)limit, V, vb, st);
     }
     const int sum_appearance = (V > 1 && !geometry_only) ? 1 : 0;
-    fnx::launch_geom_backward(channels, s, P, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
+    fnx::launch_geom_backward(channels, s, P_all, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
                               cov3D_ptr, cov3D_stride, viewmatrix, projmatrix, campos, dL_dmean2D, dL_dconic,
                               dL_dopacity_views, dL_dcolor_views, dL_dopacity, shs ? nullptr : dL_dcolor, dL_dmean3D,
                               dL_dcov3D, dL_dsh, dL_dscale, dL_drot, limit, V, sum_appearance, vb);
     return hip_check("backward");
+}
+
+int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
+                                 int height, const float *means3D, const float *shs, const float *colors_precomp,
+                                 const float *scales, float scale_modifier, const float *rotations,
+                                 const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                 const float *campos, const float *tan_fovx, const float *tan_fovy, const int *radii,
+                                 char *geom_buffer, char *binning_buffer, int64_t binning_capacity, char *image_buffer,
+                                 const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity_views,
+                                 float *dL_dcolor_views, float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D,
+                                 float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                 int grad_splat_limit, int geometry_only, fnx_stream_t stream) {
+    return fnx_rasterize_backward_views_split(channels, V, P, D, M, background, width, height, means3D, shs,
+                                              colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                                              viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+                                              binning_buffer, binning_capacity, image_buffer, dL_dpix, dL_dmean2D,
+                                              dL_dconic, dL_dopacity_views, dL_dcolor_views, dL_dopacity, dL_dcolor,
+                                              dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, grad_splat_limit,
+                                              geometry_only, nullptr, 0, 0, stream);
 }
 
 int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,

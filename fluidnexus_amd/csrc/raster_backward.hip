@@ -98,8 +98,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
                       float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
                       const uint32_t *__restrict__ header, uint32_t capacity, uint32_t grad_limit, int P,
-                      const ViewBatch vb) {
+                      const StaticRef st, const ViewBatch vb) {
     constexpr int NV = MODE == 0 ? 6 + C : 5;
+    // static-split mode: records of splats with id >= st.id0 live in the view's static blob
+    const float4 *rec_static = nullptr;
+    const uint32_t id0 = st.base ? st.id0 : 0xFFFFFFFFu;
+    if (st.base) rec_static = reinterpret_cast<const float4 *>(st.base + st.stride * blockIdx.y + st.rec);
     {
         const int vw = blockIdx.y;  // per-view scratch, pixel gradients and screen-space accumulators
         ranges = view_at(ranges, vb.img, vw);
@@ -169,7 +173,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         if ((uint32_t)tid < cnt) {
             const uint32_t q = top - 1 - tid;
             const uint32_t id = point_list[r0 + q];
-            const float4 *rec = blend_rec + 4 * (size_t)id;
+            const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
             qm = quadrant_mask_exact(ra.x, ra.y, ra.z, ra.w, rb.x, rb.z, rc.x, rc.y, tile_x0, tile_y0);
 #pragma unroll
@@ -593,12 +597,12 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit, int V, const ViewBatch &vb) {
+                           uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
 #define FNX_LAUNCH_BB(CC, MM)                                                                                           \
     hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,    \
                        bg, blend_rec, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, \
-                       header, capacity, grad_limit, P, vb)
+                       header, capacity, grad_limit, P, st, vb)
     if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
     else if (C == 3) FNX_LAUNCH_BB(3, 1);
     else if (mode == 0) FNX_LAUNCH_BB(1, 0);

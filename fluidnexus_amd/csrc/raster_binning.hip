@@ -409,15 +409,19 @@ struct InstanceWalk {
 // items come in block order across all views -- the front blocks (nearest, largest splats, most instances) first,
 // and the long items do not end up in the tail.  (Launching one workgroup per possible item and returning early
 // from the unused ones costs ~45 ns of dispatch per workgroup.)
+// PAIRS (static-split mode): an instance is written as the pair (depth bits, id) instead of the id alone -- the blend
+// kernel merges the tile's list with the static splats' by depth.
+template <bool PAIRS>
 __global__ void __launch_bounds__(kEmitThreads)
 emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__restrict__ sorted4_all,
             const uint32_t *__restrict__ sort_ctl, const uint2 *__restrict__ rect_sorted_all, int gx, int gy,
-            const uint32_t *__restrict__ ranges_all, const uint32_t *__restrict__ blk_rel_all,
+            const uint32_t *__restrict__ starts_all, const uint32_t *__restrict__ blk_rel_all,
             uint32_t *__restrict__ emit_ctl, const uint32_t *__restrict__ emit_items,
             uint32_t *__restrict__ point_list_all, uint32_t *__restrict__ header_all, uint32_t capacity, int TW, int V,
             const ViewBatch vb) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_mask[TW][kEmitMaskWords] | s_cur[TW]
     __shared__ uint32_t s_id[kSplatBlock];
+    __shared__ uint32_t s_key[PAIRS ? kSplatBlock : 1];  // depth bits of the compacted splats
     __shared__ uint2 s_rect[kSplatBlock];    // (x0 | x1 << 16, y0 | y1 << 16), tile coordinates
     __shared__ uint32_t s_pre[kSplatBlock];  // inclusive prefix of the per-splat instance counts (current window)
     __shared__ uint32_t s_wsum[kEmitThreads / 64];
@@ -442,9 +446,11 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
     const int ry0 = (int)((long long)band * gy / nbands), ry1 = (int)((long long)(band + 1) * gy / nbands);
     const uint2 *__restrict__ rect_sorted = view_at(rect_sorted_all, vb.geom, vw);
     const uint32_t *__restrict__ blk_rel = view_at(blk_rel_all, vb.geom, vw);
-    const uint32_t *__restrict__ ranges = view_at(ranges_all, vb.img, vw);
+    const uint32_t *__restrict__ starts = view_at(starts_all, vb.img, vw);  // first list position of every tile
     uint32_t *__restrict__ header = view_at(header_all, vb.img, vw);
     uint32_t *__restrict__ point_list = view_at(point_list_all, vb.bin, vw);
+    uint2 *__restrict__ pair_list = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(point_list) + vb.bin_pairs);
+    const uint32_t kmin = PAIRS ? view_at(sort_ctl, vb.geom, vw)[SORT_CTL_KMIN] : 0u;  // sorted keys are relative to it
     // ids in depth order: where the third sort pass left them, or the fourth if it had to run
     const uint2 *__restrict__ sorted_ids =  // (relative key, id) pairs
         view_at(view_at(sort_ctl, vb.geom, vw)[SORT_CTL_WIDE] ? sorted4_all : sorted3_all, vb.geom, vw);
@@ -469,16 +475,18 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
     // thread, so the workgroup-wide prefix over l is a per-thread running sum on top of a prefix over threads).
     // Positions in the compacted list order the instances exactly like the ranks do.
     {
-        uint32_t id[kEmitPer];
+        uint32_t id[kEmitPer], key[kEmitPer];
         uint2 rc[kEmitPer];
         uint32_t have = 0;
 #pragma unroll
         for (int k = 0; k < kEmitPer; k++) {
             const int rank = blk * kSplatBlock + kEmitPer * tid + k;
-            id[k] = 0;
+            id[k] = key[k] = 0;
             rc[k] = make_uint2(0u, 0u);
             if (rank < P) {
-                id[k] = sorted_ids[rank].y;
+                const uint2 kv = sorted_ids[rank];
+                id[k] = kv.y;
+                key[k] = kv.x + kmin;
                 const uint2 rect = rect_sorted[rank];
                 // clip the tile rows to the band
                 const uint32_t y0 = max(rect.y & 0xFFFFu, (uint32_t)ry0), y1 = min(rect.y >> 16, (uint32_t)ry1);
@@ -504,6 +512,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         for (int k = 0; k < kEmitPer; k++)
             if (rc[k].x | rc[k].y) {
                 s_id[pos] = id[k];
+                if (PAIRS) s_key[PAIRS ? pos : 0] = key[k];
                 s_rect[pos] = rc[k];
                 pos++;
             }
@@ -518,7 +527,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         const bool whole = (tw0 == band_t0 && tw1 == band_t1);
         lds_barrier();
         for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
-            s_cur[i] = ranges[2 * (tw0 + i)] + rel[tw0 + i];
+            s_cur[i] = starts[tw0 + i] + rel[tw0 + i];
 #pragma unroll
             for (int q = 0; q < kEmitMaskWords; q++) s_mask[q * TW + i] = 0u;  // word-major: lanes = tiles, no bank conflicts
         }
@@ -608,6 +617,8 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
                             if (r == 0x7FFFFFFFu) point_list[0] = s_id[l];
                         } else if (FNX_EXP_EMIT == 13) {  // store, but lane-contiguous
                             point_list[(size_t)blk * 8192 + (size_t)k * kEmitThreads + tid + (r >> 30)] = s_id[l];
+                        } else if (PAIRS) {
+                            pair_list[s_cur[t] + r] = make_uint2(s_key[PAIRS ? l : 0], s_id[l]);
                         } else {
                             point_list[s_cur[t] + r] = s_id[l];
                         }
@@ -688,19 +699,20 @@ void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sort
 }
 
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
-                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *ranges, const uint32_t *blk_rel,
+                 const uint32_t *sort_ctl, const uint2 *rect_sorted, const uint32_t *starts, const uint32_t *blk_rel,
                  uint32_t *emit_ctl, const uint32_t *emit_items, uint32_t *point_list, uint32_t *header,
-                 uint32_t capacity, int V, const ViewBatch &vb) {
+                 uint32_t capacity, int pairs, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
     const int TW = T < kEmitTileWindow ? T : kEmitTileWindow;
     const size_t lds = (size_t)TW * 4 * (kEmitMaskWords + 1);
-    // resident workgroups for this LDS size (host-side queries, cached)
-    static int n_cu = 0, wgs_small = 0, wgs_large = 0;
+    const void *kernel = pairs ? (const void *)emit_kernel<true> : (const void *)emit_kernel<false>;
+    // resident workgroups for this LDS size (host-side queries, cached per kernel variant)
+    static int n_cu = 0, wgs_cache[2][2] = {{0, 0}, {0, 0}};
     const bool large = TW > 1024;  // large images: static + dynamic LDS exceeds the default 64 KiB limit
-    int &wgs = large ? wgs_large : wgs_small;
+    int &wgs = wgs_cache[pairs ? 1 : 0][large ? 1 : 0];
     if (wgs == 0) {
         if (large)
-            (void)hipFuncSetAttribute((const void *)emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kEmitTileWindow * 4 * (kEmitMaskWords + 1));
         if (n_cu == 0) {
             int dev = 0;
@@ -710,7 +722,7 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
         }
         int per_cu = 0;
         const size_t lds_max = (size_t)kEmitTileWindow * 4 * (kEmitMaskWords + 1);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)emit_kernel, kEmitThreads,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kEmitThreads,
                                                          large ? lds_max : (size_t)1024 * 4 * (kEmitMaskWords + 1)) !=
                 hipSuccess || per_cu <= 0)
             per_cu = 1;
@@ -718,9 +730,64 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
         wgs = n_cu * per_cu;
     }
     const int items_bound = splat_blocks(P) * V * kEmitBands;  // never more workgroups than items
-    hipLaunchKernelGGL(emit_kernel, dim3(wgs < items_bound ? wgs : items_bound), dim3(kEmitThreads), lds, s, P, T, sorted3,
-                       sorted4, sort_ctl, rect_sorted, gx, gy, ranges, blk_rel, emit_ctl, emit_items, point_list, header,
-                       capacity, TW, V, vb);
+    const dim3 grid(wgs < items_bound ? wgs : items_bound), block(kEmitThreads);
+    if (pairs)
+        hipLaunchKernelGGL(emit_kernel<true>, grid, block, lds, s, P, T, sorted3, sorted4, sort_ctl, rect_sorted, gx, gy,
+                           starts, blk_rel, emit_ctl, emit_items, point_list, header, capacity, TW, V, vb);
+    else
+        hipLaunchKernelGGL(emit_kernel<false>, grid, block, lds, s, P, T, sorted3, sorted4, sort_ctl, rect_sorted, gx, gy,
+                           starts, blk_rel, emit_ctl, emit_items, point_list, header, capacity, TW, V, vb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Static-split mode, once per frame: after the static subset went through preprocess / sort / emit as a splat set
+// of its own (local ids 0 .. P_static-1), pack what the per-iteration kernels need into the view's static blob:
+// (depth bits, global id) pairs in list order, the exclusive tile prefix, radii and blend records.
+__global__ void __launch_bounds__(256)
+static_pack_kernel(int P, int T, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ dyn_start,
+                   const uint32_t *__restrict__ header, const int *__restrict__ radii, const float4 *__restrict__ blend_rec,
+                   char *__restrict__ blob, size_t blob_stride, size_t off_header, size_t off_starts, size_t off_radii,
+                   size_t off_rec, size_t off_pairs, uint32_t id0, uint32_t r_capacity, const ViewBatch vb) {
+    const int vw = blockIdx.y;
+    point_list = view_at(point_list, vb.bin, vw);
+    dyn_start = view_at(dyn_start, vb.img, vw);
+    header = view_at(header, vb.img, vw);
+    radii += (size_t)vw * P;  // the caller's [V, P_static] array of the static stage 1
+    blend_rec = view_at(blend_rec, vb.geom, vw);
+    blob += blob_stride * vw;
+    uint32_t *o_header = reinterpret_cast<uint32_t *>(blob + off_header);
+    uint32_t *o_starts = reinterpret_cast<uint32_t *>(blob + off_starts);
+    int *o_radii = reinterpret_cast<int *>(blob + off_radii);
+    float4 *o_rec = reinterpret_cast<float4 *>(blob + off_rec);
+    uint2 *o_pairs = reinterpret_cast<uint2 *>(blob + off_pairs);
+    const uint32_t R = header[HDR_NUM_RENDERED];
+    const bool fits = R <= r_capacity && header[HDR_STATUS] == 0u;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        o_header[SHDR_NUM_RENDERED] = fits ? R : 0u;
+        o_header[SHDR_P] = (uint32_t)P;
+        o_header[SHDR_ID0] = id0;
+    }
+    if (i <= (size_t)T) o_starts[i] = !fits ? 0u : (i < (size_t)T ? dyn_start[i] : R);
+    if (i < (size_t)P) o_radii[i] = radii[i];
+    if (i < 4 * (size_t)P) o_rec[i] = blend_rec[i];
+    if (fits && i < (size_t)R) {
+        const uint32_t id = point_list[i];
+        o_pairs[i] = make_uint2(__float_as_uint(blend_rec[4 * (size_t)id + 1].w), id + id0);
+    }
+}
+
+void launch_static_pack(hipStream_t s, int P, int W, int H, const uint32_t *point_list, const uint32_t *dyn_start,
+                        const uint32_t *header, const int *radii, const float4 *blend_rec, char *blob,
+                        size_t blob_stride, const fnx_static_layout_t &L, uint32_t id0, uint32_t r_capacity, int V,
+                        const ViewBatch &vb) {
+    const int T = tiles_x(W) * tiles_y(H);
+    size_t n = (size_t)r_capacity;
+    if (4 * (size_t)P > n) n = 4 * (size_t)P;
+    if ((size_t)T + 1 > n) n = (size_t)T + 1;
+    hipLaunchKernelGGL(static_pack_kernel, dim3((unsigned)((n + 255) / 256), V), dim3(256), 0, s, P, T, point_list,
+                       dyn_start, header, radii, blend_rec, blob, blob_stride, L.header, L.starts, L.radii, L.blend_rec,
+                       L.pairs, id0, r_capacity, vb);
 }
 
 }  // namespace fnx

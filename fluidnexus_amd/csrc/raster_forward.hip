@@ -99,13 +99,23 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
-                  float4 *__restrict__ blend_rec, int prefiltered, const ViewBatch vb) {
+                  float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb) {
     __shared__ uint32_t s_min[4];
     const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
+    radii += (size_t)vw * vb.radii_stride;
+    {
+        // static-split mode: the workgroups behind the per-call splats copy the static splats' radii out of the
+        // view's static blob (the caller's radii array covers all splats)
+        const int nb_dyn = (P + 255) / 256;
+        if ((int)blockIdx.x >= nb_dyn) {
+            const int k = ((int)blockIdx.x - nb_dyn) * 256 + (int)threadIdx.x;
+            if (k < st.P) radii[(size_t)st.id0 + k] = reinterpret_cast<const int *>(st.base + st.stride * vw + st.radii)[k];
+            return;
+        }
+    }
     view += 16 * vw;
     proj += 16 * vw;
     if (campos) campos += 3 * vw;
-    radii += (size_t)vw * P;
     clamped = view_at(clamped, vb.geom, vw);
     means2D = view_at(means2D, vb.geom, vw);
     depths = view_at(depths, vb.geom, vw);
@@ -202,15 +212,20 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
 // depending on the block's instance count, in block order (nearest = heaviest first).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ ranges,
-                 uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
+                 uint32_t *__restrict__ dyn_start, uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
-                 uint32_t *__restrict__ emit_items, size_t geom_stride) {
+                 uint32_t *__restrict__ emit_items, size_t geom_stride, const StaticRef st) {
     __shared__ uint32_t s_part[1024];
     blk_total = view_at(blk_total, geom_stride, blockIdx.y);
     emit_items = view_at(emit_items, geom_stride, blockIdx.y);
     tile_count = view_at(tile_count, img_stride, blockIdx.y);
     ranges = view_at(ranges, img_stride, blockIdx.y);
+    dyn_start = view_at(dyn_start, img_stride, blockIdx.y);
     header = view_at(header, img_stride, blockIdx.y);
+    // static-split mode: `ranges` address the merged list of a tile (static + per-call instances), dyn_start the
+    // tile's slice of the per-call instances alone
+    const uint32_t *st_starts =
+        st.base ? reinterpret_cast<const uint32_t *>(st.base + st.stride * blockIdx.y + st.starts) : nullptr;
     const int tid = threadIdx.x;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
@@ -227,15 +242,19 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
     }
     uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = b; i < e; i++) {
-        const uint32_t c = tile_count[i];
-        ranges[2 * i] = c ? run : 0u;
-        ranges[2 * i + 1] = c ? run + c : 0u;
-        run += c;
+        const uint32_t cd = tile_count[i];
+        const uint32_t s0 = st_starts ? st_starts[i] : 0u, cs = st_starts ? st_starts[i + 1] - s0 : 0u;
+        const uint32_t c = cd + cs, at = run + s0;
+        ranges[2 * i] = c ? at : 0u;
+        ranges[2 * i + 1] = c ? at + c : 0u;
+        dyn_start[i] = run;
+        run += cd;
     }
     if (tid == 1023) {
         header[HDR_NUM_RENDERED] = s_part[1023];
         header[HDR_STATUS] = 0u;
         header[HDR_CAPACITY] = 0u;
+        header[HDR_NUM_STATIC] = st_starts ? st_starts[T] : 0u;
     }
     // emission work items: exclusive prefix of the per-block band counts
     __syncthreads();
@@ -282,13 +301,24 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
 // (quadrant_mask) and every wave gets its own compacted, still depth-ordered index list, so a wave
 // only walks entries that can reach one of its pixels.  Per pixel the arithmetic and its order are
 // exactly the reference's; culled pairs are pairs it would have skipped (alpha < 1/255).
-template <int C>
+//
+// SPLIT (static-split mode, include/fnx_raster.h): a tile has TWO depth-ordered streams of (depth bits, id)
+// pairs -- the static splats' (binned once per frame) and this call's -- and the kernel merges them lazily: while
+// batch b is blended, the next 256 entries of the merged order are found by a merge-path search over the next 256
+// candidates of each stream (held in LDS), their records are requested, and the candidates after them are
+// prefetched.  Ties in depth go to the per-call stream (lower ids), as in the reference's stable sort of ids
+// emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
+// pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
+template <int C, bool SPLIT>
 __global__ void __launch_bounds__(256)
-blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
+blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
-                     uint32_t capacity, uint32_t *__restrict__ status_out, const ViewBatch vb) {
+                     uint32_t capacity, uint32_t *__restrict__ status_out, const uint32_t *__restrict__ tile_count,
+                     const uint32_t *__restrict__ dyn_start, const StaticRef st, int materialize_all,
+                     const ViewBatch vb) {
+    const char *static_blob = nullptr;
     {
         const int vw = blockIdx.y;
         ranges = view_at(ranges, vb.img, vw);
@@ -299,12 +329,20 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
         blend_rec = view_at(blend_rec, vb.geom, vw);
         out_color += (size_t)vw * C * H * W;
         out_depth += (size_t)vw * H * W;
+        if (SPLIT) {
+            tile_count = view_at(tile_count, vb.img, vw);
+            dyn_start = view_at(dyn_start, vb.img, vw);
+            static_blob = st.base + st.stride * vw;
+        }
     }
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
     __shared__ float s_col[C][256];
     __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 4];
     __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
+    __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  // merge windows: depth bits [static | per-call]
+    __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
+    __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
     if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
@@ -337,19 +375,92 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
     float pd = 0.f;
     uint32_t id_ahead = 0;
-    if (r0 + (uint32_t)tid < r1) {
-        const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
-        pa = rec[0];
-        pb = rec[1];
-        pc = rec[2];
-        if (C > 2) pd = rec[3].x;
+    // SPLIT state: the two streams of the tile, how far each has been merged, the next window of each in registers
+    const uint2 *sp = nullptr, *fp = nullptr;
+    const float4 *rec_s = nullptr;
+    uint32_t ns = 0, nf = 0, si = 0, fj = 0, my_id = 0;
+    uint2 ws = make_uint2(0u, 0u), wf = ws;
+    auto record_of = [&](uint32_t id) -> const float4 * {
+        return (SPLIT && id >= st.id0) ? rec_s + 4 * (size_t)(id - st.id0) : blend_rec + 4 * (size_t)id;
+    };
+    auto load_windows = [&]() {  // the next (up to) 256 entries of each stream behind (si, fj)
+        ws = (si + (uint32_t)tid < ns) ? sp[si + tid] : make_uint2(0xFFFFFFFFu, 0u);
+        wf = (fj + (uint32_t)tid < nf) ? fp[fj + tid] : make_uint2(0xFFFFFFFFu, 0u);
+    };
+    auto store_windows = [&]() {
+        s_wk[0][SPLIT ? tid : 0] = ws.x;
+        s_wi[0][SPLIT ? tid : 0] = ws.y;
+        s_wk[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.x;
+        s_wi[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.y;
+    };
+    // Merge path: slot t of the next batch holds the (t+1)-th smallest of the two windows in LDS.  i = number of
+    // static entries among the first t; a static entry precedes a per-call one only if its depth bits are SMALLER.
+    auto merge_batch = [&](uint32_t cnt_next) -> uint32_t {
+        uint32_t id = 0;
+        if ((uint32_t)tid < cnt_next) {
+            const uint32_t nsw = min(256u, ns - si), nfw = min(256u, nf - fj);
+            const uint32_t *ks = s_wk[0], *kf = s_wk[SPLIT ? 1 : 0];
+            const uint32_t t = (uint32_t)tid;
+            uint32_t lo = t > nfw ? t - nfw : 0u, hi = min(t, nsw);
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ks[mid] < kf[t - mid - 1]) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t i = lo, j = t - lo;
+            const bool from_static = !(j < nfw && (i >= nsw || kf[j] <= ks[i]));
+            id = from_static ? s_wi[0][i] : s_wi[SPLIT ? 1 : 0][j];
+            if (t == cnt_next - 1) s_adv = i + (from_static ? 1u : 0u);
+        }
+        return id;
+    };
+    if (SPLIT) {
+        const uint32_t *starts = reinterpret_cast<const uint32_t *>(static_blob + st.starts);
+        const uint32_t s0 = starts[tile];
+        ns = starts[tile + 1] - s0;
+        sp = reinterpret_cast<const uint2 *>(static_blob + st.pairs) + s0;
+        rec_s = reinterpret_cast<const float4 *>(static_blob + st.rec);
+        nf = tile_count[tile];
+        fp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(point_list) + vb.bin_pairs) + dyn_start[tile];
+        // batch 0: merge, request its records, prefetch the windows behind it
+        load_windows();
+        store_windows();
+        __syncthreads();
+        const uint32_t cnt0 = min(256u, r1 - r0);
+        my_id = merge_batch(cnt0);
+        __syncthreads();
+        if (cnt0) {
+            const uint32_t a = s_adv;
+            si += a;
+            fj += cnt0 - a;
+        }
+        if ((uint32_t)tid < cnt0) {
+            const float4 *rec = record_of(my_id);
+            pa = rec[0];
+            pb = rec[1];
+            pc = rec[2];
+            if (C > 2) pd = rec[3].x;
+        }
+        load_windows();
+    } else {
+        if (r0 + (uint32_t)tid < r1) {
+            const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
+            pa = rec[0];
+            pb = rec[1];
+            pc = rec[2];
+            if (C > 2) pd = rec[3].x;
+        }
+        if (r0 + 256u + (uint32_t)tid < r1) id_ahead = point_list[r0 + 256u + tid];
     }
-    if (r0 + 256u + (uint32_t)tid < r1) id_ahead = point_list[r0 + 256u + tid];
+    bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
+        const bool all_done = __syncthreads_count(done) == 256;
+        if (all_done) {
+            if (!SPLIT || !materialize_all) break;
+            blending = false;
+        }
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
-        if ((uint32_t)tid < cnt) {
+        if ((uint32_t)tid < cnt && blending) {
             qm = quadrant_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
             s_ra[tid] = pa;
             s_rb[tid] = pb;
@@ -357,14 +468,19 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
             if (C > 1) s_col[C > 1 ? 1 : 0][tid] = pc.w;
             if (C > 2) s_col[C > 2 ? 2 : 0][tid] = pd;
         }
-        if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
-            const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
-            pa = rec[0];
-            pb = rec[1];
-            pc = rec[2];
-            if (C > 2) pd = rec[3].x;
+        if (SPLIT) {
+            if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
+            store_windows();
+        } else {
+            if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
+                const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
+                pa = rec[0];
+                pb = rec[1];
+                pc = rec[2];
+                if (C > 2) pd = rec[3].x;
+            }
+            if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
         }
-        if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
         uint32_t rank[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -381,7 +497,29 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const u
                 s_list[q][off] = (uint8_t)tid;
             }
         }
+        uint32_t next_cnt = 0, next_id = 0;
+        if (SPLIT) {
+            next_cnt = base + 256u < r1 ? min(256u, r1 - base - 256u) : 0u;
+            next_id = merge_batch(next_cnt);
+        }
         __syncthreads();
+        if (SPLIT) {
+            if (next_cnt) {
+                const uint32_t a = s_adv;
+                si += a;
+                fj += next_cnt - a;
+            }
+            my_id = next_id;
+            if ((uint32_t)tid < next_cnt) {  // next batch's records: in flight while this batch is blended
+                const float4 *rec = record_of(my_id);
+                pa = rec[0];
+                pb = rec[1];
+                pc = rec[2];
+                if (C > 2) pd = rec[3].x;
+            }
+            load_windows();
+            if (!blending) continue;
+        }
         // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
         const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
@@ -464,12 +602,13 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 uint32_t *key_min_blk, uint2 *rect,
-                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
+                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st) {
     const int gx = tiles_x(W), gy = tiles_y(H);
-    hipLaunchKernelGGL((preprocess_kernel<C>), dim3((P + 255) / 256, V), dim3(256), 0, s, P, D, M, means3D, scales,
+    const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
+    hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, key_min_blk, rect, blend_rec, prefiltered, vb);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -478,38 +617,43 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
-                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb) {
+                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb);
+                               blend_rec, prefiltered, V, vb, st);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb);
+                               blend_rec, prefiltered, V, vb, st);
 }
 
-void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *header, int P, int H,
-                      uint32_t *sort_scratch_words, int V, const ViewBatch &vb) {
+void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
+                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, int V, const ViewBatch &vb,
+                      const StaticRef &st) {
     const SortScratch L = sort_scratch(P);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, header, vb.img,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
-                       sort_scratch_words + L.emit_items, vb.geom);
+                       sort_scratch_words + L.emit_items, vb.geom, st);
 }
 
-void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, const uint32_t *point_list,
+void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
-                          uint32_t *status_out, int V, const ViewBatch &vb) {
+                          uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
-    if (C == 3)
-        hipLaunchKernelGGL((blend_forward_kernel<3>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out, vb);
-    else
-        hipLaunchKernelGGL((blend_forward_kernel<1>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,
-                           blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out, vb);
+#define FNX_LAUNCH_BF(CC, SS)                                                                                          \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,   \
+                       blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
+                       tile_count, dyn_start, st, materialize_all, vb)
+    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);
+    else if (C == 3) FNX_LAUNCH_BF(3, false);
+    else if (st.base) FNX_LAUNCH_BF(1, true);
+    else FNX_LAUNCH_BF(1, false);
+#undef FNX_LAUNCH_BF
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

@@ -267,10 +267,58 @@ class ViewBatch:
         self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
 
 
+class StaticBin:
+    """The LAST P_static splats of a view batch's arrays, binned once (include/fnx_raster.h, static-split
+    extension): the frozen background Gaussians of render_dynamics seen from the fixed cameras of a frame.
+    Arguments are the STATIC subset's arrays ([P_static, ...], same conventions as GaussianRasterizer.forward);
+    `id_offset` = number of per-call splats in front of them in the full arrays.  One host sync (instance counts).
+    Pass the object as `static_bin=` to GaussianRasterizerViews.forward with the FULL arrays: only the leading
+    id_offset splats are then preprocessed / sorted / binned per call, the result is bit-identical."""
+
+    materialize_all = False  # debug: every forward writes the whole merged point_list (parity tests)
+
+    def __init__(self, view_batch, means3D, opacities, id_offset, shs=None, colors_precomp=None, scales=None,
+                 rotations=None, cov3D_precomp=None, channels=3):
+        lib = _lib.raster()
+        if not means3D.is_cuda:
+            raise RuntimeError("fluidnexus_amd rasteriser: tensors must be on a HIP device (no CPU path)")
+        dev = means3D.device
+        vb, rs = view_batch, view_batch.settings[0]
+        V, P = vb.V, means3D.shape[0]
+        if P == 0:
+            raise ValueError("StaticBin needs at least one static splat")
+        H, W = int(rs.image_height), int(rs.image_width)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        f = lambda t: empty if t is None else _f32c(t.detach())  # noqa: E731
+        means3D, opacities = f(means3D), f(opacities)
+        shs, colors_precomp, scales, rotations, cov3D_precomp = f(shs), f(colors_precomp), f(scales), f(rotations), f(cov3D_precomp)
+        M = shs.shape[1] if shs.numel() else 0
+        stream = torch.cuda.current_stream().cuda_stream
+        u8 = dict(dtype=torch.uint8, device=dev)
+        gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
+        geom, img = torch.empty(V * gbytes, **u8), torch.empty(V * ibytes, **u8)
+        radii = torch.empty(V, P, dtype=torch.int32, device=dev)
+        _lib.check(lib.fnx_forward_stage1_views(
+            int(channels), V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(shs),
+            _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+            _ptr(cov3D_precomp), vb.view.data_ptr(), vb.proj.data_ptr(), vb.campos.data_ptr(), vb.tan_x, vb.tan_y,
+            int(bool(rs.prefiltered)), radii.data_ptr(), stream))
+        n, self.R = C.c_int(0), []
+        for v in range(V):
+            _lib.check(lib.fnx_read_num_rendered(img.data_ptr() + v * ibytes, W, H, stream, C.byref(n)))
+            self.R.append(int(n.value))
+        self.R_cap = max(self.R)
+        scratch = torch.empty(V * lib.fnx_binning_bytes(self.R_cap), **u8)
+        self.blob = torch.empty(V * lib.fnx_static_bytes(P, W, H, self.R_cap), **u8)
+        _lib.check(lib.fnx_static_finalize_views(V, geom.data_ptr(), scratch.data_ptr(), img.data_ptr(), P, W, H,
+                                                 int(id_offset), self.R_cap, radii.data_ptr(), self.blob.data_ptr(), stream))
+        self.view_batch, self.P, self.id_offset, self.channels, self.W, self.H = vb, P, int(id_offset), int(channels), W, H
+
+
 def rasterize_gaussians_views(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                              view_batch, channels=3, grad_splat_limit=None):
+                              view_batch, channels=3, grad_splat_limit=None, static_bin=None):
     return _RasterizeGaussiansViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit)
+                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit, static_bin)
 
 
 class _RasterizeGaussiansViews(torch.autograd.Function):
@@ -281,7 +329,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch,
-                channels, grad_splat_limit=None):
+                channels, grad_splat_limit=None, static_bin=None):
         lib = _lib.raster()
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -292,6 +340,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         V, P = vbatch.V, means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         Cn = int(channels)
+        if static_bin is not None:
+            return _RasterizeGaussiansViews._forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                           cov3Ds_precomp, vbatch, Cn, grad_splat_limit, static_bin)
         means3D = _f32c(means3D)
         sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
@@ -343,6 +394,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
+        ctx.static_bin = None
         ctx.grad_splat_limit = -1 if grad_splat_limit is None else int(grad_splat_limit)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, depth)
@@ -350,15 +402,82 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         return color, radii, depth
 
     @staticmethod
+    def _forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch, Cn,
+                       grad_splat_limit, sb):
+        """Static-split forward: the trailing sb.P splats were binned once (StaticBin); this call preprocesses, sorts
+        and bins only the leading ones and the blend kernel merges the two streams of every tile."""
+        lib = _lib.raster()
+        dev = means3D.device
+        rs = vbatch.settings[0]
+        V, P_all = vbatch.V, means3D.shape[0]
+        P = P_all - sb.P
+        H, W = int(rs.image_height), int(rs.image_width)
+        if sb.view_batch is not vbatch or sb.id_offset != P or sb.channels != Cn or P <= 0:
+            raise ValueError("static_bin was built for another view batch / splat split / channel count")
+        if grad_splat_limit is not None and int(grad_splat_limit) > P:
+            raise ValueError("static splats take no gradients: grad_splat_limit must not exceed the per-call splat count")
+        means3D = _f32c(means3D)
+        sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
+        scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
+        M = sh.shape[1] if sh.numel() else 0
+        stream = torch.cuda.current_stream().cuda_stream
+        u8 = dict(dtype=torch.uint8, device=dev)
+        gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
+        geom = torch.empty(V * gbytes, **u8)
+        img = torch.empty(V * ibytes, **u8)
+        color = torch.empty(V, Cn, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(V, P_all, dtype=torch.int32, device=dev)
+        _lib.check(lib.fnx_forward_stage1_views_split(
+            Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
+            _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+            _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
+            vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), sb.blob.data_ptr(), sb.P, sb.R_cap,
+            stream))
+        key = (dev.index, W, H, Cn, P, "split")
+        known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
+        synced = _HOST_SYNC or not known
+        if synced:
+            n, cap = C.c_int(0), 0
+            for v in range(V):
+                _lib.check(lib.fnx_read_num_rendered(img.data_ptr() + v * ibytes, W, H, stream, C.byref(n)))
+                cap = max(cap, int(n.value))
+            if not _HOST_SYNC:
+                cap = int(cap * _CAP_SLACK) + 1024
+                _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), cap)
+        else:
+            cap = known
+            _capacity_hwm[key] = cap
+        binning = torch.empty(V * lib.fnx_binning_bytes_split(cap, sb.R_cap), **u8)
+        status_ptr = None
+        if not synced:
+            ring, slot = _status_slots(dev, V, key)
+            status_ptr = ring[slot:slot + V].data_ptr()
+        _lib.check(lib.fnx_forward_stage2_views_split(
+            Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
+            color.data_ptr(), depth.data_ptr(), status_ptr, sb.blob.data_ptr(), sb.P, sb.R_cap,
+            int(bool(StaticBin.materialize_all)), stream))
+        ctx.vbatch = vbatch
+        ctx.capacity = cap
+        ctx.channels = Cn
+        ctx.static_bin = sb
+        ctx.grad_splat_limit = P if grad_splat_limit is None else int(grad_splat_limit)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii, depth)
+        ctx.set_materialize_grads(False)
+        return color, radii, depth
+
+    @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
         if grad_out_color is None:
-            return (None,) * 11
+            return (None,) * 12
         lib = _lib.raster()
         vbatch, Cn = ctx.vbatch, ctx.channels
         rs = vbatch.settings[0]
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         dev = means3D.device
         V, P = vbatch.V, means3D.shape[0]
+        sb = ctx.static_bin
         H, W = int(rs.image_height), int(rs.image_width)
         M = sh.shape[1] if sh.numel() else 0
         need = ctx.needs_input_grad
@@ -378,19 +497,23 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         if P != 0:
             dL = _f32c(grad_out_color)
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(lib.fnx_rasterize_backward_views(
-                Cn, V, P, int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H, means3D.data_ptr(), _ptr(sh),
-                _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp),
-                vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(), vbatch.tan_x, vbatch.tan_y,
-                radii.data_ptr(), geom.data_ptr(), _ptr(binning), ctx.capacity, img.data_ptr(), dL.data_ptr(),
-                g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity_v.data_ptr(), g_colors_v.data_ptr(),
-                g_opacity.data_ptr(), g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr(),
-                g_sh.data_ptr() if M else None, g_scales.data_ptr(), g_rot.data_ptr(), ctx.grad_splat_limit,
-                geometry_only, stream))
+            args = (Cn, V, P - (sb.P if sb is not None else 0), int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H,
+                    means3D.data_ptr(), _ptr(sh),
+                    _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp),
+                    vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(), vbatch.tan_x, vbatch.tan_y,
+                    radii.data_ptr(), geom.data_ptr(), _ptr(binning), ctx.capacity, img.data_ptr(), dL.data_ptr(),
+                    g_means2D.data_ptr(), g_conic.data_ptr(), g_opacity_v.data_ptr(), g_colors_v.data_ptr(),
+                    g_opacity.data_ptr(), g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr(),
+                    g_sh.data_ptr() if M else None, g_scales.data_ptr(), g_rot.data_ptr(), ctx.grad_splat_limit,
+                    geometry_only)
+            if sb is None:
+                _lib.check(lib.fnx_rasterize_backward_views(*args, stream))
+            else:  # the gradient arrays span all splats; rows of the static ones stay zero
+                _lib.check(lib.fnx_rasterize_backward_views_split(*args, sb.blob.data_ptr(), sb.P, sb.R_cap, stream))
         if V == 1 and not geometry_only:  # a single view accumulates straight into its per-view arrays
             g_opacity, g_colors = g_opacity_v, g_colors_v
         return (g_means3D.view(P, 3), g_means2D.view(V, P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
-                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None)
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -468,6 +591,7 @@ class GaussianRasterizerViews(nn.Module):
 
     channels = 3
     grad_splat_limit = None
+    static_bin = None  # a StaticBin over the trailing splats of the arrays passed to forward (static-split mode)
 
     def __init__(self, raster_settings_list, channels=None):
         super().__init__()
@@ -491,4 +615,5 @@ class GaussianRasterizerViews(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians_views(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                         cov3D_precomp, self.view_batch, self.channels, self.grad_splat_limit)
+                                         cov3D_precomp, self.view_batch, self.channels, self.grad_splat_limit,
+                                         self.static_bin)

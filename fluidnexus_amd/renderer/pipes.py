@@ -158,6 +158,37 @@ def _view_batch(GRsetting, cameras, bg_color, scaling_modifier, sh_degree):
     return hit[0]
 
 
+# Static-split mode of the view-batched pipe (include/fnx_raster.h): while the background Gaussians take no gradient
+# they are binned once per (camera batch, background state) and only the fluid Gaussians go through preprocess / sort /
+# binning every iteration.  FNX_STATIC_SPLIT=0 or set_static_split(False) restores the one-set path.
+import os as _os
+
+_STATIC_SPLIT = _os.environ.get("FNX_STATIC_SPLIT", "1") != "0"
+_STATIC_BIN_CACHE: dict = {}
+
+
+def set_static_split(enabled: bool):
+    global _STATIC_SPLIT
+    _STATIC_SPLIT = bool(enabled)
+    _STATIC_BIN_CACHE.clear()
+
+
+def _static_bin(gm, vbatch, means3D, opacity, scales, rotations, colors, n_fluid, channels):
+    """StaticBin over the background rows [n_fluid:] of the concatenated arrays, rebuilt when the camera batch or any
+    raw background tensor changes (object or version).  The entry holds the objects it is keyed on."""
+    from ..rasterizer import StaticBin
+    raws = [getattr(gm, f"_gs_{n}") for n in ("xyz", "opacity", "scales", "rotation", "color")]
+    versions = tuple(t._version for t in raws)
+    hit = _STATIC_BIN_CACHE.get(id(gm))
+    if (hit is not None and hit[0] is gm and hit[1] is vbatch and hit[3] == versions and hit[4] == (n_fluid, channels)
+            and all(a is b for a, b in zip(hit[2], raws))):
+        return hit[5]
+    sb = StaticBin(vbatch, means3D[n_fluid:], opacity[n_fluid:], n_fluid, colors_precomp=colors[n_fluid:],
+                   scales=scales[n_fluid:], rotations=rotations[n_fluid:], channels=channels)
+    _STATIC_BIN_CACHE[id(gm)] = (gm, vbatch, raws, versions, (n_fluid, channels), sb)
+    return sb
+
+
 _ZERO = {}
 
 
@@ -208,7 +239,12 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
                                                      gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
     if not (gpf_only or gs_only) and not any(
             getattr(gm, f"_gs_{n}").requires_grad for n in ("xyz", "opacity", "scales", "rotation", "color")):
-        rasterizer.grad_splat_limit = render_xyz.shape[0]
+        n_fluid = render_xyz.shape[0]
+        rasterizer.grad_splat_limit = n_fluid
+        if _STATIC_SPLIT and 0 < n_fluid < means3D.shape[0]:
+            with torch.no_grad():
+                rasterizer.static_bin = _static_bin(gm, rasterizer.view_batch, means3D, opacity, scales, rotations,
+                                                    colors, n_fluid, rasterizer.channels)
     image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
                                      opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
                                      cov3D_precomp=None)

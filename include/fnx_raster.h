@@ -171,6 +171,69 @@ int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const
                                  float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
                                  fnx_stream_t stream);
 
+/*
+ * Static-split extension.  In the reference's dynamics stages most Gaussians are frozen: render_dynamics
+ * concatenates the optimised fluid Gaussians with the static background ones (renderer/pipe_dynamics.py:46-57),
+ * and the cameras of a frame do not move, so within a frame the background's per-tile, depth-ordered instance
+ * lists are the same in every iteration (rasterizer_impl.cu:259-296 rebuilds them every call).  Here the caller
+ * may declare the LAST P_static splats of its arrays static:
+ *   once per frame   fnx_forward_stage1_views over the static subset alone (pointers offset to it) followed by
+ *                    fnx_static_finalize_views, which emits its instances and packs what later calls need --
+ *                    per-tile (depth bits, id) lists, tile starts, radii, blend records -- into V "static blobs";
+ *   every iteration  the *_split entry points below preprocess / sort / emit only the P_dyn leading splats and
+ *                    the blend kernel merges the two depth-ordered streams of a tile while it stages them, batch
+ *                    by batch, as far as the tile's pixels need them (ties in depth: lower id first, as in the
+ *                    reference's stable sort; static ids are the larger ones).
+ * Results are bit-identical to the unsplit calls over all P_dyn + P_static splats: colour, depth, radii, final_T,
+ * n_contrib, and the prefix of point_list that the blend consumed (everything the backward reads); with
+ * materialize_all != 0 the whole merged point_list is written, for parity tests.  Static splats receive no
+ * gradients (grad_splat_limit is clamped to P_dyn); a NULL static_blobs selects the unsplit behaviour.
+ *
+ * Sizes: per-iteration geometry blobs are fnx_geom_bytes(P_dyn, W, H); binning blobs
+ * fnx_binning_bytes_split(capacity, R_static_capacity) where capacity bounds the DYNAMIC instances of a view and
+ * R_static_capacity is the value given to fnx_static_finalize_views (>= every view's static instance count);
+ * static blobs fnx_static_bytes(P_static, W, H, R_static_capacity), view v at v times that.  radii is [V, P_dyn +
+ * P_static] (the static part is copied from the blob), the gradient arrays keep their [.., P_dyn + P_static, ..]
+ * shapes.  The header words 0..2 of the image blob count DYNAMIC instances (capacity check); word 3 holds the
+ * view's static instance count.
+ */
+size_t fnx_static_bytes(int P_static, int width, int height, int64_t R_static_capacity);
+size_t fnx_binning_bytes_split(int64_t capacity, int64_t R_static_capacity);
+/* geom_buffers / image_buffers: the blobs of a completed fnx_forward_stage1_views over the static subset;
+ * binning_scratch: V * fnx_binning_bytes(R_static_capacity) bytes of scratch; id_offset: id of the first static
+ * splat in the caller's full arrays (= P_dyn).  Fails with FNX_ERR_CAPACITY status if a view has more static
+ * instances than R_static_capacity (read them with fnx_read_num_rendered first). */
+int fnx_static_finalize_views(int V, char *geom_buffers, char *binning_scratch, char *image_buffers, int P_static,
+                              int width, int height, int id_offset, int64_t R_static_capacity,
+                              const int *radii /* [V, P_static] as written by that stage 1 */, char *static_blobs,
+                              fnx_stream_t stream);
+int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffers, char *image_buffers, int P_dyn, int D, int M,
+                                   int width, int height, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *opacities, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                   const float *viewmatrices, const float *projmatrices, const float *cam_pos,
+                                   const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   fnx_stream_t stream);
+int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char *binning_buffers,
+                                   int64_t binning_capacity, char *image_buffers, int P_dyn, int width, int height,
+                                   const float *background, float *out_color, float *out_depth, uint32_t *status_out,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   int materialize_all, fnx_stream_t stream);
+int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
+                                       int height, const float *means3D, const float *shs,
+                                       const float *colors_precomp, const float *scales, float scale_modifier,
+                                       const float *rotations, const float *cov3D_precomp,
+                                       const float *viewmatrices, const float *projmatrices, const float *campos,
+                                       const float *tan_fovx, const float *tan_fovy, const int *radii,
+                                       char *geom_buffers, char *binning_buffers, int64_t binning_capacity,
+                                       char *image_buffers, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                                       float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
+                                       float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                       float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                                       const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                       fnx_stream_t stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-25): present[i] = view-space z > 0.2 (auxiliary.h:138). */
 int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                      fnx_stream_t stream);
@@ -215,20 +278,32 @@ typedef struct {
     size_t total;
 } fnx_geom_layout_t;
 typedef struct {
-    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen  */
+    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split) */
     size_t final_T;     /* f32[H*W]                                                 */
     size_t n_contrib;   /* u32[H*W]                                                 */
-    size_t ranges;      /* u32[2T] per-tile [start,end)                             */
-    size_t tile_count;  /* u32[T]                                                   */
+    size_t ranges;      /* u32[2T] per-tile [start,end) in point_list               */
+    size_t tile_count;  /* u32[T]   instances emitted by this call (split: the dynamic ones) */
+    size_t dyn_start;   /* u32[T]   split mode: start of the tile's dynamic (key, id) pairs */
     size_t total;
 } fnx_image_layout_t;
 typedef struct {
-    size_t point_list; /* u32[R] Gaussian ids sorted by (tile, depth bits, id)      */
+    size_t point_list; /* u32[R (+ R_static)] Gaussian ids sorted by (tile, depth bits, id) */
+    size_t pairs;      /* split mode: u32[2R] (depth bits, id) of the dynamic instances, per tile in depth order */
     size_t total;
 } fnx_binning_layout_t;
+typedef struct {
+    size_t header;     /* u32[8]: [0] static instances of the view, [1] P_static, [2] id of the first static splat */
+    size_t starts;     /* u32[T+1] exclusive prefix of the per-tile static instance counts */
+    size_t radii;      /* i32[P_static]                                             */
+    size_t blend_rec;  /* f32[16 P_static] packed blend records (fnx_geom_layout_t) */
+    size_t pairs;      /* u32[2 R_static] (depth bits, global id), per tile in (depth bits, id) order */
+    size_t total;
+} fnx_static_layout_t;
 void fnx_geom_layout(int P, int width, int height, fnx_geom_layout_t *out);
 void fnx_image_layout(int width, int height, fnx_image_layout_t *out);
 void fnx_binning_layout(int64_t num_rendered, fnx_binning_layout_t *out);
+void fnx_binning_layout_split(int64_t capacity, int64_t R_static_capacity, fnx_binning_layout_t *out);
+void fnx_static_layout(int P_static, int width, int height, int64_t R_static_capacity, fnx_static_layout_t *out);
 
 #ifdef __cplusplus
 }

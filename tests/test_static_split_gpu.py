@@ -1,0 +1,214 @@
+"""-m gpu: static-split mode (include/fnx_raster.h: fnx_static_finalize_views + the *_split entry points,
+rasterizer.StaticBin) against the one-set path over the same splats.
+
+The trailing splats are binned once; every forward preprocesses / sorts / bins only the leading ones and the blend
+kernel merges the two depth-ordered streams of a tile.  Everything the reference defines must come out BIT-IDENTICAL
+to the unsplit call: colour, depth, radii, final_T, n_contrib, tile ranges and (with materialize_all) the whole
+point_list; gradients of the leading splats agree within the fp32 atomic-order tolerance of the blend backward."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fluidnexus_amd import synthetic as S  # noqa: E402
+
+
+def _settings(cams, W, H, bg, fov=0.8):
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings
+    return [GaussianRasterizationSettings(image_height=H, image_width=W, tan_fov_x=math.tan(fov * 0.5),
+                                          tan_fov_y=math.tan(fov * 0.5), bg=bg, scale_modifier=1.0,
+                                          view_matrix=c.world_view_transform, proj_matrix=c.full_proj_transform,
+                                          sh_degree=0, campos=c.camera_center, prefiltered=False) for c in cams]
+
+
+def _scene(P_dyn, P_static, channels, seed, static_box=0.45, ties=0):
+    a = S.random_gaussians(P_dyn, seed=seed, box=0.25, log_scale=(-5.2, -3.6), channels=channels,
+                           center=(0.34, 0.3, -0.225))
+    b = S.random_gaussians(P_static, seed=seed + 1, box=static_box, log_scale=(-4.8, -2.6), channels=channels,
+                           center=(0.34, 0.3, -0.225))
+    if ties:  # static splats at exactly the positions of some dynamic ones: equal depth bits in every view
+        b["means3D"][:ties] = a["means3D"][:ties]
+    return {k: np.concatenate([a[k], b[k]], 0) for k in a}
+
+
+def _blob(t, off, n, dtype):
+    al = (-t.data_ptr()) % 256
+    es = torch.empty(0, dtype=dtype).element_size()
+    return t[al + off: al + off + n * es].view(dtype)
+
+
+def _close(a, b, rtol=2e-4):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-20) < rtol
+
+
+@pytest.mark.parametrize("channels,P_dyn,P_static,ties,static_box", [(3, 5000, 3000, 0, 0.45), (1, 3000, 6000, 0, 0.45),
+                                                                      (3, 4000, 4000, 500, 0.45), (3, 6000, 800, 0, 0.08)])
+def test_split_equals_unsplit(channels, P_dyn, P_static, ties, static_box):
+    from fluidnexus_amd import _lib
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews, StaticBin, ViewBatch
+    dev = torch.device("cuda")
+    W, H, V = 144, 112, 3
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    P = P_dyn + P_static
+    g = _scene(P_dyn, P_static, channels, seed=21, static_box=static_box, ties=ties)
+    cams = S.arc_cameras(V, W, H, device="cuda")
+    bg = torch.tensor([0.2, 0.5, 0.1], device=dev)
+    vb = ViewBatch(_settings(cams, W, H, bg))
+    rng = np.random.RandomState(5)
+    dL = torch.tensor(rng.normal(size=(V, channels, H, W)).astype(np.float32), device=dev)
+    names = ("means3D", "opacities", "scales", "rotations", "colors")
+
+    def leaves():
+        return {n: torch.tensor(g[n], dtype=torch.float32, device=dev, requires_grad=True) for n in names}
+
+    def run(L, static_bin):
+        rv = GaussianRasterizerViews(vb, channels=channels)
+        rv.grad_splat_limit = P_dyn
+        rv.static_bin = static_bin
+        screen = torch.zeros(V, P, 3, device=dev, requires_grad=True)
+        im, ra, de = rv(means3D=L["means3D"], means2D=screen, opacities=L["opacities"], colors_precomp=L["colors"],
+                        scales=L["scales"], rotations=L["rotations"])
+        saved = im.grad_fn.saved_tensors  # (..., radii, sh, geom, binning, img)
+        (im * dL).sum().backward()
+        torch.cuda.synchronize()
+        return im, ra, de, screen, saved[-2], saved[-1]
+
+    A = leaves()
+    im_a, ra_a, de_a, sc_a, bin_a, img_a = run(A, None)
+    B = leaves()
+    with torch.no_grad():
+        sb = StaticBin(vb, B["means3D"][P_dyn:], B["opacities"][P_dyn:], P_dyn, colors_precomp=B["colors"][P_dyn:],
+                       scales=B["scales"][P_dyn:], rotations=B["rotations"][P_dyn:], channels=channels)
+    assert min(sb.R) > 0 and sb.P == P_static
+    StaticBin.materialize_all = True
+    try:
+        im_b, ra_b, de_b, sc_b, bin_b, img_b = run(B, sb)
+    finally:
+        StaticBin.materialize_all = False
+
+    assert torch.equal(ra_a, ra_b), "radii"
+    assert torch.equal(im_a.view(torch.int32), im_b.view(torch.int32)), "colour not bit-identical"
+    assert torch.equal(de_a.view(torch.int32), de_b.view(torch.int32)), "depth not bit-identical"
+    lib = _lib.raster()
+    IL = _lib.image_layout(W, H)
+    ib = lib.fnx_image_bytes(W, H)
+    tot_static = 0
+    for v in range(V):
+        ia, ibv = img_a[v * ib:(v + 1) * ib], img_b[v * ib:(v + 1) * ib]
+        for name, n, dt in (("final_T", H * W, torch.int32), ("n_contrib", H * W, torch.int32), ("ranges", 2 * T, torch.int32)):
+            assert torch.equal(_blob(ia, getattr(IL, name), n, dt), _blob(ibv, getattr(IL, name), n, dt)), (name, v)
+        ha, hb = _blob(ia, IL.header, 8, torch.int32).tolist(), _blob(ibv, IL.header, 8, torch.int32).tolist()
+        assert hb[0] + hb[3] == ha[0] and hb[3] == sb.R[v] and hb[1] == 0
+        tot_static += hb[3]
+        # the whole merged list (materialize_all) equals the one-set point_list
+        R = ha[0]
+        cap_a = (bin_a.numel() // V)
+        cap_b = (bin_b.numel() // V)
+        pa = _blob(bin_a[v * cap_a:(v + 1) * cap_a], 0, R, torch.int32)
+        pb = _blob(bin_b[v * cap_b:(v + 1) * cap_b], 0, R, torch.int32)
+        assert torch.equal(pa, pb), f"merged point_list of view {v}"
+    assert tot_static > 0
+    # gradients: leading splats agree, static rows are zero
+    assert float(A["means3D"].grad[:P_dyn].abs().max()) > 0
+    for n in names:
+        assert _close(B[n].grad[:P_dyn], A[n].grad[:P_dyn]), n
+        assert float(B[n].grad[P_dyn:].abs().max()) == 0.0, n
+    assert _close(sc_b.grad[:, :P_dyn], sc_a.grad[:, :P_dyn])
+
+    # without materialize_all the prefix the backward needs is there: same gradients again
+    C = leaves()
+    im_c, ra_c, de_c, sc_c, _, _ = run(C, sb)
+    assert torch.equal(im_a.view(torch.int32), im_c.view(torch.int32))
+    for n in names:
+        assert _close(C[n].grad[:P_dyn], A[n].grad[:P_dyn]), n
+
+
+def test_split_single_view_and_empty_streams():
+    """V = 1; a static set that covers only a corner (most tiles have no static entries) and per-call splats that
+    leave many tiles empty: tiles with only one of the two streams, and with neither."""
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews, StaticBin, ViewBatch
+    dev = torch.device("cuda")
+    W, H = 160, 128
+    a = S.random_gaussians(2000, seed=3, box=0.08, log_scale=(-5.5, -4.5), channels=3, center=(-0.3, 0.0, 0.0))
+    b = S.random_gaussians(1500, seed=4, box=0.08, log_scale=(-5.5, -4.5), channels=3, center=(0.3, 0.2, 0.0))
+    g = {k: np.concatenate([a[k], b[k]], 0) for k in a}
+    cam = S.front_camera(W, H, device="cuda")
+    bg = torch.zeros(3, device=dev)
+    vb = ViewBatch(_settings([cam], W, H, bg))
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    kw = dict(means3D=t["means3D"], opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"],
+              rotations=t["rotations"])
+    P = 3500
+    rv = GaussianRasterizerViews(vb)
+    im_a, ra_a, de_a = rv(means2D=torch.zeros(1, P, 3, device=dev), **kw)
+    sb = StaticBin(vb, t["means3D"][2000:], t["opacities"][2000:], 2000, colors_precomp=t["colors"][2000:],
+                   scales=t["scales"][2000:], rotations=t["rotations"][2000:])
+    rv.static_bin = sb
+    im_b, ra_b, de_b = rv(means2D=torch.zeros(1, P, 3, device=dev), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(ra_a, ra_b)
+    assert torch.equal(im_a.view(torch.int32), im_b.view(torch.int32))
+    assert torch.equal(de_a.view(torch.int32), de_b.view(torch.int32))
+    assert float(im_a.abs().max()) > 0 and int((im_a.sum(1) == 0).sum()) > 100  # empty regions exist
+
+
+def test_split_capacity_overflow_is_reported():
+    """Sync-free split forward with a too small capacity for the per-call instances: nothing is rendered, the status
+    ring reports FNX_ERR_CAPACITY."""
+    from fluidnexus_amd import _lib, rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews, StaticBin, ViewBatch
+    dev = torch.device("cuda")
+    W, H, V = 96, 96, 2
+    g = _scene(3000, 2000, 3, seed=8)
+    cams = S.arc_cameras(V, W, H, device="cuda")
+    vb = ViewBatch(_settings(cams, W, H, torch.zeros(3, device=dev)))
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    kw = dict(means3D=t["means3D"], opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"],
+              rotations=t["rotations"])
+    sb = StaticBin(vb, t["means3D"][3000:], t["opacities"][3000:], 3000, colors_precomp=t["colors"][3000:],
+                   scales=t["scales"][3000:], rotations=t["rotations"][3000:])
+    rv = GaussianRasterizerViews(vb)
+    rv.static_bin = sb
+    rasterizer.set_host_sync(False)
+    try:
+        rv(means2D=torch.zeros(V, 5000, 3, device=dev), **kw)  # seeds the high-water mark (synchronising)
+        rasterizer.check_status()
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), W, H, 3, 3000, "split")
+        assert key in rasterizer._capacity_hwm
+        rasterizer._capacity_hwm[key] = 64
+        rv(means2D=torch.zeros(V, 5000, 3, device=dev), **kw)
+        with pytest.raises(_lib.FnxError) as e:
+            rasterizer.check_status()
+        assert e.value.code == _lib.FNX_ERR_CAPACITY
+    finally:
+        rasterizer._capacity_hwm.pop(key, None)
+        rasterizer.set_host_sync(True)
+
+
+def test_hot_loop_split_matches_one_set():
+    """The view-batched hot loop with and without the static split: the same batch gradient (read from Adam's first
+    moment after one step, which is (1 - beta1) times it) and the same rendered batch."""
+    from fluidnexus_amd.harness import HotLoop, build_smoke_frame
+    from fluidnexus_amd.renderer import pipes
+    res = {}
+    for split in (False, True):
+        pipes.set_static_split(split)
+        try:
+            gm, cams = build_smoke_frame(P_fluid=6000, P_background=3000, hidden_dims=(8, 20, 8), n_views=3, size=128,
+                                         seed=1)
+            loop = HotLoop(gm, cams, image_loss="fused", fused_physics=True, defer_visual_backward=True,
+                           capturable=True, batched_views=True, fused_step=True)
+            loop.make_targets()
+            loop.iteration()
+            torch.cuda.synchronize()
+            res[split] = gm.optimizer.state[gm._estimate_xyz_nn]["exp_avg"].detach().clone()
+            assert (id(gm) in pipes._STATIC_BIN_CACHE) == split
+        finally:
+            pipes.set_static_split(True)
+    scale = res[False].abs().max().item()
+    assert scale > 0
+    assert (res[True] - res[False]).abs().max().item() < 5e-4 * scale
