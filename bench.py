@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native FluidNexus hot path.
 
-Metric (BASELINE.json): train iters/sec, 300k Gaussians x 5 views @ 512^2 (config 3:
-FluidNexus-Smoke frame, ch3 rasteriser, image + exyz + gas + next-gas losses, Adam step).
-One "step" = one iteration of the per-frame optimisation loop over one batch of synthetic views,
-exactly the op sequence of entries_fluid_nexus/train_physical_particle.py:329-432
-(fluidnexus_amd/harness.py).  All inputs are resident in HBM before the timed region.
+Metric (BASELINE.json): train iters/sec + rasterise ms, 300k Gaussians x 5 views @ 512^2.
+One "step" = one iteration of the per-frame optimisation loop over one batch of synthetic views
+(fluidnexus_amd/harness.py); all inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--scaling {auto,weak,strong}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: one process per GPU; Gaussians/particles replicated; every rank renders its own 5
-views of a 5N-view batch (weak scaling: per-GPU work fixed); one RCCL all-reduce(sum) of the
-leaf gradient per iteration, then the reference's 1/batch scaling and a replicated Adam step.
-`value` counts 5-view iterations: (5N views per step / 5) * steps / seconds.
+Workloads (BASELINE.json `configs`):
+  config 2  ScalarReal frame: 100k grey Gaussians (gm_fluid, render_fluid, 1-channel rasteriser), 5 views,
+            render-only loss (L1 + D-SSIM + distance_loss), first-frame stage: the positions are the leaf.
+  config 3  FluidNexus-Smoke frame: 200k fluid + 100k static background Gaussians (render_dynamics, 3 channels),
+            24.8k hidden particles, image + distance + exyz + gas + next-gas losses, Adam.   [default at --gpus 1, 2]
+  config 4  = config 3's scene, its 5 views sharded over 4 ranks (2/1/1/1).                  [default at --gpus 4]
+  config 5  FluidNexus-Ball scene: 350k fluid + 150k background Gaussians + 28k hidden particles, 8 views on a
+            ring, every view rendered by the 3-channel AND the 1-channel rasteriser.          [default at --gpus 8]
+Multi-GPU (one process per GPU, Gaussians / particles replicated, one RCCL all-reduce(sum) of the leaf gradient per
+iteration, then the reference's 1/batch scaling and a replicated Adam step):
+  --scaling strong (default): the config's views are sharded round-robin over the ranks (view v -> rank v mod N);
+            `value` = iterations of the whole batch per second.
+  --scaling weak: every rank renders the config's full view count of an N-times larger batch (per-GPU work fixed);
+            `value` counts nominal-batch iterations: N * steps / seconds.
 
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
@@ -33,57 +41,162 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-P_FLUID, P_BACKGROUND, VIEWS, SIZE = 200_000, 100_000, 5, 512
-HIDDEN_DIMS = (20, 62, 20)  # 24,800 hidden particles (reference cap: 28,000)
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIZE = 512
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 4 * 1.0  # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
+VALU_MEASURED_WAVE_INSTR = 933e9                   # tools/micro/pk_rate.hip on this chip
+PROFILE_TAG = "r02"
+
+CONFIGS = {
+    2: dict(workload="BASELINE configs[1]: ScalarReal single frame, 100k grey Gaussians (gm_fluid / render_fluid / ch1), "
+                     "5 views @512^2, render-only loss (L1 + D-SSIM + distance_loss), first-frame stage (positions = leaf), Adam",
+            views=5, channels=1, stage="first"),
+    3: dict(workload="BASELINE configs[2]: FluidNexus-Smoke frame, 200k fluid + 100k background Gaussians, "
+                     "24800 hidden particles, ch3, L1+D-SSIM + distance + exyz + gas + next-gas losses, Adam",
+            views=5, channels=3, stage="physical"),
+    4: dict(workload="BASELINE configs[3]: FluidNexus-Smoke frame (config 3's scene), 5 views sharded over the ranks "
+                     "(2/1/1/1 on 4 GPUs), RCCL all-reduce of the leaf gradient",
+            views=5, channels=3, stage="physical"),
+    5: dict(workload="BASELINE configs[4]: FluidNexus-Ball scene, 350k fluid + 150k background Gaussians, 28072 hidden "
+                     "particles, 8 views on a ring, ch3 (fluid + background) AND ch1 (fluid) rasterisers per view, "
+                     "L1+D-SSIM on both + distance + exyz + gas + next-gas losses, Adam",
+            views=8, channels=3, stage="physical"),
+}
 
 
-def cpu_baseline(gm, cams, bg, seconds_budget=30.0):
-    """The CPU oracle (oracle/raster_oracle.c, OpenMP over all host cores) timed on ONE view of the
-    same workload: rasteriser forward + backward.  Reported as 5-view iterations per second of the
-    rasteriser alone (losses / physics / Adam are not in the CPU sample)."""
-    from oracle import raster_oracle as O
-    O.build()
-    cores = os.cpu_count() or 1
-    O.set_threads(cores)
-    cam = cams[0]
+def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
+    """(gm, cams, loop) of the configuration with `n_views` cameras in the batch."""
+    from fluidnexus_amd import harness as Hn
+    graph = not (a.no_graph or a.host_sync)
+    if cfg_id == 2:
+        gm, cams = Hn.build_scalar_real_frame(100_000, n_views=n_views, size=SIZE, seed=0, device=dev)
+        cfg = dict(Hn.SCALAR_REAL)
+        if a.no_distance:
+            cfg["lambda_first_distance"] = 0.0
+        loop = Hn.FirstFrameLoop(gm, cams, rd_pipe="render_fluid", rank=rank, world=world, cfg=cfg, capturable=graph,
+                                 force_all_reduce=use_dist)
+        return gm, cams, loop
+    if cfg_id in (3, 4):
+        gm, cams = Hn.build_smoke_frame(200_000, 100_000, (20, 62, 20), n_views=n_views, size=SIZE, seed=0, device=dev)
+    else:
+        gm, cams = Hn.build_ball_frame(350_000, 150_000, (22, 58, 22), n_views=n_views, size=SIZE, seed=0, device=dev)
+    cfg = dict(Hn.SMOKE)
+    if a.no_distance:
+        cfg["lambda_current_distance"] = 0.0
+    view_mode = a.views
+    if a.unfused_physics or a.image_loss == "torch":
+        view_mode = "serial"  # the batched / branch modes build on the fused loss nodes
+    if view_mode == "branches" and not graph:
+        view_mode = "serial"
+    if cfg_id == 5 and view_mode != "batched":
+        raise SystemExit("config 5 (both rasterisers per view) needs --views batched")
+    loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once,
+                      image_loss="torch" if a.image_loss == "torch" else "fused", fused_physics=not a.unfused_physics,
+                      defer_visual_backward=not a.unfused_physics, capturable=graph, cfg=cfg,
+                      parallel_views=view_mode == "branches", batched_views=view_mode == "batched",
+                      fused_step=view_mode == "batched" and graph and not a.torch_adam, dual_channel=cfg_id == 5)
+    loop.view_mode = view_mode
+    return gm, cams, loop
+
+
+def scene_arrays(gm, cfg_id):
+    """(xyz, opacity, scales, rotations, colours) of everything the configuration's main render sees, on the host."""
     with torch.no_grad():
+        if cfg_id == 2:
+            return (gm.get_visual_xyz.detach().cpu().numpy(), gm.get_visual_opacity.cpu().numpy(),
+                    gm.get_visual_scaling.cpu().numpy(), gm.get_visual_rotation.cpu().numpy(), gm.get_visual_color.cpu().numpy())
         xyz = torch.cat([gm.get_visual_xyz_from_nn() / gm.scale_factor, gm.get_gs_xyz], 0).cpu().numpy()
         opac = torch.cat([gm.get_visual_opacity, gm.get_gs_opacity], 0).cpu().numpy()
         scales = torch.cat([gm.get_visual_scaling, gm.get_gs_scaling], 0).cpu().numpy()
         rots = torch.cat([gm.get_visual_rotation, gm.get_gs_rotation], 0).cpu().numpy()
         cols = torch.cat([gm.get_visual_color.repeat(1, 3), gm.get_gs_color], 0).cpu().numpy()
+    return xyz, opac, scales, rots, cols
+
+
+def cpu_baseline(gm, cams, bg, cfg_id, views, channels):
+    """The CPU oracle (oracle/raster_oracle.c, OpenMP over all host cores) timed on ONE view of the same workload:
+    rasteriser forward + backward.  Reported as whole-batch iterations per second of the rasteriser alone (losses /
+    physics / Adam are not in the CPU sample)."""
+    from oracle import raster_oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    cam = cams[0]
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
     tan = math.tan(cam.FoVx * 0.5)
     t0 = time.perf_counter()
     f = O.forward(xyz, opac, bg.cpu().numpy(), cam.world_view_transform.cpu().numpy(),
                   cam.full_proj_transform.cpu().numpy(), cam.camera_center.cpu().numpy(), SIZE, SIZE, tan, tan,
-                  colors_precomp=cols, scales=scales, rotations=rots)
+                  colors_precomp=cols, scales=scales, rotations=rots, channels=channels)
     t1 = time.perf_counter()
-    O.backward(f, np.ones((3, SIZE, SIZE), np.float32))
+    O.backward(f, np.ones((channels, SIZE, SIZE), np.float32))
     t2 = time.perf_counter()
     per_view = t2 - t0
-    return {"value": 1.0 / (VIEWS * per_view), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/raster_oracle.c (OpenMP, {cores} threads), rasteriser only: 1 of {VIEWS} views "
-                      f"fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, R={f['num_rendered']}; value = 1/({VIEWS} x that)"}
+    return {"value": 1.0 / (views * per_view), "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/raster_oracle.c (OpenMP, {cores} threads), rasteriser only (ch{channels}): 1 of {views} views "
+                      f"fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, R={f['num_rendered']}; value = 1/({views} x that)"}
+
+
+def rasterise_timing(gm, cams, views, cfg_id, channels, bg):
+    """Rasteriser alone on this rank's views, HIP-event timed on the current stream: forward, and forward + backward
+    with ALL gradients (means, opacity, colour, scales, rotations: the visual-particle stage's MODE 0 backward)."""
+    from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews
+    from fluidnexus_amd.renderer.pipes import _settings
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
+    dev = bg.device
+    _, GRsetting, _ = get_render_pipe("render_fluid" if channels == 1 else "render_dynamics")
+    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, 0) for v in views], channels=channels)
+    L = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in
+         dict(means3D=xyz, opacities=opac, scales=scales, rotations=rots, colors=cols).items()}
+    P, V = xyz.shape[0], len(views)
+    dL = torch.ones(V, channels, SIZE, SIZE, device=dev)
+
+    def once(backward):
+        screen = torch.zeros(V, P, 3, device=dev, requires_grad=True)
+        im, _, _ = rv(means3D=L["means3D"], means2D=screen, opacities=L["opacities"], colors_precomp=L["colors"],
+                      scales=L["scales"], rotations=L["rotations"])
+        if backward:
+            torch.autograd.grad([im], list(L.values()), grad_outputs=[dL])
+
+    out = {}
+    for name, bw in (("forward", False), ("forward_backward_all_gradients", True)):
+        once(bw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            once(bw)
+        e1.record()
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) / 5 / V
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="auto", choices=["auto", "2", "3", "4", "5"],
+                    help="BASELINE.json configuration (1-based); auto: 3 at 1-2 GPUs, 4 at 4 GPUs, 5 at 8 GPUs")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="strong (auto): the config's views sharded over the ranks; weak: the config's view count per rank")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single process: run rank 0's share of the views of an N-rank strong-scaling run, no communication")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
-    ap.add_argument("--image-loss", default="auto", choices=["auto", "torch", "fused"])
+    ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
     ap.add_argument("--physics-once", action="store_true",
-                    help="evaluate the view-independent physics terms once per iteration instead of once per view")
+                    help="add the view-independent physics terms once per iteration instead of once per view")
+    ap.add_argument("--no-distance", action="store_true", help="drop the distance_loss term (round-1 behaviour)")
+    ap.add_argument("--no-static-split", action="store_true", help="bin the static background Gaussians every iteration")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph-iters", type=int, default=5,
                     help="iterations recorded per hipGraph (reduced to a divisor of --steps; 1 in multi-GPU runs)")
     ap.add_argument("--views", default="batched", choices=["batched", "branches", "serial"],
                     help="the views of an iteration: one view-batched launch sequence (default), one rasteriser call "
                          "per view on parallel streams / graph branches, or one call per view in series")
-    ap.add_argument("--serial-views", action="store_true", help="same as --views serial")
     ap.add_argument("--torch-adam", action="store_true", help="gradient mean + optimiser step with torch ops / torch.optim.Adam")
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
@@ -107,32 +220,27 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fluidnexus_amd import _lib, rasterizer
-    from fluidnexus_amd.harness import HotLoop, build_smoke_frame
-    _lib.raster()  # fail loudly if the HIP library is missing
-
-    # every rank renders VIEWS views of the VIEWS*world-view batch (weak scaling)
-    gm, cams = build_smoke_frame(P_FLUID, P_BACKGROUND, HIDDEN_DIMS, n_views=VIEWS * world, size=SIZE, seed=0,
-                                 device=dev)
-    image_loss = a.image_loss
-    if image_loss == "auto":
-        try:
-            from fluidnexus_amd import losses  # noqa: F401
-            image_loss = "fused"
-        except Exception:
-            image_loss = "torch"
-    view_mode = "serial" if a.serial_views else a.views
-    if a.unfused_physics or image_loss != "fused":
-        view_mode = "serial"  # the batched / branch modes build on the fused loss nodes
-    if view_mode == "branches" and (a.no_graph or a.host_sync):
-        view_mode = "serial"
-    loop = HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once, image_loss=image_loss,
-                   fused_physics=not a.unfused_physics, defer_visual_backward=not a.unfused_physics,
-                   capturable=not (a.no_graph or a.host_sync),
-                   parallel_views=view_mode == "branches", batched_views=view_mode == "batched",
-                   fused_step=view_mode == "batched" and not (a.no_graph or a.host_sync) and not a.torch_adam)
-    loop.make_targets()
     from fluidnexus_amd.harness import shard_views
+    from fluidnexus_amd.renderer import pipes
+    _lib.raster()  # fail loudly if the HIP library is missing
+    if a.no_static_split:
+        pipes.set_static_split(False)
+
+    cfg_id = int(a.config) if a.config != "auto" else {4: 4, 8: 5}.get(world, 3)
+    C = CONFIGS[cfg_id]
+    scaling = "strong" if a.scaling == "auto" else a.scaling
+    if world == 1:
+        scaling = "strong" if a.scaling == "auto" else a.scaling  # one rank: the two coincide
+    nominal_views = C["views"]
+    n_views = nominal_views * world if scaling == "weak" else nominal_views
+    shard_world = world
+    gm, cams, loop = build_workload(cfg_id, n_views, dev, rank, world, a, use_dist)
     loop_views = shard_views(len(cams), rank, world)
+    if a.emulate_world > 1:
+        assert world == 1, "--emulate-world is a single-process mode"
+        shard_world = a.emulate_world
+        loop_views = loop.view_subset = shard_views(len(cams), 0, shard_world)
+    loop.make_targets()
     if not a.host_sync:
         rasterizer.set_host_sync(False)
 
@@ -155,7 +263,8 @@ def main():
         except Exception as e:  # fall back to eager launches, say so in the JSON
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             loop.use_graph(False)
-            loop.parallel_views = False
+            if hasattr(loop, "parallel_views"):
+                loop.parallel_views = False
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -173,38 +282,52 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if not a.host_sync:
-        rasterizer.check_status()
+        rasterizer.check_status()  # raises if a replayed forward overflowed its binning capacity
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events
-    # cannot be read back from a replayed graph, so in graph mode the same iteration is run eagerly a
-    # few more times (outside the timed region) with the event hooks on.
+    # Roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events cannot
+    # be read back from a replayed graph, so in graph mode the same iteration is run eagerly a few more times
+    # (outside the timed region) with the event hooks on.
     if graph_mode:
         loop.use_graph(False)
-        loop.parallel_views = False  # kernels one at a time, so the event pairs time single kernels
+        if hasattr(loop, "parallel_views"):
+            loop.parallel_views = False  # kernels one at a time, so the event pairs time single kernels
         _lib.profile_enable(True)
         for _ in range(5):
             loop.iteration()
         torch.cuda.synchronize()
     prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "sort_and_counts",
-                                                                 "preprocess", "emit"))}
+                                                                 "preprocess", "emit", "blend_forward_ch1",
+                                                                 "blend_backward_ch1"))}
     _lib.profile_enable(False)
-    # instance / visible counts of this rank's views (for the algorithmic byte count)
-    R_views, P_vis_views = [], []
-    with torch.no_grad():
-        for v in loop_views:
-            pkg = loop.render_func(cams[v], gm, None, loop.background, GRsetting=loop.GRsetting,
-                                   GRzer=loop.GRzer, pos_type="guess_visual_nn", scale=True)
-            P_vis_views.append(int((pkg["radii"] > 0).sum().item()))
-            rasterizer.check_status()
-            R_views.append(rasterizer.last_num_rendered)
+    Cn = C["channels"]
+    if Cn == 1:  # the configuration's main render is the 1-channel one
+        prof["blend_forward"], prof["blend_backward"] = prof.pop("blend_forward_ch1"), prof.pop("blend_backward_ch1")
+    view_mode = getattr(loop, "view_mode", "batched")
     views_per_launch = len(loop_views) if view_mode == "batched" else 1
-    R = sum(R_views) / len(R_views)
-    P_vis = sum(P_vis_views) / len(P_vis_views)
-    Cn = 3
+    # instance / visible counts of this rank's views (one-set binning over all splats: the algorithmic byte count of
+    # SURVEY 8(d) does not depend on how the implementation splits the work)
+    R_views, P_vis_views = [], []
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
+    P_total = xyz.shape[0]
+    if loop_views:
+        from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
+        from fluidnexus_amd.renderer.pipes import _settings
+        _, GRsetting, GRzer = get_render_pipe("render_fluid" if Cn == 1 else "render_dynamics")
+        t = [torch.tensor(x, device=dev) for x in (xyz, opac, scales, rots, cols)]
+        with torch.no_grad():
+            for v in loop_views:
+                rz = GRzer(_settings(GRsetting, cams[v], loop.background, 1.0, 0))
+                _, radii, _ = rz(means3D=t[0], means2D=torch.zeros_like(t[0]), opacities=t[1], colors_precomp=t[4],
+                                 scales=t[2], rotations=t[3])
+                P_vis_views.append(int((radii > 0).sum().item()))
+                rasterizer.check_status()
+                R_views.append(rasterizer.last_num_rendered)
+    R = sum(R_views) / max(len(R_views), 1)
+    P_vis = sum(P_vis_views) / max(len(P_vis_views), 1)
     bwd_ms, bwd_n = prof["blend_backward"]
     # blend backward reads per instance id 4 + xy 8 + conic_opacity 16 + depth 4 + colour 4C,
     # per pixel dL_dpix C + final_T + n_contrib, and writes per visible splat 2+3+1+C accumulated gradients;
@@ -212,51 +335,95 @@ def main():
     alg_bytes = int(views_per_launch * (R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)))
     avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-    # HBM traffic of the same kernel from the PMC counters: a separate rocprofv3 --pmc run of this command
-    # (profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes); null if absent
-    traffic, kname = None, "fnx::blend_backward_kernel<3, 1>" if not a.unfused_physics else "fnx::blend_backward_kernel<3, 0>"
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f).get("void " + kname)
-        if t:
-            traffic = t["fetch_bytes"] + t["write_bytes"]
-    except OSError:
-        pass
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "views_per_launch": views_per_launch,
+    # whole-iteration algorithmic bytes (B_view = 324 P + 132 R + 44 HW for ch3, 308 P + 116 R + 28 HW for ch1)
+    per_view = (324 * P_total + 132 * R + 44 * SIZE * SIZE) if Cn == 3 else (308 * P_total + 116 * R + 28 * SIZE * SIZE)
+    iter_bytes = per_view * len(cams)
+    # HBM traffic / VALU instructions of the dominant kernel: separate rocprofv3 --pmc passes of this command
+    # (tools/collect_profiles.sh -> profiles/<tag>_pmc_traffic.json, <tag>_sq_counters.json), null if absent
+    kname = f"fnx::blend_backward_kernel<{Cn}, 1>" if not a.unfused_physics else f"fnx::blend_backward_kernel<{Cn}, 0>"
+    suffix = "" if cfg_id == 3 else f"_config{cfg_id}"
+    traffic = valu = None
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_traffic.json")) as f:
+                t = json.load(f).get("void " + kname)
+            if t and traffic is None:
+                traffic = {"bytes_per_launch": t["fetch_bytes"] + t["write_bytes"],
+                           "source": f"profiles/{tag}{suffix}_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+        except OSError:
+            pass
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_sq_counters.json")) as f:
+                t = json.load(f).get("void " + kname)
+            if t and valu is None:
+                valu = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "counter_run_launch_us": t["us"],
+                        "source": f"profiles/{tag}{suffix}_sq_counters.json (separate rocprofv3 --pmc SQ_INSTS_VALU pass)"}
+        except OSError:
+            pass
+    roofline = {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "kernel": kname, "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "views_per_launch": views_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (every instance read once) against "
+                        "HBM peak, as the contract defines them; the kernel is VALU-issue-bound: its lists saturate "
+                        "early and sit in L2, see hbm_traffic_frac and valu",
+                "traffic_source": traffic["source"] if traffic else None,
+                "hbm_traffic_frac": (traffic["bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_s > 0 else None,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
-
-    views_per_step = VIEWS * world
-    value = (views_per_step / VIEWS) * a.steps / dt
+    if valu and avg_s > 0:
+        rate = valu["wave_instructions_per_launch"] / avg_s
+        roofline["valu"] = dict(valu, wave_instructions_per_s=rate, frac_of_measured_issue_rate=rate / VALU_MEASURED_WAVE_INSTR,
+                                frac_of_spec_issue_rate=rate / VALU_SPEC_WAVE_INSTR,
+                                spec="1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz = 614 G wave-instr/s "
+                                     "(78.6 T lane-FMA/s); measured on this chip 933 G/s (tools/micro/pk_rate.hip)")
+    nominal_iters = (len(cams) / nominal_views) * a.steps  # weak scaling: N nominal batches per step
+    value = nominal_iters / dt
+    roofline["iteration_algorithmic"] = {"bytes": int(iter_bytes), "GBps": iter_bytes * a.steps / dt / 1e9,
+                                         "frac_of_hbm_peak": iter_bytes * a.steps / dt / 1e9 / HBM_PEAK_GBS}
+    metric = {2: "train iters/sec (ScalarReal: 100k Gaussians x 5 views @512^2, ch1, render-only loss)",
+              3: "train iters/sec (300k Gaussians x 5 views @512^2, physics losses on)",
+              4: "train iters/sec (300k Gaussians x 5 views @512^2, physics losses on)",
+              5: "train iters/sec (500k Gaussians x 8 views @512^2, ch3 + ch1 rasterisers, physics losses on)"}[cfg_id]
+    ms = None
+    try:
+        if loop_views:
+            ms = rasterise_timing(gm, cams, loop_views, cfg_id, Cn, loop.background)
+    except Exception as e:
+        print(f"[bench] rasteriser-only timing failed: {type(e).__name__}: {e}", file=sys.stderr)
     out = {
-        "metric": "train iters/sec (300k Gaussians x 5 views @512^2, physics losses on)",
+        "metric": metric,
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: FluidNexus-Smoke frame, 200k fluid + 100k background Gaussians, "
-                               f"{HIDDEN_DIMS[0] * HIDDEN_DIMS[1] * HIDDEN_DIMS[2]} hidden particles, ch3, "
-                               "L1+D-SSIM + exyz + gas + next-gas losses, Adam",
-                   "views_per_rank": VIEWS, "global_views_per_step": views_per_step, "image": f"{SIZE}x{SIZE}",
-                   "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
-                   "parallelism": f"views sharded over {world} rank(s), RCCL all-reduce of the leaf gradient",
-                   "host_sync": bool(a.host_sync), "image_loss": image_loss,
+        "config": {"workload": C["workload"], "baseline_config": cfg_id,
+                   "views_this_rank": len(loop_views), "global_views_per_step": len(cams), "image": f"{SIZE}x{SIZE}",
+                   "gaussians": P_total, "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
+                   "parallelism": (f"views sharded round-robin over {shard_world} rank(s)"
+                                   + (" (emulated: rank 0's share, no communication)" if a.emulate_world > 1 else "")
+                                   + ", RCCL all-reduce of the leaf gradient"),
+                   "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
+                   "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2),
+                   "distance_loss": not a.no_distance,
                    "launch": (f"hipGraph replay, {loop.graph_iterations} whole iteration(s) per graph" if graph_mode
                               else "eager"),
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
                              "branches": "one rasteriser call per view, views as parallel graph branches",
                              "serial": "one rasteriser call per view, in series"}[view_mode],
-                   "physics": ("once per iteration" if a.physics_once else "per view (as the reference)")
-                   + (", op-by-op autograd" if a.unfused_physics else ", one fused autograd node")},
+                   "physics": None if cfg_id == 2 else
+                   (("value and gradient evaluated once per iteration, the gradient added once per view "
+                     "(equal to the reference's per-view evaluation, tpp:368-404)" if not a.physics_once
+                     else "added once per iteration")
+                    + (", op-by-op autograd" if a.unfused_physics else ", one fused launch sequence"))},
         "roofline": roofline,
-        "rasterise_ms_per_view": {"forward": sum(prof[k][0] for k in ("preprocess", "sort_and_counts", "emit", "blend_forward"))
-                                  / max(prof["blend_forward"][1], 1) / views_per_launch,
-                                  "backward_blend": bwd_ms / max(bwd_n, 1) / views_per_launch},
+        "rasterise_ms_per_view": dict(
+            ms or {},
+            hot_loop_forward=sum(prof[k][0] for k in ("preprocess", "sort_and_counts", "emit", "blend_forward", "blend_forward_ch1")
+                                 if k in prof) / max(prof["blend_forward"][1], 1) / max(views_per_launch, 1),
+            hot_loop_backward_blend_geometry_only=bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)),
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background)
+            out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background, cfg_id, nominal_views, Cn)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

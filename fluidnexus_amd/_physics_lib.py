@@ -11,7 +11,7 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
            "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
-           "fnx_grid_cell_items", "fnx_visual_interp_backward_cells")
+           "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials")
 
 
 def physics():
@@ -30,6 +30,10 @@ def physics():
     lib.fnx_grid_bytes.argtypes = [i]
     lib.fnx_grid_build.restype = i
     lib.fnx_grid_build.argtypes = [p, i, f, p, p]
+    lib.fnx_distance_loss_partials.restype = i
+    lib.fnx_distance_loss_partials.argtypes = [i]
+    lib.fnx_distance_loss.restype = i
+    lib.fnx_distance_loss.argtypes = [p, i, f, p, p, p, p]
     lib.fnx_density_forward.restype = i
     lib.fnx_density_forward.argtypes = [p, i, p, f, f, p, p, p]
     lib.fnx_density_backward.restype = i

@@ -2,10 +2,12 @@
 //
 // Neighbour search: uniform hash grid with cell edge H.  Points are bucketed by a hash of their
 // integer cell (count -> scan -> fill, LDS-free: the clouds are 10^4..10^5 points and these
-// kernels are latency-, not bandwidth-bound); a query walks the 27 surrounding cells and accepts a
-// candidate only if its own integer cell equals the cell being visited, which makes hash collisions
-// harmless (no double counting).  Bucket records are float4 (x, y, z, id) so a query streams 16 B
-// per candidate, coalesced within a bucket.
+// kernels are latency-, not bandwidth-bound); a query walks the buckets of the 27 surrounding cells and accepts
+// every candidate that passes the distance test.  The low 9 bits of a bucket id are the cell coordinates mod 8
+// (cell_hash), so those 27 cells land in 27 different buckets: a point within H of the query is met exactly
+// once, and points of far cells that share a bucket fail the distance test -- hash collisions are harmless
+// without a cell comparison.  Bucket records are float4 (x, y, z, id) so a query streams 16 B per candidate,
+// coalesced within a bucket.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -648,6 +650,49 @@ __device__ __forceinline__ float half_sum31(float v) {
     return v;
 }
 
+// ---- pairwise distance loss (fnx_distance_loss) --------------------------------------------------------
+// utils/loss_utils.py:98-121: loss = sum over ORDERED pairs i != j with d_ij < thr of (thr - d_ij)^2 (the dense
+// torch.cdist matrix holds every unordered pair twice); d loss / d x_i = -4 sum_j (thr - d_ij) (x_i - x_j) / d_ij,
+// zero for coincident points (cdist's backward).  Radius-limited: hash grid with cell = thr, 8 lanes per point.
+__global__ void __launch_bounds__(256)
+distance_loss_kernel(const float *__restrict__ xyz, int N, float inv_cell, float thr, uint32_t mask,
+                     const uint32_t *__restrict__ start, const float4 *__restrict__ rec, float *__restrict__ partial,
+                     float *__restrict__ grad) {
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const int ii = min(i, N - 1);
+    float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < N)
+        for_neighbours<8>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, thr * thr, mask, start, rec,
+                          [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
+                              if ((int)j == i) return;
+                              const float d = sqrtf(r2);
+                              const float t = thr - d;
+                              if (!(t > 0.f)) return;
+                              acc += t * t;
+                              if (d > 0.f) {
+                                  const float k = -4.0f * t / d;
+                                  ax += k * ex;
+                                  ay += k * ey;
+                                  az += k * ez;
+                              }
+                          });
+    if (grad) {
+        ax = oct_sum7(ax);
+        ay = oct_sum7(ay);
+        az = oct_sum7(az);
+        if (sub == 7 && i < N) {
+            grad[3 * i + 0] = ax;
+            grad[3 * i + 1] = ay;
+            grad[3 * i + 2] = az;
+        }
+    }
+    __shared__ float s_w[4];
+    acc = wave_sum63(acc);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
 // per grid slot: velocity of the hidden particle stored there, u = (x - x_prev) / secs
 __global__ void __launch_bounds__(256)
 slot_velocity_kernel(const float4 *__restrict__ rec, int N, const float *__restrict__ prev, float secs,
@@ -1233,6 +1278,20 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
     hipLaunchKernelGGL(knn_mean_dist2_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, N, 1.0f / cell,
                        cell, g.M - 1, g.start, g.rec, mean_dist2);
     return hip_check("knn_mean_dist2");
+}
+
+int fnx_distance_loss_partials(int N) { return N > 0 ? (N + 31) / 32 : 0; }
+
+int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, float *partials, float *grad,
+                      fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !grid || !partials || !(threshold > 0.f))
+        return fail(FNX_ERR_INVALID_ARG, "distance_loss: bad argument");
+    if (int rc = fnx_grid_build(xyz, N, threshold, grid, stream)) return rc;
+    GridView g = carve(grid, N);
+    hipLaunchKernelGGL(distance_loss_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, xyz, N,
+                       1.0f / threshold, threshold, g.M - 1, g.start, g.rec, partials, grad);
+    return hip_check("distance_loss");
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,

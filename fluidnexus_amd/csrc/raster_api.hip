@@ -198,7 +198,7 @@ int make_static_ref(const char *static_blobs, int P_dyn, int P_static, int W, in
 
 // Optional in-library kernel timing (bench.py roofline): HIP events recorded on the caller's
 // stream around one kernel class; elapsed times are summed when read.
-constexpr int kProfClasses = 5;  // 0 blend_forward, 1 blend_backward, 2 sort + counts + scans, 3 preprocess, 4 emit
+constexpr int kProfClasses = 7;  // 0 blend_forward, 1 blend_backward, 2 sort + counts + scans, 3 preprocess, 4 emit (5, 6: blend forward / backward of the 1-channel rasteriser)
 struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
@@ -407,7 +407,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
                      bin.point_list, img.header, cap, st.base ? 1 : 0, V, vb);
     }
     {
-        ProfScope ps(0, s);
+        ProfScope ps(channels == 3 ? 0 : 5, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, st, materialize_all, V, vb);
@@ -538,7 +538,7 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
     const size_t cov3D_stride = cov3D_precomp ? 0 : vb.geom;
     {
-        ProfScope ps(1, s);
+        ProfScope ps(channels == 3 ? 1 : 6, s);
         fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P_all, width, height, img.ranges, bin.point_list,
                                    background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
                                    dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,

@@ -36,8 +36,9 @@ class GaussianModel:
         self.opacity_inverse_activation = inv_sigmoid
         self.rotation_activation = torch.nn.functional.normalize
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, device="cuda", **kwargs):
         e = torch.empty(0)
+        self.device = device  # the reference hard-codes "cuda"; CPU is for host-side tests of the bookkeeping only
         self.active_sh_degree = 0
         # hidden (physics) particles
         self._xyz = self._estimate_xyz = self._force = self._velocity = self._imass = self._buoyancy = e
@@ -69,20 +70,58 @@ class GaussianModel:
         self.fit_color = self.fit_opacity = self.fit_scales = self.fit_rotation = True
         self.setup_functions()
 
-    # -- constants (setup_constants :83-140 without the emitter/PBF parts) -------------------------
-    def setup_constants(self, H=2.0, KNN_K=100, p0=1.5, secs=0.033, k=3, buoyancy_max_y=0.0):
-        self.H, self.KNN_K, self.p0, self._secs, self.k = float(H), int(KNN_K), float(p0), float(secs), int(k)
+    # defaults of arguments/__init__.py:298-345 for the fields setup_constants reads from `optim_args`
+    _OPTIM_DEFAULTS = dict(secs=0.01, alpha=-1.5, buoyancy_decay_rate=0.0, buoyancy_max_y=0.0, beta=0.1, H=2.0,
+                           min_neighbors=-1, remove_out_boundary=False, p0=2.0, k=10, KNN_K=100,
+                           new_hidden_particles_per_sec=15, new_visual_particles_per_sec=15,
+                           emitter_points_off_y0=False, emit_ratio_hidden=1.32, emit_ratio_visual=1.32,
+                           fit_xyz=False, fit_color=True, fit_opacity=True, fit_scales=True, fit_rotation=True,
+                           extra_visual_ratio=0.0, extra_visual_num=0, extra_visual_y_min=0.16, extra_visual_min_num=0,
+                           extra_visual_pilar_radius=0.06, extra_visual_pilar_radius_delta=0.0015,
+                           pos_lr_scale_factor=1.0, init_hidden_velocity=0.0, record_time=False)
+
+    def setup_constants(self, optim_args=None, **kw):
+        """gm_dynamics.py:83-186: the constants of the model from the entry scripts' `optim_args` namespace
+        (missing attributes fall back to the reference's argparse defaults); keyword arguments override single
+        fields (H=, KNN_K=, p0=, secs=, k=, ...), which is how the synthetic harness calls it.  The tensors the
+        reference allocates on "cuda" here live on self.device.  Wind force and rigid-body parameters
+        (:141-165) are outside this build."""
+        defaults = dict(self._OPTIM_DEFAULTS)
+        if optim_args is None:
+            defaults.update(p0=1.5, secs=0.033, k=3)  # configs/fluid_nexus_smoke_dynamics.json, as the harness uses them
+        unknown = set(kw) - set(defaults)
+        if unknown:
+            raise TypeError(f"setup_constants: unknown field(s) {sorted(unknown)}")
+        get = lambda n: kw[n] if n in kw else getattr(optim_args, n, defaults[n])  # noqa: E731
+        self.H, self.KNN_K, self.p0, self._secs, self.k = float(get("H")), int(get("KNN_K")), float(get("p0")), float(get("secs")), get("k")
         self.H2, self.H6, self.H9 = self.H ** 2, self.H ** 6, self.H ** 9
         self.EPSILON = 1e-8
-        self.buoyancy_max_y = float(buoyancy_max_y)
+        self.buoyancy_max_y = float(get("buoyancy_max_y"))
         self.poly6_term1 = 315.0 / (64.0 * np.pi * self.H9)
         self.spiky_grad_term1 = 45.0 / (np.pi * self.H6)
+        self.beta = get("beta")
+        self.remove_out_boundary = bool(get("remove_out_boundary"))
+        self.new_hidden_particles_per_sec = get("new_hidden_particles_per_sec")
+        self.new_visual_particles_per_sec = get("new_visual_particles_per_sec")
+        self.visual_timer = self.hidden_timer = 0.0
+        self.emitter_points_off_y0 = get("emitter_points_off_y0")
+        self.emit_ratio_hidden, self.emit_ratio_visual = get("emit_ratio_hidden"), get("emit_ratio_visual")
+        self.emit_counter = 0
+        self.scale_factor = 100.0
+        for n in ("fit_xyz", "fit_color", "fit_opacity", "fit_scales", "fit_rotation", "extra_visual_ratio",
+                  "extra_visual_num", "extra_visual_y_min", "extra_visual_min_num", "extra_visual_pilar_radius",
+                  "extra_visual_pilar_radius_delta", "pos_lr_scale_factor", "init_hidden_velocity", "record_time"):
+            setattr(self, n, get(n))
+        self.total_iterations = self.total_sim_iterations = self.total_tb_log_iterations = 0
+        self.constant_color, self.constant_scale, self.constant_opacity = 0.7, -5.9, 0.1
+        self.setup_solver_constants(alpha=get("alpha"), buoyancy_decay_rate=get("buoyancy_decay_rate"),
+                                    min_neighbors=get("min_neighbors"))
 
     def setup_solver_constants(self, alpha=0.0, buoyancy_decay_rate=0.0, min_neighbors=-1, gravity=(0.0, -9.8, 0.0)):
         """The PBF solver constants of setup_constants (gm_dynamics.py:84,100-111,133)."""
         self.alpha, self.buoyancy_decay_rate, self.min_neighbors = float(alpha), float(buoyancy_decay_rate), int(min_neighbors)
         self.RELAXATION, self.K_P, self.E_P, self.DQ_P = 0.01, 0.2, 4, 0.25
-        self._gravity = torch.tensor(gravity, dtype=torch.float32).reshape(1, 3)
+        self._gravity = torch.tensor(gravity, dtype=torch.float32).reshape(1, 3)  # read on the host (_host_gravity)
         self.lamb_corr_denom = float(self.poly6_term1 * (self.H2 - self.DQ_P * self.DQ_P * self.H * self.H) ** 3)
 
     # -- PBF predictor / solver of the per-frame step (gm_dynamics.py:978-1183, 1323-1398) on fused kernels --
@@ -362,9 +401,103 @@ class GaussianModel:
     def get_covariance(self, scaling_modifier=1):
         return self.covariance_activation(self.get_visual_scaling, scaling_modifier, self._visual_rotation)
 
+    # -- particle creation of the first frame (gm_dynamics.py:504-610, 1656-1691) ---------------------------
+    @torch.no_grad()
+    def detach_visual_and_scale(self):
+        """:504-506"""
+        self._visual_xyz = self._visual_xyz.detach().clone().requires_grad_(False) * self.scale_factor
+        self._visual_grid = None
+        self.invalidate_caches()
+
+    @torch.no_grad()
+    def create_particles_visual(self, model_args):
+        """:508-555: visual particles of the first frame in world units, a thin plume (radius <= small_max) plus an
+        optional thick foot; the draws come from numpy's global generator in the reference's order (y, y_thick,
+        radius, radius_thick, theta), so a seeded run reproduces the reference's cloud."""
+        n, n_thick = int(model_args.init_visual_num_pts), max(int(model_args.init_thick_visual_num_pts), 0)
+        self.visual_x_mid, self.visual_z_mid = model_args.init_x_mid, model_args.init_z_mid
+        y = np.random.uniform(model_args.init_visual_y_min, model_args.init_visual_y_max, (n, 1))
+        if n_thick > 0:
+            y = np.concatenate((y, np.random.uniform(model_args.init_visual_y_thick_min, model_args.init_visual_y_max,
+                                                     (n_thick, 1))), axis=0)
+        radius = np.random.random((n, 1)) * model_args.init_visual_radius_small_max
+        if n_thick > 0:
+            radius = np.concatenate((radius, np.random.random((n_thick, 1)) * model_args.init_visual_radius_max), axis=0)
+        theta = np.random.random((n + n_thick, 1)) * 2 * np.pi
+        xyz = np.concatenate((radius * np.cos(theta) + self.visual_x_mid, y, radius * np.sin(theta) + self.visual_z_mid), axis=1)
+        self._visual_xyz = torch.from_numpy(xyz).float().to(self.device)
+        self._visual_grid = None
+        self.visual_particles_created = True
+
+    @staticmethod
+    def _pillar_lattice(x_mid, z_mid, radius_max, y_min, y_max, delta):
+        """Lattice points (x outermost, z innermost, like the reference's triple loop) inside the cylinder."""
+        xr = np.arange(x_mid - radius_max, x_mid + radius_max + delta, delta)
+        yr = np.arange(y_min, y_max, delta)
+        zr = np.arange(z_mid - radius_max, z_mid + radius_max + delta, delta)
+        X, Y, Z = np.meshgrid(xr, yr, zr, indexing="ij")
+        keep = (X - x_mid) ** 2 + (Z - z_mid) ** 2 <= radius_max ** 2
+        return np.stack((X[keep], Y[keep], Z[keep]), axis=1)
+
+    @torch.no_grad()
+    def _init_hidden_state(self, xyz_world):
+        """State tensors of freshly created hidden particles (:586-606)."""
+        dev, N = self.device, xyz_world.shape[0]
+        self._xyz = torch.from_numpy(xyz_world * self.scale_factor).float().to(dev)
+        z = lambda *shape: torch.zeros(shape, requires_grad=False, dtype=torch.float, device=dev)  # noqa: E731
+        self._estimate_xyz = z(N, 3)
+        self._buoyancy = torch.ones((N, 3), dtype=torch.float, device=dev) * (self._gravity.to(dev) * self.alpha)
+        self._force, self._velocity = z(N, 3), z(N, 3)
+        self._velocity[:, 1] = getattr(self, "init_hidden_velocity", 0.0)
+        self._imass = torch.ones((N, 1), dtype=torch.float, device=dev)
+        self._counts = z(N, 1)
+        self._particle_id = torch.arange(N, device=dev).unsqueeze(1)
+        self._particle_id_max = N
+        self.hidden_particles_created = True
+        self.invalidate_caches()
+
+    @torch.no_grad()
+    def create_particles_hidden(self, model_args):
+        """:557-608: hidden particles on a regular lattice (spacing init_hidden_delta) filling a vertical pillar,
+        scaled to simulation units, at rest except for init_hidden_velocity upwards."""
+        self._init_hidden_state(self._pillar_lattice(model_args.init_x_mid, model_args.init_z_mid,
+                                                     model_args.init_hidden_radius_max, model_args.init_hidden_y_min,
+                                                     model_args.init_hidden_y_max, model_args.init_hidden_delta))
+
+    def _constant_visual_attributes(self, n):
+        dev = self._visual_xyz.device
+        rot = torch.zeros((n, 4), dtype=torch.float, device=dev)
+        rot[:, 0] = 1.0
+        return (torch.zeros((n, 1), dtype=torch.float, device=dev) + self.constant_color,
+                torch.zeros((n, 3), dtype=torch.float, device=dev) + self.constant_scale, rot,
+                inv_sigmoid(self.constant_opacity * torch.ones((n, 1), dtype=torch.float, device=dev)))
+
+    def prepare_visual_particles_for_rendering(self):
+        """:1656-1669: constant grey / log-scale / identity rotation / opacity for every visual particle."""
+        assert self._visual_xyz.shape[0] > 0, "No visual particles to render"
+        self._visual_color, self._visual_scales, self._visual_rotation, self._visual_opacity = \
+            self._constant_visual_attributes(self._visual_xyz.shape[0])
+
+    def prepare_future_visual_particles_for_rendering(self, use_level_two_future=False):
+        """:1671-1691: with use_level_two_future only the newly emitted particles get the constants."""
+        if not use_level_two_future:
+            return self.prepare_visual_particles_for_rendering()
+        new = self._constant_visual_attributes(self._visual_xyz.shape[0] - self._visual_color.shape[0])
+        for name, t in zip(("color", "scales", "rotation", "opacity"), new):
+            setattr(self, f"_visual_{name}", torch.cat((getattr(self, f"_visual_{name}"), t), dim=0))
+
     # -- physics ------------------------------------------------------------------------------------
     def poly6(self, r2):
         return (r2 < self.H2) * self.poly6_term1 * ((self.H2 - r2) ** 3)
+
+    def spiky_grad(self, r, rlen):
+        """:193-199: gradient of the spiky kernel for difference vectors r [E,3] of lengths rlen [E] (the PBF
+        kernels evaluate the same expression per pair, csrc/physics.hip)."""
+        mask = (rlen < self.H) & (rlen > 0)
+        r_norm = r / (rlen.unsqueeze(-1) + self.EPSILON)
+        grad = -r_norm * self.spiky_grad_term1 * (self.H - rlen).unsqueeze(-1) ** 2
+        grad[~mask] = 0.0
+        return grad
 
     def get_guess_hidden_particles_from_nn(self):
         if self.buoyancy_max_y > 0.0:
@@ -478,11 +611,17 @@ class GaussianModel:
                                  lr_final=a.position_lr_final * self.spatial_lr_scale,
                                  lr_delay_mult=a.position_lr_delay_mult, max_steps=a.position_lr_max_steps)
 
-    def training_setup_first_visual(self, optim_args):
+    def training_setup_first_visual(self, optim_args, capturable=False):
+        """:349-370.  `capturable`: Adam state on the device (fused step / hipGraph), as training_setup_current."""
+        self.percent_dense = getattr(optim_args, "percent_dense", 0.01)
+        n, dev = self._visual_xyz.shape[0], self._visual_xyz.device
+        self.visual_xyz_gradient_accum = torch.zeros((n, 1), dtype=torch.float, device=dev)
+        self.visual_denom = torch.zeros((n, 1), dtype=torch.float, device=dev)
         self._visual_xyz = nn.Parameter(self._visual_xyz.detach().clone().requires_grad_(True))
+        self._visual_grid = None
         lr = optim_args.position_lr_init * self.spatial_lr_scale * self.pos_lr_scale_factor
         self.optimizer = torch.optim.Adam([{"params": [self._visual_xyz], "lr": lr, "name": "visual_xyz"}], lr=0.0,
-                                          eps=1e-15)
+                                          eps=1e-15, capturable=bool(capturable), fused=bool(capturable))
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
     def training_setup_current(self, optim_args, capturable=False):
@@ -557,6 +696,22 @@ class GaussianModel:
         self._grad_cache_used = True
 
     # -- explicit chain of the view-batched hot loop (harness.HotLoop, batched_views) -------------------------
+    def render_means_from_visual(self):
+        """Rasteriser positions of the first-frame stage (pos_type="visual", no scaling): [visual particles | static
+        background Gaussians] as a leaf in the same resident buffer as render_means_from_nn(); the fluid rows are one
+        copy of the _visual_xyz parameter per call, their gradient rows are the parameter's gradient."""
+        raw = self._visual_xyz.detach()
+        V, G = raw.shape[0], self._gs_xyz.shape[0]
+        key = (id(self._gs_xyz), self._gs_xyz._version, V, G, raw.device)
+        if getattr(self, "_render_means", None) is None or self._render_means[0] != key:
+            buf = torch.empty(V + G, 3, dtype=torch.float32, device=raw.device)
+            buf[V:] = self._gs_xyz.detach()
+            self._render_means = (key, buf.requires_grad_(True))
+        buf = self._render_means[1]
+        with torch.no_grad():
+            buf[:V].copy_(raw)
+        return buf
+
     def render_means_from_nn(self):
         """Rasteriser positions of the physical-particle stage, [visual particles advected by the hidden ones /
         scale_factor | static background Gaussians], as a LEAF tensor in a resident buffer: the background rows are

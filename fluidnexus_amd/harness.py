@@ -28,7 +28,8 @@ from .utils.loss_utils import l1_loss, l2_loss, ssim
 
 # constants of configs/fluid_nexus_smoke_dynamics.json + arguments/__init__.py
 SMOKE = dict(H=2.0, KNN_K=100, p0=1.5, secs=0.033, k=3, lambda_dssim=0.2, lambda_image=1.0, lambda_exyz=0.1,
-             lambda_gas_constraints=1.0, lambda_next_gas_constraints=0.1, lambda_current_distance=0.0,
+             lambda_gas_constraints=1.0, lambda_next_gas_constraints=0.1, lambda_current_distance=0.1,
+             distance_threshold_visual=0.002,
              position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
              position_lr_max_steps=30000)
 
@@ -40,13 +41,39 @@ SMOKE_L2 = dict(lambda_dssim=0.2, lambda_image=1.0, lambda_consistency_color=0.1
                 visual_scales_lr=0.005, visual_rotation_lr=0.001)
 
 
+# first-frame stage of configs/scalar_real.json (ScalarReal, ch1): positions of the visual particles are the leaf
+SCALAR_REAL = dict(lambda_dssim=0.2, lambda_first_distance=1.0, distance_threshold_visual=0.00625,
+                   position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                   position_lr_max_steps=30000)
+
+
 def shard_views(n_views: int, rank: int, world: int):
     """view v of the iteration's batch -> rank v mod world (5 views on 4 GPUs = 2/1/1/1)."""
     return [v for v in range(n_views) if v % world == rank]
 
 
+def build_scalar_real_frame(P=100_000, n_views=5, size=512, seed=0, device="cuda"):
+    """BASELINE config 2 state: a ScalarReal-like plume of P grey Gaussians in a gm_fluid model (no background set),
+    positions in world units as in the first-frame stage, cameras on the 120 degree arc."""
+    from .helpers.helper_gaussian import get_model
+    gm = get_model("gm_fluid")(device=device)
+    gm.setup_constants(H=SMOKE["H"], KNN_K=SMOKE["KNN_K"], p0=SMOKE["p0"], secs=SMOKE["secs"], k=SMOKE["k"])
+    fluid = S.plume_gaussians(P, seed=seed, channels=1)
+    gm._visual_xyz = torch.from_numpy(fluid["means3D"]).to(device)
+    gm.prepare_visual_particles_for_rendering()  # grey 0.7, log-scale -5.9, opacity 0.1 (gm_fluid.py:1529-1536)
+    cams = S.arc_cameras(n_views, size, size, device=device)
+    return gm, cams
+
+
+def build_ball_frame(P_fluid=350_000, P_background=150_000, hidden_dims=(22, 58, 22), n_views=8, size=512, seed=0,
+                     device="cuda"):
+    """BASELINE config 5 state: 500k Gaussians (fluid plume + static background) + a 28k-particle velocity field
+    (the reference's max_hidden_particles), 8 views on a full ring."""
+    return build_smoke_frame(P_fluid, P_background, hidden_dims, n_views, size, seed, device, ring=True)
+
+
 def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62, 20), n_views=5, size=512, seed=0,
-                      device="cuda"):
+                      device="cuda", ring=False):
     """BASELINE config 3 state: V visual fluid Gaussians + static background Gaussians + N hidden
     particles on a jittered unit lattice filling the plume (scaled units, < KNN_K neighbours each)."""
     rng = np.random.RandomState(seed)
@@ -81,7 +108,7 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
     gm._imass = t(np.ones((N, 1)))
     gm._buoyancy = t(np.tile(np.array([[0.0, 1.96, 0.0]]), (N, 1)))
     gm._force = t(np.zeros((N, 3)))
-    cams = S.arc_cameras(n_views, size, size, device=device)
+    cams = (S.ring_cameras if ring else S.arc_cameras)(n_views, size, size, device=device)
     return gm, cams
 
 
@@ -91,9 +118,16 @@ class HotLoop:
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
                  force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False,
-                 fused_step=False):
+                 fused_step=False, dual_channel=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
+        self.view_subset = None
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
+        # BASELINE config 5: every view is also rendered by the 1-channel rasteriser (fluid only, render_fluid) and
+        # compared with a 1-channel target; both image terms drive the same particle positions
+        self.dual_channel = bool(dual_channel)
+        if self.dual_channel:
+            assert batched_views, "dual_channel is implemented for the view-batched loop"
+            _, self.GRsetting1, self.GRzer1 = get_render_pipe("render_fluid")
         self.log_scalars = log_scalars
         self.physics_per_view = physics_per_view
         self.image_loss = image_loss
@@ -133,6 +167,11 @@ class HotLoop:
         # default stream would drag that stream into the capture.
         self.stream = torch.cuda.Stream(device=dev) if capturable else None
 
+    def _mine(self, batch):
+        """Views of the batch this rank renders: its round-robin share, or an explicit `view_subset` (single-process
+        emulation of one rank's share of a larger run: the batch mean still divides by the whole batch)."""
+        return list(self.view_subset) if self.view_subset is not None else shard_views(batch, self.rank, self.world)
+
     @torch.no_grad()
     def make_targets(self, shift=0.3):
         """Synthetic ground truth: the scene rendered with the hidden particles displaced by `shift`."""
@@ -148,6 +187,11 @@ class HotLoop:
             pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
                                    pos_type="guess_visual_nn", scale=True)
             cam.original_image = pkg["render"].detach().clamp(0, 1).clone()
+            if self.dual_channel:
+                from .renderer.pipes import render_fluid
+                pkg1 = render_fluid(cam, gm, None, self.background, GRsetting=self.GRsetting1, GRzer=self.GRzer1,
+                                    pos_type="guess_visual_nn", scale=True)
+                cam.original_image_ch1 = pkg1["render"].detach().clamp(0, 1).clone()
         gm._estimate_xyz_nn.data.copy_(keep)
 
     def _image_loss(self, image, gt_image):
@@ -272,7 +316,7 @@ class HotLoop:
         gm.update_learning_rate_current(self.itr)
         gm.zero_gradient_cache_current()
         batch = len(self.cams)
-        mine = shard_views(batch, self.rank, self.world)
+        mine = self._mine(batch)
         main = torch.cuda.current_stream()
         while len(self.view_streams) < len(mine):
             self.view_streams.append(torch.cuda.Stream(device=gm._xyz.device))
@@ -293,6 +337,10 @@ class HotLoop:
                 pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
                                        pos_type="guess_visual_nn", scale=True)
                 loss, _, _ = self._image_loss(pkg["render"], cam.original_image)
+                if self.cfg.get("lambda_current_distance", 0.0) > 0:  # tpp:365-366
+                    from .utils.loss_utils import distance_loss
+                    loss = loss + self.cfg["lambda_current_distance"] * distance_loss(
+                        pkg["render_xyz"], self.cfg["distance_threshold_visual"])
                 torch.autograd.grad(loss, [gm._estimate_xyz_nn], allow_unused=True)  # -> deferred visual backward
             main.wait_stream(s)
         if gp is not None:
@@ -304,12 +352,16 @@ class HotLoop:
         gm.optimizer.step()
         gm.optimizer.zero_grad()
 
-    def _gt_stack(self, mine):
-        """Ground-truth images of this rank's views as one [V,3,H,W] tensor (stacked once)."""
-        key = tuple((v, id(self.cams[v].original_image)) for v in mine)
-        if self._gt_cache is None or self._gt_cache[0] != key:
-            self._gt_cache = (key, torch.stack([self.cams[v].original_image for v in mine]).contiguous())
-        return self._gt_cache[1]
+    def _gt_stack(self, mine, attr="original_image"):
+        """Ground-truth images of this rank's views as one [V,C,H,W] tensor (stacked once; the entry keeps the
+        images it was built from)."""
+        if self._gt_cache is None:
+            self._gt_cache = {}
+        imgs = [getattr(self.cams[v], attr) for v in mine]
+        hit = self._gt_cache.get(attr)
+        if hit is None or len(hit[0]) != len(imgs) or any(a is not b for a, b in zip(hit[0], imgs)):
+            hit = self._gt_cache[attr] = (imgs, torch.stack(imgs).contiguous())
+        return hit[1]
 
     def _iteration_body_batched(self, phase="all"):
         """Same iteration with this rank's views rendered, compared and back-propagated by ONE launch
@@ -324,7 +376,7 @@ class HotLoop:
         gm.update_learning_rate_current(self.itr)
         gm.zero_gradient_cache_current()
         batch = len(self.cams)
-        mine = shard_views(batch, self.rank, self.world)
+        mine = self._mine(batch)
         with torch.no_grad():
             gm.get_visual_xyz_from_nn()  # hidden-particle grid + the one visual forward of this iteration (memoised)
         # The physics terms depend on the particle state only: their ~50 small kernels run on a side
@@ -351,8 +403,22 @@ class HotLoop:
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
+        means3D = gm.render_means_from_nn() if mine else None  # leaf: [advected visual / scale_factor | background]
+        gd = None
+        if mine and c.get("lambda_current_distance", 0.0) > 0:
+            # distance_loss(render_xyz) (tpp:365-366) is the same for every view: evaluated once (radius-limited
+            # kernel) on a branch of its own, added once per local view to the gradient of the rendered positions
+            from .physics import distance_loss_value_and_grad
+            if getattr(self, "dist_stream", None) is None:
+                self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
+            fork_d = torch.cuda.Event()
+            fork_d.record(main)
+            self.dist_stream.wait_event(fork_d)
+            with torch.cuda.stream(self.dist_stream):
+                n_vis = gm._visual_xyz.shape[0]
+                dval, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis], c["distance_threshold_visual"])
+                self.last_distance = dval
         if mine:
-            means3D = gm.render_means_from_nn()  # leaf: [advected visual / scale_factor | background]
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                         scale=True, means3D=means3D)
@@ -362,7 +428,21 @@ class HotLoop:
                                                              c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
-            g_means, = torch.autograd.grad([pkg["render"]], [means3D], grad_outputs=[dimg])
+            outs, seeds = [pkg["render"]], [dimg]
+            if self.dual_channel:
+                from .renderer.pipes import render_fluid_views
+                n_fluid = means3D.shape[0] - gm.get_gs_xyz.shape[0]
+                pkg1 = render_fluid_views([self.cams[v] for v in mine], gm, None, self.background,
+                                          GRsetting=self.GRsetting1, GRzer=self.GRzer1, pos_type="guess_visual_nn",
+                                          scale=True, means3D=means3D[:n_fluid])
+                _, _, dimg1 = image_loss_value_and_grad(pkg1["render"].detach(), self._gt_stack(mine, "original_image_ch1"),
+                                                        c["lambda_dssim"], c["lambda_image"], grey=False)
+                outs.append(pkg1["render"])
+                seeds.append(dimg1)
+            g_means, = torch.autograd.grad(outs, [means3D], grad_outputs=seeds)
+            if gd is not None:
+                main.wait_stream(self.dist_stream)
+                g_means[:gd.shape[0]].add_(gd, alpha=float(c["lambda_current_distance"]) * len(mine))
             gm.defer_render_means_gradient(g_means)  # -> the one hidden<-visual backward of the iteration
         if gp is not None:
             main.wait_stream(self.side_stream)
@@ -405,12 +485,16 @@ class HotLoop:
         gm.update_learning_rate_current(self.itr)
         gm.zero_gradient_cache_current()
         batch = len(self.cams)  # the benchmark renders every view each iteration (BASELINE: 5 views/iter)
-        mine = shard_views(batch, self.rank, self.world)
+        mine = self._mine(batch)
         for n, v in enumerate(mine):
             cam = self.cams[v]
             pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
                                    pos_type="guess_visual_nn", scale=True)
             loss, l1_value, ssim_value = self._image_loss(pkg["render"], cam.original_image)
+            if self.cfg.get("lambda_current_distance", 0.0) > 0:  # tpp:365-366
+                from .utils.loss_utils import distance_loss
+                loss = loss + self.cfg["lambda_current_distance"] * distance_loss(pkg["render_xyz"],
+                                                                                 self.cfg["distance_threshold_visual"])
             if self.physics_per_view:
                 loss = loss + self._physics_loss()          # as the reference: once per view (tpp:368-389)
             elif n == 0 and self.rank == 0:
@@ -468,7 +552,7 @@ class HotLoopLevelTwo:
         gm.total_iterations += 1
         gm.zero_gradient_cache_current_level_two()
         batch = len(self.cams)
-        for v in shard_views(batch, self.rank, self.world):
+        for v in self._mine(batch):
             cam = self.cams[v]
             pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
                                    pos_type="visual", scale=True)
@@ -497,3 +581,158 @@ class HotLoopLevelTwo:
         gm.set_batch_gradient_current_level_two(batch)
         gm.optimizer.step()
         gm.optimizer.zero_grad()
+
+
+class FirstFrameLoop:
+    """First-frame stage (entries_fluid_nexus/train_physical_particle.py:103-163 with render_dynamics + the grey-mean
+    image term; entries_scalar_real/train_physical_particle.py:97-165 with render_fluid on the 1-channel image): the
+    positions of the visual particles are the leaf, pos_type="visual", loss = L1 + D-SSIM (+ lambda_first_distance x
+    distance_loss(visual_xyz, distance_threshold_visual)), gradient mean over the batch, Adam(eps = 1e-15).
+    The views of the batch go through one view-batched launch sequence; `capture()` records k iterations as one
+    hipGraph.  Multi-GPU: views sharded, one all-reduce of the position gradient."""
+
+    def __init__(self, gm, cams, rd_pipe="render_fluid", rank=0, world=1, cfg=SCALAR_REAL, capturable=True,
+                 force_all_reduce=False, log_scalars=False):
+        self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
+        self.view_subset = None
+        self.rd_pipe = rd_pipe
+        self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
+        assert rd_pipe in ("render_fluid", "render_dynamics")
+        self.grey = rd_pipe == "render_dynamics"  # tpp:131-135 compares grey-mean images; ScalarReal is single-channel
+        self.force_all_reduce, self.log_scalars = force_all_reduce, log_scalars
+        self.background = torch.zeros(3, device=gm._visual_xyz.device)
+        args = SimpleNamespace(**{k: cfg[k] for k in ("position_lr_init", "position_lr_final", "position_lr_delay_mult",
+                                                      "position_lr_max_steps")})
+        gm.training_setup_first_visual(args, capturable=capturable)
+        self.capturable = capturable
+        self.stream = torch.cuda.Stream(device=gm._visual_xyz.device) if capturable else None
+        self.graph, self.graph_iterations, self._replay, self._reduce_buf = None, 1, False, None
+        self.itr, self.last, self._gt = 0, {}, None
+
+    @property
+    def multi(self):
+        return self.world > 1 or self.force_all_reduce
+
+    def _mine(self, batch):
+        return list(self.view_subset) if self.view_subset is not None else shard_views(batch, self.rank, self.world)
+
+    @torch.no_grad()
+    def make_targets(self, shift=(0.004, 0.002, 0.0)):
+        """Synthetic ground truth: the scene rendered with the visual particles displaced by `shift` (world units)."""
+        gm = self.gm
+        keep = gm._visual_xyz.data.clone()
+        gm._visual_xyz.data += torch.tensor(shift, device=keep.device)
+        for cam in self.cams:
+            pkg = self.render_func(cam, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                   pos_type="visual")
+            cam.original_image = pkg["render"].detach().clamp(0, 1).clone()
+        gm._visual_xyz.data.copy_(keep)
+        self._gt = None
+
+    def _gt_stack(self, mine):
+        imgs = [self.cams[v].original_image for v in mine]
+        if self._gt is None or len(self._gt[0]) != len(imgs) or any(a is not b for a, b in zip(self._gt[0], imgs)):
+            self._gt = (imgs, torch.stack(imgs).contiguous())
+        return self._gt[1]
+
+    def _local_gradient(self):
+        """Sum over this rank's views of d loss_v / d visual_xyz as a list of (tensor, scale) terms."""
+        from .losses import image_loss_value_and_grad
+        from .renderer.pipes import render_dynamics_views, render_fluid_views
+        gm, c = self.gm, self.cfg
+        mine = self._mine(len(self.cams))
+        param = gm._visual_xyz
+        V = param.shape[0]
+        terms = []
+        if mine:
+            cams = [self.cams[v] for v in mine]
+            if self.rd_pipe == "render_fluid":
+                means = param
+                pkg = render_fluid_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                         pos_type="visual", means3D=means)
+            else:
+                means = gm.render_means_from_visual()
+                pkg = render_dynamics_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                            pos_type="visual", scale=False, means3D=means)
+            loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine),
+                                                             c["lambda_dssim"], 1.0, grey=self.grey)
+            if self.log_scalars:
+                self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
+            g, = torch.autograd.grad([pkg["render"]], [means], grad_outputs=[dimg])
+            terms.append((g[:V], 1.0))
+            if c.get("lambda_first_distance", 0.0) > 0:
+                # the same for every view (tpp:141-144): evaluated once, added once per local view
+                from .physics import distance_loss_value_and_grad
+                _, gd = distance_loss_value_and_grad(param.detach(), c["distance_threshold_visual"])
+                terms.append((gd, float(c["lambda_first_distance"]) * len(mine)))
+        return terms
+
+    def _body(self, phase="all"):
+        from . import physics
+        gm = self.gm
+        self.itr += 1
+        gm.total_iterations += 1
+        gm.update_learning_rate_first_visual(self.itr)
+        batch = len(self.cams)
+        terms = self._local_gradient()
+        if self.multi:
+            buf = self._reduce_buf
+            buf.zero_()
+            for t, sc in terms:
+                buf.add_(t, alpha=sc)
+            if phase == "local":
+                return
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            terms = [(buf, 1.0)]
+        physics.adam_step(gm._visual_xyz, gm.optimizer, terms, batch)
+
+    def _finish(self):
+        from . import physics
+        physics.adam_step(self.gm._visual_xyz, self.gm.optimizer, [(self._reduce_buf, 1.0)], len(self.cams))
+
+    def capture(self, warmup=2, iterations=1):
+        from . import rasterizer
+        assert self.capturable and not rasterizer._HOST_SYNC
+        if self.multi and self._reduce_buf is None:
+            self._reduce_buf = torch.zeros_like(self.gm._visual_xyz.detach())
+        for _ in range(warmup):
+            self.iteration()
+        torch.cuda.synchronize()
+        rasterizer._pending_status.clear()
+        g = torch.cuda.CUDAGraph()
+        itr0, tot0 = self.itr, self.gm.total_iterations
+        with torch.cuda.graph(g, stream=self.stream):
+            if self.multi:  # local gradient | all-reduce outside the graph | one-kernel step launched eagerly
+                self._body(phase="local")
+                iterations = 1
+            else:
+                for _ in range(int(iterations)):
+                    self._body()
+        self.itr, self.gm.total_iterations = itr0, tot0
+        self.graph, self.graph_iterations, self._replay = g, int(iterations), True
+        return g
+
+    @property
+    def iterations_per_call(self):
+        return self.graph_iterations if (self.graph is not None and self._replay) else 1
+
+    def use_graph(self, enabled):
+        self._replay = bool(enabled) and self.graph is not None
+
+    def iteration(self):
+        if self.multi and self._reduce_buf is None:
+            self._reduce_buf = torch.zeros_like(self.gm._visual_xyz.detach())
+        if self.stream is None:
+            return self._body()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if self.graph is not None and self._replay:
+                self.itr += self.graph_iterations
+                self.gm.total_iterations += self.graph_iterations
+                self.graph.replay()
+                if self.multi:
+                    dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
+                    self._finish()
+            else:
+                self._body()
+        torch.cuda.current_stream().wait_stream(self.stream)

@@ -243,6 +243,45 @@ def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
     return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next), memo)
 
 
+class _DistanceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, threshold):
+        loss, grad = distance_loss_value_and_grad(positions.detach(), threshold)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g, None
+
+
+def distance_loss_value_and_grad(positions, threshold, need_grad=True):
+    """(loss, d loss / d positions [N,3]) of utils/loss_utils.distance_loss(positions, threshold)
+    (loss_utils.py:98-121: every pair closer than `threshold` pays (threshold - distance)^2, counted in both
+    orders) on a hash grid with cell = threshold instead of the reference's dense N x N torch.cdist -- the same
+    sum, but O(N) memory, so it stays usable at 10^5 particles."""
+    lib = PL.physics()
+    x = _req(positions.detach())
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise RuntimeError("positions must have dimensions (num_points, 3)")
+    N = x.shape[0]
+    if N == 0:
+        z = torch.zeros((), dtype=torch.float32, device=x.device)
+        return z, torch.zeros_like(x)
+    grid = torch.empty(lib.fnx_grid_bytes(N), dtype=torch.uint8, device=x.device)
+    partials = torch.empty(lib.fnx_distance_loss_partials(N), dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x) if need_grad else None
+    PL.check(lib.fnx_distance_loss(x.data_ptr(), N, float(threshold), grid.data_ptr(), partials.data_ptr(),
+                                   grad.data_ptr() if need_grad else None, _stream()))
+    return partials.sum(), grad
+
+
+def distance_loss(positions, threshold):
+    """Differentiable drop-in for utils/loss_utils.distance_loss on device tensors (one autograd node)."""
+    return _DistanceLoss.apply(positions, float(threshold))
+
+
 def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=None, scale=1.0):
     """Gradient mean + Adam step of `param` in one kernel (fnx_adam_step), on the state of `optimizer`
     (a torch.optim.Adam with amsgrad = False, weight_decay = 0 whose only parameter is `param`).

@@ -98,14 +98,15 @@ def check_status():
     if not _pending_status and not _captured_status:
         return
     host = {d: r.cpu() for d, r in _status_ring.items()}  # one small D2H copy per device, synchronising
-    first, err = True, None
+    err = None
+    if _pending_status:  # the most recent eager forward (per-call instances; the static ones of a split forward on top)
+        dev_index, slot, _ = _pending_status[-1]
+        last_num_rendered = int(host[dev_index][slot][0]) + int(host[dev_index][slot][3])
     entries = list(reversed(_pending_status)) + list(_captured_status)
     _pending_status.clear()
     for dev_index, slot, key in entries:
         n, status, cap = (int(x) for x in host[dev_index][slot][:3])
         _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n * _CAP_SLACK) + 1024)
-        if first:
-            last_num_rendered, first = n, False
         if status == _lib.FNX_ERR_CAPACITY and err is None:
             err = _lib.FnxError(status, f"binning capacity {cap} < num_rendered {n}")
     if err is not None:
@@ -174,6 +175,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 n = C.c_int(0)
                 _lib.check(lib.fnx_read_num_rendered(img.data_ptr(), W, H, stream, C.byref(n)))
                 num_rendered = cap = int(n.value)
+                global last_num_rendered
+                last_num_rendered = num_rendered
                 if not _HOST_SYNC:
                     _capacity_hwm[key] = cap = int(num_rendered * _CAP_SLACK) + 1024
             else:

@@ -72,6 +72,27 @@ def _static_attributes(gm, pos_type, gs_only):
     return out
 
 
+_FLUID_CACHE: dict = {}
+
+
+def _fluid_attributes(gm, pos_type):
+    """_attributes(), kept resident while none of the raw tensors requires grad (position-only stages): the
+    activations are the same for every view and every iteration of the stage."""
+    fam = _ATTR.get(pos_type, "visual")
+    names = ([f"_{n}_dummy" for n in ("opacity", "scales", "rotation", "color")] if fam == "dummy"
+             else [f"_{fam}_{n}" for n in ("opacity", "scales", "rotation", "color")])
+    raws = [getattr(gm, n) for n in names]
+    if any(t.requires_grad for t in raws):
+        return _attributes(gm, pos_type)
+    key = (pos_type,) + tuple(t._version for t in raws)
+    hit = _FLUID_CACHE.get(id(gm))
+    if hit is not None and hit[0] == key and hit[2] is gm and all(a is b for a, b in zip(hit[3], raws)):
+        return hit[1]
+    out = tuple(t.float().contiguous() for t in _attributes(gm, pos_type))
+    _FLUID_CACHE[id(gm)] = (key, out, gm, raws)
+    return out
+
+
 def _screen_space_like(xyz):
     """Zero tensor whose .grad receives the 2D-mean gradients (pipe_dynamics.py:59-66)."""
     p = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -265,6 +286,30 @@ def render_fluid(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0
                                      colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
                                      rotations=rotations.float(), cov3D_precomp=None)
     return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, render_xyz, rotations, colors, scales)
+
+
+def render_fluid_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
+                       GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, means3D=None,
+                       **kwargs):
+    """render_fluid for all cameras of a training batch in one rasteriser call (extension, like
+    render_dynamics_views): "render" [V,1,H,W], "radii" [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3].
+    `means3D`: positions prepared by the caller (a leaf to differentiate with respect to) instead of the pos_type
+    lookup and scaling."""
+    from ..rasterizer import GaussianRasterizerViews
+    if means3D is None:
+        raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    else:
+        raw_render_xyz = render_xyz = means3D
+    opacity, scales, rotations, colors = _fluid_attributes(gm, pos_type)
+    V = len(viewpoint_cameras)
+    screen = _zero_scalar(render_xyz).expand((V,) + tuple(render_xyz.shape)).requires_grad_()
+    rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
+                                                     gm.active_sh_degree), channels=getattr(GRzer, "channels", 1))
+    image, radii, depth = rasterizer(means3D=render_xyz.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
+                                     opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
+                                     cov3D_precomp=None)
+    return _LazyPackage(_pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, render_xyz, rotations,
+                              colors, scales, visibility=False))
 
 
 def render_background(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,

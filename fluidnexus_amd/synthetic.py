@@ -63,6 +63,17 @@ def arc_cameras(n, W, H, target=(0.34, 0.3, -0.225), distance=1.6, arc_deg=120.0
     return cams
 
 
+def ring_cameras(n, W, H, target=(0.34, 0.3, -0.225), distance=1.6, fov=0.8, height=0.3, device="cuda"):
+    """n views evenly spaced on a full 360 degree ring around `target` (BASELINE config 5: 8 synthetic views)."""
+    cams = []
+    for i in range(n):
+        a = 2.0 * math.pi * i / n
+        eye = (target[0] + distance * math.sin(a), height, target[2] + distance * math.cos(a))
+        R, T = look_at(eye, target)
+        cams.append(Camera(R, T, fov, fov, W, H, uid=i, device=device))
+    return cams
+
+
 def front_camera(W, H, distance=2.0, fov=0.8, device="cuda"):
     """config 1 camera: on +z at `distance`, looking at the origin."""
     R, T = look_at((0.0, 0.0, distance), (0.0, 0.0, 0.0))

@@ -58,8 +58,13 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 
 def distance_loss(positions, threshold):
-    """Penalise particle pairs closer than `threshold` (dense N x N; only usable for small N --
-    the BASELINE benchmark shapes switch it off, SURVEY finding 7)."""
+    """Penalise particle pairs closer than `threshold` (loss_utils.py:98-121).  Device tensors go through the
+    radius-limited fused kernel (fluidnexus_amd.physics.distance_loss: hash grid with cell = threshold, value and
+    gradient in one launch sequence, O(N) memory); the dense N x N torch form below is the reference's own
+    expression, kept for host tensors (small N only: 300k points would need 360 GB)."""
+    if positions.is_cuda:
+        from ..physics import distance_loss as _fused
+        return _fused(positions, threshold)
     d = torch.cdist(positions, positions, p=2)
     mask = d < threshold
     mask.fill_diagonal_(False)

@@ -133,6 +133,16 @@ int fnx_visual_advect(float *visual, int V, const float *hidden, const float *ve
  * ~(volume / N)^(1/3) is fast. */
 int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *mean_dist2, fnx_stream_t stream);
 
+/* Pairwise distance loss of FluidDynamics/utils/loss_utils.py:98-121 (distance_loss(positions, threshold), called
+ * per view at entries_fluid_nexus/train_physical_particle.py:141-144,365-366), radius-limited instead of a dense
+ * N x N torch.cdist:  loss = sum over ordered pairs i != j with |x_i - x_j| < threshold of (threshold - |x_i - x_j|)^2.
+ * `grid`: fnx_grid_bytes(N) bytes of scratch (a hash grid with cell = threshold is built in it);
+ * partials [fnx_distance_loss_partials(N)]: per-workgroup sums, loss = their sum (deterministic);
+ * grad [N,3] (may be NULL): d loss / d xyz, zero for coincident points like torch.cdist's backward. */
+int fnx_distance_loss_partials(int N);
+int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, float *partials, float *grad,
+                      fnx_stream_t stream);
+
 /* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
  * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
  *   g = ((g0 s0 + g1 s1) + g2 s2) * inv_batch            (NULL terms are skipped; n = number of floats)

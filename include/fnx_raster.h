@@ -241,7 +241,7 @@ int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const
 /*
  * Optional kernel timing for benchmarks: when enabled, HIP events are recorded on the caller's
  * stream around one kernel class per launch (0 blend forward, 1 blend backward, 2 depth sort +
- * instance counting + scans, 3 preprocess, 4 instance emission).  fnx_profile_read blocks on those events
+ * instance counting + scans, 3 preprocess, 4 instance emission; 5 / 6 blend forward / backward of channels == 1).  fnx_profile_read blocks on those events
  * and returns the summed duration and the number of launches since fnx_profile_enable(1).
  */
 int fnx_profile_enable(int on);

@@ -146,3 +146,25 @@ class PbfOracle(PhysicsOracle):
         vv = torch.zeros(V, 3).index_add_(0, row, velocity[col] * p6.unsqueeze(-1))
         s = torch.zeros(V).index_add_(0, row, p6).clamp_min(self.EPSILON)
         return visual + vv * self.secs / s.unsqueeze(-1)
+
+
+def distance_loss_oracle(positions, threshold):
+    """utils/loss_utils.py:98-121 restated in float64 with explicit differences (no matrix-multiply distance form):
+    loss = sum over ordered pairs i != j with d_ij < threshold of (threshold - d_ij)^2 and its gradient
+    -4 sum_j (threshold - d_ij) (x_i - x_j) / d_ij (zero for coincident points, as torch.cdist's backward).
+    Pinned by tests/golden/distance_loss.npz = the reference's own function on float64 copies of the points
+    (its fp32 evaluation is stored too: it is noisier than this restatement).  O(N^2) memory in blocks."""
+    x = np.asarray(positions, dtype=np.float64)
+    thr = float(np.float32(threshold))
+    N = x.shape[0]
+    loss, grad = 0.0, np.zeros_like(x)
+    for a in range(0, N, 1024):
+        diff = x[a:a + 1024, None, :] - x[None, :, :]
+        d = np.sqrt((diff ** 2).sum(-1))
+        m = d < thr
+        m[np.arange(diff.shape[0]), a + np.arange(diff.shape[0])] = False
+        t = np.where(m, thr - d, 0.0)
+        loss += float((t ** 2).sum())
+        k = np.where(m & (d > 0), -4.0 * t / np.where(d > 0, d, 1.0), 0.0)
+        grad[a:a + 1024] = (k[..., None] * diff).sum(1)
+    return loss, grad

@@ -137,6 +137,37 @@ def gen_losses():
     np.savez(os.path.join(OUT, "loss_utils.npz"), **out)
 
 
+def gen_distance():
+    """distance_loss (loss_utils.py:98-121) on clouds shaped like the benchmark's visual particles.  The reference
+    evaluates torch.cdist in fp32 (matrix-multiply form for N > 25: |x|^2 + |y|^2 - 2 x.y, which loses digits for
+    close pairs), so both its fp32 value / gradient and the same function on float64 inputs are stored: the fused
+    kernel is compared tightly with the float64 result and the fp32 reference must lie within its own noise of it."""
+    from utils.loss_utils import distance_loss
+    rng = np.random.RandomState(7)
+    out = {}
+    clouds = {
+        # plume-like: cylinder r 0.1, height 0.6, world units; ~0.3 neighbours within thr on average
+        "plume": (np.stack([0.34 + 0.1 * np.sqrt(rng.uniform(size=4000)) * np.cos(t := rng.uniform(0, 2 * np.pi, 4000)),
+                            rng.uniform(-0.02, 0.6, 4000), -0.225 + 0.1 * np.sqrt(rng.uniform(size=4000)) * np.sin(t)], 1),
+                  0.0125),
+        # dense blob in scaled units: many pairs under the threshold, some exactly coincident
+        "blob": (np.concatenate([rng.normal(scale=0.6, size=(1500, 3)), np.zeros((3, 3)), np.full((2, 3), 0.25)], 0), 0.2),
+        # no pair under the threshold
+        "sparse": (rng.uniform(0, 10, size=(300, 3)), 0.01),
+    }
+    for tag, (xyz, thr) in clouds.items():
+        x32 = torch.tensor(xyz, dtype=torch.float32, requires_grad=True)
+        x64 = torch.tensor(x32.detach().numpy().astype(np.float64), requires_grad=True)  # the same points
+        v32 = distance_loss(x32, thr)
+        v32.backward()
+        v64 = distance_loss(x64, float(np.float32(thr)))
+        v64.backward()
+        out[f"pos_{tag}"], out[f"thr_{tag}"] = x32.detach().numpy(), np.float32(thr)
+        out[f"loss32_{tag}"], out[f"grad32_{tag}"] = np.float32(v32.item()), x32.grad.numpy()
+        out[f"loss64_{tag}"], out[f"grad64_{tag}"] = np.float64(v64.item()), x64.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "distance_loss.npz"), **out)
+
+
 def gen_general():
     from utils.general_utils import get_expon_lr_func, inv_sigmoid
     out = {}
@@ -415,6 +446,7 @@ if __name__ == "__main__":
     gen_graphics()
     gen_sh()
     gen_losses()
+    gen_distance()
     gen_general()
     gen_physics()
     gen_pbf()

@@ -1,5 +1,8 @@
-"""-m gpu: BASELINE config 3 at FULL size (200k fluid + 100k background Gaussians, 5 views at 512 x 512) through the
-C ABI, checked with size-independent properties instead of the CPU oracle (which needs minutes at this size):
+"""-m gpu: every single-GPU BASELINE configuration at FULL size through the C ABI -- config 3 / 4 (200k fluid + 100k
+background Gaussians, 5 views at 512 x 512, 3 channels), config 2 (ScalarReal-like plume of 100k grey Gaussians, 5 views,
+1 channel) and config 5's per-rank scene (350k fluid + 150k background, views of the 8-camera ring, 3 channels, and the
+fluid alone through the 1-channel rasteriser) -- checked with size-independent properties instead of the CPU oracle
+(which needs minutes at this size):
 
   binning   every tile list is ordered by (depth bits, id) -- the unique order the reference's stable radix sort of
             (tile | depth) keys emitted in id order produces; every listed splat's rectangle contains the tile; the
@@ -20,21 +23,35 @@ pytestmark = pytest.mark.gpu
 
 from fluidnexus_amd import synthetic as S  # noqa: E402
 
-P_FLUID, P_BG, SIZE, VIEWS = 200_000, 100_000, 512, 5
+SIZE = 512
+SCENES = {
+    # name: (fluid, background, channels, views, ring cameras, least instance count per view)
+    "smoke_ch3": (200_000, 100_000, 3, 5, False, 2_000_000),      # BASELINE configs 3 and 4
+    "scalar_real_ch1": (100_000, 0, 1, 5, False, 100_000),        # BASELINE config 2
+    "ball_ch3": (350_000, 150_000, 3, 8, True, 3_000_000),        # BASELINE config 5, colour rasteriser
+    "ball_fluid_ch1": (350_000, 0, 1, 8, True, 350_000),          # BASELINE config 5, 1-channel rasteriser (fluid only)
+}
 
 
-@pytest.fixture(scope="module")
-def scene():
-    g = S.smoke_scene(P_FLUID, P_BG, seed=0, channels=3)
-    cams = S.arc_cameras(VIEWS, SIZE, SIZE, device="cpu")
-    return g, cams
+class _Scene:
+    def __init__(self, name):
+        pf, pb, self.C, self.V, ring, self.min_R = SCENES[name]
+        self.name, self.P = name, pf + pb
+        self.g = S.smoke_scene(pf, pb, seed=0, channels=self.C) if pb else S.plume_gaussians(pf, seed=0, channels=self.C)
+        self.cams = (S.ring_cameras if ring else S.arc_cameras)(self.V, SIZE, SIZE, device="cpu")
 
 
-def _run(g, cam, bg, colors=None):
+@pytest.fixture(scope="module", params=list(SCENES))
+def scene(request):
+    return _Scene(request.param)
+
+
+def _run(sc, cam, bg, colors=None):
     from tests.hip_harness import HipRun, scene_kwargs
+    g = sc.g
     kw = scene_kwargs(g, cam, SIZE, SIZE, 0.8)
     return HipRun(bg=bg, colors_precomp=g["colors"] if colors is None else colors, scales=g["scales"],
-                  rotations=g["rotations"], **kw)
+                  rotations=g["rotations"], channels=sc.C, **kw)
 
 
 def _rects(means2D, radii, gx, gy):
@@ -49,15 +66,16 @@ def _rects(means2D, radii, gx, gy):
 
 @pytest.mark.parametrize("view", [0, 2, 4])
 def test_full_size_binning_properties(scene, view):
-    g, cams = scene
-    h = _run(g, cams[view], np.zeros(3, np.float32))
+    g, cams = scene.g, scene.cams
+    P_ALL = scene.P
+    h = _run(scene, cams[view], np.zeros(3, np.float32))
     it = h.intermediates()
     gx = gy = SIZE // 16
     T = gx * gy
     ranges, plist = it["ranges"].astype(np.int64), it["point_list"].astype(np.int64)
     radii, touched = it["radii"], it["tiles_touched"].astype(np.int64)
     vis = radii > 0
-    assert vis.sum() > 0.9 * (P_FLUID + P_BG) and h.R > 2_000_000
+    assert vis.sum() > 0.9 * P_ALL and h.R > scene.min_R
     # checksum of checksums
     lens = ranges[:, 1] - ranges[:, 0]
     assert touched[vis].sum() == h.R == lens.sum() and touched[~vis].sum() == 0
@@ -76,7 +94,7 @@ def test_full_size_binning_properties(scene, view):
     tx, ty = tile_of % gx, tile_of // gx
     assert ((tx >= x0[plist]) & (tx < x1[plist]) & (ty >= y0[plist]) & (ty < y1[plist])).all()
     assert (((x1 - x0) * (y1 - y0))[vis] == touched[vis]).all()
-    assert np.unique(tile_of * (P_FLUID + P_BG) + plist).size == h.R
+    assert np.unique(tile_of * P_ALL + plist).size == h.R
     # per-pixel state
     assert (it["final_T"] >= 0).all() and (it["final_T"] <= 1).all()
     ncon = it["n_contrib"].astype(np.int64).reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(T, 256)
@@ -84,16 +102,16 @@ def test_full_size_binning_properties(scene, view):
 
 
 def test_full_size_blend_deterministic_and_affine(scene):
-    g, cams = scene
+    g, cams = scene.g, scene.cams
     rng = np.random.RandomState(1)
     c1, c2 = g["colors"], rng.uniform(0, 1, size=g["colors"].shape).astype(np.float32)
-    bg1, bg2 = np.array([0.1, 0.2, 0.3], np.float32), np.array([0.9, 0.0, 0.4], np.float32)
+    bg1, bg2 = np.array([0.1, 0.2, 0.3], np.float32), np.array([0.9, 0.0, 0.4], np.float32)  # ch1 reads entry 0
     a, b = np.float32(0.75), np.float32(0.25)
-    A = _run(g, cams[1], bg1, c1)
-    A2 = _run(g, cams[1], bg1, c1)
+    A = _run(scene, cams[1], bg1, c1)
+    A2 = _run(scene, cams[1], bg1, c1)
     assert torch.equal(A.color, A2.color) and torch.equal(A.depth, A2.depth)
-    B = _run(g, cams[1], bg2, c2)
-    M = _run(g, cams[1], a * bg1 + b * bg2, a * c1 + b * c2)
+    B = _run(scene, cams[1], bg2, c2)
+    M = _run(scene, cams[1], a * bg1 + b * bg2, a * c1 + b * c2)
     want = a * A.color.double() + b * B.color.double()
     assert (M.color.double() - want).abs().max().item() < 5e-6  # the blend is affine in (colours, background)
     assert torch.equal(M.depth, A.depth)  # geometry only
@@ -101,34 +119,35 @@ def test_full_size_blend_deterministic_and_affine(scene):
 
 def test_full_size_view_batch_equals_single_view(scene):
     from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews
-    g, cams = scene
+    g, cams = scene.g, scene.cams
+    VIEWS = min(scene.V, 5)
     dev = torch.device("cuda")
     bg = torch.tensor([0.0, 0.1, 0.2], device=dev)
     t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
     tan = math.tan(0.4)
-    gcams = S.arc_cameras(VIEWS, SIZE, SIZE, device=dev)
+    gcams = (S.ring_cameras if SCENES[scene.name][4] else S.arc_cameras)(scene.V, SIZE, SIZE, device=dev)[:VIEWS]
     settings = [GaussianRasterizationSettings(image_height=SIZE, image_width=SIZE, tan_fov_x=tan, tan_fov_y=tan, bg=bg,
                                               scale_modifier=1.0, view_matrix=c.world_view_transform,
                                               proj_matrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
                                               prefiltered=False) for c in gcams]
     from fluidnexus_amd.rasterizer import ViewBatch
     with torch.no_grad():
-        color, radii, depth = GaussianRasterizerViews(ViewBatch(settings))(
-            means3D=t["means3D"], means2D=torch.zeros(VIEWS, P_FLUID + P_BG, 3, device=dev), shs=None,
+        color, radii, depth = GaussianRasterizerViews(ViewBatch(settings), channels=scene.C)(
+            means3D=t["means3D"], means2D=torch.zeros(VIEWS, scene.P, 3, device=dev), shs=None,
             colors_precomp=t["colors"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
             cov3D_precomp=None)
     for v in (0, 3):
-        h = _run(g, cams[v], bg.cpu().numpy())
+        h = _run(scene, cams[v], bg.cpu().numpy())
         assert torch.equal(color[v], h.color) and torch.equal(depth[v], h.depth) and torch.equal(radii[v], h.radii)
 
 
 def test_full_size_backward_linear_and_consistent_with_forward(scene):
-    g, cams = scene
+    g, cams = scene.g, scene.cams
     rng = np.random.RandomState(2)
     bg = np.array([0.2, 0.2, 0.2], np.float32)
-    h = _run(g, cams[2], bg)
-    d1 = rng.normal(size=(3, SIZE, SIZE)).astype(np.float32)
-    d2 = rng.normal(size=(3, SIZE, SIZE)).astype(np.float32)
+    h = _run(scene, cams[2], bg)
+    d1 = rng.normal(size=(scene.C, SIZE, SIZE)).astype(np.float32)
+    d2 = rng.normal(size=(scene.C, SIZE, SIZE)).astype(np.float32)
     g1, g2, g12 = h.backward(d1), h.backward(d2), h.backward(d1 + 2.0 * d2)
     for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"):
         want = g1[k].astype(np.float64) + 2.0 * g2[k].astype(np.float64)
@@ -136,7 +155,7 @@ def test_full_size_backward_linear_and_consistent_with_forward(scene):
         assert np.abs(g12[k] - want).max() / scale < 2e-4, k  # linear in dL/dpixel (fp32 atomics order)
     # the forward is affine in the colours: <dL/dcolours, dc> = <dL/dpixels, C(c + dc) - C(c)>
     dc = rng.normal(size=g["colors"].shape).astype(np.float32) * 0.1
-    h2 = _run(g, cams[2], bg, g["colors"] + dc)
+    h2 = _run(scene, cams[2], bg, g["colors"] + dc)
     lhs = float((g1["dL_dcolors"].astype(np.float64) * dc).sum())
     rhs = float(((h2.color.double() - h.color.double()).cpu().numpy() * d1).sum())
     assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0)

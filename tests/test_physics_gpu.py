@@ -282,3 +282,27 @@ def test_visual_backward_cells_equals_particle_walk():
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert (np.abs(a).sum(1) == 0).sum() >= 50 and ((np.abs(a).sum(1) == 0) == (np.abs(b).sum(1) == 0)).all()
     assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("tag", ["plume", "blob", "sparse"])
+def test_distance_loss_matches_reference_golden(tag):
+    """fnx_distance_loss (radius-limited, hash grid) against the reference's dense distance_loss evaluated on float64
+    copies of the points (tests/golden/distance_loss.npz), value and gradient; also through the autograd drop-in
+    utils.loss_utils.distance_loss."""
+    import torch
+    from fluidnexus_amd.physics import distance_loss_value_and_grad
+    from fluidnexus_amd.utils.loss_utils import distance_loss
+    D = np.load(os.path.join(os.path.dirname(__file__), "golden", "distance_loss.npz"))
+    pos = torch.tensor(D[f"pos_{tag}"], device="cuda")
+    thr = float(D[f"thr_{tag}"])
+    loss, grad = distance_loss_value_and_grad(pos, thr)
+    ref_l, ref_g = float(D[f"loss64_{tag}"]), D[f"grad64_{tag}"]
+    scale = np.abs(ref_g).max() + 1e-30
+    assert abs(loss.item() - ref_l) <= 2e-5 * max(ref_l, 1e-12) + 1e-12
+    assert np.abs(grad.cpu().numpy() - ref_g).max() <= 2e-5 * scale + 1e-12
+    if tag != "sparse":
+        assert ref_l > 0 and scale > 0
+    x = pos.clone().requires_grad_(True)
+    v = distance_loss(x, thr) * 3.0
+    v.backward()
+    assert np.abs(x.grad.cpu().numpy() - 3.0 * ref_g).max() <= 6e-5 * scale + 1e-12

@@ -41,3 +41,20 @@ def test_physics_oracle_matches_reference(tag):
     guess = o.guess_hidden_particles_from_nn(t["x_nn"], t["x_prev"], t["buoyancy"], t["force"]).numpy()
     assert np.allclose(guess, G[f"guess_{tag}"], rtol=1e-6, atol=1e-6)
     assert np.allclose(o.poly6(torch.tensor(G[f"poly6_r2_{tag}"])).numpy(), G[f"poly6_{tag}"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["plume", "blob", "sparse"])
+def test_distance_loss_oracle_matches_reference(tag):
+    """The float64 restatement against the reference's distance_loss on float64 copies of the same points; the
+    reference's own fp32 evaluation (cdist's matrix-multiply form) agrees with both only to its cancellation noise."""
+    from oracle.physics_oracle import distance_loss_oracle
+    D = np.load(os.path.join(os.path.dirname(__file__), "golden", "distance_loss.npz"))
+    loss, grad = distance_loss_oracle(D[f"pos_{tag}"], D[f"thr_{tag}"])
+    g64 = D[f"grad64_{tag}"]
+    scale = np.abs(g64).max() + 1e-30
+    assert abs(loss - float(D[f"loss64_{tag}"])) <= 1e-9 * max(1.0, abs(loss))
+    assert np.abs(grad - g64).max() <= 1e-9 * scale + 1e-30
+    if tag != "sparse":
+        assert loss > 0
+        assert abs(float(D[f"loss32_{tag}"]) - loss) <= 1e-3 * loss          # the reference's fp32 noise
+        assert np.abs(D[f"grad32_{tag}"] - g64).max() <= 2e-2 * scale

@@ -48,14 +48,24 @@ def _close(a, b, rtol=2e-4):
 @pytest.mark.parametrize("channels,P_dyn,P_static,ties,static_box", [(3, 5000, 3000, 0, 0.45), (1, 3000, 6000, 0, 0.45),
                                                                       (3, 4000, 4000, 500, 0.45), (3, 6000, 800, 0, 0.08)])
 def test_split_equals_unsplit(channels, P_dyn, P_static, ties, static_box):
+    W, H, V = 144, 112, 3
+    g = _scene(P_dyn, P_static, channels, seed=21, static_box=static_box, ties=ties)
+    _check_split(g, channels, P_dyn, P_static, W, H, S.arc_cameras(V, W, H, device="cuda"))
+
+
+def test_split_equals_unsplit_full_size():
+    """BASELINE config 3 at full size: 200k fluid (per-call) + 100k background (static), 5 views at 512 x 512."""
+    g = S.smoke_scene(200_000, 100_000, seed=0, channels=3)
+    _check_split(g, 3, 200_000, 100_000, 512, 512, S.arc_cameras(5, 512, 512, device="cuda"))
+
+
+def _check_split(g, channels, P_dyn, P_static, W, H, cams):
     from fluidnexus_amd import _lib
     from fluidnexus_amd.rasterizer import GaussianRasterizerViews, StaticBin, ViewBatch
     dev = torch.device("cuda")
-    W, H, V = 144, 112, 3
+    V = len(cams)
     T = ((W + 15) // 16) * ((H + 15) // 16)
     P = P_dyn + P_static
-    g = _scene(P_dyn, P_static, channels, seed=21, static_box=static_box, ties=ties)
-    cams = S.arc_cameras(V, W, H, device="cuda")
     bg = torch.tensor([0.2, 0.5, 0.1], device=dev)
     vb = ViewBatch(_settings(cams, W, H, bg))
     rng = np.random.RandomState(5)
