@@ -27,17 +27,37 @@ def build(force: bool = False) -> str:
     return so
 
 
+def _load(so):
+    L = C.CDLL(so)
+    L.fnx_oracle_preprocess.restype = C.c_int64
+    L.fnx_oracle_expf.restype = C.c_float
+    L.fnx_oracle_expf.argtypes = [C.c_float]
+    L.fnx_oracle_max_threads.restype = C.c_int
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
-        _LIB = C.CDLL(so)
-        _LIB.fnx_oracle_preprocess.restype = C.c_int64
-        _LIB.fnx_oracle_expf.restype = C.c_float
-        _LIB.fnx_oracle_expf.argtypes = [C.c_float]
-        _LIB.fnx_oracle_max_threads.restype = C.c_int
+        _LIB = _load(so)
+    return _LIB
+
+
+def use_variant(name=None):
+    """Switch every later call of this module to another build of the same source: "fma" = liboracle_fma.so
+    (-ffp-contract=fast -mfma, built on demand; tools/fp_contract_report.py), None = the parity checker."""
+    global _LIB
+    if name is None:
+        _LIB = None
+        return lib()
+    so = os.path.join(_HERE, f"liboracle_{name}.so")
+    src = os.path.join(_HERE, "raster_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
+    _LIB = _load(so)
     return _LIB
 
 

@@ -102,6 +102,32 @@ def gen_sh():
     np.savez(os.path.join(OUT, "sh_utils.npz"), **out)
 
 
+def gen_sh_positions():
+    """SH colour as the SH pipe evaluates it (renderer/pipe.py:74-82): directions from the camera centre to the
+    Gaussian centres, normalised, eval_sh + 0.5 clamped at 0 -- with autograd gradients with respect to the SH
+    coefficients AND the positions (the direction-normalisation path, backward.cu:125-131 / auxiliary.h:95-118)."""
+    from utils.sh_utils import eval_sh
+    rng = np.random.RandomState(11)
+    P = 300
+    campos = np.array([0.3, -0.2, 0.1], np.float32)
+    d = rng.normal(size=(P, 3))
+    pos = (campos + d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.6, 1.0, size=(P, 1))).astype(np.float32)
+    sh = (rng.normal(size=(P, 16, 3)) * 0.5).astype(np.float32)
+    out = dict(pos=pos, campos=campos, sh=sh)
+    for deg in range(4):
+        x = torch.tensor(pos, requires_grad=True)
+        s = torch.tensor(sh, requires_grad=True)
+        dir_pp = x - torch.tensor(campos).repeat(P, 1)
+        dirs = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        rgb = torch.clamp_min(eval_sh(deg, s.transpose(1, 2), dirs) + 0.5, 0.0)
+        w = torch.tensor(rng.normal(size=(P, 3)), dtype=torch.float32)
+        (rgb * w).sum().backward()
+        out[f"rgb{deg}"], out[f"w{deg}"] = rgb.detach().numpy(), w.numpy()
+        out[f"dsh{deg}"] = s.grad.numpy()
+        out[f"dpos{deg}"] = x.grad.numpy() if x.grad is not None else np.zeros_like(pos)  # degree 0 ignores the direction
+    np.savez_compressed(os.path.join(OUT, "sh_positions.npz"), **out)
+
+
 def gen_losses():
     from utils.image_utils import psnr
     from utils.loss_utils import distance_loss, l1_loss, l2_loss, l2_loss_consistency, ssim
@@ -445,6 +471,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
     gen_sh()
+    gen_sh_positions()
     gen_losses()
     gen_distance()
     gen_general()
