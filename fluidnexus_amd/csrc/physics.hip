@@ -52,10 +52,12 @@ inline size_t grid_bytes(int N) {
     return off + kAlign;
 }
 
-inline GridView carve(char *blob, int N) {
+// M_override: a smaller table than buckets_for(N) inside a blob of the standard size (fnx_distance_loss: more points
+// per bucket, a shorter scan)
+inline GridView carve(char *blob, int N, uint32_t M_override = 0) {
     char *b = (char *)(((uintptr_t)blob + kAlign - 1) / kAlign * kAlign);
     GridView g;
-    g.M = buckets_for(N);
+    g.M = M_override ? M_override : buckets_for(N);
     size_t off = 0;
     g.header = (uint32_t *)(b + off); off = align_up(off + 64);
     g.count = (uint32_t *)(b + off);  off = align_up(off + (size_t)g.M * 4);
@@ -653,29 +655,41 @@ __device__ __forceinline__ float half_sum31(float v) {
 // ---- pairwise distance loss (fnx_distance_loss) --------------------------------------------------------
 // utils/loss_utils.py:98-121: loss = sum over ORDERED pairs i != j with d_ij < thr of (thr - d_ij)^2 (the dense
 // torch.cdist matrix holds every unordered pair twice); d loss / d x_i = -4 sum_j (thr - d_ij) (x_i - x_j) / d_ij,
-// zero for coincident points (cdist's backward).  Radius-limited: hash grid with cell = thr, 8 lanes per point.
+// zero for coincident points (cdist's backward).  Radius-limited: hash grid with cell = 2 thr, so everything within
+// thr of a point lies in the 2 x 2 x 2 cells on the point's side of its own cell (8 buckets instead of 27; they are
+// part of the 3 x 3 x 3 neighbourhood, hence 8 different buckets, see cell_hash); 8 lanes per point, one bucket each.
 __global__ void __launch_bounds__(256)
 distance_loss_kernel(const float *__restrict__ xyz, int N, float inv_cell, float thr, uint32_t mask,
                      const uint32_t *__restrict__ start, const float4 *__restrict__ rec, float *__restrict__ partial,
                      float *__restrict__ grad) {
     const int i = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
-    const int ii = min(i, N - 1);
     float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    if (i < N)
-        for_neighbours<8>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, thr * thr, mask, start, rec,
-                          [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
-                              if ((int)j == i) return;
-                              const float d = sqrtf(r2);
-                              const float t = thr - d;
-                              if (!(t > 0.f)) return;
-                              acc += t * t;
-                              if (d > 0.f) {
-                                  const float k = -4.0f * t / d;
-                                  ax += k * ex;
-                                  ay += k * ey;
-                                  az += k * ez;
-                              }
-                          });
+    if (i < N) {
+        const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        const int3 c = cell_of(px, py, pz, inv_cell);
+        const float fx = px * inv_cell - (float)c.x, fy = py * inv_cell - (float)c.y, fz = pz * inv_cell - (float)c.z;
+        const int3 cc = make_int3(c.x + ((sub & 1) ? (fx < 0.5f ? -1 : 1) : 0), c.y + ((sub & 2) ? (fy < 0.5f ? -1 : 1) : 0),
+                                  c.z + ((sub & 4) ? (fz < 0.5f ? -1 : 1) : 0));
+        const uint32_t h = cell_hash(cc, mask);
+        const float thr2 = thr * thr;
+        for (uint32_t s = start[h], s1 = start[h + 1]; s < s1; s++) {
+            const float4 q = rec[s];
+            if ((int)__float_as_uint(q.w) == i) continue;
+            const float ex = px - q.x, ey = py - q.y, ez = pz - q.z;
+            const float r2 = ex * ex + ey * ey + ez * ez;
+            if (!(r2 < thr2)) continue;
+            const float d = sqrtf(r2);
+            const float t = thr - d;
+            if (!(t > 0.f)) continue;
+            acc += t * t;
+            if (d > 0.f) {
+                const float k = -4.0f * t / d;
+                ax += k * ex;
+                ay += k * ey;
+                az += k * ez;
+            }
+        }
+    }
     if (grad) {
         ax = oct_sum7(ax);
         ay = oct_sum7(ay);
@@ -1287,10 +1301,20 @@ int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, floa
     if (N == 0) return FNX_OK;
     if (N < 0 || !xyz || !grid || !partials || !(threshold > 0.f))
         return fail(FNX_ERR_INVALID_ARG, "distance_loss: bad argument");
-    if (int rc = fnx_grid_build(xyz, N, threshold, grid, stream)) return rc;
-    GridView g = carve(grid, N);
-    hipLaunchKernelGGL(distance_loss_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, xyz, N,
-                       1.0f / threshold, threshold, g.M - 1, g.start, g.rec, partials, grad);
+    // table of at most 32768 buckets (one round of the single-workgroup scan); far cells that share a bucket are
+    // rejected by the distance test, a bucket holds N / M points on average
+    uint32_t M = 4096;
+    while (M < 32768u && M < (uint32_t)N / 4u) M <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    GridView g = carve(grid, N, M);
+    const float inv = 1.0f / (2.0f * threshold);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((M + 255) / 256), dim3(256), 0, s, g.count, (size_t)M);
+    hipLaunchKernelGGL(grid_count_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xyz, N, inv, M - 1, g.count);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, M, g.count, g.start, g.cursor);
+    hipLaunchKernelGGL(grid_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, xyz, N, inv, M - 1, g.start, g.cursor,
+                       g.rec);
+    hipLaunchKernelGGL(distance_loss_kernel, dim3((N + 31) / 32), dim3(256), 0, s, xyz, N, inv, threshold, M - 1,
+                       g.start, g.rec, partials, grad);
     return hip_check("distance_loss");
 }
 

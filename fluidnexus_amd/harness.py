@@ -377,11 +377,16 @@ class HotLoop:
         gm.zero_gradient_cache_current()
         batch = len(self.cams)
         mine = self._mine(batch)
+        main = torch.cuda.current_stream()
+        # hidden-particle grid + the one visual forward of this iteration (memoised), then the leaf of the rasteriser
+        # positions [advected visual / scale_factor | background].  The main chain's next kernel is enqueued BEFORE the
+        # side branches fork: a captured graph keeps the first successor of a node on the node's hardware queue, and a
+        # hop of the critical path between queues costs ~10 us (rocprof timeline), a hop of a side branch nothing.
         with torch.no_grad():
-            gm.get_visual_xyz_from_nn()  # hidden-particle grid + the one visual forward of this iteration (memoised)
+            gm.get_visual_xyz_from_nn()
+        means3D = gm.render_means_from_nn() if mine else None
         # The physics terms depend on the particle state only: their ~50 small kernels run on a side
         # stream (a parallel branch of the captured graph) underneath the rasteriser's launch sequence.
-        main = torch.cuda.current_stream()
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream(device=gm._xyz.device)
         gp, n_phys = None, 0
@@ -403,25 +408,27 @@ class HotLoop:
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
-        means3D = gm.render_means_from_nn() if mine else None  # leaf: [advected visual / scale_factor | background]
         gd = None
-        if mine and c.get("lambda_current_distance", 0.0) > 0:
-            # distance_loss(render_xyz) (tpp:365-366) is the same for every view: evaluated once (radius-limited
-            # kernel) on a branch of its own, added once per local view to the gradient of the rendered positions
-            from .physics import distance_loss_value_and_grad
-            if getattr(self, "dist_stream", None) is None:
-                self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
-            fork_d = torch.cuda.Event()
-            fork_d.record(main)
-            self.dist_stream.wait_event(fork_d)
-            with torch.cuda.stream(self.dist_stream):
-                n_vis = gm._visual_xyz.shape[0]
-                dval, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis], c["distance_threshold_visual"])
-                self.last_distance = dval
         if mine:
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                         GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                         scale=True, means3D=means3D)
+            if c.get("lambda_current_distance", 0.0) > 0:
+                # distance_loss(render_xyz) (tpp:365-366) is the same for every view: evaluated once (radius-limited
+                # kernel) and added once per local view to the gradient of the rendered positions.  Its branch forks
+                # behind the rasteriser forward: next to the throughput-bound blend / loss kernels its ~200k-point
+                # grid build costs its own few microseconds of work, next to the latency-bound depth sort it
+                # stretched the critical path by 100 us (rocprof timeline, round 2).
+                from .physics import distance_loss_value_and_grad
+                if getattr(self, "dist_stream", None) is None:
+                    self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
+                fork_d = torch.cuda.Event()
+                fork_d.record(main)
+                self.dist_stream.wait_event(fork_d)
+                with torch.cuda.stream(self.dist_stream):
+                    n_vis = gm._visual_xyz.shape[0]
+                    self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
+                                                                          c["distance_threshold_visual"])
             # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
             # that saves the ones seed and its copies), then back through the rasteriser
             loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],

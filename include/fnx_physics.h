@@ -136,7 +136,7 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
 /* Pairwise distance loss of FluidDynamics/utils/loss_utils.py:98-121 (distance_loss(positions, threshold), called
  * per view at entries_fluid_nexus/train_physical_particle.py:141-144,365-366), radius-limited instead of a dense
  * N x N torch.cdist:  loss = sum over ordered pairs i != j with |x_i - x_j| < threshold of (threshold - |x_i - x_j|)^2.
- * `grid`: fnx_grid_bytes(N) bytes of scratch (a hash grid with cell = threshold is built in it);
+ * `grid`: fnx_grid_bytes(N) bytes of scratch (a hash grid with cell = 2 threshold is built in it);
  * partials [fnx_distance_loss_partials(N)]: per-workgroup sums, loss = their sum (deterministic);
  * grad [N,3] (may be NULL): d loss / d xyz, zero for coincident points like torch.cdist's backward. */
 int fnx_distance_loss_partials(int N);
