@@ -81,8 +81,7 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
     gm.setup_constants(H=SMOKE["H"], KNN_K=SMOKE["KNN_K"], p0=SMOKE["p0"], secs=SMOKE["secs"], k=SMOKE["k"])
     center = np.array([0.34, 0.0, -0.225])
     fluid = S.plume_gaussians(P_fluid, seed=seed, channels=1)
-    bgd = S.random_gaussians(P_background, seed=seed + 1, box=0.6, log_scale=(-5.0, -3.0), channels=3,
-                             center=(0.34, 0.3, -0.225))
+    bgd = S.backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=3)  # behind the plume, never in front
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
     sf = gm.scale_factor
     # visual particles live in scaled units (x100); constant attributes as gm_dynamics.py:171-173
@@ -385,14 +384,33 @@ class HotLoop:
         with torch.no_grad():
             gm.get_visual_xyz_from_nn()
         means3D = gm.render_means_from_nn() if mine else None
-        # The physics terms depend on the particle state only: their ~50 small kernels run on a side
-        # stream (a parallel branch of the captured graph) underneath the rasteriser's launch sequence.
+        # Side branches of the iteration.  Their fork POINTS are recorded where their inputs are ready, but their
+        # kernels are enqueued behind the rasteriser forward: a captured graph keeps the first-enqueued successor of a
+        # node on the node's hardware queue, and the critical path must not be the one that hops.
+        #   physics terms (depend on the particle state only: ~12 small kernels under preprocess + sort + emit)
+        #   distance_loss(render_xyz) (tpp:365-366; the same for every view: evaluated once by the radius-limited
+        #     kernel, added once per local view).  It forks between the rasteriser's binning stage and its emit /
+        #     blend stage: next to the throughput-bound blend kernels its 200k-point grid build costs its own few
+        #     microseconds of work, next to the latency-bound depth sort it stretched the critical path by 100 us.
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream(device=gm._xyz.device)
-        gp, n_phys = None, 0
+            self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
+        gp, n_phys, gd = None, 0, None
+        fork = torch.cuda.Event()
+        fork.record(main)
+        use_dist = bool(mine) and c.get("lambda_current_distance", 0.0) > 0
+        if mine:
+            from . import rasterizer
+            fork_d = torch.cuda.Event()
+            if use_dist:
+                rasterizer.set_between_stages_hook(lambda: fork_d.record(torch.cuda.current_stream()))
+            try:
+                pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
+                                            GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
+                                            scale=True, means3D=means3D)
+            finally:
+                rasterizer.set_between_stages_hook(None)
         if self.physics_per_view or self.rank == 0:
-            fork = torch.cuda.Event()
-            fork.record(main)
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
                 # work items of the hidden-particle grid for the cell-by-cell hidden<-visual backward at the end
@@ -408,22 +426,9 @@ class HotLoop:
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
-        gd = None
         if mine:
-            pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
-                                        GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
-                                        scale=True, means3D=means3D)
-            if c.get("lambda_current_distance", 0.0) > 0:
-                # distance_loss(render_xyz) (tpp:365-366) is the same for every view: evaluated once (radius-limited
-                # kernel) and added once per local view to the gradient of the rendered positions.  Its branch forks
-                # behind the rasteriser forward: next to the throughput-bound blend / loss kernels its ~200k-point
-                # grid build costs its own few microseconds of work, next to the latency-bound depth sort it
-                # stretched the critical path by 100 us (rocprof timeline, round 2).
+            if use_dist:
                 from .physics import distance_loss_value_and_grad
-                if getattr(self, "dist_stream", None) is None:
-                    self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
-                fork_d = torch.cuda.Event()
-                fork_d.record(main)
                 self.dist_stream.wait_event(fork_d)
                 with torch.cuda.stream(self.dist_stream):
                     n_vis = gm._visual_xyz.shape[0]

@@ -37,6 +37,17 @@ _captured_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
+_between_stages_hook = None  # called (no arguments) between the binning stage and the emit / blend stage of a view batch
+
+
+def set_between_stages_hook(fn):
+    """`fn()` runs on the host right after the view-batched forward has enqueued its first stage (preprocess, depth
+    sort, counts, scans) and before it enqueues emission + blending: a caller can record an event there to hang a
+    side branch under the throughput-bound blend kernels instead of under the latency-bound sort.  None removes it."""
+    global _between_stages_hook
+    _between_stages_hook = fn
+
+
 def set_host_sync(enabled: bool, initial_capacity: int | None = None):
     """enabled=False: never read num_rendered back inside forward (see module docstring)."""
     global _HOST_SYNC
@@ -387,6 +398,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                 _capacity_hwm[key] = cap
             bbytes = lib.fnx_binning_bytes(cap)
             binning = torch.empty(V * bbytes, **u8)
+            if _between_stages_hook is not None:
+                _between_stages_hook()
             status_ptr = None
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 ring, slot = _status_slots(dev, V, key)
@@ -452,6 +465,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             cap = known
             _capacity_hwm[key] = cap
         binning = torch.empty(V * lib.fnx_binning_bytes_split(cap, sb.R_cap), **u8)
+        if _between_stages_hook is not None:
+            _between_stages_hook()
         status_ptr = None
         if not synced:
             ring, slot = _status_slots(dev, V, key)

@@ -43,12 +43,34 @@ def plume_gaussians(P, seed=0, center=(0.34, 0.0, -0.225), radius=0.1, y_range=(
                 colors=np.full((P, channels), grey, np.float32))
 
 
-def smoke_scene(P_fluid, P_background, seed=0, channels=3):
-    """config 3/4/5 cloud: fluid plume (visual particles) + static background Gaussians
-    (box around the plume, log-scale U(-5,-3), opacity sigmoid(N), RGB U(0,1))."""
+PLUME_TARGET = (0.34, 0.3, -0.225)  # what the benchmark cameras look at
+
+
+def backdrop_gaussians(P, seed=0, ring=False, channels=3, target=PLUME_TARGET, log_scale=(-5.0, -3.0)):
+    """Static background Gaussians of configs 3/4/5 (log-scale U(-5,-3), opacity sigmoid(N), RGB U(0,1)) placed
+    BEHIND the plume as seen from the benchmark cameras, like the room behind the smoke in the reference's captures:
+      arc cameras (z > target z, 120 degree arc): a slab 0.4 .. 1.0 m behind the plume, 3 m wide, 1.6 m high;
+      ring cameras (full circle at 1.6 m): a cylindrical wall of radius 2.2 .. 2.6 m around the plume axis -- every
+      camera sees the far side of it behind the plume, the near side is behind the camera.
+    (Round 1 scattered them in a box AROUND the plume: the opaque cloud hid the plume from every camera, so the
+    fluid's image gradient was identically zero -- a benchmark of a loop that cannot see what it optimises.)"""
+    g = random_gaussians(P, seed=seed, box=1.0, log_scale=log_scale, channels=channels)
+    rng = np.random.RandomState(seed + 1000)
+    if ring:
+        ang = rng.uniform(0, 2 * math.pi, size=P)
+        rad = rng.uniform(2.2, 2.6, size=P)
+        xyz = np.stack([target[0] + rad * np.sin(ang), rng.uniform(-0.5, 1.1, size=P), target[2] + rad * np.cos(ang)], 1)
+    else:
+        xyz = np.stack([target[0] + rng.uniform(-1.5, 1.5, size=P), target[1] + rng.uniform(-0.8, 0.8, size=P),
+                        target[2] - rng.uniform(0.4, 1.0, size=P)], 1)
+    g["means3D"] = xyz.astype(np.float32)
+    return g
+
+
+def smoke_scene(P_fluid, P_background, seed=0, channels=3, ring=False):
+    """config 3/4/5 cloud: fluid plume (visual particles) in front of static background Gaussians."""
     fluid = plume_gaussians(P_fluid, seed=seed, channels=channels)
-    bgd = random_gaussians(P_background, seed=seed + 1, box=0.6, log_scale=(-5.0, -3.0), channels=channels,
-                           center=(0.34, 0.3, -0.225))
+    bgd = backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=channels)
     return {k: np.concatenate([fluid[k], bgd[k]], axis=0) for k in fluid}
 
 
