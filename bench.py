@@ -77,7 +77,8 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
                                  force_all_reduce=use_dist)
         return gm, cams, loop
     if cfg_id in (3, 4):
-        gm, cams = Hn.build_smoke_frame(200_000, 100_000, (20, 62, 20), n_views=n_views, size=SIZE, seed=0, device=dev)
+        gm, cams = Hn.build_smoke_frame(200_000, 100_000, (20, 62, 20), n_views=n_views, size=SIZE, seed=0, device=dev,
+                                        occluding=a.scene == "r01")
     else:
         gm, cams = Hn.build_ball_frame(350_000, 150_000, (22, 58, 22), n_views=n_views, size=SIZE, seed=0, device=dev)
     cfg = dict(Hn.SMOKE)
@@ -184,6 +185,9 @@ def main():
                     help="strong (auto): the config's views sharded over the ranks; weak: the config's view count per rank")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: run rank 0's share of the views of an N-rank strong-scaling run, no communication")
+    ap.add_argument("--scene", default="backdrop", choices=["backdrop", "r01"],
+                    help="configs 3 / 4: background behind the plume (default), or the round-1 layout (a cloud AROUND "
+                         "the plume that hides it from every camera: zero image gradient; for like-for-like comparisons)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -403,7 +407,7 @@ def main():
                                    + ", RCCL all-reduce of the leaf gradient"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
                    "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2),
-                   "distance_loss": not a.no_distance,
+                   "distance_loss": not a.no_distance, "scene": a.scene if cfg_id in (3, 4) else "backdrop",
                    "launch": (f"hipGraph replay, {loop.graph_iterations} whole iteration(s) per graph" if graph_mode
                               else "eager"),
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",

@@ -338,7 +338,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
     __shared__ float s_col[C][256];
-    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 16];  // a group reads up to kGroup - 1 slots past the end
     __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
     __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  // merge windows: depth bits [static | per-call]
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
@@ -531,15 +531,21 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         // together, the alphas evaluated as straight-line predicated code (the scheduler interleaves
         // the independent chains), then a short select-only recurrence in list order.  Per pixel the
         // arithmetic and its order are unchanged.
-        constexpr int kGroup = 4;
+#ifndef FNX_FWD_GROUP
+#define FNX_FWD_GROUP 4
+#endif
+        constexpr int kGroup = FNX_FWD_GROUP;
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(done)) break;
-            const uint32_t j4 = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0]));
+            uint32_t j4[kGroup / 4];
+#pragma unroll
+            for (int k = 0; k < kGroup / 4; k++)
+                j4[k] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0 + 4 * k]));
             float alpha[kGroup], depth[kGroup], col[kGroup][C];
             bool hit[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t j = (j4 >> (8 * k)) & 255u;
+                const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
                 const float4 ra = s_ra[j];
                 const float4 rb = s_rb[j];
 #pragma unroll
@@ -554,7 +560,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
                 const bool live = hit[k] && !done;
-                const uint32_t j = (j4 >> (8 * k)) & 255u;
+                const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
                 const float test_T = Tr * (1 - alpha[k]);
                 const bool stop = live && (test_T < 0.0001f);
                 const bool take = live && !stop;

@@ -73,7 +73,7 @@ def build_ball_frame(P_fluid=350_000, P_background=150_000, hidden_dims=(22, 58,
 
 
 def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62, 20), n_views=5, size=512, seed=0,
-                      device="cuda", ring=False):
+                      device="cuda", ring=False, occluding=False):
     """BASELINE config 3 state: V visual fluid Gaussians + static background Gaussians + N hidden
     particles on a jittered unit lattice filling the plume (scaled units, < KNN_K neighbours each)."""
     rng = np.random.RandomState(seed)
@@ -81,7 +81,8 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
     gm.setup_constants(H=SMOKE["H"], KNN_K=SMOKE["KNN_K"], p0=SMOKE["p0"], secs=SMOKE["secs"], k=SMOKE["k"])
     center = np.array([0.34, 0.0, -0.225])
     fluid = S.plume_gaussians(P_fluid, seed=seed, channels=1)
-    bgd = S.backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=3)  # behind the plume, never in front
+    # behind the plume, never in front (occluding=True: the round-1 layout, a cloud around the plume that hides it)
+    bgd = S.backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=3, occluding=occluding)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
     sf = gm.scale_factor
     # visual particles live in scaled units (x100); constant attributes as gm_dynamics.py:171-173

@@ -46,7 +46,7 @@ def plume_gaussians(P, seed=0, center=(0.34, 0.0, -0.225), radius=0.1, y_range=(
 PLUME_TARGET = (0.34, 0.3, -0.225)  # what the benchmark cameras look at
 
 
-def backdrop_gaussians(P, seed=0, ring=False, channels=3, target=PLUME_TARGET, log_scale=(-5.0, -3.0)):
+def backdrop_gaussians(P, seed=0, ring=False, channels=3, target=PLUME_TARGET, log_scale=(-5.0, -3.0), occluding=False):
     """Static background Gaussians of configs 3/4/5 (log-scale U(-5,-3), opacity sigmoid(N), RGB U(0,1)) placed
     BEHIND the plume as seen from the benchmark cameras, like the room behind the smoke in the reference's captures:
       arc cameras (z > target z, 120 degree arc): a slab 0.4 .. 1.0 m behind the plume, 3 m wide, 1.6 m high;
@@ -54,6 +54,8 @@ def backdrop_gaussians(P, seed=0, ring=False, channels=3, target=PLUME_TARGET, l
       camera sees the far side of it behind the plume, the near side is behind the camera.
     (Round 1 scattered them in a box AROUND the plume: the opaque cloud hid the plume from every camera, so the
     fluid's image gradient was identically zero -- a benchmark of a loop that cannot see what it optimises.)"""
+    if occluding:  # the round-1 layout, kept for like-for-like comparisons with round-1 numbers (bench.py --scene r01)
+        return random_gaussians(P, seed=seed, box=0.6, log_scale=log_scale, channels=channels, center=target)
     g = random_gaussians(P, seed=seed, box=1.0, log_scale=log_scale, channels=channels)
     rng = np.random.RandomState(seed + 1000)
     if ring:
@@ -67,10 +69,10 @@ def backdrop_gaussians(P, seed=0, ring=False, channels=3, target=PLUME_TARGET, l
     return g
 
 
-def smoke_scene(P_fluid, P_background, seed=0, channels=3, ring=False):
+def smoke_scene(P_fluid, P_background, seed=0, channels=3, ring=False, occluding=False):
     """config 3/4/5 cloud: fluid plume (visual particles) in front of static background Gaussians."""
     fluid = plume_gaussians(P_fluid, seed=seed, channels=channels)
-    bgd = backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=channels)
+    bgd = backdrop_gaussians(P_background, seed=seed + 1, ring=ring, channels=channels, occluding=occluding)
     return {k: np.concatenate([fluid[k], bgd[k]], axis=0) for k in fluid}
 
 

@@ -55,12 +55,14 @@ def _run(sc, cam, bg, colors=None):
 
 
 def _rects(means2D, radii, gx, gy):
-    """ch3 auxiliary.h:46-57 (getRect) on the library's own means2D / radii."""
-    r = radii.astype(np.int64)
-    x0 = np.clip(((means2D[:, 0] - r) / 16).astype(np.int64), 0, gx)
-    y0 = np.clip(((means2D[:, 1] - r) / 16).astype(np.int64), 0, gy)
-    x1 = np.clip(((means2D[:, 0] + r + 15) / 16).astype(np.int64), 0, gx)
-    y1 = np.clip(((means2D[:, 1] + r + 15) / 16).astype(np.int64), 0, gy)
+    """ch3 auxiliary.h:46-57 (getRect) on the library's own means2D / radii, in fp32 like the reference (a splat far
+    off-screen has a coarse ulp: p - r may round across a multiple of 16 that the exact difference does not reach)."""
+    r = radii.astype(np.float32)
+    f16, f1 = np.float32(16), np.float32(1)  # (p + r + 16 - 1) / 16 is evaluated left to right
+    x0 = np.clip(((means2D[:, 0] - r) / f16).astype(np.int64), 0, gx)
+    y0 = np.clip(((means2D[:, 1] - r) / f16).astype(np.int64), 0, gy)
+    x1 = np.clip(((((means2D[:, 0] + r) + f16) - f1) / f16).astype(np.int64), 0, gx)
+    y1 = np.clip(((((means2D[:, 1] + r) + f16) - f1) / f16).astype(np.int64), 0, gy)
     return x0, y0, x1, y1
 
 
