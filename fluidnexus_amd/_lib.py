@@ -29,11 +29,11 @@ class GeomLayout(C.Structure):
 
 class ImageLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "total")]
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "acc_final", "total")]
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "total")]
+    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "bstate", "bwd_items", "total")]
 
 
 class StaticLayout(C.Structure):

@@ -19,6 +19,14 @@ inline int tiles_y(int H) { return (H + 15) / 16; }
 constexpr int kSplatBlock = 1024;
 constexpr int kSortChunk = 1024;
 constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB
+// The blend kernels walk a tile's list in batches of kBlendBatch entries.  The forward leaves, for every batch b >= 1 it
+// blends, the per-pixel state in front of the batch (transmittance + accumulated colour, 16 bytes per pixel) in slot
+// (first list position of the tile) / kBlendBatch + b - 1 -- unique, because a tile owns ceil(len / 256) - 1 <=
+// floor(len / 256) such slots -- and one work item (tile | batch << 14) per batch that holds a contributor, so the
+// backward can run the batches of a tile as independent workgroups.
+constexpr int kBlendBatch = 256;
+constexpr size_t kBlendStateBytes = 256 * 16;
+inline size_t blend_state_slots(size_t list_capacity) { return list_capacity / kBlendBatch + 2; }
 // Depth sort digits: 9 bits.  Keys are sorted relative to the smallest visible key, so three passes order any
 // view whose depths span less than 2^27 ulps (a far/near ratio of ~2^16); the fourth pass runs only beyond that.
 constexpr int kSortBits = 9;
@@ -98,6 +106,7 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     o->ranges = off;      off = align_up(off + t * 8);
     o->tile_count = off;  off = align_up(off + t * 4);
     o->dyn_start = off;   off = align_up(off + t * 4);
+    o->acc_final = off;   off = align_up(off + n * 4 * 3);
     o->total = off + kAlign;
 }
 
@@ -108,6 +117,9 @@ inline void binning_layout(int64_t R, int64_t R_static, bool split, fnx_binning_
     size_t off = 0;
     o->point_list = off; off = align_up(off + (r + rs) * 4);
     o->pairs = off;      off = align_up(off + (split ? r * 8 : 0));
+    // forward -> backward hand-over per batch of kBlendBatch list entries (see blend_state_slots)
+    o->bstate = off;     off = align_up(off + blend_state_slots(r + rs) * kBlendStateBytes);
+    o->bwd_items = off;  off = align_up(off + (blend_state_slots(r + rs) + kMaxTiles) * 4);
     o->total = off + kAlign;
 }
 
@@ -131,6 +143,7 @@ constexpr int kMaxViews = FNX_MAX_VIEWS;
 struct ViewBatch {
     size_t geom, img, bin;  // bytes between consecutive views' blobs (0 for a single view)
     size_t bin_pairs;       // byte offset of the (key, id) pair array inside a binning blob (static-split mode)
+    size_t bin_bstate, bin_items;  // byte offsets of the per-batch blend state and the backward work items
     size_t radii_stride;    // elements between consecutive views' radii (= total splat count)
     float tan_fovx[kMaxViews], tan_fovy[kMaxViews], focal_x[kMaxViews], focal_y[kMaxViews];
 };
@@ -147,6 +160,6 @@ struct StaticRef {
 enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
 
 // header words inside the image blob
-enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3 };
+enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4 };
 
 }  // namespace fnx

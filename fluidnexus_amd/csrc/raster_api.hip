@@ -40,15 +40,16 @@ void launch_static_pack(hipStream_t s, int P, int W, int H, const uint32_t *poin
                         const ViewBatch &vb);
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
+                          float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
+                          float *acc_final, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
-                           const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
-                           float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st);
+                           const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
+                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                           const uint32_t *header, uint32_t capacity, uint32_t grad_limit, int V, const ViewBatch &vb,
+                           const StaticRef &st);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -126,6 +127,7 @@ struct Img {
     uint32_t *ranges;
     uint32_t *tile_count;
     uint32_t *dyn_start;
+    float *acc_final;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -138,6 +140,7 @@ Img carve_img(char *blob, int W, int H) {
     i.ranges = (uint32_t *)(b + L.ranges);
     i.tile_count = (uint32_t *)(b + L.tile_count);
     i.dyn_start = (uint32_t *)(b + L.dyn_start);
+    i.acc_final = (float *)(b + L.acc_final);
     return i;
 }
 struct Bin {
@@ -167,6 +170,8 @@ int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *t
     fnx::binning_layout(capacity, R_static, split, &BL);
     vb->bin = BL.total;
     vb->bin_pairs = BL.pairs;
+    vb->bin_bstate = BL.bstate;
+    vb->bin_items = BL.bwd_items;
     vb->radii_stride = (size_t)P + (size_t)(split ? P_static : 0);
     for (int v = 0; v < V; v++) {
         vb->tan_fovx[v] = tan_fovx[v];
@@ -410,7 +415,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         ProfScope ps(channels == 3 ? 0 : 5, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
-                                  img.tile_count, img.dyn_start, st, materialize_all, V, vb);
+                                  img.tile_count, img.dyn_start, img.acc_final, st, materialize_all, V, vb);
     }
     return hip_check("stage2");
 }
@@ -540,8 +545,8 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     {
         ProfScope ps(channels == 3 ? 1 : 6, s);
         fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P_all, width, height, img.ranges, bin.point_list,
-                                   background, g.blend_rec, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D,
-                                   dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
+                                   background, g.blend_rec, img.final_T, img.n_contrib, img.acc_final, dL_dpix,
+                                   dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
                                    (uint32_t)limit, V, vb, st);
     }
     const int sum_appearance = (V > 1 && !geometry_only) ? 1 : 0;
@@ -580,11 +585,13 @@ int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const fl
                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                            float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
                               fnx_stream_t stream) {
-    (void)R;
+    // R = the binning capacity the forward ran with (num_rendered in the callback form): the binning blob's layout
+    // depends on it
     if (P != 0 && !dL_dcolor) return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (R < 0) return fail(FNX_ERR_INVALID_ARG, "R must be the forward's binning capacity");
     return fnx_rasterize_backward_views(channels, 1, P, D, M, background, width, height, means3D, shs, colors_precomp,
                                         scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                        campos, &tan_fovx, &tan_fovy, radii, geom_buffer, binning_buffer, 0,
+                                        campos, &tan_fovx, &tan_fovy, radii, geom_buffer, binning_buffer, R,
                                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                                         dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                                         grad_splat_limit, geometry_only, stream);

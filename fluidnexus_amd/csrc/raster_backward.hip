@@ -13,6 +13,9 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
+#ifndef FNX_BWD_WGS_PER_CU
+#define FNX_BWD_WGS_PER_CU 8  // resident-ish workgroups of the blend backward per compute unit (all views together)
+#endif
 #ifndef FNX_ABLATE
 #define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
 #endif
@@ -85,8 +88,19 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
     return base + k;
 }
 
-// Back-to-front pass of one tile.  Same quadrant / compacted-list structure as the forward blend;
-// additionally a wave only receives entries in front of its own deepest contributor.
+// Gradient pass over the tile lists.  The reference walks a tile's list back to front, one workgroup per tile,
+// rebuilding T by division and the colour behind an entry by a recurrence (backward.cu:384-536): its running time is
+// the LENGTH of the deepest list, and a scene whose lists do not saturate early (a semi-transparent plume: thousands
+// of contributing entries per pixel) leaves most of the chip idle behind a few hundred sequential walks.  Here the
+// unit of work is one BATCH of 256 list entries (fnx_state.h, kBlendBatch): the forward stored the per-pixel
+// (T, accumulated colour) in front of every batch and appended one work item per batch that holds a contributor, so
+// the batches of a tile are independent workgroups.  Inside a batch the entries are walked FRONT to back with the
+// forward's own arithmetic (T and the colour prefix come out bit-identical to the forward's), and
+//     dL/dalpha_i = sum_ch dL_ch (c_i T_i - S_i / (1 - alpha_i)) - T_final / (1 - alpha_i) (bg . dL),
+//     S_i = colour accumulated BEHIND entry i = final accumulated colour - prefix including i,
+// which is the reference's (c - accum_rec) T with accum_rec = S_i / T_{i+1} written without the recurrence.
+// Same quadrant / compacted-list structure as the forward blend; a wave only receives entries in front of its own
+// deepest contributor.
 // MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
 // MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients.
 // Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
@@ -95,10 +109,10 @@ __global__ void __launch_bounds__(256)
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                       int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
                       const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
-                      const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmean2D,
-                      float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
-                      const uint32_t *__restrict__ header, uint32_t capacity, uint32_t grad_limit, int P,
-                      const StaticRef st, const ViewBatch vb) {
+                      const float *__restrict__ acc_final, const float *__restrict__ dL_dpixels,
+                      float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
+                      float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
+                      uint32_t grad_limit, int P, const StaticRef st, const ViewBatch vb) {
     constexpr int NV = MODE == 0 ? 6 + C : 5;
     // static-split mode: records of splats with id >= st.id0 live in the view's static blob
     const float4 *rec_static = nullptr;
@@ -109,6 +123,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         ranges = view_at(ranges, vb.img, vw);
         final_Ts = view_at(final_Ts, vb.img, vw);
         n_contrib = view_at(n_contrib, vb.img, vw);
+        acc_final = view_at(acc_final, vb.img, vw);
         header = view_at(header, vb.img, vw);
         point_list = view_at(point_list, vb.bin, vw);
         blend_rec = view_at(blend_rec, vb.geom, vw);
@@ -129,49 +144,61 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ uint32_t s_cnt[4][4];
     __shared__ uint32_t s_max[4];
     if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] != 0u) return;
-    const int tile = xcd_tile_b(blockIdx.x, T);
-    const int tx = tile % gx, ty = tile / gx;
+    const uint32_t n_items = header[HDR_BWD_ITEMS];
+    const uint32_t *items = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(point_list) + vb.bin_items);
+    const float4 *bstate_all = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(point_list) + vb.bin_bstate);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const uint32_t pix_id = (uint32_t)W * py + px;
-    const float pxf = (float)px, pyf = (float)py;
-    const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
-    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
-    if (r1 == r0) return;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    const float T_final = inside ? final_Ts[pix_id] : 0.f;
-    float Tr = T_final;
-    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
-    float accum_rec[C], dL_dpixel[C], last_color[C];
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) {
-        accum_rec[ch] = 0.f;
-        last_color[ch] = 0.f;
-        dL_dpixel[ch] = inside ? dL_dpixels[(size_t)ch * H * W + pix_id] : 0.f;
-    }
-    float last_alpha = 0.f;
-    float bg_dot_dpixel = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
 
-    // entry q (0-based from the front) is used by a pixel iff q < its n_contrib (backward.cu:467-469):
-    // a wave needs nothing behind its own max, the tile nothing behind the max of its waves
-    uint32_t m = last_contributor;
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) s_max[w] = m;
-    __syncthreads();
-    const uint32_t qmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t item = items[it];
+        const int tile = (int)(item & 0x3FFFu);
+        const uint32_t b = item >> 14;
+        const int tx = tile % gx, ty = tile / gx;
+        const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const uint32_t pix_id = (uint32_t)W * py + px;
+        const float pxf = (float)px, pyf = (float)py;
+        const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
+        const uint32_t r0 = ranges[2 * tile];
+        const uint32_t q0 = b << 8;  // list position of the batch's first entry
 
-    for (uint32_t top = qmax; top > 0;) {
-        const uint32_t cnt = min(256u, top);
-        // stage entries q = top-1 ... top-cnt (slot t <-> q = top-1-t), zero the slot accumulators
+        const float T_final = inside ? final_Ts[pix_id] : 0.f;
+        const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+        float dL_dpixel[C], total[C], pre[C];
+        float Tr = 1.0f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+            dL_dpixel[ch] = inside ? dL_dpixels[(size_t)ch * H * W + pix_id] : 0.f;
+            total[ch] = inside ? acc_final[(size_t)ch * H * W + pix_id] : 0.f;
+            pre[ch] = 0.f;
+        }
+        if (b) {  // state in front of the batch, as the forward left it
+            const float4 stt = bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
+            Tr = stt.x;
+            pre[0] = stt.y;
+            if (C > 1) pre[C > 1 ? 1 : 0] = stt.z;
+            if (C > 2) pre[C > 2 ? 2 : 0] = stt.w;
+        }
+        float bg_dot_dpixel = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+
+        // entry q (0-based from the front) is used by a pixel iff q < its n_contrib (backward.cu:467-469):
+        // a wave needs nothing behind its own max, the batch nothing behind the max of the tile's waves
+        uint32_t m = last_contributor;
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        __syncthreads();  // the previous item is done with the LDS arrays
+        if (lane == 0) s_max[w] = m;
         __syncthreads();
+        const uint32_t qmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        const uint32_t cnt = min(256u, qmax - min(qmax, q0));
+
+        // stage entries q = q0 + t (slot t), zero the slot accumulators
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
-            const uint32_t q = top - 1 - tid;
+            const uint32_t q = q0 + tid;
             const uint32_t id = point_list[r0 + q];
             const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
@@ -211,7 +238,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 
         for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
             const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[w][i]);
-            const uint32_t q = top - 1 - j;
+            const uint32_t q = q0 + j;
             const bool wants = s_id[j] < grad_limit;  // wave-uniform
             float val[NV];
 #pragma unroll
@@ -230,22 +257,22 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     if (active) {
                         // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
                         // the backward is compared within fp32 summation tolerance, not bit for bit
-                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                        Tr = Tr * inv_1ma;
-                        const float dchannel_dcolor = alpha * Tr;
+                        const float one_m = 1 - alpha;
+                        const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
+                        const float Tb = Tr;  // transmittance in front of the entry
+                        const float dchannel_dcolor = alpha * Tb;
                         float dL_dalpha = 0.0f;
 #pragma unroll
                         for (int ch = 0; ch < C; ch++) {
                             const float c = s_col[ch][j];
-                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                            last_color[ch] = c;
+                            pre[ch] = pre[ch] + c * alpha * Tb;  // the forward's accumulation, same association
+                            const float behind = total[ch] - pre[ch];
                             const float dL_dchannel = dL_dpixel[ch];
-                            dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+                            dL_dalpha += (c * Tb - behind * inv_1ma) * dL_dchannel;
                             if (MODE == 0) val[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)] = dchannel_dcolor * dL_dchannel;
                         }
-                        last_alpha = alpha;
+                        Tr = Tb * one_m;  // the forward's test_T
                         if (wants) {
-                            dL_dalpha *= Tr;
                             dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                             const float dL_dG = rb.y * dL_dalpha;
                             const float gdx = G * dx;
@@ -292,7 +319,6 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 }
             }
         }
-        top -= cnt;
     }
 }
 
@@ -595,14 +621,23 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 // ---------------------------------------------------------------------------------------------
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
-                           const uint32_t *n_contrib, const float *dL_dpixels, float *dL_dmean2D, float *dL_dconic,
+                           const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
+                           float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
+    // persistent workgroups striding over the view's work items (their number is only known on the device)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const int G = (n_cu * FNX_BWD_WGS_PER_CU + V - 1) / V;
 #define FNX_LAUNCH_BB(CC, MM)                                                                                           \
-    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,    \
-                       bg, blend_rec, final_Ts, n_contrib, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, \
-                       header, capacity, grad_limit, P, st, vb)
+    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(G, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,    \
+                       bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity,  \
+                       dL_dcolors, header, capacity, grad_limit, P, st, vb)
     if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
     else if (C == 3) FNX_LAUNCH_BB(3, 1);
     else if (mode == 0) FNX_LAUNCH_BB(1, 0);

@@ -255,6 +255,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         header[HDR_STATUS] = 0u;
         header[HDR_CAPACITY] = 0u;
         header[HDR_NUM_STATIC] = st_starts ? st_starts[T] : 0u;
+        header[HDR_BWD_ITEMS] = 0u;  // the blend forward appends the backward's work items
     }
     // emission work items: exclusive prefix of the per-block band counts
     __syncthreads();
@@ -314,10 +315,10 @@ __global__ void __launch_bounds__(256)
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                     float *__restrict__ out_color, float *__restrict__ out_depth, const uint32_t *__restrict__ header,
+                     float *__restrict__ out_color, float *__restrict__ out_depth, uint32_t *__restrict__ header,
                      uint32_t capacity, uint32_t *__restrict__ status_out, const uint32_t *__restrict__ tile_count,
-                     const uint32_t *__restrict__ dyn_start, const StaticRef st, int materialize_all,
-                     const ViewBatch vb) {
+                     const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final, const StaticRef st,
+                     int materialize_all, const ViewBatch vb) {
     const char *static_blob = nullptr;
     {
         const int vw = blockIdx.y;
@@ -329,6 +330,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         blend_rec = view_at(blend_rec, vb.geom, vw);
         out_color += (size_t)vw * C * H * W;
         out_depth += (size_t)vw * H * W;
+        acc_final = view_at(acc_final, vb.img, vw);
         if (SPLIT) {
             tile_count = view_at(tile_count, vb.img, vw);
             dyn_start = view_at(dyn_start, vb.img, vw);
@@ -343,6 +345,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  // merge windows: depth bits [static | per-call]
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
+    __shared__ uint32_t s_qmax[4];
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
     if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
@@ -451,6 +454,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         if (r0 + 256u + (uint32_t)tid < r1) id_ahead = point_list[r0 + 256u + tid];
     }
+    // forward -> backward hand-over (fnx_state.h, kBlendBatch): per-pixel state in front of every batch after the first
+    float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
+                     (size_t)(r0 >> 8) * 256 + tid;
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
         const bool all_done = __syncthreads_count(done) == 256;
@@ -458,6 +464,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
+        if (blending && base != r0)
+            bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt && blending) {
@@ -579,8 +587,25 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         final_T[pix_id] = Tr;
         n_contrib[pix_id] = last_contributor;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) out_color[(size_t)ch * H * W + pix_id] = acc[ch] + Tr * bg[ch];
+        for (int ch = 0; ch < C; ch++) {
+            out_color[(size_t)ch * H * W + pix_id] = acc[ch] + Tr * bg[ch];
+            acc_final[(size_t)ch * H * W + pix_id] = acc[ch];
+        }
         out_depth[pix_id] = Dm;
+    }
+    // one backward work item per batch that holds a contributor of some pixel of the tile
+    uint32_t m = last_contributor;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (lane == 0) s_qmax[w] = m;
+    __syncthreads();
+    const uint32_t qmax = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
+    const uint32_t nb = (qmax + 255u) >> 8;
+    if (nb) {
+        if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
+        __syncthreads();
+        uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
+        for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << 14);
     }
 }
 
@@ -647,14 +672,14 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
-                          float *out_color, float *out_depth, const uint32_t *header, uint32_t capacity,
+                          float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
+                          float *acc_final, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
 #define FNX_LAUNCH_BF(CC, SS)                                                                                          \
     hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,   \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
-                       tile_count, dyn_start, st, materialize_all, vb)
+                       tile_count, dyn_start, acc_final, st, materialize_all, vb)
     if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);
     else if (C == 3) FNX_LAUNCH_BF(3, false);
     else if (st.base) FNX_LAUNCH_BF(1, true);

@@ -535,6 +535,7 @@ class HotLoopLevelTwo:
                  log_scalars=False):
         from .utils.loss_utils import l2_loss_consistency
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
+        self.view_subset = None
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.image_loss, self.log_scalars = image_loss, log_scalars
         self.background = torch.zeros(3, device=gm._visual_xyz.device)
@@ -542,6 +543,9 @@ class HotLoopLevelTwo:
         self._cons = l2_loss_consistency
         gm.training_setup_current_level_two(SimpleNamespace(**{k: cfg[k] for k in cfg if k.endswith("_lr")}))
         self.last = {}
+
+    def _mine(self, batch):
+        return list(self.view_subset) if self.view_subset is not None else shard_views(batch, self.rank, self.world)
 
     @torch.no_grad()
     def make_targets(self, noise=0.3, seed=0):

@@ -204,6 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ring[slot].copy_(img[al:al + 32].view(torch.int32))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.capacity = cap if P else 0  # the binning blob's layout depends on it
         ctx.channels = Cn
         ctx.grad_splat_limit = -1 if grad_splat_limit is None else int(grad_splat_limit)
         ctx.aux = (bg, view, proj, campos)
@@ -241,7 +242,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             need = ctx.needs_input_grad  # (means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, ...)
             geometry_only = int(not (need[2] or need[3] or need[4]) and M == 0)
             _lib.check(lib.fnx_rasterize_backward_ex(
-                Cn, P, int(rs.sh_degree), M, max(ctx.num_rendered, 0), bg.data_ptr(), W, H, means3D.data_ptr(),
+                Cn, P, int(rs.sh_degree), M, int(ctx.capacity), bg.data_ptr(), W, H, means3D.data_ptr(),
                 _ptr(sh), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3Ds_precomp), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), float(rs.tan_fov_x),
                 float(rs.tan_fov_y), radii.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr(), dL.data_ptr(),

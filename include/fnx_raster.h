@@ -89,8 +89,9 @@ int fnx_forward_stage2(int channels, char *geom_buffer, char *binning_buffer, in
 int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_t stream);
 
 /*
- * Rasterizer::backward (rasterizer.h:56-83).  R is accepted for signature parity and ignored
- * (the instance count lives in image_buffer).  dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
+ * Rasterizer::backward (rasterizer.h:56-83).  R = the forward's return value (num_rendered) as in the reference; with
+ * the two-stage forward it is the binning capacity stage 2 ran with (the binning blob's layout depends on it; the
+ * instance count itself lives in image_buffer).  dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
  * dL_dcolor [P,C], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
  */
 int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float *background, int width, int height,
@@ -278,17 +279,23 @@ typedef struct {
     size_t total;
 } fnx_geom_layout_t;
 typedef struct {
-    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split) */
+    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split),
+                           [4] backward work items                                                          */
     size_t final_T;     /* f32[H*W]                                                 */
     size_t n_contrib;   /* u32[H*W]                                                 */
     size_t ranges;      /* u32[2T] per-tile [start,end) in point_list               */
     size_t tile_count;  /* u32[T]   instances emitted by this call (split: the dynamic ones) */
     size_t dyn_start;   /* u32[T]   split mode: start of the tile's dynamic (key, id) pairs */
+    size_t acc_final;   /* f32[3 H W] (C planes used) colour accumulated by the blend before the background term */
     size_t total;
 } fnx_image_layout_t;
 typedef struct {
     size_t point_list; /* u32[R (+ R_static)] Gaussian ids sorted by (tile, depth bits, id) */
     size_t pairs;      /* split mode: u32[2R] (depth bits, id) of the dynamic instances, per tile in depth order */
+    size_t bstate;     /* f32[(R / 256 + 2) * 256 * 4] per-pixel (T, colour) in front of every 256-entry batch b >= 1 the
+                          forward blended: slot (tile's first list position) / 256 + b - 1                          */
+    size_t bwd_items;  /* u32[...] backward work items (tile | batch << 14) written by the forward; their count is
+                          header word 4                                                                             */
     size_t total;
 } fnx_binning_layout_t;
 typedef struct {

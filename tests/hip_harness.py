@@ -96,7 +96,7 @@ class HipRun:
                  dL_dmeans3D=z(P, 3), dL_dcov3D=z(P, 6), dL_dsh=z(P, M, 3), dL_dscales=z(P, 3), dL_drotations=z(P, 4))
         dL = _t(dL_dcolor, dev).reshape(Cn, self.H, self.W).contiguous()
         _lib.check(self.lib.fnx_rasterize_backward_ex(
-            Cn, P, self.D, M, self.R, _p(self.bg), self.W, self.H, _p(self.means3D), _p(self.shs), _p(self.colors),
+            Cn, P, self.D, M, self.cap, _p(self.bg), self.W, self.H, _p(self.means3D), _p(self.shs), _p(self.colors),
             _p(self.scales), self.mod, _p(self.rots), _p(self.cov), _p(self.view), _p(self.proj), _p(self.campos),
             self.tanx, self.tany, _p(self.radii), self.geom.data_ptr(), _p(self.binning), self.img.data_ptr(),
             dL.data_ptr(), g["dL_dmeans2D"].data_ptr(), g["dL_dconic"].data_ptr(), g["dL_dopacity"].data_ptr(),
