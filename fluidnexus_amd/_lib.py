@@ -29,7 +29,7 @@ class GeomLayout(C.Structure):
 
 class ImageLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "acc_final", "total")]
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "acc_final", "deep_list", "tile_deep", "total")]
 
 
 class BinningLayout(C.Structure):
@@ -52,6 +52,7 @@ SYMBOLS = (
     "fnx_rasterize_backward_views",
     "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
+    "fnx_set_deep_threshold",
 )
 
 
@@ -114,9 +115,11 @@ def raster():
     lib.fnx_static_finalize_views.restype = i
     lib.fnx_static_finalize_views.argtypes = [i, p, p, p, i, i, i, i, c_int64, p, p, p]
     lib.fnx_forward_stage1_views_split.restype = i
-    lib.fnx_forward_stage1_views_split.argtypes = lib.fnx_forward_stage1_views.argtypes[:-1] + [p, i, c_int64, p]
+    lib.fnx_forward_stage1_views_split.argtypes = lib.fnx_forward_stage1_views.argtypes[:-1] + [p, i, c_int64, p, p]
     lib.fnx_forward_stage2_views_split.restype = i
-    lib.fnx_forward_stage2_views_split.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p, i, c_int64, i, p]
+    lib.fnx_forward_stage2_views_split.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p, i, c_int64, i, p, p]
+    lib.fnx_set_deep_threshold.restype = i
+    lib.fnx_set_deep_threshold.argtypes = [C.c_uint]
     lib.fnx_rasterize_backward_views_split.restype = i
     lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]
     lib.fnx_binning_layout_split.argtypes = [c_int64, c_int64, C.POINTER(BinningLayout)]

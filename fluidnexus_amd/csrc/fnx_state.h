@@ -107,6 +107,8 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     o->tile_count = off;  off = align_up(off + t * 4);
     o->dyn_start = off;   off = align_up(off + t * 4);
     o->acc_final = off;   off = align_up(off + n * 4 * 3);
+    o->deep_list = off;   off = align_up(off + t * 4);
+    o->tile_deep = off;   off = align_up(off + t);
     o->total = off + kAlign;
 }
 
@@ -160,6 +162,6 @@ struct StaticRef {
 enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
 
 // header words inside the image blob
-enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4 };
+enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4, HDR_DEEP_COUNT = 5 };
 
 }  // namespace fnx

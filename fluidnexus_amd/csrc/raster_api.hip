@@ -22,7 +22,8 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
                        const ViewBatch &vb, const StaticRef &st);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
-                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, int V, const ViewBatch &vb,
+                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, const uint32_t *depth_hint,
+                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, int V, const ViewBatch &vb,
                       const StaticRef &st);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
@@ -42,7 +43,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          float *acc_final, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
+                          float *acc_final, const uint32_t *deep_list, const uint8_t *tile_deep, uint32_t *depth_hint,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -128,6 +130,8 @@ struct Img {
     uint32_t *tile_count;
     uint32_t *dyn_start;
     float *acc_final;
+    uint32_t *deep_list;
+    uint8_t *tile_deep;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -141,6 +145,8 @@ Img carve_img(char *blob, int W, int H) {
     i.tile_count = (uint32_t *)(b + L.tile_count);
     i.dyn_start = (uint32_t *)(b + L.dyn_start);
     i.acc_final = (float *)(b + L.acc_final);
+    i.deep_list = (uint32_t *)(b + L.deep_list);
+    i.tile_deep = (uint8_t *)(b + L.tile_deep);
     return i;
 }
 struct Bin {
@@ -208,6 +214,7 @@ struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
 };
+uint32_t g_deep_min = 1024;  // list depth from which a tile goes to the blend forward's deep variant
 bool g_prof_on = false;
 ProfClass g_prof[kProfClasses];
 
@@ -281,7 +288,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
                                    const float *viewmatrix, const float *projmatrix, const float *cam_pos,
                                    const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   fnx_stream_t stream) {
+                                   const uint32_t *depth_hint, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
     if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
@@ -330,7 +337,8 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
     fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
-    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, V, vb, st);
+    fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
+                          g_deep_min, img.deep_list, img.tile_deep, V, vb, st);
     }
     return hip_check("stage1");
 }
@@ -344,7 +352,7 @@ int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image
     return fnx_forward_stage1_views_split(channels, V, geom_buffer, image_buffer, P, D, M, width, height, means3D, shs,
                                           colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                                           viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, radii,
-                                          nullptr, 0, 0, stream);
+                                          nullptr, 0, 0, nullptr, stream);
 }
 
 int fnx_forward_stage1(int channels, char *geom_buffer, char *image_buffer, int P, int D, int M, int width, int height,
@@ -385,7 +393,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
                                    int64_t binning_capacity, char *image_buffer, int P, int width, int height,
                                    const float *background, float *out_color, float *out_depth, uint32_t *status_out,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   int materialize_all, fnx_stream_t stream) {
+                                   int materialize_all, uint32_t *depth_hint, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
     if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
@@ -415,7 +423,8 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         ProfScope ps(channels == 3 ? 0 : 5, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
-                                  img.tile_count, img.dyn_start, img.acc_final, st, materialize_all, V, vb);
+                                  img.tile_count, img.dyn_start, img.acc_final, img.deep_list, img.tile_deep, depth_hint,
+                                  st, materialize_all, V, vb);
     }
     return hip_check("stage2");
 }
@@ -427,7 +436,7 @@ int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffer, char
     if (V > 1 && P > 0 && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
     return fnx_forward_stage2_views_split(channels, V, geom_buffer, binning_buffer, binning_capacity, image_buffer, P,
                                           width, height, background, out_color, out_depth, status_out, nullptr, 0, 0, 0,
-                                          stream);
+                                          nullptr, stream);
 }
 
 // Once per frame: instances of the static subset (already through fnx_forward_stage1_views as a splat set of its own)
@@ -610,6 +619,11 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
                                      tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
                                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                      dL_dscale, dL_drot, -1, 0, stream);
+}
+
+int fnx_set_deep_threshold(unsigned int min_depth) {
+    g_deep_min = min_depth ? min_depth : 1u;
+    return FNX_OK;
 }
 
 int fnx_profile_enable(int on) {

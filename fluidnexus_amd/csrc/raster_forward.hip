@@ -214,8 +214,15 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ ranges,
                  uint32_t *__restrict__ dyn_start, uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
-                 uint32_t *__restrict__ emit_items, size_t geom_stride, const StaticRef st) {
+                 uint32_t *__restrict__ emit_items, size_t geom_stride, const uint32_t *__restrict__ depth_hint,
+                 uint32_t deep_min, uint32_t *__restrict__ deep_list, uint8_t *__restrict__ tile_deep,
+                 const StaticRef st) {
     __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_deep_n;
+    if (threadIdx.x == 0) s_deep_n = 0;
+    deep_list = view_at(deep_list, img_stride, blockIdx.y);
+    tile_deep = view_at(tile_deep, img_stride, blockIdx.y);
+    if (depth_hint) depth_hint += (size_t)blockIdx.y * T;
     blk_total = view_at(blk_total, geom_stride, blockIdx.y);
     emit_items = view_at(emit_items, geom_stride, blockIdx.y);
     tile_count = view_at(tile_count, img_stride, blockIdx.y);
@@ -249,8 +256,14 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         ranges[2 * i + 1] = c ? at + c : 0u;
         dyn_start[i] = run;
         run += cd;
+        // tiles that went deep in the previous forward of this view go to the blend's deep variant
+        const bool deep = depth_hint && c && depth_hint[i] >= deep_min;
+        tile_deep[i] = deep ? 1 : 0;
+        if (deep) deep_list[atomicAdd(&s_deep_n, 1u)] = (uint32_t)i;
     }
+    __syncthreads();
     if (tid == 1023) {
+        header[HDR_DEEP_COUNT] = s_deep_n;
         header[HDR_NUM_RENDERED] = s_part[1023];
         header[HDR_STATUS] = 0u;
         header[HDR_CAPACITY] = 0u;
@@ -310,15 +323,28 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
 // prefetched.  Ties in depth go to the per-call stream (lower ids), as in the reference's stable sort of ids
 // emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
 // pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
-template <int C, bool SPLIT>
-__global__ void __launch_bounds__(256)
+//
+// HELPERS > 0 ("deep" variant, 256 (1 + HELPERS) threads): for tiles whose lists do not saturate early -- a
+// semi-transparent plume: thousands of contributing entries per pixel, where the time of the launch is the time of
+// the longest sequential walk.  Waves 0-3 own the pixels as before; HELPERS extra waves per quadrant evaluate the
+// alphas of the quadrant's list entries (independent of the blending state) chunk by chunk into LDS, and the owners
+// only run the short recurrence T -> T (1 - alpha) over them: the same arithmetic per (pixel, entry) in the same
+// order, with the ~35 instructions of the alpha evaluation taken off the sequential path.  Which tiles go to which
+// variant is decided from the depth each tile reached in the previous forward of the same view (depth_hint,
+// tile_scan_kernel): a performance hint only, either variant renders any tile.
+template <int C, bool SPLIT, int HELPERS>
+__global__ void __launch_bounds__(256 * (1 + HELPERS))
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_depth, uint32_t *__restrict__ header,
                      uint32_t capacity, uint32_t *__restrict__ status_out, const uint32_t *__restrict__ tile_count,
-                     const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final, const StaticRef st,
-                     int materialize_all, const ViewBatch vb) {
+                     const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
+                     const uint32_t *__restrict__ deep_list, const uint8_t *__restrict__ tile_deep,
+                     uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb) {
+    constexpr bool DEEP = HELPERS > 0;
+    constexpr int kThreads = 256 * (1 + HELPERS);
+    constexpr int kChunk = 8 * (DEEP ? HELPERS : 1);  // list entries per alpha chunk and quadrant: 8 per helper wave
     const char *static_blob = nullptr;
     {
         const int vw = blockIdx.y;
@@ -331,6 +357,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         out_color += (size_t)vw * C * H * W;
         out_depth += (size_t)vw * H * W;
         acc_final = view_at(acc_final, vb.img, vw);
+        deep_list = view_at(deep_list, vb.img, vw);
+        tile_deep = view_at(tile_deep, vb.img, vw);
+        if (depth_hint) depth_hint += (size_t)vw * T;
         if (SPLIT) {
             tile_count = view_at(tile_count, vb.img, vw);
             dyn_start = view_at(dyn_start, vb.img, vw);
@@ -346,20 +375,29 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
     __shared__ uint32_t s_qmax[4];
+    __shared__ float s_alpha[DEEP ? 2 : 1][DEEP ? 4 : 1][kChunk][DEEP ? 64 : 1];  // [buffer][quadrant][entry][pixel]
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
     if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity) return;
-    const int tile = xcd_tile(blockIdx.x, T);
-    const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wq = w & 3, role = w >> 2;  // quadrant; 0 = owner of the quadrant's pixels, 1.. = alpha helper
+    const bool stager = tid < 256;        // waves 0-3 own the pixels, stage the batches and merge the streams
+    const uint32_t n_work = DEEP ? header[HDR_DEEP_COUNT] : 1u;
+  for (uint32_t work = DEEP ? blockIdx.x : 0u; work < n_work; work += DEEP ? gridDim.x : 1u) {
+    if (DEEP) __syncthreads();  // the previous tile is done with the LDS arrays
+    const int tile = DEEP ? (int)deep_list[work] : xcd_tile(blockIdx.x, T);
+    if (!DEEP && tile_deep[tile]) return;  // the deep variant renders it
+    const int tx = tile % gx, ty = tile / gx;
     // The blend loop multiplies the colour of an entry it does NOT take by alpha = 0 instead of selecting per
     // channel, and the last group of a list reads up to three slots past its end: every colour slot must hold a
     // finite value from the start (0 * garbage could be NaN).  Colours are assumed finite, like everywhere else.
+    if (stager) {
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
-    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
+        for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
+    }
+    const int px = tx * FNX_TILE_X + (wq & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (wq >> 1) * 8 + (lane >> 3);
+    const bool inside = stager && px < W && py < H;  // helper waves carry no pixel state
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
@@ -387,10 +425,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         return (SPLIT && id >= st.id0) ? rec_s + 4 * (size_t)(id - st.id0) : blend_rec + 4 * (size_t)id;
     };
     auto load_windows = [&]() {  // the next (up to) 256 entries of each stream behind (si, fj)
+        if (!stager) return;
         ws = (si + (uint32_t)tid < ns) ? sp[si + tid] : make_uint2(0xFFFFFFFFu, 0u);
         wf = (fj + (uint32_t)tid < nf) ? fp[fj + tid] : make_uint2(0xFFFFFFFFu, 0u);
     };
     auto store_windows = [&]() {
+        if (!stager) return;
         s_wk[0][SPLIT ? tid : 0] = ws.x;
         s_wi[0][SPLIT ? tid : 0] = ws.y;
         s_wk[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.x;
@@ -444,7 +484,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (C > 2) pd = rec[3].x;
         }
         load_windows();
-    } else {
+    } else if (stager) {
         if (r0 + (uint32_t)tid < r1) {
             const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
             pa = rec[0];
@@ -459,12 +499,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      (size_t)(r0 >> 8) * 256 + tid;
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
-        const bool all_done = __syncthreads_count(done) == 256;
+        const bool all_done = __syncthreads_count(done) == kThreads;
         if (all_done) {
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
-        if (blending && base != r0)
+        if (blending && base != r0 && stager)
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
@@ -479,7 +519,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (SPLIT) {
             if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
             store_windows();
-        } else {
+        } else if (stager) {
             if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
                 const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
                 pa = rec[0];
@@ -494,7 +534,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         for (int q = 0; q < 4; q++) {
             const unsigned long long m = __ballot((qm >> q) & 1u);
             rank[q] = (uint32_t)__popcll(m & lt_mask);
-            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(m);
+            if (lane == 0 && stager) s_cnt[w][q] = (uint32_t)__popcll(m);
         }
         __syncthreads();
 #pragma unroll
@@ -530,8 +570,56 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
         const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
+            (int)(s_cnt[0][wq] + s_cnt[1][wq] + s_cnt[2][wq] + s_cnt[3][wq]));
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
+        if constexpr (DEEP) {
+            // chunk k of every quadrant's list: the helpers of the quadrant write its alphas (0 = "not a hit": a hit
+            // has alpha >= 1/255) while the owner blends chunk k - 1; one barrier per chunk, two buffers
+            uint32_t n_max = 0;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) n_max = max(n_max, s_cnt[0][qq] + s_cnt[1][qq] + s_cnt[2][qq] + s_cnt[3][qq]);
+            const uint32_t n_chunks = (n_max + kChunk - 1) / kChunk;
+            for (uint32_t kc = 0; kc <= n_chunks; kc++) {
+                if (role != 0) {
+                    if (kc < n_chunks) {
+#pragma unroll 4
+                        for (uint32_t e = (uint32_t)role - 1u; e < (uint32_t)kChunk; e += (uint32_t)HELPERS) {
+                            const uint32_t i = kc * kChunk + e;
+                            if (i >= n_w) break;
+                            const uint32_t j = s_list[wq][i];
+                            const float4 ra = s_ra[j];
+                            const float4 rb = s_rb[j];
+                            const float dx = ra.x - pxf, dy = ra.y - pyf;
+                            const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
+                            const bool ok = !(power > 0.0f) && !(power < rb.z);
+                            const float alpha = fminf(0.99f, rb.y * exp_fixed_in_range(power));
+                            s_alpha[kc & 1][wq][e][lane] = (ok && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
+                        }
+                    }
+                } else if (kc > 0 && !__all(done)) {
+                    const uint32_t i0 = (kc - 1) * kChunk;
+#pragma unroll 4
+                    for (uint32_t e = 0; e < (uint32_t)kChunk; e++) {
+                        if (i0 + e >= n_w) break;
+                        const uint32_t j = s_list[wq][i0 + e];
+                        const float a = s_alpha[(kc - 1) & 1][wq][e][lane];
+                        const bool live = (a > 0.0f) && !done;
+                        const float test_T = Tr * (1 - a);
+                        const bool stop = live && (test_T < 0.0001f);
+                        const bool take = live && !stop;
+                        done = done || stop;
+                        const float a_eff = take ? a : 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) acc[ch] = acc[ch] + s_col[ch][j] * a_eff * Tr;
+                        Dm = (take && Tr > 0.5f && test_T < 0.5f) ? s_rb[j].w : Dm;
+                        Tr = take ? test_T : Tr;
+                        last_contributor = take ? pos0 + j : last_contributor;
+                    }
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         // The only state carried from entry to entry is (T, colour, depth, done); power / exp / alpha
         // of an entry do not depend on it.  A lone wave runs ~500 cycles per entry when everything is
         // evaluated in list order (dependent LDS reads + a 60-instruction chain), and the kernel time
@@ -539,6 +627,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         // together, the alphas evaluated as straight-line predicated code (the scheduler interleaves
         // the independent chains), then a short select-only recurrence in list order.  Per pixel the
         // arithmetic and its order are unchanged.
+#ifndef FNX_DEEP_HELPERS
+#define FNX_DEEP_HELPERS 3  // alpha helper waves per quadrant in the blend forward's deep variant
+#endif
 #ifndef FNX_FWD_GROUP
 #define FNX_FWD_GROUP 4
 #endif
@@ -597,7 +688,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     uint32_t m = last_contributor;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) s_qmax[w] = m;
+    if (lane == 0 && stager) s_qmax[w] = m;
     __syncthreads();
     const uint32_t qmax = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
     const uint32_t nb = (qmax + 255u) >> 8;
@@ -605,8 +696,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
         __syncthreads();
         uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
-        for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << 14);
+        for (uint32_t k = tid; k < nb; k += kThreads) items[k] = (uint32_t)tile | (k << 14);
     }
+    if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: next forward's variant choice
+  }  // tiles of this workgroup
 }
 
 // rasterizer_impl.cu:52-63
@@ -662,28 +755,45 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
-                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, int V, const ViewBatch &vb,
+                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, const uint32_t *depth_hint,
+                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, int V, const ViewBatch &vb,
                       const StaticRef &st) {
     const SortScratch L = sort_scratch(P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
-                       sort_scratch_words + L.emit_items, vb.geom, st);
+                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, deep_list, tile_deep, st);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          float *acc_final, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
+                          float *acc_final, const uint32_t *deep_list, const uint8_t *tile_deep, uint32_t *depth_hint,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
-#define FNX_LAUNCH_BF(CC, SS)                                                                                          \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,   \
-                       blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
-                       tile_count, dyn_start, acc_final, st, materialize_all, vb)
-    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);
-    else if (C == 3) FNX_LAUNCH_BF(3, false);
-    else if (st.base) FNX_LAUNCH_BF(1, true);
-    else FNX_LAUNCH_BF(1, false);
+    constexpr int kHelpers = FNX_DEEP_HELPERS;
+#define FNX_LAUNCH_BF(CC, SS, HH, GRID)                                                                                \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, HH>), GRID, dim3(256 * (1 + HH)), 0, s, T, gx, ranges, point_list, \
+                       W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,     \
+                       tile_count, dyn_start, acc_final, deep_list, tile_deep, depth_hint, st, materialize_all, vb)
+    if (depth_hint) {
+        // deep variant first (few, long tiles): persistent workgroups striding over the view's deep-tile list
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        }
+        const dim3 grid((2 * n_cu + V - 1) / V, V);
+        if (C == 3 && st.base) FNX_LAUNCH_BF(3, true, kHelpers, grid);
+        else if (C == 3) FNX_LAUNCH_BF(3, false, kHelpers, grid);
+        else if (st.base) FNX_LAUNCH_BF(1, true, kHelpers, grid);
+        else FNX_LAUNCH_BF(1, false, kHelpers, grid);
+    }
+    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true, 0, dim3(T, V));
+    else if (C == 3) FNX_LAUNCH_BF(3, false, 0, dim3(T, V));
+    else if (st.base) FNX_LAUNCH_BF(1, true, 0, dim3(T, V));
+    else FNX_LAUNCH_BF(1, false, 0, dim3(T, V));
 #undef FNX_LAUNCH_BF
 }
 

@@ -37,6 +37,18 @@ _captured_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
+_DEEP_VARIANT = True  # depth hints on: long, non-saturating tiles go to the blend forward's deep variant
+
+
+def set_deep_variant(enabled: bool, min_depth: int | None = None):
+    """Switch the depth-hint mechanism (ViewBatch.depth_hint) on / off; `min_depth`: list depth from which a tile is
+    sent to the deep variant (library-wide, default 1024)."""
+    global _DEEP_VARIANT
+    _DEEP_VARIANT = bool(enabled)
+    if min_depth is not None:
+        _lib.check(_lib.raster().fnx_set_deep_threshold(int(min_depth)))
+
+
 _between_stages_hook = None  # called (no arguments) between the binning stage and the emit / blend stage of a view batch
 
 
@@ -280,6 +292,22 @@ class ViewBatch:
         self.bg = _f32c(rs0.bg)
         self.tan_x = (C.c_float * self.V)(*[float(rs.tan_fov_x) for rs in settings_list])
         self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
+        self._depth_hint = {}
+
+    def depth_hint(self, channels):
+        """u32 [V, T]: how deep every tile of every view went in the previous forward of this batch (per channel
+        count: the 1- and 3-channel renders of a frame see different splat sets).  The forward keeps it up to date
+        and uses it to send long, non-saturating tiles to the blend's deep variant (include/fnx_raster.h)."""
+        if not _DEEP_VARIANT:
+            return None
+        h = self._depth_hint.get(channels)
+        if h is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # allocated by the first eager forward; a capture that comes first simply runs without it
+            rs = self.settings[0]
+            T = ((int(rs.image_width) + 15) // 16) * ((int(rs.image_height) + 15) // 16)
+            h = self._depth_hint[channels] = torch.zeros(self.V, T, dtype=torch.int32, device=self.view.device)
+        return h
 
 
 class StaticBin:
@@ -377,11 +405,13 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             color = torch.empty(V, Cn, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(V, P, dtype=torch.int32, device=dev)
-            _lib.check(lib.fnx_forward_stage1_views(
+            hint = vbatch.depth_hint(Cn)
+            hint_ptr = hint.data_ptr() if hint is not None else None
+            _lib.check(lib.fnx_forward_stage1_views_split(
                 Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
                 _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
-                vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), stream))
+                vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), None, 0, 0, hint_ptr, stream))
             key = (dev.index, W, H, Cn, P)
             known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
             synced = _HOST_SYNC or not known
@@ -405,9 +435,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 ring, slot = _status_slots(dev, V, key)
                 status_ptr = ring[slot:slot + V].data_ptr()
-            _lib.check(lib.fnx_forward_stage2_views_status(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
-                                                           P, W, H, vbatch.bg.data_ptr(), radii.data_ptr(),
-                                                           color.data_ptr(), depth.data_ptr(), status_ptr, stream))
+            _lib.check(lib.fnx_forward_stage2_views_split(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                                          P, W, H, vbatch.bg.data_ptr(), color.data_ptr(),
+                                                          depth.data_ptr(), status_ptr, None, 0, 0, 0, hint_ptr, stream))
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
@@ -445,12 +475,14 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         color = torch.empty(V, Cn, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(V, P_all, dtype=torch.int32, device=dev)
+        hint = vbatch.depth_hint(Cn)
+        hint_ptr = hint.data_ptr() if hint is not None else None
         _lib.check(lib.fnx_forward_stage1_views_split(
             Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
             _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
             _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
             vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), sb.blob.data_ptr(), sb.P, sb.R_cap,
-            stream))
+            hint_ptr, stream))
         key = (dev.index, W, H, Cn, P, "split")
         known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
         synced = _HOST_SYNC or not known
@@ -475,7 +507,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         _lib.check(lib.fnx_forward_stage2_views_split(
             Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
             color.data_ptr(), depth.data_ptr(), status_ptr, sb.blob.data_ptr(), sb.P, sb.R_cap,
-            int(bool(StaticBin.materialize_all)), stream))
+            int(bool(StaticBin.materialize_all)), hint_ptr, stream))
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
