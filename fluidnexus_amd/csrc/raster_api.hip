@@ -22,9 +22,9 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
                        const ViewBatch &vb, const StaticRef &st);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
-                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, const uint32_t *depth_hint,
-                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, int V, const ViewBatch &vb,
-                      const StaticRef &st);
+                      uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
+                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, uint32_t *tile_qmax, int V,
+                      const ViewBatch &vb, const StaticRef &st);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
@@ -44,7 +44,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *deep_list, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
+                          uint32_t *tile_qmax, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -132,6 +132,7 @@ struct Img {
     float *acc_final;
     uint32_t *deep_list;
     uint8_t *tile_deep;
+    uint32_t *tile_qmax;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -147,6 +148,7 @@ Img carve_img(char *blob, int W, int H) {
     i.acc_final = (float *)(b + L.acc_final);
     i.deep_list = (uint32_t *)(b + L.deep_list);
     i.tile_deep = (uint8_t *)(b + L.tile_deep);
+    i.tile_qmax = (uint32_t *)(b + L.tile_qmax);
     return i;
 }
 struct Bin {
@@ -288,7 +290,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
                                    const float *viewmatrix, const float *projmatrix, const float *cam_pos,
                                    const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   const uint32_t *depth_hint, fnx_stream_t stream) {
+                                   uint32_t *depth_hint, fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
     if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
@@ -338,7 +340,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
-                          g_deep_min, img.deep_list, img.tile_deep, V, vb, st);
+                          g_deep_min, img.deep_list, img.tile_deep, img.tile_qmax, V, vb, st);
     }
     return hip_check("stage1");
 }
@@ -424,7 +426,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.deep_list, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb);
+                                  img.tile_qmax, st, materialize_all, V, vb);
     }
     return hip_check("stage2");
 }

@@ -215,17 +215,18 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffers, char
                                    const float *viewmatrices, const float *projmatrices, const float *cam_pos,
                                    const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   const uint32_t *depth_hint, fnx_stream_t stream);
+                                   uint32_t *depth_hint, fnx_stream_t stream);
 int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char *binning_buffers,
                                    int64_t binning_capacity, char *image_buffers, int P_dyn, int width, int height,
                                    const float *background, float *out_color, float *out_depth, uint32_t *status_out,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
                                    int materialize_all, uint32_t *depth_hint, fnx_stream_t stream);
 /* depth_hint (may be NULL): u32[V, T] owned by the caller and kept across calls with the same cameras.  Stage 2 records
- * in it how deep (list position of the last contributor) every tile of every view went; stage 1 of the NEXT call sends
- * the tiles that went at least fnx_set_deep_threshold() deep (default 1024) to the blend's "deep" variant, which takes
- * the per-entry alpha evaluation off the sequential path of a long, non-saturating list (csrc/raster_forward.hip).
- * Purely a scheduling hint: results are bit-identical whichever variant renders a tile.  Zero-fill it once. */
+ * in it how deep (list position of the last contributor) every tile of every view went; stage 1 of the NEXT call reads
+ * it (and clears it for that call's stage 2) and sends the tiles that went at least fnx_set_deep_threshold() deep
+ * (default 1024) to the blend's "deep" variant: one workgroup per 8x8 quadrant, helper waves take the per-entry alpha
+ * evaluation off the sequential path of a long, non-saturating list (csrc/raster_forward.hip).  Purely a scheduling
+ * hint: results are bit-identical whichever variant renders a tile.  Zero-fill it once. */
 int fnx_set_deep_threshold(unsigned int min_depth);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
@@ -295,6 +296,7 @@ typedef struct {
     size_t acc_final;   /* f32[3 H W] (C planes used) colour accumulated by the blend before the background term */
     size_t deep_list;   /* u32[T]   tiles rendered by the blend forward's deep variant (count: header word 5) */
     size_t tile_deep;   /* u8[T]    1 for those tiles                                */
+    size_t tile_qmax;   /* u32[T]   batches of the tile that have a backward work item */
     size_t total;
 } fnx_image_layout_t;
 typedef struct {

@@ -1,0 +1,40 @@
+"""Developer tool: time the view-batched forward of config 3 with per-kernel breakdown (eager, events around the call)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fluidnexus_amd import rasterizer
+from fluidnexus_amd.harness import build_smoke_frame, build_scalar_real_frame
+from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
+from fluidnexus_amd.renderer.pipes import render_dynamics_views, render_fluid_views
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if cfg == 3:
+    gm, cams = build_smoke_frame()
+    gm.training_setup_current(__import__("types").SimpleNamespace(position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01, position_lr_max_steps=30000))
+    _, S_, Z_ = get_render_pipe("render_dynamics")
+    f = lambda: render_dynamics_views(cams, gm, None, bg, GRsetting=S_, GRzer=Z_, pos_type="guess_visual_nn", scale=True)
+else:
+    gm, cams = build_scalar_real_frame()
+    _, S_, Z_ = get_render_pipe("render_fluid")
+    f = lambda: render_fluid_views(cams, gm, None, bg, GRsetting=S_, GRzer=Z_, pos_type="visual")
+bg = torch.zeros(3, device="cuda")
+rasterizer.set_host_sync(False)
+with torch.no_grad():
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+print("forward ms", e0.elapsed_time(e1) / 10)
+import ctypes as C
+from fluidnexus_amd import _lib
+lib = _lib.raster()
+if hasattr(lib, "fnx_debug_fwd_clock"):
+    buf = (C.c_ulonglong * 16)()
+    lib.fnx_debug_fwd_clock(buf)
+    names = ["loop top", "all_done barrier", "stage+ballots", "barrier A", "lists+merge", "barrier B", "advance+loads", "chunk loop",
+             "sum n_w", "chunk iterations", "batches", "", "", "", "", "list length"]
+    print({n: int(v) for n, v in zip(names, buf) if n})
