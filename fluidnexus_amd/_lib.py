@@ -29,7 +29,7 @@ class GeomLayout(C.Structure):
 
 class ImageLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
-                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "acc_final", "deep_list", "tile_deep", "tile_qmax", "total")]
+                ("header", "final_T", "n_contrib", "ranges", "tile_count", "dyn_start", "acc_final", "tile_order", "tile_deep", "total")]
 
 
 class BinningLayout(C.Structure):

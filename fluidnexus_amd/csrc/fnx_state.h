@@ -107,9 +107,8 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     o->tile_count = off;  off = align_up(off + t * 4);
     o->dyn_start = off;   off = align_up(off + t * 4);
     o->acc_final = off;   off = align_up(off + n * 4 * 3);
-    o->deep_list = off;   off = align_up(off + t * 4);
+    o->tile_order = off;  off = align_up(off + t * 4);
     o->tile_deep = off;   off = align_up(off + t);
-    o->tile_qmax = off;   off = align_up(off + t * 4);
     o->total = off + kAlign;
 }
 

@@ -23,8 +23,8 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const ViewBatch &vb, const StaticRef &st);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
-                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, uint32_t *tile_qmax, int V,
-                      const ViewBatch &vb, const StaticRef &st);
+                      uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
+                      const StaticRef &st);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
@@ -43,8 +43,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          float *acc_final, const uint32_t *deep_list, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          uint32_t *tile_qmax, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
+                          float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -130,9 +130,8 @@ struct Img {
     uint32_t *tile_count;
     uint32_t *dyn_start;
     float *acc_final;
-    uint32_t *deep_list;
+    uint32_t *tile_order;
     uint8_t *tile_deep;
-    uint32_t *tile_qmax;
 };
 Img carve_img(char *blob, int W, int H) {
     fnx_image_layout_t L;
@@ -146,9 +145,8 @@ Img carve_img(char *blob, int W, int H) {
     i.tile_count = (uint32_t *)(b + L.tile_count);
     i.dyn_start = (uint32_t *)(b + L.dyn_start);
     i.acc_final = (float *)(b + L.acc_final);
-    i.deep_list = (uint32_t *)(b + L.deep_list);
+    i.tile_order = (uint32_t *)(b + L.tile_order);
     i.tile_deep = (uint8_t *)(b + L.tile_deep);
-    i.tile_qmax = (uint32_t *)(b + L.tile_qmax);
     return i;
 }
 struct Bin {
@@ -216,7 +214,7 @@ struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
 };
-uint32_t g_deep_min = 1024;  // list depth from which a tile goes to the blend forward's deep variant
+uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
 bool g_prof_on = false;
 ProfClass g_prof[kProfClasses];
 
@@ -340,7 +338,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
-                          g_deep_min, img.deep_list, img.tile_deep, img.tile_qmax, V, vb, st);
+                          g_deep_min, img.tile_order, img.tile_deep, V, vb, st);
     }
     return hip_check("stage1");
 }
@@ -425,8 +423,8 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         ProfScope ps(channels == 3 ? 0 : 5, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
-                                  img.tile_count, img.dyn_start, img.acc_final, img.deep_list, img.tile_deep, depth_hint,
-                                  img.tile_qmax, st, materialize_all, V, vb);
+                                  img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
+                                  st, materialize_all, V, vb);
     }
     return hip_check("stage2");
 }

@@ -5,6 +5,19 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
+#ifdef FNX_EXP_CLOCK  // developer timing: per-phase cycles of every wave's thread 0 of workgroup (0, 0) of the blend forward
+__device__ unsigned long long g_fwd_clock[64];
+extern "C" int fnx_debug_fwd_clock(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_clock), sizeof(g_fwd_clock));
+}
+#define FNX_CLK(i) { const unsigned long long tn = clock64(); if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_fwd_clock[16 * w + (i)] += tn - t_last; t_last = tn; }
+#else
+#define FNX_CLK(i)
+#endif
+#ifndef FNX_DEEP_PRIO
+#define FNX_DEEP_PRIO 3  // wave priority (0..3) of the tiles that went deep in the previous forward
+#endif
+
 namespace fnx {
 
 // ---------------------------------------------------------------------------------------------
@@ -206,6 +219,15 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     if (threadIdx.x == 0) key_min_blk[blockIdx.x] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
 }
 
+// XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order, speed only), so
+// hand each XCD a contiguous band of tiles -> neighbouring tiles share splat records in one L2.
+__device__ __forceinline__ int xcd_tile(int bid, int T) {
+    const int q = T >> 3, r = T & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
 // rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.  It also lays out the
 // emission work items of the view (raster_binning.hip): per rank block, 1..kEmitBands bands of tile rows
@@ -215,14 +237,13 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  uint32_t *__restrict__ dyn_start, uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
                  uint32_t *__restrict__ emit_items, size_t geom_stride, uint32_t *__restrict__ depth_hint,
-                 uint32_t deep_min, uint32_t *__restrict__ deep_list, uint8_t *__restrict__ tile_deep,
-                 uint32_t *__restrict__ tile_qmax, int write_hint, const StaticRef st) {
+                 uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
+                 const StaticRef st) {
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_deep_n;
     if (threadIdx.x == 0) s_deep_n = 0;
-    deep_list = view_at(deep_list, img_stride, blockIdx.y);
+    tile_order = view_at(tile_order, img_stride, blockIdx.y);
     tile_deep = view_at(tile_deep, img_stride, blockIdx.y);
-    tile_qmax = view_at(tile_qmax, img_stride, blockIdx.y);
     if (depth_hint) depth_hint += (size_t)blockIdx.y * T;
     blk_total = view_at(blk_total, geom_stride, blockIdx.y);
     emit_items = view_at(emit_items, geom_stride, blockIdx.y);
@@ -257,17 +278,39 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         ranges[2 * i + 1] = c ? at + c : 0u;
         dyn_start[i] = run;
         run += cd;
-        // tiles that went deep in the previous forward of this view go to the blend's deep variant
+        // Tiles that went deep in the previous forward of this view (a list that does not saturate: thousands of
+        // contributing entries per pixel) are handed to the first workgroups of the blend launch, at raised wave
+        // priority: their sequential walks are the critical path of the launch and must not start last.
         const bool deep = depth_hint && c && depth_hint[i] >= deep_min;
         tile_deep[i] = deep ? 1 : 0;
-        if (deep) deep_list[atomicAdd(&s_deep_n, 1u)] = (uint32_t)i;
-        tile_qmax[i] = 0u;                                    // batches of the tile that already have a work item
-        if (write_hint) depth_hint[i] = 0u;                     // the blend of this forward records the new depth
+        if (deep) tile_order[atomicAdd(&s_deep_n, 1u)] = (uint32_t)i;
+        if (depth_hint) depth_hint[i] = 0u;  // the blend of this forward records the new depth
     }
     __syncthreads();
+    {
+        // the other tiles follow in the XCD-aware order (xcd_tile): position = deep count + rank among the others
+        const uint32_t nd = s_deep_n;
+        uint32_t mine = 0;
+        for (int k = b; k < e; k++) mine += tile_deep[xcd_tile(k, T)] ? 0u : 1u;
+        __syncthreads();
+        s_part[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t at = nd + s_part[tid] - mine;
+        for (int k = b; k < e; k++) {
+            const int t = xcd_tile(k, T);
+            if (!tile_deep[t]) tile_order[at++] = (uint32_t)t;
+        }
+        __syncthreads();
+        if (tid == 0) header[HDR_DEEP_COUNT] = nd;
+    }
     if (tid == 1023) {
-        header[HDR_DEEP_COUNT] = s_deep_n;
-        header[HDR_NUM_RENDERED] = s_part[1023];
+        header[HDR_NUM_RENDERED] = run;  // thread 1023 owns the last chunk of tiles: its running sum is the total
         header[HDR_STATUS] = 0u;
         header[HDR_CAPACITY] = 0u;
         header[HDR_NUM_STATIC] = st_starts ? st_starts[T] : 0u;
@@ -303,25 +346,6 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
     }
 }
 
-#ifdef FNX_EXP_CLOCK  // developer timing of the deep blend variant: per-phase cycles of workgroup (0, 0)
-__device__ unsigned long long g_fwd_clock[16];
-extern "C" int fnx_debug_fwd_clock(unsigned long long *host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_clock), sizeof(g_fwd_clock));
-}
-#define FNX_CLK(i) { const unsigned long long tn = clock64(); if (DEEP && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_fwd_clock[i] += tn - t_last; t_last = tn; }
-#else
-#define FNX_CLK(i)
-#endif
-
-// XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order, speed only), so
-// hand each XCD a contiguous band of tiles -> neighbouring tiles share splat records in one L2.
-__device__ __forceinline__ int xcd_tile(int bid, int T) {
-    const int q = T >> 3, r = T & 7;
-    const int xcd = bid & 7, k = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + k;
-}
-
 // K5: front-to-back alpha blending, one 256-thread workgroup per 16x16 tile
 // (ch3 forward.cu:249-373).  Wave w owns the 8x8 quadrant (w & 1, w >> 1).  A batch of 256 list
 // entries is staged once in LDS; while staging, each entry is tested against the four quadrants
@@ -336,18 +360,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
 // prefetched.  Ties in depth go to the per-call stream (lower ids), as in the reference's stable sort of ids
 // emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
 // pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
-//
-// DEEP variant: for tiles whose lists do not saturate early -- a semi-transparent plume: thousands of contributing
-// entries per pixel.  One 8x8 quadrant of such a tile keeps a whole SIMD busy for the length of the list, and a few
-// hundred such tiles leave most of the chip idle behind a few hundred sequential walks.  Here a workgroup renders ONE
-// QUADRANT of one tile (4x the units to spread over the compute units): wave 0 owns the quadrant's 64 pixels, waves
-// 1-3 ("helpers", on the other SIMDs) evaluate the alphas of the quadrant's list entries -- which do not depend on the
-// blending state -- chunk by chunk into LDS, and the owner only runs the recurrence T -> T (1 - alpha) over them: the
-// same arithmetic per (pixel, entry) in the same order, with the ~45 instructions of the alpha evaluation off the
-// sequential path.  All four waves stage the tile's batches (and merge the two streams) exactly like the normal
-// variant.  Which tiles go to which variant is decided from the depth each tile reached in the previous forward of
-// the same view (depth_hint, tile_scan_kernel): a scheduling hint only, either variant renders any tile.
-template <int C, bool SPLIT, bool DEEP>
+template <int C, bool SPLIT>
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
@@ -355,16 +368,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      float *__restrict__ out_color, float *__restrict__ out_depth, uint32_t *__restrict__ header,
                      uint32_t capacity, uint32_t *__restrict__ status_out, const uint32_t *__restrict__ tile_count,
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
-                     const uint32_t *__restrict__ deep_list, const uint8_t *__restrict__ tile_deep,
-                     uint32_t *__restrict__ depth_hint, uint32_t *__restrict__ tile_qmax, const StaticRef st,
-                     int materialize_all, const ViewBatch vb) {
-    constexpr int HELPERS = 3;
-    constexpr int kThreads = 256;
-#ifndef FNX_DEEP_PER_HELPER
-#define FNX_DEEP_PER_HELPER 16
-#endif
-    constexpr int kPerHelper = FNX_DEEP_PER_HELPER;            // list entries a helper wave evaluates per chunk
-    constexpr int kChunk = kPerHelper * (DEEP ? HELPERS : 1);  // list entries per alpha chunk and quadrant
+                     const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
+                     uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb) {
     const char *static_blob = nullptr;
     {
         const int vw = blockIdx.y;
@@ -377,9 +382,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         out_color += (size_t)vw * C * H * W;
         out_depth += (size_t)vw * H * W;
         acc_final = view_at(acc_final, vb.img, vw);
-        deep_list = view_at(deep_list, vb.img, vw);
+        tile_order = view_at(tile_order, vb.img, vw);
         tile_deep = view_at(tile_deep, vb.img, vw);
-        tile_qmax = view_at(tile_qmax, vb.img, vw);
         if (depth_hint) depth_hint += (size_t)vw * T;
         if (SPLIT) {
             tile_count = view_at(tile_count, vb.img, vw);
@@ -396,31 +400,24 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
     __shared__ uint32_t s_qmax[4];
-    __shared__ float s_alpha[DEEP ? 2 : 1][kChunk][DEEP ? 64 : 1];  // [buffer][entry][pixel] of the workgroup's quadrant
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
     if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr bool stager = true;  // every thread stages (kept as a name for the places that are staging work)
-    const uint32_t n_work = DEEP ? 4u * header[HDR_DEEP_COUNT] : 1u;  // deep: one unit per quadrant of a deep tile
-  for (uint32_t work = DEEP ? blockIdx.x : 0u; work < n_work; work += DEEP ? gridDim.x : 1u) {
-    if (DEEP) __syncthreads();  // the previous unit is done with the LDS arrays
-    const int tile = DEEP ? (int)deep_list[work >> 2] : xcd_tile(blockIdx.x, T);
-    if (!DEEP && tile_deep[tile]) return;  // the deep variant renders it
-    // quadrant whose pixels this wave works for, and its role there: 0 = owner of the pixels, 1.. = alpha helper
-    const int wq = DEEP ? (int)(work & 3u) : w, role = DEEP ? w : 0;
+    // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
+    // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
+    // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
+    const int tile = (int)tile_order[blockIdx.x];
+    if (tile_deep[tile]) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
     const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // The blend loop multiplies the colour of an entry it does NOT take by alpha = 0 instead of selecting per
     // channel, and the last group of a list reads up to three slots past its end: every colour slot must hold a
     // finite value from the start (0 * garbage could be NaN).  Colours are assumed finite, like everywhere else.
-    if (stager) {
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
-    }
-    const int px = tx * FNX_TILE_X + (wq & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (wq >> 1) * 8 + (lane >> 3);
-    const bool inside = role == 0 && px < W && py < H;  // helper waves carry no pixel state
-    const int pix_slot = wq * 64 + lane;                 // position of the pixel in the tile's per-batch state
+    for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
+    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
@@ -448,12 +445,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         return (SPLIT && id >= st.id0) ? rec_s + 4 * (size_t)(id - st.id0) : blend_rec + 4 * (size_t)id;
     };
     auto load_windows = [&]() {  // the next (up to) 256 entries of each stream behind (si, fj)
-        if (!stager) return;
         ws = (si + (uint32_t)tid < ns) ? sp[si + tid] : make_uint2(0xFFFFFFFFu, 0u);
         wf = (fj + (uint32_t)tid < nf) ? fp[fj + tid] : make_uint2(0xFFFFFFFFu, 0u);
     };
     auto store_windows = [&]() {
-        if (!stager) return;
         s_wk[0][SPLIT ? tid : 0] = ws.x;
         s_wi[0][SPLIT ? tid : 0] = ws.y;
         s_wk[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.x;
@@ -507,7 +502,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (C > 2) pd = rec[3].x;
         }
         load_windows();
-    } else if (stager) {
+    } else {
         if (r0 + (uint32_t)tid < r1) {
             const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
             pa = rec[0];
@@ -519,27 +514,26 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     }
     // forward -> backward hand-over (fnx_state.h, kBlendBatch): per-pixel state in front of every batch after the first
     float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
-                     (size_t)(r0 >> 8) * 256 + pix_slot;
+                     (size_t)(r0 >> 8) * 256 + tid;
 #ifdef FNX_EXP_CLOCK
     unsigned long long t_last = clock64();
-    if (DEEP && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[i] = 0; g_fwd_clock[15] = (r1 - r0); }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[16 * w + i] = 0; g_fwd_clock[16 * w + 15] = r1 - r0; }
 #endif
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
         FNX_CLK(0)
-        const bool all_done = __syncthreads_count(done) == kThreads;
+        const bool all_done = __syncthreads_count(done) == 256;
         FNX_CLK(1)
         if (all_done) {
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
-        if (blending && base != r0 && role == 0)
+        if (blending && base != r0)
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt && blending) {
             qm = quadrant_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
-            if (DEEP) qm &= 1u << wq;  // only this unit's quadrant
             s_ra[tid] = pa;
             s_rb[tid] = pb;
             s_col[0][tid] = pc.z;
@@ -549,7 +543,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (SPLIT) {
             if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
             store_windows();
-        } else if (stager) {
+        } else {
             if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
                 const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
                 pa = rec[0];
@@ -564,11 +558,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         for (int q = 0; q < 4; q++) {
             const unsigned long long m = __ballot((qm >> q) & 1u);
             rank[q] = (uint32_t)__popcll(m & lt_mask);
-            if (lane == 0 && stager) s_cnt[w][q] = (uint32_t)__popcll(m);
+            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(m);
         }
-        FNX_CLK(2)
         __syncthreads();
-        FNX_CLK(3)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if ((qm >> q) & 1u) {
@@ -582,9 +574,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             next_cnt = base + 256u < r1 ? min(256u, r1 - base - 256u) : 0u;
             next_id = merge_batch(next_cnt);
         }
-        FNX_CLK(4)
         __syncthreads();
-        FNX_CLK(5)
         if (SPLIT) {
             if (next_cnt) {
                 const uint32_t a = s_adv;
@@ -603,92 +593,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (!blending) continue;
         }
         // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
-#ifndef FNX_ABL_FWD
-#define FNX_ABL_FWD 0  // timing experiments (tools/build_variant.py): 1 = stage and merge only, no blending
-#endif
-        const uint32_t n_w = FNX_ABL_FWD == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)(s_cnt[0][wq] + s_cnt[1][wq] + s_cnt[2][wq] + s_cnt[3][wq]));
+        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
-        if constexpr (DEEP) {
-            // chunk k of every quadrant's list: the helpers of the quadrant write its alphas (0 = "not a hit": a hit
-            // has alpha >= 1/255) while the owner blends chunk k - 1; one barrier per chunk, two buffers
-            const uint32_t n_max = n_w;  // one quadrant per workgroup
-            FNX_CLK(6)
-            const uint32_t n_chunks = (n_max + kChunk - 1) / kChunk;
-            for (uint32_t kc = 0; kc <= n_chunks; kc++) {
-                if (role != 0) {
-                    // helper `role` evaluates entries [kPerHelper (role - 1), kPerHelper role) of chunk kc, four at a time: the LDS
-                    // reads of a group are issued together and the four alpha chains interleave (as in the normal
-                    // variant's loop); slots past the end of the list are written with garbage the owner ignores
-                    if (kc < n_chunks) {
-#pragma unroll 2
-                        for (int g = 0; g < kPerHelper / 4; g++) {
-                            const uint32_t e0 = (uint32_t)kPerHelper * ((uint32_t)role - 1u) + 4u * (uint32_t)g;
-                            const uint32_t i0 = kc * kChunk + e0;
-                            if (i0 >= n_w) break;
-                            const uint32_t j4 =
-                                (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[wq][i0]));
-                            float al[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const uint32_t j = (j4 >> (8 * k)) & 255u;
-                                const float4 ra = s_ra[j];
-                                const float4 rb = s_rb[j];
-                                const float dx = ra.x - pxf, dy = ra.y - pyf;
-                                const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
-                                const bool ok = !(power > 0.0f) && !(power < rb.z);
-                                const float alpha = fminf(0.99f, rb.y * exp_fixed_in_range(power));
-                                al[k] = (ok && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; k++) s_alpha[kc & 1][e0 + k][lane] = al[k];
-                        }
-                    }
-                } else if (kc > 0) {
-                    // the owner blends chunk kc - 1, eight entries per step: every LDS read of the step first, then
-                    // the select-only recurrence in list order
-#pragma unroll 1
-                    for (uint32_t e0 = 0; e0 < (uint32_t)kChunk; e0 += 8) {
-                        const uint32_t i0 = (kc - 1) * kChunk + e0;
-                        if (i0 >= n_w || __all(done)) break;
-                        uint32_t j4[2];
-                        j4[0] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[wq][i0]));
-                        j4[1] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[wq][i0 + 4]));
-                        float al[8], depth[8], col[8][C];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
-                            const float av = s_alpha[(kc - 1) & 1][e0 + k][lane];
-                            al[k] = (i0 + k < n_w) ? av : 0.0f;
-                            depth[k] = s_rb[j].w;
-#pragma unroll
-                            for (int ch = 0; ch < C; ch++) col[k][ch] = s_col[ch][j];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
-                            const bool live = (al[k] > 0.0f) && !done;
-                            const float test_T = Tr * (1 - al[k]);
-                            const bool stop = live && (test_T < 0.0001f);
-                            const bool take = live && !stop;
-                            done = done || stop;
-                            const float a_eff = take ? al[k] : 0.0f;
-#pragma unroll
-                            for (int ch = 0; ch < C; ch++) acc[ch] = acc[ch] + col[k][ch] * a_eff * Tr;
-                            Dm = (take && Tr > 0.5f && test_T < 0.5f) ? depth[k] : Dm;
-                            Tr = take ? test_T : Tr;
-                            last_contributor = take ? pos0 + j : last_contributor;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            FNX_CLK(7)
-#ifdef FNX_EXP_CLOCK
-            if (DEEP && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_fwd_clock[8] += n_w; g_fwd_clock[9] += n_chunks + 1; g_fwd_clock[10] += 1; }
-#endif
-            continue;
-        }
         // The only state carried from entry to entry is (T, colour, depth, done); power / exp / alpha
         // of an entry do not depend on it.  A lone wave runs ~500 cycles per entry when everything is
         // evaluated in list order (dependent LDS reads + a 60-instruction chain), and the kernel time
@@ -696,13 +603,14 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         // together, the alphas evaluated as straight-line predicated code (the scheduler interleaves
         // the independent chains), then a short select-only recurrence in list order.  Per pixel the
         // arithmetic and its order are unchanged.
-#ifndef FNX_DEEP_WGS_PER_CU
-#define FNX_DEEP_WGS_PER_CU 4  // workgroups of the blend forward's deep variant per compute unit (all views together)
-#endif
 #ifndef FNX_FWD_GROUP
 #define FNX_FWD_GROUP 4
 #endif
         constexpr int kGroup = FNX_FWD_GROUP;
+        FNX_CLK(2)
+#ifdef FNX_EXP_CLOCK
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
+#endif
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(done)) break;
             uint32_t j4[kGroup / 4];
@@ -742,6 +650,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 last_contributor = take ? pos0 + j : last_contributor;
             }
         }
+        FNX_CLK(3)
     }
     if (inside) {
         final_T[pix_id] = Tr;
@@ -753,9 +662,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         out_depth[pix_id] = Dm;
     }
-    // one backward work item per batch that holds a contributor of some pixel of the tile.  The quadrants of a deep
-    // tile finish in any order: the tile's batch count so far sits in tile_qmax (zeroed by tile_scan), an atomic max
-    // tells each finisher which batches it is the first to reach.
+    // one backward work item per batch that holds a contributor of some pixel of the tile
     uint32_t m = last_contributor;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
@@ -763,19 +670,13 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __syncthreads();
     const uint32_t qmax = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
     const uint32_t nb = (qmax + 255u) >> 8;
-    if (tid == 0) {
-        const uint32_t before = nb ? atomicMax(&tile_qmax[tile], nb) : nb;
-        s_qmax[0] = before;
-        s_adv = nb > before ? atomicAdd(&header[HDR_BWD_ITEMS], nb - before) : 0u;
-        if (depth_hint && qmax) atomicMax(&depth_hint[tile], qmax);  // how deep the tile went: next forward's variant choice
-    }
-    __syncthreads();
-    const uint32_t nb0 = s_qmax[0];
-    if (nb > nb0) {
+    if (nb) {
+        if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
+        __syncthreads();
         uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
-        for (uint32_t k = tid; k < nb - nb0; k += kThreads) items[k] = (uint32_t)tile | ((nb0 + k) << 14);
+        for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << 14);
     }
-  }  // tiles of this workgroup
+    if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: the next forward's tile order
 }
 
 // rasterizer_impl.cu:52-63
@@ -832,45 +733,29 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
-                      uint32_t deep_min, uint32_t *deep_list, uint8_t *tile_deep, uint32_t *tile_qmax, int V,
-                      const ViewBatch &vb, const StaticRef &st) {
+                      uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
+                      const StaticRef &st) {
     const SortScratch L = sort_scratch(P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
-                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, deep_list, tile_deep, tile_qmax,
-                       depth_hint ? 1 : 0, st);
+                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, tile_order, tile_deep, st);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
                           const float4 *blend_rec, const float *bg, float *final_T, uint32_t *n_contrib,
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
-                          float *acc_final, const uint32_t *deep_list, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          uint32_t *tile_qmax, const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
+                          float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
-#define FNX_LAUNCH_BF(CC, SS, DD, GRID)                                                                                \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, DD>), GRID, dim3(256), 0, s, T, gx, ranges, point_list, W, H,     \
+#define FNX_LAUNCH_BF(CC, SS)                                                                                          \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,   \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
-                       tile_count, dyn_start, acc_final, deep_list, tile_deep, depth_hint, tile_qmax, st,              \
-                       materialize_all, vb)
-    if (depth_hint) {
-        // deep variant first (few, long units): persistent workgroups striding over the view's deep (tile, quadrant) units
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        }
-        const dim3 grid((FNX_DEEP_WGS_PER_CU * n_cu + V - 1) / V, V);
-        if (C == 3 && st.base) FNX_LAUNCH_BF(3, true, true, grid);
-        else if (C == 3) FNX_LAUNCH_BF(3, false, true, grid);
-        else if (st.base) FNX_LAUNCH_BF(1, true, true, grid);
-        else FNX_LAUNCH_BF(1, false, true, grid);
-    }
-    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true, false, dim3(T, V));
-    else if (C == 3) FNX_LAUNCH_BF(3, false, false, dim3(T, V));
-    else if (st.base) FNX_LAUNCH_BF(1, true, false, dim3(T, V));
-    else FNX_LAUNCH_BF(1, false, false, dim3(T, V));
+                       tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb)
+    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);
+    else if (C == 3) FNX_LAUNCH_BF(3, false);
+    else if (st.base) FNX_LAUNCH_BF(1, true);
+    else FNX_LAUNCH_BF(1, false);
 #undef FNX_LAUNCH_BF
 }
 

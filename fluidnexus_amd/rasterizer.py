@@ -37,12 +37,12 @@ _captured_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
 
 
-_DEEP_VARIANT = True  # depth hints on: long, non-saturating tiles go to the blend forward's deep variant
+_DEEP_VARIANT = True  # depth hints on: tiles whose lists went deep in the previous forward are scheduled first
 
 
 def set_deep_variant(enabled: bool, min_depth: int | None = None):
-    """Switch the depth-hint mechanism (ViewBatch.depth_hint) on / off; `min_depth`: list depth from which a tile is
-    sent to the deep variant (library-wide, default 1024)."""
+    """Switch the depth-hint mechanism (ViewBatch.depth_hint) on / off; `min_depth`: list depth from which a tile
+    counts as deep (library-wide, default 1024)."""
     global _DEEP_VARIANT
     _DEEP_VARIANT = bool(enabled)
     if min_depth is not None:
@@ -297,7 +297,7 @@ class ViewBatch:
     def depth_hint(self, channels):
         """u32 [V, T]: how deep every tile of every view went in the previous forward of this batch (per channel
         count: the 1- and 3-channel renders of a frame see different splat sets).  The forward keeps it up to date
-        and uses it to send long, non-saturating tiles to the blend's deep variant (include/fnx_raster.h)."""
+        and uses it to start long, non-saturating tiles first, at raised wave priority (include/fnx_raster.h)."""
         if not _DEEP_VARIANT:
             return None
         h = self._depth_hint.get(channels)

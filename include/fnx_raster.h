@@ -223,10 +223,10 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char
                                    int materialize_all, uint32_t *depth_hint, fnx_stream_t stream);
 /* depth_hint (may be NULL): u32[V, T] owned by the caller and kept across calls with the same cameras.  Stage 2 records
  * in it how deep (list position of the last contributor) every tile of every view went; stage 1 of the NEXT call reads
- * it (and clears it for that call's stage 2) and sends the tiles that went at least fnx_set_deep_threshold() deep
- * (default 1024) to the blend's "deep" variant: one workgroup per 8x8 quadrant, helper waves take the per-entry alpha
- * evaluation off the sequential path of a long, non-saturating list (csrc/raster_forward.hip).  Purely a scheduling
- * hint: results are bit-identical whichever variant renders a tile.  Zero-fill it once. */
+ * it (and clears it for that call's stage 2): the tiles that went at least fnx_set_deep_threshold() deep (default 1024)
+ * -- lists that do not saturate, thousands of contributing entries per pixel -- are given to the first workgroups of
+ * the blend forward, at raised wave priority, because the launch ends when the longest sequential walk ends
+ * (csrc/raster_forward.hip).  Purely a scheduling hint: results are bit-identical with any tile order. Zero-fill it once. */
 int fnx_set_deep_threshold(unsigned int min_depth);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
@@ -287,16 +287,16 @@ typedef struct {
 } fnx_geom_layout_t;
 typedef struct {
     size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split),
-                           [4] backward work items, [5] tiles of the deep blend variant                     */
+                           [4] backward work items, [5] tiles scheduled first ("deep")                      */
     size_t final_T;     /* f32[H*W]                                                 */
     size_t n_contrib;   /* u32[H*W]                                                 */
     size_t ranges;      /* u32[2T] per-tile [start,end) in point_list               */
     size_t tile_count;  /* u32[T]   instances emitted by this call (split: the dynamic ones) */
     size_t dyn_start;   /* u32[T]   split mode: start of the tile's dynamic (key, id) pairs */
     size_t acc_final;   /* f32[3 H W] (C planes used) colour accumulated by the blend before the background term */
-    size_t deep_list;   /* u32[T]   tiles rendered by the blend forward's deep variant (count: header word 5) */
+    size_t tile_order;  /* u32[T]   tile of every workgroup of the blend forward: the tiles that went deep in the previous
+                           forward of the view first (their count: header word 5), then the XCD-aware order          */
     size_t tile_deep;   /* u8[T]    1 for those tiles                                */
-    size_t tile_qmax;   /* u32[T]   batches of the tile that have a backward work item */
     size_t total;
 } fnx_image_layout_t;
 typedef struct {

@@ -1,7 +1,7 @@
-"""-m gpu: the blend forward's "deep" variant (helper waves evaluate the alphas of a long, non-saturating tile list into
-LDS, the pixel owners only run the transmittance recurrence; tiles are routed by the depth they reached in the previous
-forward of the same view batch) against the normal variant: every output the reference defines must be bit-identical,
-the hand-over to the backward too."""
+"""-m gpu: depth hints (include/fnx_raster.h).  The forward records how deep every tile's list was walked; the next
+forward of the same view batch hands the tiles that went deep -- lists that do not saturate: thousands of contributing
+entries per pixel -- to the first workgroups of the blend launch at raised wave priority.  A scheduling hint only:
+every output the reference defines, and the hand-over to the backward, must be bit-identical with and without it."""
 import math
 
 import numpy as np
@@ -20,7 +20,7 @@ def _blob(t, off, n, dtype):
 
 
 @pytest.mark.parametrize("channels,split", [(1, False), (3, True), (3, False)])
-def test_deep_variant_equals_normal_variant(channels, split):
+def test_deep_first_tile_order_changes_nothing(channels, split):
     from fluidnexus_amd import _lib, rasterizer
     from fluidnexus_amd.rasterizer import (GaussianRasterizationSettings, GaussianRasterizerViews, StaticBin, ViewBatch)
     dev = torch.device("cuda")
@@ -77,9 +77,9 @@ def test_deep_variant_equals_normal_variant(channels, split):
     finally:
         rasterizer.set_deep_variant(True, 1024)
     first, second, third = outs
-    assert all(v["header"][5] == 0 for v in first["views"])  # no history: every tile through the normal variant
+    assert all(v["header"][5] == 0 for v in first["views"])  # no history: the plain XCD-aware tile order
     deep = [v["header"][5] for v in second["views"]]
-    assert min(deep) > 0 and max(deep) < T, deep           # history: the plume tiles through the deep variant
+    assert min(deep) > 0 and max(deep) < T, deep           # history: the plume tiles are scheduled first
     assert int(first["hint"].max()) > 1000                 # ... because they went this deep
     for other in (second, third):
         assert torch.equal(first["im"].view(torch.int32), other["im"].view(torch.int32)), "colour not bit-identical"

@@ -33,8 +33,8 @@ import ctypes as C
 from fluidnexus_amd import _lib
 lib = _lib.raster()
 if hasattr(lib, "fnx_debug_fwd_clock"):
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 64)()
     lib.fnx_debug_fwd_clock(buf)
-    names = ["loop top", "all_done barrier", "stage+ballots", "barrier A", "lists+merge", "barrier B", "advance+loads", "chunk loop",
-             "sum n_w", "chunk iterations", "batches", "", "", "", "", "list length"]
-    print({n: int(v) for n, v in zip(names, buf) if n})
+    for w in range(4):
+        v = [int(x) for x in buf[16 * w:16 * w + 16]]
+        print("wave", w, dict(loop_top=v[0], all_done_barrier=v[1], stage_merge=v[2], blend_loop=v[3], sum_n_w=v[8], batches=v[9], list_length=v[15]))
