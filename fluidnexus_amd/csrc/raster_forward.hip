@@ -391,10 +391,17 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             static_blob = st.base + st.stride * vw;
         }
     }
-    __shared__ float4 s_ra[256];  // x, y, conic a, conic b
-    __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, depth
-    __shared__ float s_col[C][256];
-    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][256 + 16];  // a group reads up to kGroup - 1 slots past the end
+#ifndef FNX_FWD_GROUP
+#define FNX_FWD_GROUP 4
+#endif
+    constexpr int kGroup = FNX_FWD_GROUP;  // list entries per step of the blend loop
+    // staged batch: three 16-byte records per slot; slot 256 is a NULL record (opacity 0 at the origin: alpha = 0)
+    // that the tail of every quadrant list points to, so the blend loop needs no end-of-list test per entry
+    __shared__ float4 s_ra[257];  // x, y, conic a, conic b
+    __shared__ float4 s_rb[257];  // conic c, opacity, exp-skip threshold, -
+    __shared__ float4 s_rc[257];  // colour (C channels), depth in .w
+    // per-quadrant lists of LDS byte offsets (slot * 16) of the entries that can reach the quadrant, depth order
+    __shared__ __attribute__((aligned(4))) uint16_t s_list[4][256 + kGroup];
     __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
     __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  // merge windows: depth bits [static | per-call]
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
@@ -411,11 +418,13 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     if (tile_deep[tile]) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // The blend loop multiplies the colour of an entry it does NOT take by alpha = 0 instead of selecting per
-    // channel, and the last group of a list reads up to three slots past its end: every colour slot must hold a
-    // finite value from the start (0 * garbage could be NaN).  Colours are assumed finite, like everywhere else.
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) s_col[ch][tid] = 0.f;
+    // The blend loop multiplies the colour of an entry a pixel does NOT take by alpha = 0 instead of selecting per
+    // channel (colours are assumed finite, like everywhere else).
+    if (tid == 0) {
+        s_ra[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rb[256] = make_float4(0.f, 0.f, -87.0f, 0.f);
+        s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;
@@ -423,7 +432,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    bool done = !inside;
+    // 1 while the pixel is still blending, 0 once it has stopped (T would drop below 1e-4) or if it is outside the image:
+    // an arithmetic mask instead of a predicate, so that the recurrence below needs no lane-mask logic
+    float alive = inside ? 1.0f : 0.0f;
     float Tr = 1.0f;
     uint32_t last_contributor = 0;
     float acc[C];
@@ -522,7 +533,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
         FNX_CLK(0)
-        const bool all_done = __syncthreads_count(done) == 256;
+        const bool all_done = __syncthreads_count(alive == 0.0f) == 256;
         FNX_CLK(1)
         if (all_done) {
             if (!SPLIT || !materialize_all) break;
@@ -536,9 +547,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             qm = quadrant_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
             s_ra[tid] = pa;
             s_rb[tid] = pb;
-            s_col[0][tid] = pc.z;
-            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = pc.w;
-            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = pd;
+            s_rc[tid] = make_float4(pc.z, C > 1 ? pc.w : 0.f, C > 2 ? pd : 0.f, pb.w);
         }
         if (SPLIT) {
             if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
@@ -566,8 +575,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if ((qm >> q) & 1u) {
                 uint32_t off = rank[q];
                 for (int k = 0; k < w; k++) off += s_cnt[k][q];
-                s_list[q][off] = (uint8_t)tid;
+                s_list[q][off] = (uint16_t)(tid * 16);
             }
+        }
+        if (tid < 4 * kGroup) {  // the tail of every list: kGroup pointers to the NULL record
+            const int q = tid / kGroup;
+            s_list[q][s_cnt[0][q] + s_cnt[1][q] + s_cnt[2][q] + s_cnt[3][q] + tid % kGroup] = (uint16_t)(256 * 16);
         }
         uint32_t next_cnt = 0, next_id = 0;
         if (SPLIT) {
@@ -596,58 +609,54 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
-        // The only state carried from entry to entry is (T, colour, depth, done); power / exp / alpha
-        // of an entry do not depend on it.  A lone wave runs ~500 cycles per entry when everything is
-        // evaluated in list order (dependent LDS reads + a 60-instruction chain), and the kernel time
-        // is the time of the deepest tile.  So: kGroup entries per step, all LDS reads issued
-        // together, the alphas evaluated as straight-line predicated code (the scheduler interleaves
-        // the independent chains), then a short select-only recurrence in list order.  Per pixel the
-        // arithmetic and its order are unchanged.
-#ifndef FNX_FWD_GROUP
-#define FNX_FWD_GROUP 4
-#endif
-        constexpr int kGroup = FNX_FWD_GROUP;
+        // The only state carried from entry to entry is (T, colour, depth, alive); power / exp / alpha of an entry do
+        // not depend on it.  A lone wave issues one instruction every ~4.5 cycles, and the launch ends when the deepest
+        // tile's walk ends, so the loop is written for few instructions per entry: kGroup entries per step, all LDS
+        // reads (three 16-byte records per entry, addressed by the byte offsets in the list) issued together, the
+        // alphas evaluated as straight-line code (the scheduler interleaves the independent chains), then the
+        // recurrence in list order with the arithmetic mask `alive` instead of lane predicates:
+        //   a = alpha if the entry hits the pixel (power <= 0, alpha >= 1/255) else 0;  ae = a * alive
+        //   test_T = T (1 - ae);  stop = test_T < 1e-4  (T >= 1e-4 always, so stop implies ae > 0: forward.cu:336-340)
+        //   an entry that is not applied (ae = 0 or stop) adds colour * 0 and leaves T as it is (T * 1 = T).
+        // Per pixel the arithmetic on applied entries and its order are exactly the reference's.
         FNX_CLK(2)
 #ifdef FNX_EXP_CLOCK
         if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
 #endif
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
-            if (__all(done)) break;
-            uint32_t j4[kGroup / 4];
+            if (__all(alive == 0.0f)) break;
+            uint32_t jw[kGroup / 2];
 #pragma unroll
-            for (int k = 0; k < kGroup / 4; k++)
-                j4[k] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0 + 4 * k]));
-            float alpha[kGroup], depth[kGroup], col[kGroup][C];
-            bool hit[kGroup];
+            for (int k = 0; k < kGroup / 2; k++)
+                jw[k] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0 + 2 * k]));
+            float a_h[kGroup];
+            float4 rc[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
-                const float4 ra = s_ra[j];
-                const float4 rb = s_rb[j];
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) col[k][ch] = s_col[ch][j];
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+                const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+                rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
                 const float dx = ra.x - pxf, dy = ra.y - pyf;
                 const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
-                const bool ok = !(power > 0.0f) && !(power < rb.z) && (i0 + k < n_w);
-                alpha[k] = fminf(0.99f, rb.y * exp_fixed_in_range(power));  // consumed only where ok (thr <= power <= 0)
-                hit[k] = ok && !(alpha[k] < 1.0f / 255.0f);
-                depth[k] = rb.w;
+                // below -87 the fixed exp is exactly 0 (alpha = 0 < 1/255): clamping keeps the guard-free exp in range
+                const float alpha = fminf(0.99f, rb.y * exp_fixed_in_range(fmaxf(power, -87.0f)));
+                a_h[k] = (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const bool live = hit[k] && !done;
-                const uint32_t j = (j4[k >> 2] >> (8 * (k & 3))) & 255u;
-                const float test_T = Tr * (1 - alpha[k]);
-                const bool stop = live && (test_T < 0.0001f);
-                const bool take = live && !stop;
-                done = done || stop;
-                // a pixel that does not take the entry adds col * 0 * T = 0: one select instead of one per channel
-                const float a_eff = take ? alpha[k] : 0.0f;
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) acc[ch] = acc[ch] + col[k][ch] * a_eff * Tr;
-                Dm = (take && Tr > 0.5f && test_T < 0.5f) ? depth[k] : Dm;
-                Tr = take ? test_T : Tr;
-                last_contributor = take ? pos0 + j : last_contributor;
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const float ae = a_h[k] * alive;
+                const float test_T = Tr * (1 - ae);
+                const bool stop = test_T < 0.0001f;
+                const float a_eff = stop ? 0.0f : ae;
+                acc[0] = acc[0] + rc[k].x * a_eff * Tr;
+                if (C > 1) acc[C > 1 ? 1 : 0] = acc[C > 1 ? 1 : 0] + rc[k].y * a_eff * Tr;
+                if (C > 2) acc[C > 2 ? 2 : 0] = acc[C > 2 ? 2 : 0] + rc[k].z * a_eff * Tr;
+                Dm = (Tr > 0.5f && test_T < 0.5f) ? rc[k].w : Dm;  // cannot hold for an entry that is not applied
+                Tr = stop ? Tr : test_T;
+                last_contributor = (a_eff > 0.0f) ? pos0 + (off >> 4) : last_contributor;
+                alive = stop ? 0.0f : alive;
             }
         }
         FNX_CLK(3)
