@@ -81,6 +81,25 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
                                         occluding=a.scene == "r01")
     else:
         gm, cams = Hn.build_ball_frame(350_000, 150_000, (22, 58, 22), n_views=n_views, size=SIZE, seed=0, device=dev)
+    if a.stage == "visual":
+        # the stage after the physical-particle one (train_visual_particle.py): positions fixed, colour / opacity /
+        # scales / rotation of the fluid Gaussians are the leaves; the rasteriser's full backward
+        cfg = dict(Hn.SMOKE_L2)
+        loop = Hn.HotLoopLevelTwo(gm, cams, rank=rank, world=world, cfg=cfg, batched_views=True, capturable=graph,
+                                  force_all_reduce=use_dist)
+        loop.view_mode = "batched"
+        return gm, cams, loop
+    if a.stage == "first":
+        # the first frame of a dynamics scene (entries_fluid_nexus/train_physical_particle.py:103-163): the visual
+        # particles' positions are the leaf, world units, grey-mean image term + distance loss, no physics
+        gm._visual_xyz = gm._visual_xyz / gm.scale_factor
+        cfg = dict(Hn.SCALAR_REAL)
+        if a.no_distance:
+            cfg["lambda_first_distance"] = 0.0
+        loop = Hn.FirstFrameLoop(gm, cams, rd_pipe="render_dynamics", rank=rank, world=world, cfg=cfg, capturable=graph,
+                                 force_all_reduce=use_dist)
+        loop.view_mode = "batched"
+        return gm, cams, loop
     cfg = dict(Hn.SMOKE)
     if a.no_distance:
         cfg["lambda_current_distance"] = 0.0
@@ -100,9 +119,17 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
     return gm, cams, loop
 
 
-def scene_arrays(gm, cfg_id):
+def scene_arrays(gm, cfg_id, stage="physical"):
     """(xyz, opacity, scales, rotations, colours) of everything the configuration's main render sees, on the host."""
     with torch.no_grad():
+        if cfg_id != 2 and stage in ("visual", "first"):
+            fluid = gm._visual_xyz.detach() / gm.scale_factor if stage == "visual" else gm._visual_xyz.detach()
+            xyz = torch.cat([fluid, gm.get_gs_xyz], 0).cpu().numpy()
+            opac = torch.cat([gm.get_visual_opacity, gm.get_gs_opacity], 0).cpu().numpy()
+            scales = torch.cat([gm.get_visual_scaling, gm.get_gs_scaling], 0).cpu().numpy()
+            rots = torch.cat([gm.get_visual_rotation, gm.get_gs_rotation], 0).cpu().numpy()
+            cols = torch.cat([gm.get_visual_color.repeat(1, 3), gm.get_gs_color], 0).cpu().numpy()
+            return xyz, opac, scales, rots, cols
         if cfg_id == 2:
             return (gm.get_visual_xyz.detach().cpu().numpy(), gm.get_visual_opacity.cpu().numpy(),
                     gm.get_visual_scaling.cpu().numpy(), gm.get_visual_rotation.cpu().numpy(), gm.get_visual_color.cpu().numpy())
@@ -114,7 +141,7 @@ def scene_arrays(gm, cfg_id):
     return xyz, opac, scales, rots, cols
 
 
-def cpu_baseline(gm, cams, bg, cfg_id, views, channels):
+def cpu_baseline(gm, cams, bg, cfg_id, views, channels, stage="physical"):
     """The CPU oracle (oracle/raster_oracle.c, OpenMP over all host cores) timed on ONE view of the same workload:
     rasteriser forward + backward.  Reported as whole-batch iterations per second of the rasteriser alone (losses /
     physics / Adam are not in the CPU sample)."""
@@ -123,7 +150,7 @@ def cpu_baseline(gm, cams, bg, cfg_id, views, channels):
     cores = os.cpu_count() or 1
     O.set_threads(cores)
     cam = cams[0]
-    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id, stage)
     tan = math.tan(cam.FoVx * 0.5)
     t0 = time.perf_counter()
     f = O.forward(xyz, opac, bg.cpu().numpy(), cam.world_view_transform.cpu().numpy(),
@@ -138,13 +165,13 @@ def cpu_baseline(gm, cams, bg, cfg_id, views, channels):
                       f"fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, R={f['num_rendered']}; value = 1/({views} x that)"}
 
 
-def rasterise_timing(gm, cams, views, cfg_id, channels, bg):
+def rasterise_timing(gm, cams, views, cfg_id, channels, bg, stage="physical"):
     """Rasteriser alone on this rank's views, HIP-event timed on the current stream: forward, and forward + backward
     with ALL gradients (means, opacity, colour, scales, rotations: the visual-particle stage's MODE 0 backward)."""
     from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
     from fluidnexus_amd.rasterizer import GaussianRasterizerViews
     from fluidnexus_amd.renderer.pipes import _settings
-    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id, stage)
     dev = bg.device
     _, GRsetting, _ = get_render_pipe("render_fluid" if channels == 1 else "render_dynamics")
     rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, 0) for v in views], channels=channels)
@@ -181,6 +208,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="auto", choices=["auto", "2", "3", "4", "5"],
                     help="BASELINE.json configuration (1-based); auto: 3 at 1-2 GPUs, 4 at 4 GPUs, 5 at 8 GPUs")
+    ap.add_argument("--stage", default="physical", choices=["physical", "visual", "first"],
+                    help="configs 3-5: physical = the per-frame hidden-particle loop BASELINE's metric is quoted on; visual = "
+                         "the visual-particle stage that follows it (attributes are the leaves, full rasteriser backward); "
+                         "first = the first-frame stage of a dynamics scene (visual positions are the leaf, no physics)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
                     help="strong (auto): the config's views sharded over the ranks; weak: the config's view count per rank")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -232,6 +263,8 @@ def main():
 
     cfg_id = int(a.config) if a.config != "auto" else {4: 4, 8: 5}.get(world, 3)
     C = CONFIGS[cfg_id]
+    if cfg_id == 2:
+        a.stage = "first"
     scaling = "strong" if a.scaling == "auto" else a.scaling
     if world == 1:
         scaling = "strong" if a.scaling == "auto" else a.scaling  # one rank: the two coincide
@@ -315,7 +348,7 @@ def main():
     # instance / visible counts of this rank's views (one-set binning over all splats: the algorithmic byte count of
     # SURVEY 8(d) does not depend on how the implementation splits the work)
     R_views, P_vis_views = [], []
-    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id)
+    xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id, a.stage)
     P_total = xyz.shape[0]
     if loop_views:
         from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
@@ -344,8 +377,9 @@ def main():
     iter_bytes = per_view * len(cams)
     # HBM traffic / VALU instructions of the dominant kernel: separate rocprofv3 --pmc passes of this command
     # (tools/collect_profiles.sh -> profiles/<tag>_pmc_traffic.json, <tag>_sq_counters.json), null if absent
-    kname = f"fnx::blend_backward_kernel<{Cn}, 1>" if not a.unfused_physics else f"fnx::blend_backward_kernel<{Cn}, 0>"
-    suffix = "" if cfg_id == 3 else f"_config{cfg_id}"
+    full_bwd = a.unfused_physics or a.stage == "visual"
+    kname = f"fnx::blend_backward_kernel<{Cn}, 0>" if full_bwd else f"fnx::blend_backward_kernel<{Cn}, 1>"
+    suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
     traffic = valu = None
     for tag in (PROFILE_TAG, "r01"):
         try:
@@ -388,10 +422,21 @@ def main():
               3: "train iters/sec (300k Gaussians x 5 views @512^2, physics losses on)",
               4: "train iters/sec (300k Gaussians x 5 views @512^2, physics losses on)",
               5: "train iters/sec (500k Gaussians x 8 views @512^2, ch3 + ch1 rasterisers, physics losses on)"}[cfg_id]
+    stage_note = ""
+    if cfg_id != 2 and a.stage == "visual":
+        metric = metric.replace("physics losses on", "visual-particle stage: attribute leaves, consistency + scale terms")
+        stage_note = (" -- VISUAL-PARTICLE STAGE of this frame (train_visual_particle.py:133-222): positions fixed, colour / "
+                      "opacity / scales / rotation of the fluid Gaussians optimised, L1 + D-SSIM (RGB) + consistency + scale "
+                      "regulariser; not the stage BASELINE's metric is quoted on")
+    elif cfg_id != 2 and a.stage == "first":
+        metric = metric.replace("physics losses on", "first-frame stage: visual positions are the leaf, no physics terms")
+        stage_note = (" -- FIRST-FRAME STAGE of this scene (entries_fluid_nexus/train_physical_particle.py:103-163): visual "
+                      "particle positions optimised, grey-mean L1 + D-SSIM + distance loss; not the stage BASELINE's metric "
+                      "is quoted on")
     ms = None
     try:
         if loop_views:
-            ms = rasterise_timing(gm, cams, loop_views, cfg_id, Cn, loop.background)
+            ms = rasterise_timing(gm, cams, loop_views, cfg_id, Cn, loop.background, a.stage)
     except Exception as e:
         print(f"[bench] rasteriser-only timing failed: {type(e).__name__}: {e}", file=sys.stderr)
     out = {
@@ -399,7 +444,7 @@ def main():
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": C["workload"], "baseline_config": cfg_id,
+        "config": {"workload": C["workload"] + stage_note, "baseline_config": cfg_id, "stage": a.stage,
                    "views_this_rank": len(loop_views), "global_views_per_step": len(cams), "image": f"{SIZE}x{SIZE}",
                    "gaussians": P_total, "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
                    "parallelism": (f"views sharded round-robin over {shard_world} rank(s)"
@@ -413,7 +458,7 @@ def main():
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
                              "branches": "one rasteriser call per view, views as parallel graph branches",
                              "serial": "one rasteriser call per view, in series"}[view_mode],
-                   "physics": None if cfg_id == 2 else
+                   "physics": None if (cfg_id == 2 or a.stage != "physical") else
                    (("value and gradient evaluated once per iteration, the gradient added once per view "
                      "(equal to the reference's per-view evaluation, tpp:368-404)" if not a.physics_once
                      else "added once per iteration")
@@ -423,11 +468,12 @@ def main():
             ms or {},
             hot_loop_forward=sum(prof[k][0] for k in ("preprocess", "sort_and_counts", "emit", "blend_forward", "blend_forward_ch1")
                                  if k in prof) / max(prof["blend_forward"][1], 1) / max(views_per_launch, 1),
-            hot_loop_backward_blend_geometry_only=bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)),
+            **{"hot_loop_backward_blend_" + ("all_gradients" if full_bwd else "geometry_only"):
+               bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)}),
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background, cfg_id, nominal_views, Cn)
+            out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background, cfg_id, nominal_views, Cn, a.stage)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -637,9 +637,10 @@ class GaussianModel:
         self.optimizer.register_step_post_hook(lambda *_: self.invalidate_caches())
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
 
-    def training_setup_current_level_two(self, optim_args):
+    def training_setup_current_level_two(self, optim_args, capturable=False):
         """Visual-particle stage: colour / opacity / scales / rotation of the visual particles become
-        leaves, each behind its fit_* switch (gm_dynamics.py:416-433)."""
+        leaves, each behind its fit_* switch (gm_dynamics.py:416-433).  `capturable`: Adam state on the device and
+        torch's fused multi-tensor step (same update rule), so that the step can live inside a hipGraph."""
         groups = []
         for name in self._L2:
             if not getattr(self, f"fit_{name}", True):
@@ -647,7 +648,7 @@ class GaussianModel:
             p = nn.Parameter(getattr(self, f"_visual_{name}").detach().clone().requires_grad_(True))
             setattr(self, f"_visual_{name}", p)
             groups.append({"params": [p], "lr": getattr(optim_args, f"visual_{name}_lr"), "name": f"visual_{name}"})
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, capturable=bool(capturable), fused=bool(capturable))
 
     def update_learning_rate_first_visual(self, iteration):
         """Returns the scheduled rate; like the reference (gm_dynamics.py:435-441) it does NOT write it

@@ -532,17 +532,112 @@ class HotLoopLevelTwo:
     view, averaged over the batch (gm_dynamics.py:474-503) and applied with Adam(eps = 1e-15)."""
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, cfg=SMOKE_L2, image_loss="fused",
-                 log_scalars=False):
+                 log_scalars=False, batched_views=False, capturable=False, force_all_reduce=False):
+        """batched_views: the views of the batch through ONE view-batched render / fused image loss / backward (all
+        four attribute gradients out of the rasteriser's full backward, the static background binned once), the
+        view-independent consistency terms evaluated once and counted once per view; capturable: device-side fused
+        Adam over the four attribute groups, so that capture() can record whole iterations as a hipGraph."""
         from .utils.loss_utils import l2_loss_consistency
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.view_subset = None
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
         self.image_loss, self.log_scalars = image_loss, log_scalars
+        self.batched_views, self.capturable, self.force_all_reduce = bool(batched_views), bool(capturable), force_all_reduce
+        assert not capturable or batched_views, "graph capture is implemented for the view-batched level-two loop"
         self.background = torch.zeros(3, device=gm._visual_xyz.device)
         self.prev = {n: getattr(gm, f"_visual_{n}").detach().clone() for n in gm._L2}
         self._cons = l2_loss_consistency
-        gm.training_setup_current_level_two(SimpleNamespace(**{k: cfg[k] for k in cfg if k.endswith("_lr")}))
+        gm.training_setup_current_level_two(SimpleNamespace(**{k: cfg[k] for k in cfg if k.endswith("_lr")}),
+                                            capturable=capturable)
         self.last = {}
+        self.stream = torch.cuda.Stream(device=gm._visual_xyz.device) if capturable else None
+        self.graph, self.graph_iterations, self._replay, self._gt, self._means = None, 1, False, None, None
+
+    @property
+    def multi(self):
+        return self.world > 1 or self.force_all_reduce
+
+    def _gt_stack(self, mine):
+        imgs = [self.cams[v].original_image for v in mine]
+        if self._gt is None or len(self._gt[0]) != len(imgs) or any(a is not b for a, b in zip(self._gt[0], imgs)):
+            self._gt = (imgs, torch.stack(imgs).contiguous())
+        return self._gt[1]
+
+    def _render_means(self):
+        """[visual positions / scale_factor | background positions]: fixed in this stage, built once."""
+        gm = self.gm
+        src = (gm._visual_xyz, gm._gs_xyz)
+        if self._means is None or self._means[0][0] is not src[0] or self._means[0][1] is not src[1]:
+            with torch.no_grad():
+                self._means = (src, torch.cat([gm._visual_xyz / gm.scale_factor, gm._gs_xyz], dim=0).float().contiguous())
+        return self._means[1]
+
+    def _regularisers(self):
+        """The view-independent terms of one view's loss (train_visual_particle.py:161-194): consistency with the
+        previous frame per active attribute, and the scale-ratio regulariser."""
+        gm, c = self.gm, self.cfg
+        reg = 0.0
+        for n in gm._l2_active():
+            reg = reg + c[f"lambda_consistency_{n}"] * self._cons(getattr(gm, f"_visual_{n}"), self.prev[n])
+        if "scales" in gm._l2_active() and c["lambda_reg_scaling"] > 0:
+            sc = gm.get_visual_scaling
+            ratio = torch.max(sc, dim=1).values / torch.min(sc, dim=1).values
+            reg = reg + c["lambda_reg_scaling"] * torch.clamp_min(ratio - c["scaling_reg_ratio_threshold"], 0).mean()
+        return reg
+
+    def _body_batched(self):
+        from .losses import image_loss_value_and_grad
+        from .renderer.pipes import render_dynamics_views
+        gm, c = self.gm, self.cfg
+        gm.total_iterations += 1
+        batch = len(self.cams)
+        mine = self._mine(batch)
+        names = gm._l2_active()
+        params = [getattr(gm, f"_visual_{n}") for n in names]
+        grads = [None] * len(params)
+        if mine:
+            pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background, GRsetting=self.GRsetting,
+                                        GRzer=self.GRzer, pos_type="visual", scale=True, means3D=self._render_means())
+            loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                                                             c["lambda_image"], grey=False)
+            if self.log_scalars:
+                self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
+            reg = self._regularisers()
+            if torch.is_tensor(reg):  # one backward for the image term of all views + n_local x the per-view regularisers
+                grads = torch.autograd.grad([pkg["render"], reg], params, grad_outputs=[dimg, torch.full_like(reg, float(len(mine)))],
+                                            allow_unused=True)
+            else:
+                grads = torch.autograd.grad([pkg["render"]], params, grad_outputs=[dimg], allow_unused=True)
+        for n, p, g in zip(names, params, grads):
+            g = torch.zeros_like(p) if g is None else g
+            if self.multi:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            p.grad = g * (1.0 / batch)  # set_batch_gradient_current_level_two (gm_dynamics.py:494-503)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad()
+
+    def capture(self, warmup=2, iterations=1):
+        from . import rasterizer
+        assert self.capturable and not rasterizer._HOST_SYNC and not self.multi
+        for _ in range(warmup):
+            self.iteration()
+        torch.cuda.synchronize()
+        rasterizer._pending_status.clear()
+        g = torch.cuda.CUDAGraph()
+        tot0 = self.gm.total_iterations
+        with torch.cuda.graph(g, stream=self.stream):
+            for _ in range(int(iterations)):
+                self._body_batched()
+        self.gm.total_iterations = tot0
+        self.graph, self.graph_iterations, self._replay = g, int(iterations), True
+        return g
+
+    @property
+    def iterations_per_call(self):
+        return self.graph_iterations if (self.graph is not None and self._replay) else 1
+
+    def use_graph(self, enabled):
+        self._replay = bool(enabled) and self.graph is not None
 
     def _mine(self, batch):
         return list(self.view_subset) if self.view_subset is not None else shard_views(batch, self.rank, self.world)
@@ -565,6 +660,18 @@ class HotLoopLevelTwo:
             getattr(gm, f"_visual_{n}").data.copy_(v)
 
     def iteration(self):
+        if self.batched_views:
+            if self.stream is None:
+                return self._body_batched()
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                if self.graph is not None and self._replay:
+                    self.gm.total_iterations += self.graph_iterations
+                    self.graph.replay()
+                else:
+                    self._body_batched()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return
         gm, c = self.gm, self.cfg
         gm.total_iterations += 1
         gm.zero_gradient_cache_current_level_two()

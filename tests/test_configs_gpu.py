@@ -150,3 +150,56 @@ def test_dual_channel_hot_loop_matches_per_view_autograd():
     for i in range(3):
         loop.iteration()
     assert np.isfinite(loop.last["total"]) and np.isfinite(float(gm._estimate_xyz_nn.detach().abs().max()))
+
+
+def test_level_two_batched_matches_per_view_loop():
+    """The view-batched visual-particle stage (one render / loss / backward for the batch, static background binned
+    once, regularisers counted once per view) against the per-view loop of train_visual_particle.py:133-222: same
+    first moments after one step for all four attribute groups."""
+    from fluidnexus_amd import harness as Hn
+    res = {}
+    for mode in ("per_view", "batched"):
+        gm, cams = Hn.build_smoke_frame(P_fluid=12000, P_background=4000, hidden_dims=(6, 10, 6), n_views=3, size=128, seed=4)
+        cfg = dict(Hn.SMOKE_L2, lambda_reg_scaling=0.05, scaling_reg_ratio_threshold=1.2)
+        loop = Hn.HotLoopLevelTwo(gm, cams, cfg=cfg, batched_views=mode == "batched")
+        loop.make_targets()
+        for n in gm._L2:  # away from the previous frame's values, so that the consistency terms have a gradient
+            with torch.no_grad():
+                p = getattr(gm, f"_visual_{n}")
+                p.add_(0.01 * torch.randn(p.shape, device=p.device, generator=torch.Generator(p.device).manual_seed(7)))
+        loop.iteration()
+        torch.cuda.synchronize()
+        res[mode] = {n: _first_moment(gm, getattr(gm, f"_visual_{n}")) for n in gm._L2}
+    for n in res["per_view"]:
+        assert _close(res["batched"][n], res["per_view"][n], 1e-3), n
+
+
+def test_level_two_graph_equals_eager():
+    from fluidnexus_amd import harness as Hn
+    from fluidnexus_amd import rasterizer
+    res = {}
+    rasterizer.set_host_sync(False)
+    try:
+        for mode in ("eager", "graph"):
+            gm, cams = Hn.build_smoke_frame(P_fluid=10000, P_background=3000, hidden_dims=(6, 10, 6), n_views=2, size=96, seed=6)
+            loop = Hn.HotLoopLevelTwo(gm, cams, batched_views=True, capturable=True)
+            loop.make_targets()
+            loop.iteration()
+            rasterizer.check_status()
+            if mode == "graph":
+                loop.capture(warmup=1, iterations=2)
+                loop.iteration()
+                loop.iteration()
+            else:
+                for _ in range(5):
+                    loop.iteration()
+            torch.cuda.synchronize()
+            rasterizer.check_status()
+            res[mode] = {n: getattr(gm, f"_visual_{n}").detach().clone() for n in gm._L2}
+            assert float(gm.optimizer.state[gm._visual_color]["step"]) == 6.0
+    finally:
+        rasterizer.set_host_sync(True)
+    for n in res["eager"]:
+        moved = (res["eager"][n] - loop.prev[n]).abs().max().item()
+        assert moved > 0
+        assert (res["eager"][n] - res["graph"][n]).abs().max().item() <= 0.02 * moved + 1e-6, n

@@ -236,3 +236,65 @@ def test_mark_visible(oracle):
     vis = GaussianRasterizer(rs).mark_visible(torch.from_numpy(g["means3D"]).cuda()).cpu().numpy()
     ref = oracle.mark_visible(g["means3D"], cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy())
     assert (vis == ref).all() and 0 < vis.sum() < vis.size
+
+
+@pytest.mark.parametrize("channels", [3, 1])
+def test_callback_forward_and_plain_backward_entry_points(oracle, channels):
+    """The two entry points that mirror CudaRasterizer::Rasterizer::forward / ::backward one to one
+    (rasterizer.h:30-83): fnx_rasterize_forward with the three resize callbacks (it synchronises once to size the
+    binning buffer, like the reference's cudaMemcpy of num_rendered) and fnx_rasterize_backward with R = the forward's
+    return value -- the functions a maintainer would bind in place of the reference's."""
+    import ctypes as C
+
+    import torch
+    from fluidnexus_amd import _lib
+    from tests.hip_harness import _p, _t, scene_kwargs
+    lib = _lib.raster()
+    dev = torch.device("cuda")
+    P, W, H = 5000, 112, 80
+    g = S.random_gaussians(P, seed=6, log_scale=(-4.5, -2.5), channels=channels)
+    cam = S.front_camera(W, H, device="cpu")
+    kw = scene_kwargs(g, cam, W, H, 0.8)
+    bg = np.array([0.3, 0.1, 0.6], np.float32)
+    f = oracle.forward(kw["means3D"], kw["opacities"], bg, kw["view"], kw["proj"], kw["campos"], W, H, kw["tanx"],
+                       kw["tany"], channels=channels, colors_precomp=g["colors"], scales=g["scales"], rotations=g["rotations"])
+    t = {k: _t(v, dev) for k, v in dict(means3D=kw["means3D"], opac=kw["opacities"], bg=bg, view=kw["view"], proj=kw["proj"],
+                                         campos=kw["campos"], colors=g["colors"], scales=g["scales"], rots=g["rotations"]).items()}
+    held = {}  # the buffers the callbacks hand out (the reference's resizeFunctional keeps torch tensors alive the same way)
+
+    def make_alloc(name):
+        def alloc(nbytes, _user):
+            held[name] = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            return held[name].data_ptr()
+        return _lib.ALLOC_FN(alloc)
+
+    cbs = [make_alloc(n) for n in ("geom", "binning", "image")]
+    color = torch.zeros(channels, H, W, device=dev)
+    depth = torch.zeros(1, H, W, device=dev)
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    R = C.c_int(-1)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.fnx_rasterize_forward(
+        channels, cbs[0], None, cbs[1], None, cbs[2], None, P, 0, 0, _p(t["bg"]), W, H, _p(t["means3D"]), None, _p(t["colors"]),
+        _p(t["opac"]), _p(t["scales"]), 1.0, _p(t["rots"]), None, _p(t["view"]), _p(t["proj"]), _p(t["campos"]), kw["tanx"],
+        kw["tany"], 0, color.data_ptr(), depth.data_ptr(), radii.data_ptr(), s, C.byref(R)))
+    torch.cuda.synchronize()
+    assert R.value == f["num_rendered"] and set(held) == {"geom", "binning", "image"}
+    assert (radii.cpu().numpy() == f["radii"]).all()
+    assert (color.cpu().numpy().view(np.uint32) == f["color"].view(np.uint32)).all(), "colour not bit-exact"
+    assert (depth.cpu().numpy().view(np.uint32) == f["depth"].view(np.uint32)).all()
+    dL = np.random.RandomState(1).normal(size=(channels, H, W)).astype(np.float32)
+    go = oracle.backward(f, dL)
+    z = lambda *shape: torch.zeros(*shape, device=dev)  # noqa: E731
+    gr = dict(dL_dmeans2D=z(P, 3), dL_dconic=z(P, 2, 2), dL_dopacity=z(P, 1), dL_dcolors=z(P, channels), dL_dmeans3D=z(P, 3),
+              dL_dcov3D=z(P, 6), dL_dscales=z(P, 3), dL_drotations=z(P, 4))
+    dLt = _t(dL, dev)
+    _lib.check(lib.fnx_rasterize_backward(
+        channels, P, 0, 0, R.value, _p(t["bg"]), W, H, _p(t["means3D"]), None, _p(t["colors"]), _p(t["scales"]), 1.0,
+        _p(t["rots"]), None, _p(t["view"]), _p(t["proj"]), _p(t["campos"]), kw["tanx"], kw["tany"], radii.data_ptr(),
+        held["geom"].data_ptr(), held["binning"].data_ptr(), held["image"].data_ptr(), dLt.data_ptr(),
+        gr["dL_dmeans2D"].data_ptr(), gr["dL_dconic"].data_ptr(), gr["dL_dopacity"].data_ptr(), gr["dL_dcolors"].data_ptr(),
+        gr["dL_dmeans3D"].data_ptr(), gr["dL_dcov3D"].data_ptr(), None, gr["dL_dscales"].data_ptr(),
+        gr["dL_drotations"].data_ptr(), s))
+    torch.cuda.synchronize()
+    _assert_grads_close({k: v for k, v in go.items() if k in gr}, {k: v.cpu().numpy() for k, v in gr.items()})
