@@ -433,6 +433,9 @@ def main():
         stage_note = (" -- FIRST-FRAME STAGE of this scene (entries_fluid_nexus/train_physical_particle.py:103-163): visual "
                       "particle positions optimised, grey-mean L1 + D-SSIM + distance loss; not the stage BASELINE's metric "
                       "is quoted on")
+    knn = None
+    if cfg_id != 2 and a.stage == "physical":
+        knn = gm.knn_k_report()  # outside the timed region: are the reference's neighbour lists below their cap here?
     ms = None
     try:
         if loop_views:
@@ -458,6 +461,7 @@ def main():
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
                              "branches": "one rasteriser call per view, views as parallel graph branches",
                              "serial": "one rasteriser call per view, in series"}[view_mode],
+                   "knn_k": knn,
                    "physics": None if (cfg_id == 2 or a.stage != "physical") else
                    (("value and gradient evaluated once per iteration, the gradient added once per view "
                      "(equal to the reference's per-view evaluation, tpp:368-404)" if not a.physics_once

@@ -486,6 +486,106 @@ class GaussianModel:
         for name, t in zip(("color", "scales", "rotation", "opacity"), new):
             setattr(self, f"_visual_{name}", torch.cat((getattr(self, f"_visual_{name}"), t), dim=0))
 
+    # -- emitter (frame boundary: new particles enter at the nozzle before the next frame's optimisation) ----------
+    @staticmethod
+    def _disc_lattice(cx, cz, radius, delta, ys):
+        """Lattice points of spacing `delta` inside the disc of `radius` around (cx, cz), at heights `ys`;
+        x outermost, z innermost, like the reference's loops (:698-722).  float64 lattice, as np.arange gives."""
+        xr = np.arange(cx - radius, cx + radius + delta, delta)
+        zr = np.arange(cz - radius, cz + radius + delta, delta)
+        X, Y, Z = np.meshgrid(xr, np.asarray(list(ys), dtype=np.float64), zr, indexing="ij")
+        keep = (X - cx) ** 2 + (Z - cz) ** 2 <= radius ** 2
+        return np.stack((X[keep], Y[keep], Z[keep]), axis=1).reshape(-1, 3)
+
+    @torch.no_grad()
+    def prepare_emitter_points(self, model_args, is_future=False):
+        """:674-744: the nozzle lattices (world units) new visual / hidden particles are copied from every frame.
+        One layer each, at emitter_center_y_visual / _hidden; `is_future` lowers the visual layer by radius / 2."""
+        hd, vd = model_args.emitter_hidden_delta, model_args.emitter_visual_delta
+        cx, cz = model_args.init_x_mid, model_args.init_z_mid
+        vr, hr = vd * model_args.emitter_visual_radius_ratio, hd * model_args.emitter_hidden_radius_ratio
+        self.hidden_delta_offset, self.visual_delta_offset = hd, vd
+        vy = model_args.emitter_center_y_visual - vr / 2 if is_future else model_args.emitter_center_y_visual
+        self.visual_emitter_points = torch.tensor(self._disc_lattice(cx, cz, vr, vd, [vy]), dtype=torch.float,
+                                                  device=self.device).reshape(-1, 3)
+        self.hidden_emitter_points = torch.tensor(self._disc_lattice(cx, cz, hr, hd, [model_args.emitter_center_y_hidden]),
+                                                  dtype=torch.float, device=self.device).reshape(-1, 3)
+
+    @torch.no_grad()
+    def prepare_emitter_future_first_points(self, model_args):
+        """:746-790: the taller stacks emitted on the first two future frames: layers one delta apart from the emitter
+        height over two radii."""
+        hd, vd = model_args.emitter_hidden_delta, model_args.emitter_visual_delta
+        cx, cz = model_args.init_x_mid, model_args.init_z_mid
+        vr, hr = vd * model_args.emitter_visual_radius_ratio, hd * model_args.emitter_hidden_radius_ratio
+        vys = np.arange(model_args.emitter_center_y_visual, model_args.emitter_center_y_visual + vr * 2 + vd, vd)
+        hys = np.arange(model_args.emitter_center_y_hidden, model_args.emitter_center_y_hidden + hr * 2 + hd, hd)
+        self.visual_emitter_first_points = torch.tensor(self._disc_lattice(cx, cz, vr, vd, vys), dtype=torch.float,
+                                                        device=self.device).reshape(-1, 3)
+        self.hidden_emitter_first_points = torch.tensor(self._disc_lattice(cx, cz, hr, hd, hys), dtype=torch.float,
+                                                        device=self.device).reshape(-1, 3)
+
+    def get_emitter_points_extra_offset_visual(self, extra_visual_xyz):
+        """:821-826: jitter of +-2.5% of the visual lattice spacing."""
+        return self.visual_delta_offset * (torch.rand_like(extra_visual_xyz) - 0.5) * 0.05
+
+    def _emitted(self, points, ratio):
+        """floor(ratio) whole copies of the lattice plus a random subset of frac(ratio) of it (:862-888; the subset
+        comes from torch.randperm on the host generator, as in the reference)."""
+        whole, part = int(ratio), ratio - int(ratio)
+        out = [points.clone() * self.scale_factor for _ in range(whole)]
+        if part > 0:
+            scaled = points.clone() * self.scale_factor
+            out.append(scaled[torch.randperm(scaled.shape[0])[: int(part * scaled.shape[0])].to(scaled.device)])
+        return out
+
+    def _extra_visual(self, count_of):
+        """Copies of randomly chosen visual particles above extra_visual_y_min, jittered (:890-925)."""
+        high = self._visual_xyz[self._visual_xyz[:, 1] > self.extra_visual_y_min * self.scale_factor]
+        pick = torch.randperm(high.shape[0])[: count_of(high.shape[0])].to(high.device)
+        xyz = high[pick] / self.scale_factor
+        return (xyz + self.get_emitter_points_extra_offset_visual(xyz)) * self.scale_factor
+
+    @torch.no_grad()
+    def emit_new_particles(self, future_time_index=-1):
+        """:844-976: append this frame's new hidden particles (at rest except init_hidden_velocity, buoyancy =
+        gravity * alpha, fresh ids) and visual particles (simulation units).  The first two future frames
+        (0 <= future_time_index < 2) emit the prepare_emitter_future_first_points stacks instead."""
+        self.emit_counter += 1
+        if 0 <= future_time_index < 2:
+            new_hidden = [self.hidden_emitter_first_points.clone() * self.scale_factor]
+            new_visual = [self.visual_emitter_first_points.clone() * self.scale_factor]
+        else:
+            new_hidden = self._emitted(self.hidden_emitter_points, self.emit_ratio_hidden)
+            new_visual = self._emitted(self.visual_emitter_points, self.emit_ratio_visual)
+            if self.extra_visual_ratio > 0.0:
+                new_visual.append(self._extra_visual(
+                    lambda n: max(int(n * self.extra_visual_ratio), self.extra_visual_min_num)))
+            if self.extra_visual_num > 0:
+                new_visual.append(self._extra_visual(lambda n: self.extra_visual_num))
+        if new_hidden:
+            xyz = torch.cat(new_hidden, dim=0)
+            n, dev = xyz.shape[0], xyz.device
+            z = lambda w: torch.zeros((n, w), dtype=torch.float, device=dev)  # noqa: E731
+            vel = z(3)
+            vel[:, 1] = self.init_hidden_velocity
+            self._xyz = torch.cat((self._xyz, xyz), dim=0)
+            self._estimate_xyz = torch.cat((self._estimate_xyz, z(3)), dim=0)
+            self._buoyancy = torch.cat((self._buoyancy, torch.ones((n, 3), dtype=torch.float, device=dev)
+                                        * (self._gravity.to(dev) * self.alpha)), dim=0)
+            self._force = torch.cat((self._force, z(3)), dim=0)
+            self._velocity = torch.cat((self._velocity, vel), dim=0)
+            self._imass = torch.cat((self._imass, torch.ones((n, 1), dtype=torch.float, device=dev)), dim=0)
+            self._counts = torch.zeros((self._xyz.shape[0], 1), dtype=torch.float, device=dev)
+            ids = torch.arange(self._particle_id_max, self._particle_id_max + n, device=dev).unsqueeze(1)
+            self._particle_id = torch.cat((self._particle_id, ids), dim=0)
+            self._particle_id_max += n
+        if new_visual:
+            xyz = torch.cat(new_visual, dim=0)
+            self._visual_xyz = xyz if self._visual_xyz.shape[0] == 0 else torch.cat((self._visual_xyz, xyz), dim=0)
+        self._visual_grid = None
+        self.invalidate_caches()
+
     # -- physics ------------------------------------------------------------------------------------
     def poly6(self, r2):
         return (r2 < self.H2) * self.poly6_term1 * ((self.H2 - r2) ** 3)
@@ -604,6 +704,43 @@ class GaussianModel:
                                                float(self.EPSILON), grid.blob.data_ptr(),
                                                self._pbf_scratch(4 * V, "advect").data_ptr(), physics._stream()))
         return out
+
+    # -- KNN_K guard ---------------------------------------------------------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def _max_within(queries, points, r, chunk=2048):
+        """max over the queries of the number of `points` with distance < r (dense distances in chunks: a
+        debugging aid, not part of the optimisation loop)."""
+        best = 0
+        p = points.detach().double()
+        for i in range(0, queries.shape[0], chunk):
+            d = torch.cdist(queries[i:i + chunk].detach().double(), p)
+            best = max(best, int((d < r).sum(dim=1).max().item()))
+        return best
+
+    @torch.no_grad()
+    def knn_k_report(self):
+        """Largest neighbour-list lengths the reference's searches would see for the current state, next to the
+        cap KNN_K at which torch_cluster truncates them (radius_graph(loop=True, max_num_neighbors=KNN_K) and
+        radius(max_num_neighbors=KNN_K), gm_dynamics.py:1081-1515).  The fused kernels never truncate, so their
+        results equal the reference's exactly while every entry is <= KNN_K (include/fnx_physics.h)."""
+        est = self._estimate_xyz_nn.detach() * self.scale_factor
+        guess = self.get_guess_hidden_particles_from_nn().detach()
+        out = {"KNN_K": int(self.KNN_K),
+               "hidden_at_estimate": self._max_within(est, est, self.H),  # includes the particle itself (loop=True)
+               "hidden_at_guess": self._max_within(guess, guess, self.H)}
+        if self._visual_xyz.shape[0]:
+            out["hidden_per_visual"] = self._max_within(self._visual_xyz, est, self.H)
+        out["within_cap"] = all(v <= self.KNN_K for k, v in out.items() if k != "KNN_K")
+        return out
+
+    def assert_within_knn_k(self):
+        """Raise if any neighbour list of the current state exceeds KNN_K, i.e. if the reference would have
+        truncated it (arbitrarily, in torch_cluster's cell order) and this build's untruncated sums differ."""
+        rep = self.knn_k_report()
+        if not rep["within_cap"]:
+            raise RuntimeError(f"neighbour lists exceed KNN_K: {rep}; the reference truncates them, the fused kernels do not")
+        return rep
 
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):

@@ -467,6 +467,91 @@ def gen_background():
         torch.zeros, torch.ones, torch.Tensor.cuda, torch.cuda.empty_cache = saved
 
 
+def gen_emitter():
+    """Frame-boundary bookkeeping of gm_dynamics.GaussianModel (gm_dynamics.py:504-608, 674-976, 1656-1691): the first
+    frame's particle clouds, the nozzle lattices, emit_new_particles and the constant render attributes, run by the
+    reference's own class on the CPU (device="cuda" keywords redirected as in gen_background).  numpy / torch host
+    generators are seeded right before every call that draws from them."""
+    from types import SimpleNamespace
+    import gaussian_splatting.gm_dynamics as gmd
+
+    def to_cpu(fn):
+        def wrapped(*a, **k):
+            if k.get("device") == "cuda":
+                k = dict(k, device="cpu")
+            return fn(*a, **k)
+        return wrapped
+
+    names = ("zeros", "ones", "tensor", "arange", "from_numpy")
+    saved = tuple(getattr(torch, n) for n in names) + (torch.Tensor.cuda,)
+    for n in names:
+        setattr(torch, n, to_cpu(getattr(torch, n)))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        optim = SimpleNamespace(secs=0.033, alpha=-1.5, buoyancy_decay_rate=0.0, buoyancy_max_y=0.0, beta=0.1, H=2.0,
+                                min_neighbors=-1, remove_out_boundary=False, p0=1.5, k=3, KNN_K=100,
+                                new_hidden_particles_per_sec=15, new_visual_particles_per_sec=15,
+                                emitter_points_off_y0=False, emit_ratio_hidden=1.32, emit_ratio_visual=2.4,
+                                fit_xyz=False, fit_color=True, fit_opacity=True, fit_scales=True, fit_rotation=True,
+                                wind_force=[0.0, 0.0, 0.0], wind_power=1.0, rigid_body="sphere", rigid_particle_radius=0.5,
+                                rigid_body_center=[0.0, 0.0, 0.0], rigid_cuboid_num_one_side=2, rigid_cuboid_num=8,
+                                rigid_sphere_radius=1.0, rigid_sphere_num=10, rigid_cylinder_radius=1.0, rigid_cylinder_num=10,
+                                extra_visual_ratio=0.05, extra_visual_num=7, extra_visual_y_min=0.16, extra_visual_min_num=3,
+                                extra_visual_pilar_radius=0.06, extra_visual_pilar_radius_delta=0.0015,
+                                pos_lr_scale_factor=1.0, init_hidden_velocity=0.25)
+        model = SimpleNamespace(init_visual_num_pts=500, init_thick_visual_num_pts=120, init_x_mid=0.34, init_z_mid=-0.22,
+                                init_visual_y_min=-0.05, init_visual_y_max=0.35, init_visual_y_thick_min=0.1,
+                                init_visual_radius_small_max=0.03, init_visual_radius_max=0.07,
+                                init_hidden_radius_max=0.06, init_hidden_y_min=-0.04, init_hidden_y_max=0.12,
+                                init_hidden_delta=0.017, emitter_hidden_delta=0.017, emitter_visual_delta=0.004,
+                                emitter_center_y_hidden=-0.05, emitter_center_y_visual=-0.045,
+                                emitter_center_y_hidden_max=0.0, emitter_center_y_visual_max=0.0,
+                                emitter_visual_radius_ratio=6.3, emitter_hidden_radius_ratio=2.6)
+        out = {"optim": np.array(repr(vars(optim))), "model": np.array(repr(vars(model)))}
+        gm = gmd.GaussianModel()
+        gm.setup_constants(optim)
+        np.random.seed(11)
+        gm.create_particles_visual(model)
+        out["visual_xyz0"] = gm._visual_xyz.numpy().copy()
+        gm.create_particles_hidden(model)
+        for n in ("xyz", "estimate_xyz", "buoyancy", "force", "velocity", "imass", "counts", "particle_id"):
+            out[f"hidden0_{n}"] = getattr(gm, f"_{n}").numpy().copy()
+        out["hidden0_id_max"] = np.int64(gm._particle_id_max)
+        gm.prepare_emitter_points(model, is_future=True)
+        out["emit_future_visual"] = gm.visual_emitter_points.numpy().copy()
+        gm.prepare_emitter_points(model)
+        out["emit_visual"], out["emit_hidden"] = gm.visual_emitter_points.numpy().copy(), gm.hidden_emitter_points.numpy().copy()
+        gm.prepare_emitter_future_first_points(model)
+        out["emit_first_visual"] = gm.visual_emitter_first_points.numpy().copy()
+        out["emit_first_hidden"] = gm.hidden_emitter_first_points.numpy().copy()
+        gm.detach_visual_and_scale()
+        gm.prepare_visual_particles_for_rendering()
+        for n in ("color", "scales", "rotation", "opacity"):
+            out[f"render0_{n}"] = getattr(gm, f"_visual_{n}").numpy().copy()
+        torch.manual_seed(5)
+        gm.emit_new_particles()
+        out["visual_xyz1"] = gm._visual_xyz.numpy().copy()
+        for n in ("xyz", "estimate_xyz", "buoyancy", "force", "velocity", "imass", "counts", "particle_id"):
+            out[f"hidden1_{n}"] = getattr(gm, f"_{n}").numpy().copy()
+        gm.prepare_future_visual_particles_for_rendering(use_level_two_future=True)
+        out["render1_shapes"] = np.array([getattr(gm, f"_visual_{n}").shape[0] for n in ("color", "scales", "rotation", "opacity")])
+        out["render1_opacity_tail"] = gm._visual_opacity[-5:].numpy().copy()
+        torch.manual_seed(6)
+        gm.emit_new_particles(future_time_index=1)
+        out["visual_xyz2"], out["hidden2_xyz"] = gm._visual_xyz.numpy().copy(), gm._xyz.numpy().copy()
+        out["hidden2_id_max"], out["emit_counter"] = np.int64(gm._particle_id_max), np.int64(gm.emit_counter)
+        rng = np.random.RandomState(3)
+        r = torch.tensor(rng.normal(size=(64, 3)).astype(np.float32) * 1.2)
+        r[5] = 0.0
+        rlen = torch.norm(r, dim=1)
+        out["spiky_r"], out["spiky_grad"] = r.numpy().copy(), gm.spiky_grad(r, rlen).numpy().copy()
+        np.savez(os.path.join(OUT, "emitter.npz"), **out)
+    finally:
+        for n, f in zip(names, saved[:-1]):
+            setattr(torch, n, f)
+        torch.Tensor.cuda = saved[-1]
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
@@ -479,6 +564,7 @@ if __name__ == "__main__":
     gen_pbf()
     gen_checkpoint()
     gen_background()
+    gen_emitter()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
