@@ -197,6 +197,53 @@ __device__ __forceinline__ uint32_t quadrant_mask_exact(float x, float y, float 
     return m;
 }
 
+// Pixel of its 16x16 tile that lane `lane` of wave `w` of a blend workgroup (forward and backward) owns: a wave is an
+// 8x8 quadrant (w & 1, w >> 1), a row of 16 lanes one 4x4 block of it (block_mask_exact's bit order), lane & 15 the
+// pixel of the block, row-major.
+__device__ __forceinline__ int blend_pixel_x(int w, int lane) { return (w & 1) * 8 + ((lane >> 4) & 1) * 4 + (lane & 3); }
+__device__ __forceinline__ int blend_pixel_y(int w, int lane) { return (w >> 1) * 8 + (lane >> 5) * 4 + ((lane >> 2) & 3); }
+
+// 4x4-pixel blocks of the 16x16 tile at (tile_x0, tile_y0) that can hold a contributing pixel of the splat: the
+// footprint box test of quadrant_mask per block, refined with the exact ellipse test of quadrant_mask_exact (same
+// margins).  Bit 4 q + b <-> block (b & 1, b >> 1) of quadrant q = (q & 1, q >> 1), i.e. the block whose first pixel
+// is (8 (q & 1) + 4 (b & 1), 8 (q >> 1) + 4 (b >> 1)).
+__device__ __forceinline__ uint32_t block_mask_exact(float x, float y, float a, float b, float c, float thr, float ex,
+                                                     float ey, float tile_x0, float tile_y0) {
+    if (ex < 0.0f) return 0u;
+    const float lim = (-2.0f * thr) * 1.001f + 0.01f;
+    const float xl = x - ex, xh = x + ex, yl = y - ey, yh = y + ey;
+    const float nbc = -b / c, nba = -b / a;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int cy = 0; cy < 4; cy++) {
+        const float Yt = tile_y0 + (float)(4 * cy);
+        if (!((yl <= Yt + 3.0f) && (yh >= Yt))) continue;
+        const float Y0 = Yt - y, Y1 = Y0 + 3.0f;
+#pragma unroll
+        for (int cx = 0; cx < 4; cx++) {
+            const float Xt = tile_x0 + (float)(4 * cx);
+            if (!((xl <= Xt + 3.0f) && (xh >= Xt))) continue;
+            const float X0 = Xt - x, X1 = X0 + 3.0f;
+            float q = 0.0f;  // minimum of the quadratic form over the block (conic_min_over_rect)
+            if (!(X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f)) {
+                q = 3.0e38f;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const float X = k ? X1 : X0;
+                    const float dy = fminf(fmaxf(nbc * X, Y0), Y1);
+                    q = fminf(q, a * X * X + 2.0f * b * X * dy + c * dy * dy);
+                    const float Y = k ? Y1 : Y0;
+                    const float dx = fminf(fmaxf(nba * Y, X0), X1);
+                    q = fminf(q, a * dx * dx + 2.0f * b * dx * Y + c * Y * Y);
+                }
+            }
+            if (q > lim) continue;  // NaN keeps the block
+            m |= 1u << (4 * ((cy >> 1) * 2 + (cx >> 1)) + (cy & 1) * 2 + (cx & 1));
+        }
+    }
+    return m;
+}
+
 // Real-SH basis constants (ch3 auxiliary.h:22-39).
 __device__ static const float kSH0 = 0.28209479177387814f;
 __device__ static const float kSH1 = 0.4886025119029199f;

@@ -81,6 +81,20 @@ __device__ __forceinline__ void wave_fold_accumulate(const float (&val)[NV], flo
     }
 }
 
+// Per-row variant: every 16-lane row of the wave holds the NV values of a DIFFERENT list entry (its 4x4 block's);
+// each row's sums go to acc[v][slot] of that row's entry (`slot` is per lane, uniform within a row).  Rows with no
+// active lane add nothing.
+template <int NV>
+__device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], float (*acc)[256], uint32_t slot, int lane,
+                                                    bool row_active) {
+    const bool tail = (lane & 15) == 15;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const float t = row_sum_to_lane15(val[v]);
+        if (tail && row_active) atomicAdd(&acc[v][slot], t);
+    }
+}
+
 __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
     const int q = T >> 3, r = T & 7;
     const int xcd = bid & 7, k = bid >> 3;
@@ -99,8 +113,9 @@ __device__ __forceinline__ int xcd_tile_b(int bid, int T) {
 //     dL/dalpha_i = sum_ch dL_ch (c_i T_i - S_i / (1 - alpha_i)) - T_final / (1 - alpha_i) (bg . dL),
 //     S_i = colour accumulated BEHIND entry i = final accumulated colour - prefix including i,
 // which is the reference's (c - accum_rec) T with accum_rec = S_i / T_{i+1} written without the recurrence.
-// Same quadrant / compacted-list structure as the forward blend; a wave only receives entries in front of its own
-// deepest contributor.
+// Same structure as the forward blend: a wave is an 8x8 quadrant, each of its 16-lane rows a 4x4 block with its own
+// compacted list (block_mask_exact), the four rows walk four lists at once, and the per-entry sums are row
+// reductions; a block only receives entries in front of its own deepest contributor.
 // MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
 // MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients.
 // Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
@@ -140,9 +155,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
     __shared__ float s_col[C][256];
     __shared__ float s_acc[NV][256];
-    __shared__ uint8_t s_list[4][256];
-    __shared__ uint32_t s_cnt[4][4];
-    __shared__ uint32_t s_max[4];
+    __shared__ uint8_t s_list[16][256];  // lists 4 w .. 4 w + 3 are built and read by wave w alone
+    __shared__ uint16_t s_mask[256];
+    __shared__ uint32_t s_max[16];
     if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] != 0u) return;
     const uint32_t n_items = header[HDR_BWD_ITEMS];
     const uint32_t *items = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(point_list) + vb.bin_items);
@@ -156,7 +171,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const int tile = (int)(item & 0x3FFFu);
         const uint32_t b = item >> 14;
         const int tx = tile % gx, ty = tile / gx;
-        const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
+        const int row = lane >> 4;
+        const int px = tx * FNX_TILE_X + blend_pixel_x(w, lane), py = ty * FNX_TILE_Y + blend_pixel_y(w, lane);
         const bool inside = px < W && py < H;
         const uint32_t pix_id = (uint32_t)W * py + px;
         const float pxf = (float)px, pyf = (float)py;
@@ -186,13 +202,15 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib (backward.cu:467-469):
-        // a wave needs nothing behind its own max, the batch nothing behind the max of the tile's waves
+        // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
         uint32_t m = last_contributor;
-        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
         __syncthreads();  // the previous item is done with the LDS arrays
-        if (lane == 0) s_max[w] = m;
+        if ((lane & 15) == 0) s_max[4 * w + row] = m;
         __syncthreads();
-        const uint32_t qmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        uint32_t qmax = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) qmax = max(qmax, s_max[k]);
         const uint32_t cnt = min(256u, qmax - min(qmax, q0));
 
         // stage entries q = q0 + t (slot t), zero the slot accumulators
@@ -202,9 +220,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             const uint32_t id = point_list[r0 + q];
             const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-            qm = quadrant_mask_exact(ra.x, ra.y, ra.z, ra.w, rb.x, rb.z, rc.x, rc.y, tile_x0, tile_y0);
+            qm = block_mask_exact(ra.x, ra.y, ra.z, ra.w, rb.x, rb.z, rc.x, rc.y, tile_x0, tile_y0);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < 16; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);
             s_id[tid] = id;
             s_ra[tid] = ra;
@@ -215,35 +233,33 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
-        uint32_t rank[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long bm = __ballot((qm >> q) & 1u);
-            rank[q] = (uint32_t)__popcll(bm & lt_mask);
-            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(bm);
-        }
+        s_mask[tid] = (uint16_t)qm;
         __syncthreads();
+        uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's four lists
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if ((qm >> q) & 1u) {
-                uint32_t off = rank[q];
-                for (int k = 0; k < w; k++) off += s_cnt[k][q];
-                s_list[q][off] = (uint8_t)tid;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const bool bit = (mk >> bb) & 1u;
+                const unsigned long long bm = __ballot(bit);
+                if (bit) s_list[4 * w + bb][len[bb] + (uint32_t)__popcll(bm & lt_mask)] = (uint8_t)(64 * k + lane);
+                len[bb] += (uint32_t)__popcll(bm);
             }
         }
-        __syncthreads();
-        // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
-        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
+        const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
+        const uint32_t my_len = row == 0 ? len[0] : row == 1 ? len[1] : row == 2 ? len[2] : len[3];
+        const uint8_t *mylist = s_list[4 * w + row];
 
         for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
-            const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[w][i]);
+            const bool listed = i < my_len;  // uniform within a row
+            const uint32_t j = listed ? (uint32_t)mylist[i] : 0u;
             const uint32_t q = q0 + j;
-            const bool wants = s_id[j] < grad_limit;  // wave-uniform
+            const bool wants = listed && s_id[j] < grad_limit;  // uniform within a row
             float val[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) val[v] = 0.f;
-            bool active = q < last_contributor;
+            bool active = listed && q < last_contributor;
             if (active) {
                 const float4 ra = s_ra[j];
                 const float4 rb = s_rb[j];
@@ -292,7 +308,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #if FNX_ABLATE == 2
             { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
 #else
-            if (wants && __ballot(active) != 0ull) wave_fold_accumulate<NV>(val, s_acc, j, lane);
+            if (__ballot(active && wants) != 0ull) row_fold_accumulate<NV>(val, s_acc, j, lane, wants);
 #endif
         }
         __syncthreads();

@@ -5,6 +5,16 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
+#ifdef FNX_EXP_STATS  // developer statistics of the blend forward's inner loop (tools/deep_probe.py)
+__device__ unsigned long long g_fwd_stats[8];
+extern "C" int fnx_debug_fwd_stats(unsigned long long *host, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stats), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_stats), sizeof(g_fwd_stats));
+}
+#endif
 #ifdef FNX_EXP_CLOCK  // developer timing: per-phase cycles of every wave's thread 0 of workgroup (0, 0) of the blend forward
 __device__ unsigned long long g_fwd_clock[64];
 extern "C" int fnx_debug_fwd_clock(unsigned long long *host) {
@@ -347,11 +357,14 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 }
 
 // K5: front-to-back alpha blending, one 256-thread workgroup per 16x16 tile
-// (ch3 forward.cu:249-373).  Wave w owns the 8x8 quadrant (w & 1, w >> 1).  A batch of 256 list
-// entries is staged once in LDS; while staging, each entry is tested against the four quadrants
-// (quadrant_mask) and every wave gets its own compacted, still depth-ordered index list, so a wave
-// only walks entries that can reach one of its pixels.  Per pixel the arithmetic and its order are
-// exactly the reference's; culled pairs are pairs it would have skipped (alpha < 1/255).
+// (ch3 forward.cu:249-373).  Wave w owns the 8x8 quadrant (w & 1, w >> 1), and each ROW of 16 lanes of the wave one
+// 4x4-pixel block of it.  A batch of 256 list entries is staged once in LDS; while staging, each entry is tested
+// against the sixteen blocks (block_mask_exact), and every block gets its own compacted, still depth-ordered list:
+// the four rows of a wave walk FOUR DIFFERENT lists at the same time (the LDS reads take per-lane addresses), so
+// a lane only evaluates entries that can reach its 4x4 block.  With plume-sized splats an entry reaches ~2.2 of the
+// 4 blocks of a quadrant it touches, and ~22 of its 64 pixels: per-block lists cut the evaluated (pixel, entry)
+// pairs by a third to a half against per-quadrant lists.  Per pixel the arithmetic and its order are exactly the
+// reference's; culled pairs are pairs it would have skipped (alpha < 1/255).
 //
 // SPLIT (static-split mode, include/fnx_raster.h): a tile has TWO depth-ordered streams of (depth bits, id)
 // pairs -- the static splats' (binned once per frame) and this call's -- and the kernel merges them lazily: while
@@ -400,9 +413,11 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ float4 s_ra[257];  // x, y, conic a, conic b
     __shared__ float4 s_rb[257];  // conic c, opacity, exp-skip threshold, -
     __shared__ float4 s_rc[257];  // colour (C channels), depth in .w
-    // per-quadrant lists of LDS byte offsets (slot * 16) of the entries that can reach the quadrant, depth order
-    __shared__ __attribute__((aligned(4))) uint16_t s_list[4][256 + kGroup];
-    __shared__ uint32_t s_cnt[4][4];  // [staging wave][quadrant]
+    // per-block lists of LDS byte offsets (slot * 16) of the entries that can reach the block, depth order; lists
+    // 4 w .. 4 w + 3 are built, padded (NULL record) and read by wave w alone
+    constexpr int kListStride = (256 + kGroup + 7) & ~7;
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[16][kListStride];
+    __shared__ uint16_t s_mask[256];  // block mask of every staged entry
     __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  // merge windows: depth bits [static | per-call]
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
@@ -425,7 +440,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         s_rb[256] = make_float4(0.f, 0.f, -87.0f, 0.f);
         s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int px = tx * FNX_TILE_X + (w & 1) * 8 + (lane & 7), py = ty * FNX_TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const int row = lane >> 4;  // the wave's 4x4 block this lane belongs to (blend_pixel, fnx_device.h)
+    const int px = tx * FNX_TILE_X + blend_pixel_x(w, lane), py = ty * FNX_TILE_Y + blend_pixel_y(w, lane);
     const bool inside = px < W && py < H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
@@ -544,7 +560,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt && blending) {
-            qm = quadrant_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
+            qm = block_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
             s_ra[tid] = pa;
             s_rb[tid] = pb;
             s_rc[tid] = make_float4(pc.z, C > 1 ? pc.w : 0.f, C > 2 ? pd : 0.f, pb.w);
@@ -562,25 +578,24 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             }
             if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
         }
-        uint32_t rank[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long m = __ballot((qm >> q) & 1u);
-            rank[q] = (uint32_t)__popcll(m & lt_mask);
-            if (lane == 0) s_cnt[w][q] = (uint32_t)__popcll(m);
+        s_mask[tid] = (uint16_t)qm;
+        {  // this wave's four lists start out as NULL pointers (slot 256) from end to end
+            const uint4 nul = make_uint4(0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u);
+            uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
+            for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
         __syncthreads();
+        uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if ((qm >> q) & 1u) {
-                uint32_t off = rank[q];
-                for (int k = 0; k < w; k++) off += s_cnt[k][q];
-                s_list[q][off] = (uint16_t)(tid * 16);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool bit = (mk >> b) & 1u;
+                const unsigned long long m = __ballot(bit);
+                if (bit) s_list[4 * w + b][len[b] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
+                len[b] += (uint32_t)__popcll(m);
             }
-        }
-        if (tid < 4 * kGroup) {  // the tail of every list: kGroup pointers to the NULL record
-            const int q = tid / kGroup;
-            s_list[q][s_cnt[0][q] + s_cnt[1][q] + s_cnt[2][q] + s_cnt[3][q] + tid % kGroup] = (uint16_t)(256 * 16);
         }
         uint32_t next_cnt = 0, next_id = 0;
         if (SPLIT) {
@@ -605,9 +620,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             load_windows();
             if (!blending) continue;
         }
-        // wave-uniform values read from LDS: tell the compiler (scalar compares / address arithmetic)
-        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)(s_cnt[0][w] + s_cnt[1][w] + s_cnt[2][w] + s_cnt[3][w]));
+        const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
+        const uint16_t *mylist = s_list[4 * w + row];
         const uint32_t pos0 = base - r0 + 1;  // list position (1-based) of slot 0
         // The only state carried from entry to entry is (T, colour, depth, alive); power / exp / alpha of an entry do
         // not depend on it.  A lone wave issues one instruction every ~4.5 cycles, and the launch ends when the deepest
@@ -625,10 +639,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #endif
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(alive == 0.0f)) break;
-            uint32_t jw[kGroup / 2];
+            uint32_t jw[kGroup / 2];  // the next kGroup entries of this lane's list
 #pragma unroll
-            for (int k = 0; k < kGroup / 2; k++)
-                jw[k] = (uint32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&s_list[w][i0 + 2 * k]));
+            for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
             float a_h[kGroup];
             float4 rc[kGroup];
 #pragma unroll
@@ -643,6 +656,19 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 const float alpha = fminf(0.99f, rb.y * exp_fixed_in_range(fmaxf(power, -87.0f)));
                 a_h[k] = (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
             }
+#ifdef FNX_EXP_STATS
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const unsigned long long hit = __ballot(a_h[k] > 0.0f && alive != 0.0f);
+                const unsigned long long live = __ballot(alive != 0.0f);
+                if (lane == 0 && i0 + k < n_w) {
+                    atomicAdd(&g_fwd_stats[0], 1ull);
+                    atomicAdd(&g_fwd_stats[1], (unsigned long long)__popcll(hit));
+                    atomicAdd(&g_fwd_stats[2], hit ? 1ull : 0ull);
+                    atomicAdd(&g_fwd_stats[4], (unsigned long long)__popcll(live));
+                }
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
                 const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;

@@ -8,7 +8,7 @@ restatement built twice -- as written (liboracle.so) and with the compiler free 
 nvcc's either, but both perturb the same expressions by the same <= 1 ulp per fused operation, so the counts bound the
 size of the effect.  Output: profiles/<tag>_fp_contract_report.md (+ .json).
 
-    python tools/fp_contract_report.py [tag, default r02] [--quick]
+    python oracle/fp_contract_report.py [tag, default r02] [--quick]
 """
 import json
 import math
@@ -88,7 +88,7 @@ def main():
     json.dump(rows, open(os.path.join(out, f"{tag}_fp_contract_report.json"), "w"), indent=1)
     with open(os.path.join(out, f"{tag}_fp_contract_report.md"), "w") as f:
         f.write(f"# FMA-contraction sensitivity of the rasteriser restatement ({tag})\n\n"
-                "`python tools/fp_contract_report.py`: oracle/raster_oracle.c built as written (`-ffp-contract=off`, the parity "
+                "`python oracle/fp_contract_report.py`: oracle/raster_oracle.c built as written (`-ffp-contract=off`, the parity "
                 "checker the HIP kernels match bit for bit) against the same file built with `-ffp-contract=fast -mfma` "
                 "(the compiler fuses a*b+c, as nvcc does by default when it builds the reference).  What differs between the "
                 "two is what an nvcc build of the reference may differ in from this repository's forward, beyond `expf`.\n\n")

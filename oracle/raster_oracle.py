@@ -48,7 +48,7 @@ def lib():
 
 def use_variant(name=None):
     """Switch every later call of this module to another build of the same source: "fma" = liboracle_fma.so
-    (-ffp-contract=fast -mfma, built on demand; tools/fp_contract_report.py), None = the parity checker."""
+    (-ffp-contract=fast -mfma, built on demand; oracle/fp_contract_report.py), None = the parity checker."""
     global _LIB
     if name is None:
         _LIB = None

@@ -38,3 +38,13 @@ if hasattr(lib, "fnx_debug_fwd_clock"):
     for w in range(4):
         v = [int(x) for x in buf[16 * w:16 * w + 16]]
         print("wave", w, dict(loop_top=v[0], all_done_barrier=v[1], stage_merge=v[2], blend_loop=v[3], sum_n_w=v[8], batches=v[9], list_length=v[15]))
+if hasattr(lib, "fnx_debug_fwd_stats"):
+    buf = (C.c_ulonglong * 8)()
+    lib.fnx_debug_fwd_stats(buf, 1)
+    with torch.no_grad():
+        f()
+    torch.cuda.synchronize()
+    lib.fnx_debug_fwd_stats(buf, 0)
+    e, hits, any_hit, blocks, live, halves = [int(x) for x in buf[:6]]
+    print(f"wave-entries {e}  lanes hit/entry {hits / e:.1f} of {live / e:.1f} alive  entries with a hit {any_hit / e:.3f}  "
+          f"4x4 blocks hit/entry {blocks / e:.2f} of 4  8x4 halves hit/entry {halves / e:.2f} of 2")
