@@ -33,7 +33,7 @@ class ImageLayout(C.Structure):
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "bstate", "bwd_items", "total")]
+    _fields_ = [(n, c_size_t) for n in ("point_list", "pairs", "bstate", "bwd_items", "block_masks", "total")]
 
 
 class StaticLayout(C.Structure):

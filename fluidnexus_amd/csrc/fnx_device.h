@@ -210,35 +210,46 @@ __device__ __forceinline__ int blend_pixel_y(int w, int lane) { return (w >> 1) 
 __device__ __forceinline__ uint32_t block_mask_exact(float x, float y, float a, float b, float c, float thr, float ex,
                                                      float ey, float tile_x0, float tile_y0) {
     if (ex < 0.0f) return 0u;
+    // The minimum of q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 over a block is 0 if the centre lies in it, otherwise
+    // the least of its four edge minima (conic_min_over_rect).  The edges lie on 8 vertical and 8 horizontal lines of
+    // the tile (block starts 0 4 8 12, block ends 3 7 11 15): the per-line terms are computed once, an edge then costs
+    // a clamp (v_med3), two fused multiply-adds and a min.  Culling arithmetic is free to fuse: its margins (see
+    // quadrant_mask_exact) dwarf the rounding.
     const float lim = (-2.0f * thr) * 1.001f + 0.01f;
-    const float xl = x - ex, xh = x + ex, yl = y - ey, yh = y + ey;
-    const float nbc = -b / c, nba = -b / a;
+    const float nbc = -b / c, nba = -b / a, b2 = 2.0f * b;
+    const float ox = tile_x0 - x, oy = tile_y0 - y;
+    float LX[8], aXX[8], bX[8], sX[8], LY[8], cYY[8], bY[8], sY[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // line i: block i / 2, its start (even i) or end (odd i)
+        const float off = (float)(4 * (i >> 1) + 3 * (i & 1));
+        LX[i] = ox + off;
+        aXX[i] = a * LX[i] * LX[i];
+        bX[i] = b2 * LX[i];
+        sX[i] = nbc * LX[i];  // minimiser in dy along the vertical line
+        LY[i] = oy + off;
+        cYY[i] = c * LY[i] * LY[i];
+        bY[i] = b2 * LY[i];
+        sY[i] = nba * LY[i];  // minimiser in dx along the horizontal line
+    }
     uint32_t m = 0u;
 #pragma unroll
     for (int cy = 0; cy < 4; cy++) {
-        const float Yt = tile_y0 + (float)(4 * cy);
-        if (!((yl <= Yt + 3.0f) && (yh >= Yt))) continue;
-        const float Y0 = Yt - y, Y1 = Y0 + 3.0f;
+        const float Y0 = LY[2 * cy], Y1 = LY[2 * cy + 1];
+        const bool in_y = Y0 <= 0.0f && Y1 >= 0.0f;
 #pragma unroll
         for (int cx = 0; cx < 4; cx++) {
-            const float Xt = tile_x0 + (float)(4 * cx);
-            if (!((xl <= Xt + 3.0f) && (xh >= Xt))) continue;
-            const float X0 = Xt - x, X1 = X0 + 3.0f;
-            float q = 0.0f;  // minimum of the quadratic form over the block (conic_min_over_rect)
-            if (!(X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f)) {
-                q = 3.0e38f;
+            const float X0 = LX[2 * cx], X1 = LX[2 * cx + 1];
+            float q = 3.0e38f;
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const float X = k ? X1 : X0;
-                    const float dy = fminf(fmaxf(nbc * X, Y0), Y1);
-                    q = fminf(q, a * X * X + 2.0f * b * X * dy + c * dy * dy);
-                    const float Y = k ? Y1 : Y0;
-                    const float dx = fminf(fmaxf(nba * Y, X0), X1);
-                    q = fminf(q, a * dx * dx + 2.0f * b * dx * Y + c * Y * Y);
-                }
+            for (int k = 0; k < 2; k++) {
+                const float dy = __builtin_amdgcn_fmed3f(sX[2 * cx + k], Y0, Y1);
+                q = fminf(q, __builtin_fmaf(dy, __builtin_fmaf(c, dy, bX[2 * cx + k]), aXX[2 * cx + k]));
+                const float dx = __builtin_amdgcn_fmed3f(sY[2 * cy + k], X0, X1);
+                q = fminf(q, __builtin_fmaf(dx, __builtin_fmaf(a, dx, bY[2 * cy + k]), cYY[2 * cy + k]));
             }
-            if (q > lim) continue;  // NaN keeps the block
-            m |= 1u << (4 * ((cy >> 1) * 2 + (cx >> 1)) + (cy & 1) * 2 + (cx & 1));
+            const bool inside = in_y && X0 <= 0.0f && X1 >= 0.0f;
+            if (inside || !(q > lim))  // NaN keeps the block
+                m |= 1u << (4 * ((cy >> 1) * 2 + (cx >> 1)) + (cy & 1) * 2 + (cx & 1));
         }
     }
     return m;

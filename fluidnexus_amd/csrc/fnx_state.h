@@ -122,6 +122,7 @@ inline void binning_layout(int64_t R, int64_t R_static, bool split, fnx_binning_
     // forward -> backward hand-over per batch of kBlendBatch list entries (see blend_state_slots)
     o->bstate = off;     off = align_up(off + blend_state_slots(r + rs) * kBlendStateBytes);
     o->bwd_items = off;  off = align_up(off + (blend_state_slots(r + rs) + kMaxTiles) * 4);
+    o->block_masks = off; off = align_up(off + (r + rs) * 2);
     o->total = off + kAlign;
 }
 
@@ -146,6 +147,7 @@ struct ViewBatch {
     size_t geom, img, bin;  // bytes between consecutive views' blobs (0 for a single view)
     size_t bin_pairs;       // byte offset of the (key, id) pair array inside a binning blob (static-split mode)
     size_t bin_bstate, bin_items;  // byte offsets of the per-batch blend state and the backward work items
+    size_t bin_masks;              // byte offset of the per-entry block masks (forward -> backward)
     size_t radii_stride;    // elements between consecutive views' radii (= total splat count)
     float tan_fovx[kMaxViews], tan_fovy[kMaxViews], focal_x[kMaxViews], focal_y[kMaxViews];
 };

@@ -178,6 +178,7 @@ int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *t
     vb->bin_pairs = BL.pairs;
     vb->bin_bstate = BL.bstate;
     vb->bin_items = BL.bwd_items;
+    vb->bin_masks = BL.block_masks;
     vb->radii_stride = (size_t)P + (size_t)(split ? P_static : 0);
     for (int v = 0; v < V; v++) {
         vb->tan_fovx[v] = tan_fovx[v];

@@ -176,7 +176,6 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const bool inside = px < W && py < H;
         const uint32_t pix_id = (uint32_t)W * py + px;
         const float pxf = (float)px, pyf = (float)py;
-        const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
         const uint32_t r0 = ranges[2 * tile];
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
 
@@ -220,7 +219,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             const uint32_t id = point_list[r0 + q];
             const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-            qm = block_mask_exact(ra.x, ra.y, ra.z, ra.w, rb.x, rb.z, rc.x, rc.y, tile_x0, tile_y0);
+            qm = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(point_list) + vb.bin_masks)[r0 + q];
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);

@@ -579,6 +579,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
         }
         s_mask[tid] = (uint16_t)qm;
+        if ((uint32_t)tid < cnt && blending)  // the backward pass builds its lists from the same masks
+            reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks)[base + tid] = (uint16_t)qm;
         {  // this wave's four lists start out as NULL pointers (slot 256) from end to end
             const uint4 nul = make_uint4(0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u);
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);

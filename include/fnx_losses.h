@@ -24,7 +24,7 @@ extern "C" {
 typedef void *fnx_stream_t;
 int fnx_losses_abi_version(void);
 const char *fnx_losses_last_error(void);
-/* number of 16x16 tiles = length of `partials` / 2 */
+/* number of workgroup tiles (32x32 pixels per channel plane) = length of `partials` / 2 per image */
 int fnx_l1_ssim_tiles(int C, int H, int W, int grey);
 int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,
                         float *dmaps /* [3, Ce, H, W] */, fnx_stream_t stream);

@@ -306,6 +306,8 @@ typedef struct {
                           forward blended: slot (tile's first list position) / 256 + b - 1                          */
     size_t bwd_items;  /* u32[...] backward work items (tile | batch << 14) written by the forward; their count is
                           header word 4                                                                             */
+    size_t block_masks; /* u16[R (+ R_static)] per list entry the forward blended: which 4x4 blocks of its tile it can
+                          reach (bit 4 q + b: block b of quadrant q); the backward builds its lists from them        */
     size_t total;
 } fnx_binning_layout_t;
 typedef struct {
