@@ -20,7 +20,11 @@ __device__ unsigned long long g_fwd_clock[64];
 extern "C" int fnx_debug_fwd_clock(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_clock), sizeof(g_fwd_clock));
 }
-#define FNX_CLK(i) { const unsigned long long tn = clock64(); if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_fwd_clock[16 * w + (i)] += tn - t_last; t_last = tn; }
+__device__ unsigned long long g_fwd_wg[3 * 8192];  // per workgroup (view * T + blockIdx.x): wall start, wall end, list length
+extern "C" int fnx_debug_fwd_wg(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_wg), (size_t)n * 8);
+}
+#define FNX_CLK(i) { const unsigned long long tn = clock64(); if (wg_rank == 0 && wg_view == 0 && lane == 0) g_fwd_clock[16 * w + (i)] += tn - t_last; t_last = tn; }
 #else
 #define FNX_CLK(i)
 #endif
@@ -373,8 +377,11 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 // prefetched.  Ties in depth go to the per-call stream (lower ids), as in the reference's stable sort of ids
 // emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
 // pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
+#ifndef FNX_FWD_WAVES
+#define FNX_FWD_WAVES 3  // waves per SIMD the register allocation of the blend forward aims at
+#endif
 template <int C, bool SPLIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
@@ -384,8 +391,16 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                      uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb) {
     const char *static_blob = nullptr;
+    // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
+    // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
+    // last view's longest walks would only START once every other view has been handed out.  So the views are
+    // interleaved in chunks of 8 consecutive workgroups (one per XCD: rank % 8 stays the XCD the tile order was
+    // built for), and the deep tiles of ALL views lead the launch.
+    const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x, n_views = gridDim.y;
+    const int wg_view = (wg_linear >> 3) % n_views, wg_rank = ((wg_linear >> 3) / n_views) * 8 + (wg_linear & 7);
+    if (wg_rank >= T) return;  // gridDim.x is T rounded up to a multiple of 8
     {
-        const int vw = blockIdx.y;
+        const int vw = wg_view;
         ranges = view_at(ranges, vb.img, vw);
         final_T = view_at(final_T, vb.img, vw);
         n_contrib = view_at(n_contrib, vb.img, vw);
@@ -424,12 +439,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_qmax[4];
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
-    if (status_out && blockIdx.x == 0 && threadIdx.x < 8) status_out[8 * blockIdx.y + threadIdx.x] = header[threadIdx.x];
+    if (status_out && wg_rank == 0 && threadIdx.x < 8) status_out[8 * wg_view + threadIdx.x] = header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity) return;
     // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
     // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
-    const int tile = (int)tile_order[blockIdx.x];
+    const int tile = (int)tile_order[wg_rank];
     if (tile_deep[tile]) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -543,8 +558,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
                      (size_t)(r0 >> 8) * 256 + tid;
 #ifdef FNX_EXP_CLOCK
+    const unsigned long long wg_t0 = wall_clock64();
     unsigned long long t_last = clock64();
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[16 * w + i] = 0; g_fwd_clock[16 * w + 15] = r1 - r0; }
+    if (wg_rank == 0 && wg_view == 0 && lane == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[16 * w + i] = 0; g_fwd_clock[16 * w + 15] = r1 - r0; }
 #endif
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
@@ -637,7 +653,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         // Per pixel the arithmetic on applied entries and its order are exactly the reference's.
         FNX_CLK(2)
 #ifdef FNX_EXP_CLOCK
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
+        if (wg_rank == 0 && wg_view == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
 #endif
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(alive == 0.0f)) break;
@@ -668,6 +684,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                     atomicAdd(&g_fwd_stats[1], (unsigned long long)__popcll(hit));
                     atomicAdd(&g_fwd_stats[2], hit ? 1ull : 0ull);
                     atomicAdd(&g_fwd_stats[4], (unsigned long long)__popcll(live));
+                    atomicAdd(&g_fwd_stats[3], (unsigned long long)((i0 + k < len[0]) + (i0 + k < len[1]) + (i0 + k < len[2]) + (i0 + k < len[3])));
                 }
             }
 #endif
@@ -714,6 +731,16 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << 14);
     }
     if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: the next forward's tile order
+#ifdef FNX_EXP_CLOCK
+    if (tid == 0) {
+        const int wg = wg_view * T + wg_rank;
+        if (wg < 8192) {
+            g_fwd_wg[3 * wg] = wg_t0;
+            g_fwd_wg[3 * wg + 1] = wall_clock64();
+            g_fwd_wg[3 * wg + 2] = ((unsigned long long)qmax << 32) | (r1 - r0);
+        }
+    }
+#endif
 }
 
 // rasterizer_impl.cu:52-63
@@ -786,7 +813,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
 #define FNX_LAUNCH_BF(CC, SS)                                                                                          \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3(T, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,   \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,          \
+                       point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb)
     if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);

@@ -47,4 +47,24 @@ if hasattr(lib, "fnx_debug_fwd_stats"):
     lib.fnx_debug_fwd_stats(buf, 0)
     e, hits, any_hit, blocks, live, halves = [int(x) for x in buf[:6]]
     print(f"wave-entries {e}  lanes hit/entry {hits / e:.1f} of {live / e:.1f} alive  entries with a hit {any_hit / e:.3f}  "
-          f"4x4 blocks hit/entry {blocks / e:.2f} of 4  8x4 halves hit/entry {halves / e:.2f} of 2")
+          f"rows with a list entry per step {blocks / e:.2f} of 4")
+if hasattr(lib, "fnx_debug_fwd_wg"):
+    import numpy as np
+    n = 5 * 1024
+    buf = (C.c_ulonglong * (3 * n))()
+    lib.fnx_debug_fwd_wg(buf, 3 * n)
+    a = np.array(buf[:], dtype=np.uint64).reshape(n, 3)
+    t0, t1 = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64)
+    depth, length = (a[:, 2] >> np.uint64(32)).astype(np.int64), (a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    base = t0.min()
+    tick = 0.01  # us per tick of the 100 MHz wall clock
+    s, e = (t0 - base) * tick, (t1 - base) * tick
+    print(f"launch span {e.max():.1f} us; workgroups {n}; last start {s.max():.1f} us")
+    order = np.argsort(-e)[:8]
+    for i in order:
+        print(f"  wg {i % 1024:4d} view {i // 1024}: start {s[i]:7.1f} end {e[i]:7.1f} dur {e[i] - s[i]:7.1f} us  consumed {depth[i]:5d} of {length[i]:5d}")
+    for thr in (256, 1024, 2048, 4096):
+        m = depth < thr
+        print(f"  tiles consuming < {thr}: {m.sum():5d}, all ended by {e[m].max():7.1f} us")
+    dur = e - s
+    print(f"  sum of durations {dur.sum() / 1e3:.1f} ms = {dur.sum() / e.max():.0f} workgroups busy on average")
