@@ -83,15 +83,34 @@ __device__ __forceinline__ void wave_fold_accumulate(const float (&val)[NV], flo
 
 // Per-row variant: every 16-lane row of the wave holds the NV values of a DIFFERENT list entry (its 4x4 block's);
 // each row's sums go to acc[v][slot] of that row's entry (`slot` is per lane, uniform within a row).  Rows with no
-// active lane add nothing.
+// active lane add nothing.  Four values are folded together: 16 -> 8 lanes pairs (a | b) and (c | d) across the row
+// halves (row_ror:8), 8 -> 4 pairs the pairs across the half-row's quads (row_half_mirror), two quad permutes finish:
+// the quads of a row then hold the totals of a, c, b, d -- 11 VALU operations and ONE LDS atomic (4 lanes per row)
+// for four values instead of 4 x (5 + 1).
 template <int NV>
 __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], float (*acc)[256], uint32_t slot, int lane,
                                                     bool row_active) {
-    const bool tail = (lane & 15) == 15;
+    const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+    const int vq = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1);  // which value of a group this lane's quad ends up with
+    const bool writer = row_active && (lane & 3) == 0;
 #pragma unroll
-    for (int v = 0; v < NV; v++) {
-        const float t = row_sum_to_lane15(val[v]);
-        if (tail && row_active) atomicAdd(&acc[v][slot], t);
+    for (int g = 0; g + 4 <= NV; g += 4) {
+        const float a = val[g], b = val[g + 1], c = val[g + 2], d = val[g + 3];
+        const float s01 = (hi8 ? b : a) + FNX_DPP((hi8 ? a : b), 0x128, 0xf);
+        const float s23 = (hi8 ? d : c) + FNX_DPP((hi8 ? c : d), 0x128, 0xf);
+        float t = (hi4 ? s23 : s01) + FNX_DPP((hi4 ? s01 : s23), 0x141, 0xf);
+        t += FNX_DPP(t, 0xb1, 0xf);
+        t += FNX_DPP(t, 0x4e, 0xf);
+        if (writer) atomicAdd(&acc[g + vq][slot], t);
+    }
+#pragma unroll
+    for (int v = NV & ~3; v < NV; v++) {  // the one to three values left over: a plain row sum each
+        float t = val[v];
+        t += FNX_DPP(t, 0x128, 0xf);
+        t += FNX_DPP(t, 0x141, 0xf);
+        t += FNX_DPP(t, 0xb1, 0xf);
+        t += FNX_DPP(t, 0x4e, 0xf);
+        if (writer && (lane & 15) == 4 * (v & 3)) atomicAdd(&acc[v][slot], t);
     }
 }
 

@@ -1,17 +1,22 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun) from the repo root: collects everything profiles/ is built from into gpurun_out/r01/.
+# Run on the GPU box (through gpurun) from the repo root: collects everything profiles/ is built from into
+# gpurun_out/<tag>/.  usage: tools/collect_profiles.sh <tag> [bench.py arguments, e.g. --config 2]
 # rocprofv3 counter passes are separate runs with --kernel-trace only (no sys/hip/hsa tracing).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r01
+TAG=${1:-r02}; shift
+ARGS="$*"
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1
-EAGER="python $R/bench.py --no-cpu-baseline --no-graph --steps 5 --warmup 2"
+echo "$ARGS" > $O/args.txt
+python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py $ARGS --no-cpu-baseline > $O/stats.log 2>&1
+EAGER="python $R/bench.py $ARGS --no-cpu-baseline --no-graph --steps 5 --warmup 2"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o r -- $EAGER > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o r -- $EAGER > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
   --kernel-trace --output-format csv -d $O/pmc_sq -o r -- $EAGER > $O/pmc_sq.log 2>&1
-ls $O $O/stats | head -30
-tail -c 600 $O/bench.json
+rm -f $O/stats/r_domain_stats.csv
+ls $O
+tail -c 300 $O/bench.json

@@ -1,9 +1,10 @@
 """Build the committed summaries under profiles/ from the raw rocprofv3 output of tools/collect_profiles.sh
-(gpurun_out/r01/).  Usage: python tools/make_profiles.py [round tag, default r01]"""
+(gpurun_out/<tag>/).  Usage: python tools/make_profiles.py [tag, default r02; e.g. r02_config2]"""
 import collections, csv, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ARGS = open(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")) else ""
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -28,9 +29,10 @@ with open(os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"), "w", newline="") a
         w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 with open(os.path.join(DST, f"{TAG}_bench_kernel_stats.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({TAG})\n\n")
-    f.write("Default bench: eager warm-up iterations, hipGraph capture, graph replays (timed region), then eager "
-            "iterations with the in-library event hooks and one single-view render per view; all 5 views of an "
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {ARGS} --no-cpu-baseline ({TAG})\n\n")
+    f.write("The bench run: eager warm-up iterations, hipGraph capture, graph replays (timed region), then eager "
+            "iterations with the in-library event hooks, one single-view render per view, the rasteriser-only timing and "
+            "the KNN_K report (torch kernels); all views of an "
             f"iteration go through ONE launch of each rasteriser kernel.  Total kernel time in the trace {tot:.1f} ms.\n\n")
     f.write("| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
     for r in rows[:45]:
@@ -62,7 +64,7 @@ def durations(dirname):
 # 4. HBM traffic
 fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
 traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over `python bench.py "
-                    "--steps 5 --warmup 2 --no-cpu-baseline --no-graph`; per-launch averages over ALL launches of a kernel in that "
+                    + ARGS + " --steps 5 --warmup 2 --no-cpu-baseline --no-graph`; per-launch averages over ALL launches of a kernel in that "
                     "run (the rasteriser kernels also run single-view at the end of the bench; the blend backward only runs "
                     "view-batched, 5 views per launch). FETCH_SIZE is reported in KB and counts 64 B per 128 B request on gfx950 "
                     "(MI355X_MICROARCH.md, HBM section): fetch_bytes = 2 * FETCH_SIZE * 1024; write_bytes = WRITE_SIZE * 1024 "
@@ -77,7 +79,7 @@ json.dump(traffic, open(os.path.join(DST, f"{TAG}_pmc_traffic.json"), "w"), inde
 sq, dur = pmc("pmc_sq"), durations("pmc_sq")
 with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
     f.write(f"# SQ counters per launch ({TAG}): rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES "
-            "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -- python bench.py --no-cpu-baseline --no-graph "
+            f"SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -- python bench.py {ARGS} --no-cpu-baseline --no-graph "
             "--steps 5 --warmup 2\n\n"
             "`valu %` = SQ_INSTS_VALU / (duration x 933 G wave-instructions/s): share of the chip's MEASURED fp32 VALU issue rate "
             "(tools/micro/pk_rate.hip: dependent-free v_fma_f32 streams, 8 waves per SIMD, reach 933 G wave64 instructions/s = "
@@ -96,4 +98,8 @@ with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
                 f"{c.get('SQ_INSTS_LDS', 0) / 1e6:.2f} | {c.get('SQ_WAVES', 0):.0f} | "
                 f"{100 * c.get('SQ_INSTS_VALU', 0) / (us * 1e-6 * 933e9):.0f} | {100 * c.get('SQ_ACTIVE_INST_VALU', 0) / cap:.0f} | "
                 f"{100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} | {100 * c.get('SQ_WAIT_ANY', 0) / wc:.0f} |\n")
+# the same counters for bench.py (roofline.valu): per kernel the per-launch averages and the counter run's duration
+json.dump({"_note": "per-launch averages of the SQ counter pass (see the .md of the same name)",
+           **{k: dict(c, us=sum(dur[k]) / len(dur[k])) for k, c in sq.items() if "fnx::" in k or ("kernel" in k and "at::" not in k)}},
+          open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(DST)))
