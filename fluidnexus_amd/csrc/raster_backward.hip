@@ -13,9 +13,6 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
-#ifndef FNX_BWD_WGS_PER_CU
-#define FNX_BWD_WGS_PER_CU 8  // resident-ish workgroups of the blend backward per compute unit (all views together)
-#endif
 #ifndef FNX_ABLATE
 #define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
 #endif
@@ -146,29 +143,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const float *__restrict__ acc_final, const float *__restrict__ dL_dpixels,
                       float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
                       float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
-                      uint32_t grad_limit, int P, const StaticRef st, const ViewBatch vb) {
+                      uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb) {
     constexpr int NV = MODE == 0 ? 6 + C : 5;
-    // static-split mode: records of splats with id >= st.id0 live in the view's static blob
-    const float4 *rec_static = nullptr;
-    const uint32_t id0 = st.base ? st.id0 : 0xFFFFFFFFu;
-    if (st.base) rec_static = reinterpret_cast<const float4 *>(st.base + st.stride * blockIdx.y + st.rec);
-    {
-        const int vw = blockIdx.y;  // per-view scratch, pixel gradients and screen-space accumulators
-        ranges = view_at(ranges, vb.img, vw);
-        final_Ts = view_at(final_Ts, vb.img, vw);
-        n_contrib = view_at(n_contrib, vb.img, vw);
-        acc_final = view_at(acc_final, vb.img, vw);
-        header = view_at(header, vb.img, vw);
-        point_list = view_at(point_list, vb.bin, vw);
-        blend_rec = view_at(blend_rec, vb.geom, vw);
-        dL_dpixels += (size_t)vw * C * H * W;
-        dL_dmean2D += (size_t)vw * P * 3;
-        dL_dconic += (size_t)vw * P * 4;
-        if (MODE == 0) {
-            dL_dopacity += (size_t)vw * P;
-            dL_dcolors += (size_t)vw * P * C;
-        }
-    }
     __shared__ uint32_t s_id[256];
     __shared__ float4 s_ra[256];  // x, y, conic a, conic b
     __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
@@ -177,16 +153,47 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ uint8_t s_list[16][256];  // lists 4 w .. 4 w + 3 are built and read by wave w alone
     __shared__ uint16_t s_mask[256];
     __shared__ uint32_t s_max[16];
-    if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] != 0u) return;
-    const uint32_t n_items = header[HDR_BWD_ITEMS];
-    const uint32_t *items = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(point_list) + vb.bin_items);
-    const float4 *bstate_all = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(point_list) + vb.bin_bstate);
+    __shared__ uint32_t s_first[kMaxViews + 1];  // ticket of every view's first work item; [n_views] = all items
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
-
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint32_t item = items[it];
+    // The work items of ALL views form one queue (view 0's first); workgroup b takes items b, b + grid, b + 2 grid, ...,
+    // so every workgroup samples the whole queue (all views, shallow and deep tiles alike) and the launch is sized to
+    // the workgroups that are resident at a time (launch_blend_backward).  Handing the items out in queue order through
+    // an atomic ticket measured 7 % slower (neighbouring tiles' batches then run at the same time and meet on the same
+    // splats' accumulators).  A view whose forward overflowed its binning capacity contributes no items.
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int v = 0; v < n_views; v++) {
+            const uint32_t *h = view_at(header, vb.img, v);
+            s_first[v] = run;
+            if (!(h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
+        }
+        s_first[n_views] = run;
+    }
+    for (uint32_t ticket = blockIdx.x;; ticket += gridDim.x) {
+        __syncthreads();  // the previous item is done with the LDS arrays; s_first is written
+        if (ticket >= s_first[n_views]) break;
+        int vw = 0;
+        while (ticket >= s_first[vw + 1]) vw++;
+        // per-view scratch, pixel gradients and screen-space accumulators of the item's view
+        const uint32_t *ranges_v = view_at(ranges, vb.img, vw);
+        const float *final_Ts_v = view_at(final_Ts, vb.img, vw);
+        const uint32_t *n_contrib_v = view_at(n_contrib, vb.img, vw);
+        const float *acc_final_v = view_at(acc_final, vb.img, vw);
+        const uint32_t *point_list_v = view_at(point_list, vb.bin, vw);
+        const float4 *blend_rec_v = view_at(blend_rec, vb.geom, vw);
+        const float *dL_dpixels_v = dL_dpixels + (size_t)vw * C * H * W;
+        float *dL_dmean2D_v = dL_dmean2D + (size_t)vw * P * 3;
+        float *dL_dconic_v = dL_dconic + (size_t)vw * P * 4;
+        float *dL_dopacity_v = MODE == 0 ? dL_dopacity + (size_t)vw * P : nullptr;
+        float *dL_dcolors_v = MODE == 0 ? dL_dcolors + (size_t)vw * P * C : nullptr;
+        // static-split mode: records of splats with id >= st.id0 live in the view's static blob
+        const uint32_t id0 = st.base ? st.id0 : 0xFFFFFFFFu;
+        const float4 *rec_static = st.base ? reinterpret_cast<const float4 *>(st.base + st.stride * vw + st.rec) : nullptr;
+        const uint32_t *items = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(point_list_v) + vb.bin_items);
+        const float4 *bstate_all = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(point_list_v) + vb.bin_bstate);
+        const uint32_t item = items[ticket - s_first[vw]];
         const int tile = (int)(item & 0x3FFFu);
         const uint32_t b = item >> 14;
         const int tx = tile % gx, ty = tile / gx;
@@ -195,17 +202,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const bool inside = px < W && py < H;
         const uint32_t pix_id = (uint32_t)W * py + px;
         const float pxf = (float)px, pyf = (float)py;
-        const uint32_t r0 = ranges[2 * tile];
+        const uint32_t r0 = ranges_v[2 * tile];
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
 
-        const float T_final = inside ? final_Ts[pix_id] : 0.f;
-        const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+        const float T_final = inside ? final_Ts_v[pix_id] : 0.f;
+        const uint32_t last_contributor = inside ? n_contrib_v[pix_id] : 0u;
         float dL_dpixel[C], total[C], pre[C];
         float Tr = 1.0f;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) {
-            dL_dpixel[ch] = inside ? dL_dpixels[(size_t)ch * H * W + pix_id] : 0.f;
-            total[ch] = inside ? acc_final[(size_t)ch * H * W + pix_id] : 0.f;
+            dL_dpixel[ch] = inside ? dL_dpixels_v[(size_t)ch * H * W + pix_id] : 0.f;
+            total[ch] = inside ? acc_final_v[(size_t)ch * H * W + pix_id] : 0.f;
             pre[ch] = 0.f;
         }
         if (b) {  // state in front of the batch, as the forward left it
@@ -219,11 +226,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #pragma unroll
         for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
 
-        // entry q (0-based from the front) is used by a pixel iff q < its n_contrib (backward.cu:467-469):
+        // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
         uint32_t m = last_contributor;
         for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-        __syncthreads();  // the previous item is done with the LDS arrays
         if ((lane & 15) == 0) s_max[4 * w + row] = m;
         __syncthreads();
         uint32_t qmax = 0;
@@ -235,10 +241,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
             const uint32_t q = q0 + tid;
-            const uint32_t id = point_list[r0 + q];
-            const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec + 4 * (size_t)id;
+            const uint32_t id = point_list_v[r0 + q];
+            const float4 *rec = id >= id0 ? rec_static + 4 * (size_t)(id - id0) : blend_rec_v + 4 * (size_t)id;
             const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-            qm = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(point_list) + vb.bin_masks)[r0 + q];
+            qm = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(point_list_v) + vb.bin_masks)[r0 + q];
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);
@@ -340,16 +346,16 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 any |= (a[v] != 0.f);
             }
             if (any && FNX_ABLATE != 1) {
-                unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], a[0]);
-                unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], a[1]);
-                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], a[2]);
-                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], a[3]);
-                unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 3], a[4]);
+                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], a[0]);
+                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], a[1]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], a[2]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], a[3]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], a[4]);
                 if (MODE == 0) {
-                    unsafeAtomicAdd(&dL_dopacity[id], a[MODE == 0 ? 5 : 0]);
+                    unsafeAtomicAdd(&dL_dopacity_v[id], a[MODE == 0 ? 5 : 0]);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++)
-                        unsafeAtomicAdd(&dL_dcolors[(size_t)id * C + ch], a[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)]);
+                        unsafeAtomicAdd(&dL_dcolors_v[(size_t)id * C + ch], a[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)]);
                 }
             }
         }
@@ -653,6 +659,17 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// The grid is exactly the workgroups that are resident at a time (registers allow 5 per compute unit): a larger grid
+// would run its surplus as a second, half-empty round.
+template <int C, int MODE, typename... A>
+static void launch_blend_backward_t(int n_cu, hipStream_t s, A... args) {
+    static int per_cu = 0;
+    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blend_backward_kernel<C, MODE>, 256, 0) != hipSuccess ||
+                        per_cu <= 0))
+        per_cu = 4;
+    hipLaunchKernelGGL((blend_backward_kernel<C, MODE>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+}
+
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
@@ -667,16 +684,10 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    const int G = (n_cu * FNX_BWD_WGS_PER_CU + V - 1) / V;
-#define FNX_LAUNCH_BB(CC, MM)                                                                                           \
-    hipLaunchKernelGGL((blend_backward_kernel<CC, MM>), dim3(G, V), dim3(256), 0, s, T, gx, ranges, point_list, W, H,    \
-                       bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity,  \
-                       dL_dcolors, header, capacity, grad_limit, P, st, vb)
-    if (C == 3 && mode == 0) FNX_LAUNCH_BB(3, 0);
-    else if (C == 3) FNX_LAUNCH_BB(3, 1);
-    else if (mode == 0) FNX_LAUNCH_BB(1, 0);
-    else FNX_LAUNCH_BB(1, 1);
-#undef FNX_LAUNCH_BB
+    if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    else if (C == 3) launch_blend_backward_t<3, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    else launch_blend_backward_t<1, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
