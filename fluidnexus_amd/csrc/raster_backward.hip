@@ -145,18 +145,32 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
                       uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb) {
     constexpr int NV = MODE == 0 ? 6 + C : 5;
+#ifndef FNX_BWD_GROUP
+#define FNX_BWD_GROUP 4
+#endif
+    constexpr int kGroup = FNX_BWD_GROUP;  // list entries per step of the gradient loop
+    constexpr int kListStride = (256 + kGroup + 7) & ~7;
+    // staged batch: three 16-byte records per slot; slot 256 is a NULL record (opacity 0: alpha = 0, no gradient) that
+    // the tail of every block list points to, so the loop needs no end-of-list test per entry
     __shared__ uint32_t s_id[256];
-    __shared__ float4 s_ra[256];  // x, y, conic a, conic b
-    __shared__ float4 s_rb[256];  // conic c, opacity, exp-skip threshold, -
-    __shared__ float s_col[C][256];
+    __shared__ float4 s_ra[257];  // x, y, conic a, conic b
+    __shared__ float4 s_rb[257];  // conic c, opacity, -, 1.0 if the splat wants gradients (id < grad_limit) else 0.0
+    __shared__ float4 s_rc[257];  // colour (C channels)
     __shared__ float s_acc[NV][256];
-    __shared__ uint8_t s_list[16][256];  // lists 4 w .. 4 w + 3 are built and read by wave w alone
+    // per-block lists of LDS byte offsets (slot * 16), depth order; lists 4 w .. 4 w + 3 are built, padded and read by
+    // wave w alone
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[16][kListStride];
     __shared__ uint16_t s_mask[256];
     __shared__ uint32_t s_max[16];
     __shared__ uint32_t s_first[kMaxViews + 1];  // ticket of every view's first work item; [n_views] = all items
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
+    if (tid == 0) {
+        s_ra[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rb[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // The work items of ALL views form one queue (view 0's first); workgroup b takes items b, b + grid, b + 2 grid, ...,
     // so every workgroup samples the whole queue (all views, shallow and deep tiles alike) and the launch is sized to
     // the workgroups that are resident at a time (launch_blend_backward).  Handing the items out in queue order through
@@ -250,14 +264,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 if (q >= s_max[k]) qm &= ~(1u << k);
             s_id[tid] = id;
             s_ra[tid] = ra;
-            s_rb[tid] = rb;
-            s_col[0][tid] = rc.z;
-            if (C > 1) s_col[C > 1 ? 1 : 0][tid] = rc.w;
-            if (C > 2) s_col[C > 2 ? 2 : 0][tid] = rec[3].x;
+            s_rb[tid] = make_float4(rb.x, rb.y, 0.f, id < grad_limit ? 1.0f : 0.0f);
+            s_rc[tid] = make_float4(rc.z, C > 1 ? rc.w : 0.f, C > 2 ? rec[3].x : 0.f, 0.f);
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
         s_mask[tid] = (uint16_t)qm;
+        {  // this wave's four lists start out as NULL pointers (slot 256) from end to end
+            const uint4 nul = make_uint4(0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u);
+            uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
+            for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
+        }
         __syncthreads();
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's four lists
 #pragma unroll
@@ -267,73 +284,80 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             for (int bb = 0; bb < 4; bb++) {
                 const bool bit = (mk >> bb) & 1u;
                 const unsigned long long bm = __ballot(bit);
-                if (bit) s_list[4 * w + bb][len[bb] + (uint32_t)__popcll(bm & lt_mask)] = (uint8_t)(64 * k + lane);
+                if (bit) s_list[4 * w + bb][len[bb] + (uint32_t)__popcll(bm & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
                 len[bb] += (uint32_t)__popcll(bm);
             }
         }
         const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
-        const uint32_t my_len = row == 0 ? len[0] : row == 1 ? len[1] : row == 2 ? len[2] : len[3];
-        const uint8_t *mylist = s_list[4 * w + row];
-
-        for (uint32_t i = 0; i < (FNX_ABLATE == 3 ? 0u : n_w); i++) {
-            const bool listed = i < my_len;  // uniform within a row
-            const uint32_t j = listed ? (uint32_t)mylist[i] : 0u;
-            const uint32_t q = q0 + j;
-            const bool wants = listed && s_id[j] < grad_limit;  // uniform within a row
-            float val[NV];
+        const uint16_t *mylist = s_list[4 * w + row];
+        // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
+        // the pixel does not take has alpha = 0, which leaves T and the colour prefix exactly as they are (x * 1, + 0)
+        // and zeroes every gradient term; the NULL record behind a list's end is such an entry for every pixel.
+        for (uint32_t i0 = 0; i0 < (FNX_ABLATE == 3 ? 0u : n_w); i0 += kGroup) {
+            uint32_t jw[(kGroup + 1) / 2];
 #pragma unroll
-            for (int v = 0; v < NV; v++) val[v] = 0.f;
-            bool active = listed && q < last_contributor;
-            if (active) {
-                const float4 ra = s_ra[j];
-                const float4 rb = s_rb[j];
-                const float dx = ra.x - pxf, dy = ra.y - pyf;
-                const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
-                active = !(power > 0.0f) && !(power < rb.z);
-                if (active) {
-                    const float G = exp_fixed_in_range(power);  // here thr <= power <= 0
-                    const float alpha = fminf(0.99f, rb.y * G);
-                    active = !(alpha < 1.0f / 255.0f);
-                    if (active) {
-                        // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
-                        // the backward is compared within fp32 summation tolerance, not bit for bit
-                        const float one_m = 1 - alpha;
-                        const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
-                        const float Tb = Tr;  // transmittance in front of the entry
-                        const float dchannel_dcolor = alpha * Tb;
-                        float dL_dalpha = 0.0f;
+            for (int k = 0; k < (kGroup + 1) / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
+            float4 ra[kGroup], rb[kGroup], rc[kGroup];
 #pragma unroll
-                        for (int ch = 0; ch < C; ch++) {
-                            const float c = s_col[ch][j];
-                            pre[ch] = pre[ch] + c * alpha * Tb;  // the forward's accumulation, same association
-                            const float behind = total[ch] - pre[ch];
-                            const float dL_dchannel = dL_dpixel[ch];
-                            dL_dalpha += (c * Tb - behind * inv_1ma) * dL_dchannel;
-                            if (MODE == 0) val[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)] = dchannel_dcolor * dL_dchannel;
-                        }
-                        Tr = Tb * one_m;  // the forward's test_T
-                        if (wants) {
-                            dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-                            const float dL_dG = rb.y * dL_dalpha;
-                            const float gdx = G * dx;
-                            const float gdy = G * dy;
-                            const float dG_ddelx = -gdx * ra.z - gdy * ra.w;
-                            const float dG_ddely = -gdy * rb.x - gdx * ra.w;
-                            val[0] = dL_dG * dG_ddelx * ddelx_dx;
-                            val[1] = dL_dG * dG_ddely * ddely_dy;
-                            val[2] = -0.5f * gdx * dx * dL_dG;
-                            val[3] = -0.5f * gdx * dy * dL_dG;
-                            val[4] = -0.5f * gdy * dy * dL_dG;
-                            if (MODE == 0) val[MODE == 0 ? 5 : 0] = G * dL_dalpha;
-                        }
-                    }
-                }
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                ra[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+                rb[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+                rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
             }
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t slot = ((jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) >> 4;
+                const float dx = ra[k].x - pxf, dy = ra[k].y - pyf;
+                const float power = -0.5f * (ra[k].z * dx * dx + rb[k].x * dy * dy) - ra[k].w * dx * dy;
+                const float G = exp_fixed_in_range(fmaxf(power, -87.0f));
+                const float alpha = fminf(0.99f, rb[k].y * G);
+                // the forward's decision (blend_forward_kernel), for the entries in front of the pixel's last contributor
+                const bool active = !(power > 0.0f) && !(alpha < 1.0f / 255.0f) && (q0 + slot < last_contributor);
+                const bool wants = rb[k].w != 0.0f;  // uniform within a row
+                const float a = active ? alpha : 0.0f;
+                // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
+                // the backward is compared within fp32 summation tolerance, not bit for bit
+                const float one_m = 1 - a;
+                const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
+                const float Tb = Tr;  // transmittance in front of the entry
+                const float col[3] = {rc[k].x, rc[k].y, rc[k].z};
+                float dL_dalpha = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    const float c = col[ch];
+                    pre[ch] = pre[ch] + c * a * Tb;  // the forward's accumulation, same association
+                    const float behind = total[ch] - pre[ch];
+                    dL_dalpha += (c * Tb - behind * inv_1ma) * dL_dpixel[ch];
+                }
+                Tr = Tb * one_m;  // the forward's test_T
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                const bool emits = active && wants;
+                const float dL_da = emits ? dL_dalpha : 0.0f;
+                const float dL_dG = rb[k].y * dL_da;
+                const float Gm = active ? G : 0.0f;  // power > 0 can push the range-limited exp out of range: never into a sum
+                const float gdx = Gm * dx;
+                const float gdy = Gm * dy;
+                const float dG_ddelx = -gdx * ra[k].z - gdy * ra[k].w;
+                const float dG_ddely = -gdy * rb[k].x - gdx * ra[k].w;
+                float val[NV];
+                val[0] = dL_dG * dG_ddelx * ddelx_dx;
+                val[1] = dL_dG * dG_ddely * ddely_dy;
+                val[2] = -0.5f * gdx * dx * dL_dG;
+                val[3] = -0.5f * gdx * dy * dL_dG;
+                val[4] = -0.5f * gdy * dy * dL_dG;
+                if (MODE == 0) {
+                    val[MODE == 0 ? 5 : 0] = Gm * dL_da;
+                    const float dchannel_dcolor = emits ? a * Tb : 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) val[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)] = dchannel_dcolor * dL_dpixel[ch];
+                }
 #if FNX_ABLATE == 2
-            { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
+                { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
 #else
-            if (__ballot(active && wants) != 0ull) row_fold_accumulate<NV>(val, s_acc, j, lane, wants);
+                if (__ballot(emits) != 0ull) row_fold_accumulate<NV>(val, s_acc, slot & 255u, lane, wants);
 #endif
+            }
         }
         __syncthreads();
         if ((uint32_t)tid < cnt) {
