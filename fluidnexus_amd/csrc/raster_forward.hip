@@ -378,7 +378,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 // emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
 // pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
 #ifndef FNX_FWD_WAVES
-#define FNX_FWD_WAVES 3  // waves per SIMD the register allocation of the blend forward aims at
+#define FNX_FWD_WAVES 4  // waves per SIMD the register allocation of the blend forward aims at (4: 469 us, 3: 486 us on config 3)
 #endif
 template <int C, bool SPLIT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
