@@ -1,12 +1,13 @@
 """Build the committed summaries under profiles/ from the raw rocprofv3 output of tools/collect_profiles.sh
-(gpurun_out/<tag>/).  Usage: python tools/make_profiles.py [tag, default r02; e.g. r02_config2]"""
+(gpurun_out/<tag>/).  Usage: python tools/make_profiles.py [tag, default r02; e.g. r02_config2] [output directory,
+default profiles/].  collect_profiles.sh runs it on the GPU box (the raw traces are too large to travel back)."""
 import collections, csv, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ARGS = open(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")) else ""
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
-DST = os.path.join(ROOT, "profiles")
+DST = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
 
