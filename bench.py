@@ -456,6 +456,10 @@ def main():
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
                    "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2),
                    "distance_loss": not a.no_distance, "scene": a.scene if cfg_id in (3, 4) else "backdrop",
+                   "scene_note": ("background Gaussians BEHIND the plume: the fluid is visible to every camera and its image "
+                                  "gradient is non-zero" if (a.scene == "backdrop" or cfg_id not in (3, 4)) else
+                                  "round-1 layout: background cloud around the plume (the fluid is occluded in every view, "
+                                  "tiles saturate early); kept for like-for-like comparison with round 1"),
                    "launch": (f"hipGraph replay, {loop.graph_iterations} whole iteration(s) per graph" if graph_mode
                               else "eager"),
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
