@@ -685,6 +685,11 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                     atomicAdd(&g_fwd_stats[2], hit ? 1ull : 0ull);
                     atomicAdd(&g_fwd_stats[4], (unsigned long long)__popcll(live));
                     atomicAdd(&g_fwd_stats[3], (unsigned long long)((i0 + k < len[0]) + (i0 + k < len[1]) + (i0 + k < len[2]) + (i0 + k < len[3])));
+                    int halves = 0, rows_hit = 0;
+                    for (int h = 0; h < 8; h++) halves += ((hit >> (8 * h)) & 0xFFull) != 0;
+                    for (int h = 0; h < 4; h++) rows_hit += ((hit >> (16 * h)) & 0xFFFFull) != 0;
+                    atomicAdd(&g_fwd_stats[5], (unsigned long long)halves);
+                    atomicAdd(&g_fwd_stats[6], (unsigned long long)rows_hit);
                 }
             }
 #endif

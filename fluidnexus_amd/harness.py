@@ -151,6 +151,7 @@ class HotLoop:
         self._gt_cache = None
         self.graph_iterations = 1
         self.side_stream = None
+        self.ch1_stream = None
         self.fused_step = bool(fused_step)  # gradient mean + Adam as one kernel (batched_views only)
         if self.fused_step:
             assert self.batched_views and capturable, "fused_step needs batched_views and capturable=True"
@@ -443,13 +444,21 @@ class HotLoop:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
             outs, seeds = [pkg["render"]], [dimg]
             if self.dual_channel:
+                # the 1-channel render of the fluid (config 5) and its image term on their own stream, next to the
+                # 3-channel render: with few views per rank both blend forwards are bound by their deepest tiles' walks,
+                # not by throughput, and overlap almost entirely; autograd runs each backward on its forward's stream
                 from .renderer.pipes import render_fluid_views
+                if self.ch1_stream is None:
+                    self.ch1_stream = torch.cuda.Stream(device=gm._xyz.device)
                 n_fluid = means3D.shape[0] - gm.get_gs_xyz.shape[0]
-                pkg1 = render_fluid_views([self.cams[v] for v in mine], gm, None, self.background,
-                                          GRsetting=self.GRsetting1, GRzer=self.GRzer1, pos_type="guess_visual_nn",
-                                          scale=True, means3D=means3D[:n_fluid])
-                _, _, dimg1 = image_loss_value_and_grad(pkg1["render"].detach(), self._gt_stack(mine, "original_image_ch1"),
-                                                        c["lambda_dssim"], c["lambda_image"], grey=False)
+                self.ch1_stream.wait_event(fork)
+                with torch.cuda.stream(self.ch1_stream):
+                    pkg1 = render_fluid_views([self.cams[v] for v in mine], gm, None, self.background,
+                                              GRsetting=self.GRsetting1, GRzer=self.GRzer1, pos_type="guess_visual_nn",
+                                              scale=True, means3D=means3D[:n_fluid])
+                    _, _, dimg1 = image_loss_value_and_grad(pkg1["render"].detach(), self._gt_stack(mine, "original_image_ch1"),
+                                                            c["lambda_dssim"], c["lambda_image"], grey=False)
+                main.wait_stream(self.ch1_stream)
                 outs.append(pkg1["render"])
                 seeds.append(dimg1)
             g_means, = torch.autograd.grad(outs, [means3D], grad_outputs=seeds)

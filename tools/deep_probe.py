@@ -45,9 +45,9 @@ if hasattr(lib, "fnx_debug_fwd_stats"):
         f()
     torch.cuda.synchronize()
     lib.fnx_debug_fwd_stats(buf, 0)
-    e, hits, any_hit, blocks, live, halves = [int(x) for x in buf[:6]]
+    e, hits, any_hit, blocks, live, halves, rows_hit = [int(x) for x in buf[:7]]
     print(f"wave-entries {e}  lanes hit/entry {hits / e:.1f} of {live / e:.1f} alive  entries with a hit {any_hit / e:.3f}  "
-          f"rows with a list entry per step {blocks / e:.2f} of 4")
+          f"rows with a list entry per step {blocks / e:.2f} of 4; rows hit {rows_hit / e:.2f}; 4x2 half-rows hit {halves / e:.2f} of 8")
 if hasattr(lib, "fnx_debug_fwd_wg"):
     import numpy as np
     n = 5 * 1024
