@@ -298,3 +298,22 @@ def test_callback_forward_and_plain_backward_entry_points(oracle, channels):
         gr["dL_drotations"].data_ptr(), s))
     torch.cuda.synchronize()
     _assert_grads_close({k: v for k, v in go.items() if k in gr}, {k: v.cpu().numpy() for k, v in gr.items()})
+
+
+@pytest.mark.parametrize("channels", [3, 1])
+def test_ball_style_scene_both_rasterisers(oracle, channels):
+    """BASELINE config 5 at reduced size, one camera of the 8-camera ring: the 3-channel rasteriser sees fluid +
+    background wall, the 1-channel one the fluid alone (both run per view in that configuration).  A deep,
+    semi-transparent plume in front of a wall: many batches per tile, block lists of very different lengths."""
+    W = H = 160
+    if channels == 3:
+        g = S.smoke_scene(14_000, 6_000, seed=9, channels=3, ring=True)
+    else:
+        g = S.plume_gaussians(14_000, seed=9, channels=1)
+    cam = S.ring_cameras(8, W, H, device="cpu")[3]
+    bg = np.array([0.05, 0.1, 0.2], np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg, channels=channels)
+    it = _assert_forward_exact(f, h)
+    assert int(it["n_contrib"].max()) > 600  # the plume is deep: several 256-entry batches per tile
+    dL = np.random.RandomState(4).normal(size=(channels, H, W)).astype(np.float32)
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
