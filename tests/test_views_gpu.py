@@ -257,6 +257,60 @@ def test_views_sync_free_capacity_overflow_is_reported():
         rasterizer.set_host_sync(True)
 
 
+def test_capacity_overflow_inside_a_graph_replay_is_reported():
+    """A forward recorded into a hipGraph keeps its binning capacity; when the replayed scene has grown beyond it (the
+    splats are inflated in place between replays) the replay renders nothing for the overflowing views and the next
+    check_status() raises, although no Python ran during the replay: the captured forward's status rows are persistent
+    and re-read on every check."""
+    from fluidnexus_amd import _lib, rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews, ViewBatch
+    dev = torch.device("cuda")
+    W = H = 64
+    g = S.random_gaussians(3000, seed=2, box=0.5, log_scale=(-5.5, -4.5))
+    cams = S.arc_cameras(2, W, H, target=(0.0, 0.0, 0.0), distance=2.0, height=0.1, device=dev)
+    bg = torch.zeros(3, device=dev)
+    vb = ViewBatch(_settings(cams, W, H, bg, [0.8, 0.8]))
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    screen = torch.zeros(2, 3000, 3, device=dev)
+
+    def run():
+        return GaussianRasterizerViews(vb)(means3D=t["means3D"], means2D=screen, shs=None, colors_precomp=t["colors"],
+                                           opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                                           cov3D_precomp=None)[0]
+    stream = torch.cuda.Stream()
+    try:
+        rasterizer.set_host_sync(False)
+        rasterizer._capacity_hwm.clear()
+        rasterizer.release_captured_status()
+        with torch.no_grad():
+            run()                      # sizes the buffer (small splats)
+            rasterizer.check_status()
+            graph = torch.cuda.CUDAGraph()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                run()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=stream):
+                    out = run()
+            graph.replay()
+            torch.cuda.synchronize()
+            rasterizer.check_status()  # fits: no error, and the check does not consume the captured rows
+            small, keep = out.clone(), t["scales"].clone()
+            t["scales"].add_(2.0)      # e^2 times larger splats: several times the instances
+            graph.replay()
+            torch.cuda.synchronize()
+            with pytest.raises(_lib.FnxError):
+                rasterizer.check_status()
+            t["scales"].copy_(keep)
+            graph.replay()
+            torch.cuda.synchronize()
+            rasterizer.check_status()
+            assert torch.equal(out, small)
+    finally:
+        rasterizer.release_captured_status()
+        rasterizer.set_host_sync(True)
+
+
 def test_image_loss_value_and_grad_matches_autograd_node():
     """The hot loop's two-launch image term (scalar reduction inside the backward launch) against the autograd
     node fused_image_loss: loss, per-image terms and the gradient with respect to the rendered batch."""
