@@ -317,3 +317,26 @@ def test_ball_style_scene_both_rasterisers(oracle, channels):
     assert int(it["n_contrib"].max()) > 600  # the plume is deep: several 256-entry batches per tile
     dL = np.random.RandomState(4).normal(size=(channels, H, W)).astype(np.float32)
     _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+def test_non_finite_colour_is_a_stated_deviation(oracle):
+    """Inputs are assumed finite: the blends multiply the colour of an entry a pixel does NOT take by
+    alpha = 0 instead of skipping it, so a NaN colour also reaches the other pixels of the 4x4 blocks the splat's
+    footprint touches, where the reference leaves the pixel alone.  This pins the extent of the deviation: every
+    pixel the reference would poison is poisoned, every other NaN lies within a block of one of those, and all
+    remaining pixels are bit-identical."""
+    P, W, H = 400, 64, 64
+    g = S.random_gaussians(P, seed=12, box=0.4, log_scale=(-4.2, -3.2))
+    g["colors"][7] = np.nan
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    f, h = _run_pair(oracle, g, cam, W, H, bg)
+    ref, got = f["color"], h.intermediates()["color"]
+    nan_ref, nan_got = np.isnan(ref).any(0), np.isnan(got).any(0)
+    assert nan_ref.sum() > 0 and (nan_got | ~nan_ref).all()          # superset of the reference's poisoned pixels
+    ys, xs = np.nonzero(nan_got & ~nan_ref)
+    ry, rx = np.nonzero(nan_ref)
+    for y, x in zip(ys, xs):                                          # extras: same 4x4 block neighbourhood only
+        assert (np.maximum(np.abs(ry - y), np.abs(rx - x)) <= 4).any(), (y, x)
+    ok = ~nan_got
+    assert (got[:, ok].view(np.uint32) == ref[:, ok].view(np.uint32)).all()
