@@ -147,74 +147,25 @@ __device__ __forceinline__ void splat_footprint(float a, float b, float c, float
     ey = fy;
 }
 
-// Which 8x8 quadrants of the 16x16 tile at (tile_x0, tile_y0) the footprint box touches.
-// Bit q <-> quadrant (q & 1, q >> 1).
-__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float ex, float ey, float tile_x0, float tile_y0) {
-    if (ex < 0.0f) return 0u;
-    const float xl = x - ex, xh = x + ex, yl = y - ey, yh = y + ey;
-    const bool cx0 = (xl <= tile_x0 + 7.0f) && (xh >= tile_x0), cx1 = (xl <= tile_x0 + 15.0f) && (xh >= tile_x0 + 8.0f);
-    const bool cy0 = (yl <= tile_y0 + 7.0f) && (yh >= tile_y0), cy1 = (yl <= tile_y0 + 15.0f) && (yh >= tile_y0 + 8.0f);
-    return (uint32_t)(cx0 && cy0) | ((uint32_t)(cx1 && cy0) << 1) | ((uint32_t)(cx0 && cy1) << 2) |
-           ((uint32_t)(cx1 && cy1) << 3);
-}
-
-// Minimum of the quadratic form q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 (conic of a splat, positive
-// definite) over the rectangle [X0, X1] x [Y0, Y1] of offsets from the splat centre: 0 if the centre is
-// inside, otherwise the smallest of the four edge minima (1-D quadratics, clamped minimisers).
-__device__ __forceinline__ float conic_min_over_rect(float a, float b, float c, float X0, float X1, float Y0,
-                                                     float Y1) {
-    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
-    const float nbc = -b / c, nba = -b / a;
-    float m = 3.0e38f;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const float X = k ? X1 : X0;
-        const float dy = fminf(fmaxf(nbc * X, Y0), Y1);
-        m = fminf(m, a * X * X + 2.0f * b * X * dy + c * dy * dy);
-        const float Y = k ? Y1 : Y0;
-        const float dx = fminf(fmaxf(nba * Y, X0), X1);
-        m = fminf(m, a * dx * dx + 2.0f * b * dx * Y + c * Y * Y);
-    }
-    return m;
-}
-
-// quadrant_mask refined with the exact ellipse test: a pixel can contribute only where
-// power = -q/2 >= thr (thr = -(ln(255 o) with margins), see splat_footprint), so a quadrant whose
-// minimum of q exceeds -2 thr (plus a further 0.1 % + 0.01, far above the fp32 error of the evaluation
-// near the threshold) holds no contributing pixel.  Any NaN keeps the quadrant.
-__device__ __forceinline__ uint32_t quadrant_mask_exact(float x, float y, float a, float b, float c, float thr,
-                                                        float ex, float ey, float tile_x0, float tile_y0) {
-    uint32_t m = quadrant_mask(x, y, ex, ey, tile_x0, tile_y0);
-    if (m == 0u) return 0u;
-    const float lim = (-2.0f * thr) * 1.001f + 0.01f;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if ((m >> q) & 1u) {
-            const float X0 = tile_x0 + (float)((q & 1) * 8) - x, Y0 = tile_y0 + (float)((q >> 1) * 8) - y;
-            if (conic_min_over_rect(a, b, c, X0, X0 + 7.0f, Y0, Y0 + 7.0f) > lim) m &= ~(1u << q);
-        }
-    }
-    return m;
-}
-
 // Pixel of its 16x16 tile that lane `lane` of wave `w` of a blend workgroup (forward and backward) owns: a wave is an
 // 8x8 quadrant (w & 1, w >> 1), a row of 16 lanes one 4x4 block of it (block_mask_exact's bit order), lane & 15 the
 // pixel of the block, row-major.
 __device__ __forceinline__ int blend_pixel_x(int w, int lane) { return (w & 1) * 8 + ((lane >> 4) & 1) * 4 + (lane & 3); }
 __device__ __forceinline__ int blend_pixel_y(int w, int lane) { return (w >> 1) * 8 + (lane >> 5) * 4 + ((lane >> 2) & 3); }
 
-// 4x4-pixel blocks of the 16x16 tile at (tile_x0, tile_y0) that can hold a contributing pixel of the splat: the
-// footprint box test of quadrant_mask per block, refined with the exact ellipse test of quadrant_mask_exact (same
-// margins).  Bit 4 q + b <-> block (b & 1, b >> 1) of quadrant q = (q & 1, q >> 1), i.e. the block whose first pixel
-// is (8 (q & 1) + 4 (b & 1), 8 (q >> 1) + 4 (b >> 1)).
+// 4x4-pixel blocks of the 16x16 tile at (tile_x0, tile_y0) that can hold a contributing pixel of the splat.  A pixel
+// can contribute only where power = -q/2 >= thr (thr = -ln(255 o) with margins, see splat_footprint), so a block over
+// which the minimum of the conic's quadratic form q exceeds -2 thr (plus a further 0.1 % + 0.01, far above the fp32
+// error of the evaluation near the threshold) holds no contributing pixel.  Bit 4 q + b <-> block (b & 1, b >> 1) of
+// quadrant q = (q & 1, q >> 1), i.e. the block whose first pixel is (8 (q & 1) + 4 (b & 1), 8 (q >> 1) + 4 (b >> 1)).
 __device__ __forceinline__ uint32_t block_mask_exact(float x, float y, float a, float b, float c, float thr, float ex,
                                                      float ey, float tile_x0, float tile_y0) {
     if (ex < 0.0f) return 0u;
     // The minimum of q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 over a block is 0 if the centre lies in it, otherwise
-    // the least of its four edge minima (conic_min_over_rect).  The edges lie on 8 vertical and 8 horizontal lines of
+    // the least of its four edge minima (1-D quadratics with clamped minimisers).  The edges lie on 8 vertical and 8 horizontal lines of
     // the tile (block starts 0 4 8 12, block ends 3 7 11 15): the per-line terms are computed once, an edge then costs
-    // a clamp (v_med3), two fused multiply-adds and a min.  Culling arithmetic is free to fuse: its margins (see
-    // quadrant_mask_exact) dwarf the rounding.
+    // a clamp (v_med3), two fused multiply-adds and a min.  Culling arithmetic is free to fuse: its margins dwarf the
+    // rounding.
     const float lim = (-2.0f * thr) * 1.001f + 0.01f;
     const float nbc = -b / c, nba = -b / a, b2 = 2.0f * b;
     const float ox = tile_x0 - x, oy = tile_y0 - y;

@@ -1,14 +1,14 @@
 // Backward pass of the gfx950 Gaussian rasteriser.
 //
-//   blend_backward : per tile, back-to-front, pixel gradients -> per-splat screen-space gradients
-//                    (ch3 backward.cu:384-536)
+//   blend_backward : per batch of 256 entries of a tile's list, front to back, pixel gradients -> per-splat
+//                    screen-space gradients (ch3 backward.cu:384-536)
 //   geom_backward  : per splat, screen-space gradients -> means / cov3D / scale / rotation / SH
 //                    (ch3 backward.cu:137-263 computeCov2DCUDA fused with :332-381 preprocessCUDA;
 //                    same arithmetic, same order of the three mean-gradient terms)
 //
 // The reference issues 6+C global fp32 atomics per contributing (pixel, splat) pair.  Here each
-// pair's contribution is first summed across the 64 lanes of its wave with DPP row operations,
-// then across the tile's 4 waves in LDS, and one set of atomics per (tile, splat) reaches HBM:
+// pair's contribution is first summed across the 16 lanes of its 4x4 block with DPP row operations,
+// then across the tile's 16 blocks in LDS, and one set of atomics per (tile, batch, splat) reaches HBM:
 // ~256x fewer device-scope atomics, same sums up to fp32 association order.
 #include "fnx_device.h"
 #include "fnx_state.h"
@@ -19,67 +19,12 @@
 
 namespace fnx {
 
-// Sum over the 64 lanes of a wave; the total lands in lane 63.  DPP steps: quad swaps, row
-// shifts by 4 and 8, then row broadcasts 15 and 31 (gfx9 DPP encodings).
+// DPP row operations (gfx9 encodings): quad permutes 0xb1 / 0x4e, row_shr:4 / :8 = 0x114 / 0x118, row_ror:8 = 0x128,
+// row_half_mirror = 0x141.
 #define FNX_DPP(v, ctrl, rmask) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
-__device__ __forceinline__ float row_sum_to_lane15(float v) {  // per 16-lane row
-    v += FNX_DPP(v, 0xb1, 0xf);
-    v += FNX_DPP(v, 0x4e, 0xf);
-    v += FNX_DPP(v, 0x114, 0xf);
-    v += FNX_DPP(v, 0x118, 0xf);
-    return v;
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = row_sum_to_lane15(v);
-    v += FNX_DPP(v, 0x142, 0xa);
-    v += FNX_DPP(v, 0x143, 0xc);
-    return v;
-}
-// gfx950 lane-swap instructions: swap32(a, b) exchanges a's upper 32 lanes with b's lower 32 lanes,
-// swap16(a, b) exchanges a's odd 16-lane rows with b's even rows; adding the two results folds two
-// values at once (a's sums land in the lower half / even rows, b's in the upper half / odd rows).
-__device__ __forceinline__ float fold32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float fold16(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// Cross-lane sums of NV per-lane values of one wave, added into acc[v][slot] (LDS).  Folding tree:
-// 64 -> 32 lanes pairs values (v0|v1), 32 -> 16 pairs the pairs, then a row reduction: 26 VALU
-// operations for 9 values instead of 54, and 3 LDS atomics instead of 9.
-template <int NV>
-__device__ __forceinline__ void wave_fold_accumulate(const float (&val)[NV], float (*acc)[256], uint32_t slot, int lane) {
-    constexpr int NP = NV / 2;   // pairs after the 32-fold
-    constexpr int NQ = NP / 2;   // quads after the 16-fold
-    float s[NP > 0 ? NP : 1];
-#pragma unroll
-    for (int p = 0; p < NP; p++) s[p] = fold32(val[2 * p], val[2 * p + 1]);
-    const int row = lane >> 4;
-    const bool tail = (lane & 15) == 15;
-#pragma unroll
-    for (int k = 0; k < NQ; k++) {
-        // rows of t: [val[4k], val[4k+2], val[4k+1], val[4k+3]]
-        const float t = row_sum_to_lane15(fold16(s[2 * k], s[2 * k + 1]));
-        const int vi = 4 * k + ((row & 1) << 1) + (row >> 1);
-        if (tail) atomicAdd(&acc[vi][slot], t);
-    }
-    if constexpr (NP % 2 == 1) {  // one (lo | hi) pair left: rows 0,1 hold val[2*(NP-1)], rows 2,3 the next
-        float t = row_sum_to_lane15(s[NP - 1]);
-        t += FNX_DPP(t, 0x142, 0xa);  // lanes 31 / 63 = sums of the two halves
-        if ((lane & 31) == 31) atomicAdd(&acc[2 * (NP - 1) + (lane >> 5)][slot], t);
-    }
-    if constexpr (NV % 2 == 1) {
-        const float t = wave_sum_to_lane63(val[NV - 1]);
-        if (lane == 63) atomicAdd(&acc[NV - 1][slot], t);
-    }
-}
-
-// Per-row variant: every 16-lane row of the wave holds the NV values of a DIFFERENT list entry (its 4x4 block's);
-// each row's sums go to acc[v][slot] of that row's entry (`slot` is per lane, uniform within a row).  Rows with no
+// Cross-lane sums of the blend backward: every 16-lane row of the wave holds the NV values of a DIFFERENT list entry
+// (its 4x4 block's); each row's sums go to acc[v][slot] of that row's entry (`slot` is per lane, uniform within a row).  Rows with no
 // active lane add nothing.  Four values are folded together: 16 -> 8 lanes pairs (a | b) and (c | d) across the row
 // halves (row_ror:8), 8 -> 4 pairs the pairs across the half-row's quads (row_half_mirror), two quad permutes finish:
 // the quads of a row then hold the totals of a, c, b, d -- 11 VALU operations and ONE LDS atomic (4 lanes per row)
@@ -109,13 +54,6 @@ __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], floa
         t += FNX_DPP(t, 0x4e, 0xf);
         if (writer && (lane & 15) == 4 * (v & 3)) atomicAdd(&acc[v][slot], t);
     }
-}
-
-__device__ __forceinline__ int xcd_tile_b(int bid, int T) {
-    const int q = T >> 3, r = T & 7;
-    const int xcd = bid & 7, k = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + k;
 }
 
 // Gradient pass over the tile lists.  The reference walks a tile's list back to front, one workgroup per tile,

@@ -424,7 +424,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #endif
     constexpr int kGroup = FNX_FWD_GROUP;  // list entries per step of the blend loop
     // staged batch: three 16-byte records per slot; slot 256 is a NULL record (opacity 0 at the origin: alpha = 0)
-    // that the tail of every quadrant list points to, so the blend loop needs no end-of-list test per entry
+    // that the tail of every block list points to, so the blend loop needs no end-of-list test per entry
     __shared__ float4 s_ra[257];  // x, y, conic a, conic b
     __shared__ float4 s_rb[257];  // conic c, opacity, exp-skip threshold, -
     __shared__ float4 s_rc[257];  // colour (C channels), depth in .w
