@@ -240,6 +240,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # developer smoke test of the multi-rank code path on a one-GPU box: FNX_SINGLE_DEVICE=1 puts every rank on cuda:0,
+    # FNX_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the numbers mean nothing then
+    if os.environ.get("FNX_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("FNX_DIST_BACKEND", "nccl")
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
@@ -252,7 +257,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fnx_rccl_debug_%h_%p.log")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fluidnexus_amd import _lib, rasterizer
     from fluidnexus_amd.harness import shard_views
