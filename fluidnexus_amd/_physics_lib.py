@@ -11,7 +11,8 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
            "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
-           "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials")
+           "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials",
+           "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum")
 
 
 def physics():
@@ -42,6 +43,8 @@ def physics():
     lib.fnx_visual_interp_forward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p]
     lib.fnx_visual_interp_forward_cells.restype = i
     lib.fnx_visual_interp_forward_cells.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p]
+    lib.fnx_visual_interp_forward_cells_div.restype = i
+    lib.fnx_visual_interp_forward_cells_div.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p, f, p]
     lib.fnx_grid_cell_items_bytes.restype = C.c_size_t
     lib.fnx_grid_cell_items_bytes.argtypes = [i]
     lib.fnx_grid_cell_items.restype = i
@@ -50,6 +53,8 @@ def physics():
     lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
     lib.fnx_visual_interp_backward_cells.restype = i
     lib.fnx_visual_interp_backward_cells.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p, p]
+    lib.fnx_visual_interp_backward_cells_sum.restype = i
+    lib.fnx_visual_interp_backward_cells_sum.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p, f, p, p]
     lib.fnx_physical_stage.restype = i
     lib.fnx_physical_stage.argtypes = [p, i, f, p, p, p, p, p, f, f, f, f, f, f, f, p, i, p, p, p, p, p, p]
     fp3 = C.POINTER(C.c_float)

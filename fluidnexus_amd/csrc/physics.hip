@@ -785,7 +785,7 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                             const uint32_t *__restrict__ n_items, uint32_t hmask,
                             const uint32_t *__restrict__ hstart, const float4 *__restrict__ hrec,
                             const float4 *__restrict__ u, float *__restrict__ out, float *__restrict__ sum_w,
-                            float *__restrict__ wvel) {
+                            float *__restrict__ wvel, float *__restrict__ out_div, float divisor) {
     __shared__ float4 s_pos[kCellCand];
     __shared__ float4 s_vel[kCellCand];
     const int lane = threadIdx.x;
@@ -855,9 +855,15 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
             wvel[3 * v + 1] = ay;
             wvel[3 * v + 2] = az;
             const float Sc = fmaxf(S, eps);
-            out[3 * v + 0] = me.x + ax * secs / Sc;
-            out[3 * v + 1] = me.y + ay * secs / Sc;
-            out[3 * v + 2] = me.z + az * secs / Sc;
+            const float ox = me.x + ax * secs / Sc, oy = me.y + ay * secs / Sc, oz = me.z + az * secs / Sc;
+            out[3 * v + 0] = ox;
+            out[3 * v + 1] = oy;
+            out[3 * v + 2] = oz;
+            if (out_div) {  // the same positions in render units (x / scale_factor), where the rasteriser reads them
+                out_div[3 * v + 0] = ox / divisor;
+                out_div[3 * v + 1] = oy / divisor;
+                out_div[3 * v + 2] = oz / divisor;
+            }
         }
     }
 }
@@ -867,13 +873,18 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
 //   G = g / Sc (Sc = max(S, eps)),  c2 = [S > eps] secs (g . wvel) / Sc^2
 __global__ void __launch_bounds__(256)
 slot_visual_payload_kernel(const float4 *__restrict__ rec, int V, const float *__restrict__ sum_w,
-                           const float *__restrict__ wvel, const float *__restrict__ g, float secs, float eps,
-                           float4 *__restrict__ a0) {
+                           const float *__restrict__ wvel, const float *__restrict__ g, const float *__restrict__ g2,
+                           float scale2, float secs, float eps, float4 *__restrict__ a0) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= V) return;
     const uint32_t v = __float_as_uint(rec[s].w);
     const float S = sum_w[v], Sc = fmaxf(S, eps);
-    const float gx = g[3 * v], gy = g[3 * v + 1], gz = g[3 * v + 2];
+    float gx = g[3 * v], gy = g[3 * v + 1], gz = g[3 * v + 2];
+    if (g2) {  // upstream gradient = g + scale2 * g2 (a second term that arrives separately, e.g. the distance loss's)
+        gx = gx + scale2 * g2[3 * v];
+        gy = gy + scale2 * g2[3 * v + 1];
+        gz = gz + scale2 * g2[3 * v + 2];
+    }
     float c2 = 0.f;
     if (S > eps) c2 = secs * (gx * wvel[3 * v] + gy * wvel[3 * v + 1] + gz * wvel[3 * v + 2]) / (Sc * Sc);
     a0[s] = make_float4(gx / Sc, gy / Sc, gz / Sc, c2);
@@ -1365,6 +1376,14 @@ int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hid
                                     float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
                                     const char *visual_items, float *out, float *sum_w, float *wvel,
                                     fnx_stream_t stream) {
+    return fnx_visual_interp_forward_cells_div(visual, V, hidden, hidden_prev, N, H, secs, eps, hidden_grid, visual_grid,
+                                               visual_items, out, sum_w, wvel, nullptr, 1.0f, stream);
+}
+
+int fnx_visual_interp_forward_cells_div(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                        float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                        const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,
+                                        float divisor, fnx_stream_t stream) {
     if (V == 0) return FNX_OK;
     if (V < 0 || N < 0 || !visual || !hidden_grid || !visual_grid || !visual_items || !out || !sum_w || !wvel ||
         (N > 0 && (!hidden || !hidden_prev)))
@@ -1379,7 +1398,7 @@ int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hid
     const unsigned wgs = (unsigned)(bound < 5120 ? bound : 5120);
     hipLaunchKernelGGL(visual_forward_cells_kernel, dim3(wgs), dim3(64), 0, (hipStream_t)stream, V, 1.0f / H, H * H,
                        poly6_term1(H), secs, eps, gv.rec, (const uint2 *)(visual_items + 64),
-                       (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel);
+                       (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel, out_div, divisor);
     return hip_check("visual_interp_forward_cells");
 }
 
@@ -1393,7 +1412,7 @@ int fnx_visual_interp_backward(const float *visual, int V, const float *hidden, 
     GridView g = carve(const_cast<char *>(visual_grid), V);
     if (V > 0)
         hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
-                           V, sum_w, wvel, dL_dout, secs, eps, g.aux0);
+                           V, sum_w, wvel, dL_dout, (const float *)nullptr, 0.0f, secs, eps, g.aux0);
     hipLaunchKernelGGL(visual_backward_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden,
                        hidden_prev, N, 1.0f / H, H, H * H, poly6_term1(H), secs, g.M - 1, g.start, g.rec, g.aux0,
                        dL_dhidden);
@@ -1404,6 +1423,15 @@ int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hi
                                      float H, float secs, float eps, const char *visual_grid, const char *hidden_grid,
                                      const char *hidden_items, const float *sum_w, const float *wvel,
                                      const float *dL_dout, float *dL_dhidden, fnx_stream_t stream) {
+    return fnx_visual_interp_backward_cells_sum(visual, V, hidden, hidden_prev, N, H, secs, eps, visual_grid, hidden_grid,
+                                                hidden_items, sum_w, wvel, dL_dout, nullptr, 0.0f, dL_dhidden, stream);
+}
+
+int fnx_visual_interp_backward_cells_sum(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                         float H, float secs, float eps, const char *visual_grid,
+                                         const char *hidden_grid, const char *hidden_items, const float *sum_w,
+                                         const float *wvel, const float *dL_dout, const float *dL_dout2, float scale2,
+                                         float *dL_dhidden, fnx_stream_t stream) {
     if (N == 0) return FNX_OK;
     if (V < 0 || N < 0 || !hidden || !hidden_prev || !visual_grid || !hidden_grid || !hidden_items || !dL_dhidden ||
         (V > 0 && (!visual || !sum_w || !wvel || !dL_dout)))
@@ -1412,7 +1440,7 @@ int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hi
     GridView gh = carve(const_cast<char *>(hidden_grid), N);
     if (V > 0)
         hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
-                           V, sum_w, wvel, dL_dout, secs, eps, g.aux0);
+                           V, sum_w, wvel, dL_dout, dL_dout2, scale2, secs, eps, g.aux0);
     // workgroups stride over the items (their number is only known on the device)
     const size_t bound = (size_t)N + (size_t)N / 64 + 1;
     const unsigned wgs = (unsigned)(bound < 4096 ? bound : 4096);

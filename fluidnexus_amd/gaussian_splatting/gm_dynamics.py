@@ -678,6 +678,10 @@ class GaussianModel:
         if self._visual_memo[0] != key:
             self.flush_deferred_gradients()
             self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
+        if getattr(self, "_render_means_request", None) is not None:
+            self._visual_memo[1]["out_div"] = self._render_means_request
+        else:
+            self._visual_memo[1].pop("out_div", None)
         return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON,
                                           self._visual_grid[1], self._cached_grid("est", x), self._visual_memo[1],
                                           share_output=getattr(self, "share_visual_output", False))
@@ -856,26 +860,36 @@ class GaussianModel:
         written once, the fluid rows by one division per call.  The caller differentiates the render with respect to
         this leaf and hands the fluid rows of the gradient to defer_render_means_gradient -- the same chain as
         render_dynamics(pos_type="guess_visual_nn", scale=True) without the per-iteration cat / mul / div nodes."""
-        with torch.no_grad():
-            raw = self.get_visual_xyz_from_nn()
-        V, G = raw.shape[0], self._gs_xyz.shape[0]
-        key = (id(self._gs_xyz), self._gs_xyz._version, V, G, raw.device)
+        V, G = self._visual_xyz.shape[0], self._gs_xyz.shape[0]
+        key = (id(self._gs_xyz), self._gs_xyz._version, V, G, self._visual_xyz.device)
         if getattr(self, "_render_means", None) is None or self._render_means[0] != key:
-            buf = torch.empty(V + G, 3, dtype=torch.float32, device=raw.device)
+            buf = torch.empty(V + G, 3, dtype=torch.float32, device=self._visual_xyz.device)
             buf[V:] = self._gs_xyz.detach()
             self._render_means = (key, buf.requires_grad_(True))
         buf = self._render_means[1]
         with torch.no_grad():
-            torch.div(raw, self.scale_factor, out=buf[:V])
+            # the interpolation kernel writes the fluid rows itself (out / scale_factor) when it runs for this state
+            self._render_means_request = (buf.detach()[:V], self.scale_factor)
+            try:
+                raw = self.get_visual_xyz_from_nn()
+            finally:
+                self._render_means_request = None
+            if not self._visual_memo[1].pop("out_div_done", False):
+                torch.div(raw, self.scale_factor, out=buf[:V])
         return buf
 
-    def defer_render_means_gradient(self, g_means):
+    def defer_render_means_gradient(self, g_means, extra=None):
         """g_means: gradient with respect to render_means_from_nn()'s tensor.  Queues its fluid rows for the one
-        hidden<-visual backward of the iteration; the 1 / scale_factor of the division is applied to the result."""
+        hidden<-visual backward of the iteration; the 1 / scale_factor of the division is applied to the result.
+        `extra` = (g2 [V,3], scale2): a second gradient with respect to the fluid rows, added as scale2 * g2 inside the
+        backward kernel (the distance loss's term arrives from its own stream)."""
         memo = self._visual_memo[1]
         assert memo.get("defer") and "saved" in memo, "render_means_from_nn() first (deferred visual backward)"
         memo.setdefault("g_list", []).append(g_means[:self._visual_xyz.shape[0]])
         memo["g_scale"] = 1.0 / self.scale_factor
+        if extra is not None:
+            assert "g_extra" not in memo, "one extra gradient term per iteration"
+            memo["g_extra"] = extra
 
     def flush_deferred_gradients(self):
         """With defer_visual_backward the hidden->visual interpolation back-propagates once per

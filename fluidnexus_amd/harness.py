@@ -383,9 +383,12 @@ class HotLoop:
         # positions [advected visual / scale_factor | background].  The main chain's next kernel is enqueued BEFORE the
         # side branches fork: a captured graph keeps the first successor of a node on the node's hardware queue, and a
         # hop of the critical path between queues costs ~10 us (rocprof timeline), a hop of a side branch nothing.
-        with torch.no_grad():
-            gm.get_visual_xyz_from_nn()
-        means3D = gm.render_means_from_nn() if mine else None
+        if mine:  # the interpolation kernel writes the fluid rows of the leaf itself (positions / scale_factor)
+            means3D = gm.render_means_from_nn()
+        else:
+            means3D = None
+            with torch.no_grad():
+                gm.get_visual_xyz_from_nn()
         # Side branches of the iteration.  Their fork POINTS are recorded where their inputs are ready, but their
         # kernels are enqueued behind the rasteriser forward: a captured graph keeps the first-enqueued successor of a
         # node on the node's hardware queue, and the critical path must not be the one that hops.
@@ -462,10 +465,11 @@ class HotLoop:
                 outs.append(pkg1["render"])
                 seeds.append(dimg1)
             g_means, = torch.autograd.grad(outs, [means3D], grad_outputs=seeds)
-            if gd is not None:
+            extra = None
+            if gd is not None:  # added inside the hidden<-visual backward instead of by a pass over g_means
                 main.wait_stream(self.dist_stream)
-                g_means[:gd.shape[0]].add_(gd, alpha=float(c["lambda_current_distance"]) * len(mine))
-            gm.defer_render_means_gradient(g_means)  # -> the one hidden<-visual backward of the iteration
+                extra = (gd, float(c["lambda_current_distance"]) * len(mine))
+            gm.defer_render_means_gradient(g_means, extra)  # -> the one hidden<-visual backward of the iteration
         if gp is not None:
             main.wait_stream(self.side_stream)
         multi = self.world > 1 or self.force_all_reduce

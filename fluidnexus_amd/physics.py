@@ -99,12 +99,16 @@ class _VisualFromHidden(torch.autograd.Function):
             wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
             if visual_grid is None:
                 visual_grid = HashGrid(visual, H)
-            PL.check(lib.fnx_visual_interp_forward_cells(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N,
-                                                         H, secs, eps, hgrid.blob.data_ptr(), visual_grid.blob.data_ptr(),
-                                                         visual_grid.cell_items().data_ptr(), out.data_ptr(),
-                                                         sum_w.data_ptr(), wvel.data_ptr(), _stream()))
+            # memo["out_div"] = (tensor [V,3], divisor): the caller also wants out / divisor (the rasteriser's units),
+            # written by the same kernel; memo["out_div_done"] tells it that it was
+            div = memo.get("out_div") if memo is not None else None
+            PL.check(lib.fnx_visual_interp_forward_cells_div(
+                visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N, H, secs, eps, hgrid.blob.data_ptr(),
+                visual_grid.blob.data_ptr(), visual_grid.cell_items().data_ptr(), out.data_ptr(), sum_w.data_ptr(),
+                wvel.data_ptr(), div[0].data_ptr() if div is not None else None, float(div[1]) if div is not None else 1.0,
+                _stream()))
             if memo is not None:
-                memo.update(out=out, sum_w=sum_w, wvel=wvel)
+                memo.update(out=out, sum_w=sum_w, wvel=wvel, out_div_done=div is not None)
         if visual_grid is None:
             visual_grid = HashGrid(visual, H)
         ctx.save_for_backward(visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob)
@@ -135,19 +139,23 @@ class _VisualFromHidden(torch.autograd.Function):
         return None, dh, None, None, None, None, None, None, None
 
 
-def _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, hgrid, hitems, sum_w, wvel, g):
+def _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, hgrid, hitems, sum_w, wvel, g, extra=None):
     """dL/dhidden [N,3]: cell by cell over the hidden grid when one is at hand (`hitems`: its work items, built here
-    when None), else a wave per hidden particle."""
+    when None), else a wave per hidden particle.  `extra` = (g2, scale2): the upstream gradient is g + scale2 * g2."""
     lib = PL.physics()
     dh = torch.empty_like(hidden)
     if hgrid is not None and hgrid.N == hidden.shape[0]:
         if hitems is None:
             hitems = hgrid.cell_items(refresh=True)
-        PL.check(lib.fnx_visual_interp_backward_cells(
+        g2 = _req(extra[0]) if extra is not None else None
+        PL.check(lib.fnx_visual_interp_backward_cells_sum(
             visual.data_ptr(), visual.shape[0], hidden.data_ptr(), hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps,
             vblob.data_ptr(), hgrid.blob.data_ptr(), hitems.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
+            g2.data_ptr() if g2 is not None else None, float(extra[1]) if extra is not None else 0.0,
             dh.data_ptr(), _stream()))
     else:
+        if extra is not None:
+            g = g + extra[0] * float(extra[1])
         PL.check(lib.fnx_visual_interp_backward(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
                                                 hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
                                                 sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(), dh.data_ptr(),
@@ -165,7 +173,7 @@ def flush_deferred_visual_backward(memo):
     g = gl[0] if len(gl) == 1 else torch.stack(gl).sum(dim=0)
     g = g.contiguous()
     return _visual_backward(visual, hidden, hidden_prev, H, secs, eps, vblob, memo.get("hgrid"), memo.get("hitems"),
-                            sum_w, wvel, g)
+                            sum_w, wvel, g, memo.pop("g_extra", None))
 
 
 def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,

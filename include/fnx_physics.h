@@ -66,6 +66,12 @@ int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hid
                                     float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
                                     const char *visual_items, float *out, float *sum_w, float *wvel,
                                     fnx_stream_t stream);
+/* ... and also writes out / divisor to `out_div` [V,3] (NULL: not written): the advected positions in render units
+ * (gm_dynamics.py:1498 + pipe_dynamics.py:40, `/ scale_factor`), IEEE division like torch's, without a second pass. */
+int fnx_visual_interp_forward_cells_div(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                        float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                        const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,
+                                        float divisor, fnx_stream_t stream);
 /* dL_dhidden[j] = sum_v [ w_vj/S_v * g_v + dL/dw_vj * dW/dr2 * 2 (hidden_j - visual_v) ], S_v = max(sum_w, eps),
  * dL/dw_vj = secs * (g_v . u_j)/S_v - [sum_w_v > eps] * secs * (g_v . wvel_v)/S_v^2.
  * `visual_grid` is built over `visual` with cell = H. */
@@ -80,6 +86,14 @@ int fnx_visual_interp_backward_cells(const float *visual, int V, const float *hi
                                      float H, float secs, float eps, const char *visual_grid, const char *hidden_grid,
                                      const char *hidden_items, const float *sum_w, const float *wvel,
                                      const float *dL_dout, float *dL_dhidden, fnx_stream_t stream);
+/* ... for the upstream gradient dL_dout + scale2 * dL_dout2 (dL_dout2 NULL: dL_dout alone): a second term that
+ * arrives from elsewhere (the distance loss on the rendered positions, train_physical_particle.py:365-366) is added
+ * while the per-particle payload is formed instead of by a pass of its own. */
+int fnx_visual_interp_backward_cells_sum(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                         float H, float secs, float eps, const char *visual_grid,
+                                         const char *hidden_grid, const char *hidden_items, const float *sum_w,
+                                         const float *wvel, const float *dL_dout, const float *dL_dout2, float scale2,
+                                         float *dL_dhidden, fnx_stream_t stream);
 
 /* The three physics terms of the physical-particle stage and their gradient in one call
  * (entries_fluid_nexus/train_physical_particle.py:368-404 as one launch sequence of ~12 kernels):
