@@ -289,7 +289,7 @@ def main():
     if not a.host_sync:
         rasterizer.set_host_sync(False)
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 1)):  # at least one eager pass sizes the binning buffers before anything is captured
         loop.iteration()
     if not a.host_sync:
         rasterizer.check_status()  # also records the binning high-water mark
@@ -297,9 +297,7 @@ def main():
     if loop.capturable:
         try:
             # several iterations per graph: one launch gap per replay; the timed region still runs exactly --steps
-            gi = max(1, int(a.graph_iters))
-            while a.steps % gi:
-                gi -= 1
+            gi = max(1, min(int(a.graph_iters), a.steps))  # a remainder of --steps is run eagerly at the end
             loop.capture(warmup=1, iterations=gi)
             for _ in range(2):
                 loop.iteration()
@@ -319,9 +317,13 @@ def main():
     t0 = time.perf_counter()
     steps_done = 0
     while steps_done < a.steps:
+        if graph_mode and a.steps - steps_done < loop.iterations_per_call:
+            loop.use_graph(False)  # fewer steps left than one graph holds: the same iteration, launched eagerly
         steps_done += loop.iterations_per_call
         loop.iteration()
     assert steps_done == a.steps
+    if graph_mode:
+        loop.use_graph(True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
