@@ -604,12 +604,15 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         __syncthreads();
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
+        // a block whose 16 pixels have all stopped gets an empty list: the wave's step count is its longest list, and a
+        // finished block must not be the one that keeps it walking
+        const unsigned long long live = __ballot(alive != 0.0f);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const bool bit = (mk >> b) & 1u;
+                const bool bit = ((mk >> b) & 1u) && ((live >> (16 * b)) & 0xFFFFull) != 0ull;
                 const unsigned long long m = __ballot(bit);
                 if (bit) s_list[4 * w + b][len[b] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
                 len[b] += (uint32_t)__popcll(m);
