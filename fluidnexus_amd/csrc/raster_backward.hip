@@ -177,6 +177,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         float bg_dot_dpixel = 0.f;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+        // Everything the gradient needs from the colour channels is their dot product with dL/dpixel:
+        //   sum_ch dL_ch (c_ch T - S_ch / (1 - alpha)) = T (c . dL) - (S . dL) / (1 - alpha),
+        //   S . dL = (total . dL) - (prefix . dL), and the prefix's dot product is itself a running sum of
+        //   alpha_i T_i (c_i . dL): one scalar recurrence instead of one per channel.
+        float total_dot = 0.f, pre_dot = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+            total_dot += total[ch] * dL_dpixel[ch];
+            pre_dot += pre[ch] * dL_dpixel[ch];
+        }
+        const float tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
@@ -260,16 +271,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
                 const float Tb = Tr;  // transmittance in front of the entry
                 const float col[3] = {rc[k].x, rc[k].y, rc[k].z};
-                float dL_dalpha = 0.0f;
+                float c_dot = 0.0f;
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) {
-                    const float c = col[ch];
-                    pre[ch] = pre[ch] + c * a * Tb;  // the forward's accumulation, same association
-                    const float behind = total[ch] - pre[ch];
-                    dL_dalpha += (c * Tb - behind * inv_1ma) * dL_dpixel[ch];
-                }
+                for (int ch = 0; ch < C; ch++) c_dot += col[ch] * dL_dpixel[ch];
+                pre_dot = pre_dot + (a * Tb) * c_dot;
                 Tr = Tb * one_m;  // the forward's test_T
-                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                const float dL_dalpha = Tb * c_dot - ((total_dot - pre_dot) + tail_dot) * inv_1ma;
                 const bool emits = active && wants;
                 const float dL_da = emits ? dL_dalpha : 0.0f;
                 const float dL_dG = rb[k].y * dL_da;
