@@ -281,16 +281,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float dL_da = emits ? dL_dalpha : 0.0f;
                 const float dL_dG = rb[k].y * dL_da;
                 const float Gm = active ? G : 0.0f;  // power > 0 can push the range-limited exp out of range: never into a sum
-                const float gdx = Gm * dx;
-                const float gdy = Gm * dy;
-                const float dG_ddelx = -gdx * ra[k].z - gdy * ra[k].w;
-                const float dG_ddely = -gdy * rb[k].x - gdx * ra[k].w;
+                // Per (pixel, entry) only the weighted moments of the offset are formed: w = G dL/dG,
+                // (w dx, w dy, w dx^2, w dx dy, w dy^2).  The entry's own constants -- its conic in dG/d(mean), the
+                // -1/2 of the conic gradients, the pixel scale -- multiply the SUMS once per entry when they are flushed.
+                const float wgt = Gm * dL_dG;
+                const float wx = wgt * dx, wy = wgt * dy;
                 float val[NV];
-                val[0] = dL_dG * dG_ddelx * ddelx_dx;
-                val[1] = dL_dG * dG_ddely * ddely_dy;
-                val[2] = -0.5f * gdx * dx * dL_dG;
-                val[3] = -0.5f * gdx * dy * dL_dG;
-                val[4] = -0.5f * gdy * dy * dL_dG;
+                val[0] = wx;
+                val[1] = wy;
+                val[2] = wx * dx;
+                val[3] = wx * dy;
+                val[4] = wy * dy;
                 if (MODE == 0) {
                     val[MODE == 0 ? 5 : 0] = Gm * dL_da;
                     const float dchannel_dcolor = emits ? a * Tb : 0.0f;
@@ -315,11 +316,15 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 any |= (a[v] != 0.f);
             }
             if (any && FNX_ABLATE != 1) {
-                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], a[0]);
-                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], a[1]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], a[2]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], a[3]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], a[4]);
+                // moments -> gradients (backward.cu:512-533): dG/d(delta) = -G (a dx + b dy, c dy + b dx), conic terms
+                // -1/2 G (dx^2, dx dy, dy^2), each times dL/dG
+                const float4 ra = s_ra[tid];
+                const float cc = s_rb[tid].x;
+                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[1]) * ddelx_dx);
+                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[1] + ra.w * a[0]) * ddely_dy);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[2]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[3]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[4]);
                 if (MODE == 0) {
                     unsafeAtomicAdd(&dL_dopacity_v[id], a[MODE == 0 ? 5 : 0]);
 #pragma unroll
