@@ -73,8 +73,11 @@ __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], floa
 // MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
 // MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients.
 // Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
+#ifndef FNX_BWD_WAVES
+#define FNX_BWD_WAVES 4  // waves per SIMD the register allocation of the blend backward aims at
+#endif
 template <int C, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWD_WAVES, FNX_BWD_WAVES)))
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                       int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
                       const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
