@@ -859,10 +859,12 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
             out[3 * v + 0] = ox;
             out[3 * v + 1] = oy;
             out[3 * v + 2] = oz;
-            if (out_div) {  // the same positions in render units (x / scale_factor), where the rasteriser reads them
-                out_div[3 * v + 0] = ox / divisor;
-                out_div[3 * v + 1] = oy / divisor;
-                out_div[3 * v + 2] = oz / divisor;
+            if (out_div) {  // the same positions in render units (x / scale_factor), where the rasteriser reads them;
+                // torch divides a tensor by a scalar as x * (1 / s) with the reciprocal rounded to fp32: so does this
+                const float inv = 1.0f / divisor;
+                out_div[3 * v + 0] = ox * inv;
+                out_div[3 * v + 1] = oy * inv;
+                out_div[3 * v + 2] = oz * inv;
             }
         }
     }

@@ -67,7 +67,8 @@ int fnx_visual_interp_forward_cells(const float *visual, int V, const float *hid
                                     const char *visual_items, float *out, float *sum_w, float *wvel,
                                     fnx_stream_t stream);
 /* ... and also writes out / divisor to `out_div` [V,3] (NULL: not written): the advected positions in render units
- * (gm_dynamics.py:1498 + pipe_dynamics.py:40, `/ scale_factor`), IEEE division like torch's, without a second pass. */
+ * (gm_dynamics.py:1498 + pipe_dynamics.py:40, `/ scale_factor`), evaluated as torch evaluates tensor / scalar
+ * (x * fp32(1 / divisor)), without a second pass. */
 int fnx_visual_interp_forward_cells_div(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
                                         float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
                                         const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,

@@ -284,6 +284,45 @@ def test_visual_backward_cells_equals_particle_walk():
     assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
 
 
+def test_fused_interpolation_entry_points():
+    """fnx_visual_interp_forward_cells_div: the extra output is torch's out / divisor bit for bit;
+    fnx_visual_interp_backward_cells_sum: the backward of g + scale2 * g2 equals the backward of the summed gradient."""
+    from fluidnexus_amd import physics
+    from fluidnexus_amd import _physics_lib as PL
+    lib = PL.physics()
+    rng = np.random.RandomState(8)
+    H, secs, eps = 2.0, 1.0 / 30.0, 1e-8
+    hid = rng.uniform(0, 20, size=(5000, 3)).astype(np.float32)
+    prev = (hid - rng.normal(size=hid.shape) * 0.2).astype(np.float32)
+    vis = rng.uniform(-2, 22, size=(20000, 3)).astype(np.float32)
+    d = "cuda"
+    hid_t, prev_t, vis_t = (torch.tensor(a, device=d) for a in (hid, prev, vis))
+    V, N = vis.shape[0], hid.shape[0]
+    hg, vg = physics.HashGrid(hid_t, H), physics.HashGrid(vis_t, H)
+    s = torch.cuda.current_stream().cuda_stream
+    out, sw, wv = torch.empty(V, 3, device=d), torch.empty(V, device=d), torch.empty(V, 3, device=d)
+    out_div = torch.full((V, 3), float("nan"), device=d)
+    PL.check(lib.fnx_visual_interp_forward_cells_div(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H, secs,
+                                                     eps, hg.blob.data_ptr(), vg.blob.data_ptr(),
+                                                     vg.cell_items().data_ptr(), out.data_ptr(), sw.data_ptr(),
+                                                     wv.data_ptr(), out_div.data_ptr(), 100.0, s))
+    assert torch.equal(out_div, out / 100.0)
+    g1 = torch.tensor(rng.normal(size=(V, 3)).astype(np.float32), device=d)
+    g2 = torch.tensor(rng.normal(size=(V, 3)).astype(np.float32), device=d)
+    res = []
+    for fused in (True, False):
+        dh = torch.full((N, 3), float("nan"), device=d)
+        ga = g1 if fused else (g1 + 0.3 * g2).contiguous()
+        PL.check(lib.fnx_visual_interp_backward_cells_sum(vis_t.data_ptr(), V, hid_t.data_ptr(), prev_t.data_ptr(), N, H,
+                                                          secs, eps, vg.blob.data_ptr(), hg.blob.data_ptr(),
+                                                          hg.cell_items().data_ptr(), sw.data_ptr(), wv.data_ptr(),
+                                                          ga.data_ptr(), g2.data_ptr() if fused else None, 0.3,
+                                                          dh.data_ptr(), s))
+        torch.cuda.synchronize()
+        res.append(dh.cpu().numpy())
+    assert np.isfinite(res[0]).all() and np.abs(res[0] - res[1]).max() <= 2e-6 * np.abs(res[1]).max()
+
+
 @pytest.mark.parametrize("tag", ["plume", "blob", "sparse"])
 def test_distance_loss_matches_reference_golden(tag):
     """fnx_distance_loss (radius-limited, hash grid) against the reference's dense distance_loss evaluated on float64
