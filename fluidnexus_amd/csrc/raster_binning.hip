@@ -340,9 +340,12 @@ constexpr int kEmitPer = kSplatBlock / kEmitThreads;   // splats loaded per thre
 #endif
 constexpr int kEmitChunk = FNX_EMIT_CHUNK;             // instances per thread and sub-batch (kept in registers)
 constexpr int kEmitStage = kEmitChunk * kEmitThreads;  // instances per sub-batch
-constexpr int kEmitMaskWords = 8;                      // per-tile bitmask: 8 x 32 ranks
+#ifndef FNX_EMIT_MASK_WORDS
+#define FNX_EMIT_MASK_WORDS 8  // 256 ranks per sub-batch; measured on config 3 (5 views): 2 -> 120, 4 -> 86, 8 -> 72, 16 -> 107, 32 -> 115 us
+#endif
+constexpr int kEmitMaskWords = FNX_EMIT_MASK_WORDS;    // per-tile bitmask: 32 ranks per word
 constexpr int kEmitSpan = 32 * kEmitMaskWords;         // ranks per sub-batch
-constexpr int kEmitTileWindow = 2048;                  // <= kEmitStage: one splat never overflows a sub-batch
+constexpr int kEmitTileWindow = kEmitMaskWords <= 8 ? 2048 : (kEmitMaskWords <= 16 ? 1792 : 960);  // <= kEmitStage: one splat never overflows a sub-batch; window x (words + 1) x 4 B of LDS
 static_assert(kSplatBlock == 1024, "emit packs the rank-in-block into 10 bits");
 static_assert(kEmitTileWindow <= kEmitStage && kEmitTileWindow <= (1 << 22), "entry packing");
 
@@ -708,7 +711,7 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
     const void *kernel = pairs ? (const void *)emit_kernel<true> : (const void *)emit_kernel<false>;
     // resident workgroups for this LDS size (host-side queries, cached per kernel variant)
     static int n_cu = 0, wgs_cache[2][2] = {{0, 0}, {0, 0}};
-    const bool large = TW > 1024;  // large images: static + dynamic LDS exceeds the default 64 KiB limit
+    const bool large = lds > 40 * 1024;  // static + dynamic LDS exceeds the default 64 KiB limit
     int &wgs = wgs_cache[pairs ? 1 : 0][large ? 1 : 0];
     if (wgs == 0) {
         if (large)
@@ -723,7 +726,7 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
         int per_cu = 0;
         const size_t lds_max = (size_t)kEmitTileWindow * 4 * (kEmitMaskWords + 1);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kEmitThreads,
-                                                         large ? lds_max : (size_t)1024 * 4 * (kEmitMaskWords + 1)) !=
+                                                         large ? lds_max : (size_t)40 * 1024) !=
                 hipSuccess || per_cu <= 0)
             per_cu = 1;
         (void)hipGetLastError();
