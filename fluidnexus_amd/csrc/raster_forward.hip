@@ -658,6 +658,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #ifdef FNX_EXP_CLOCK
         if (wg_rank == 0 && wg_view == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
 #endif
+        uint32_t hit_off = 0xFFFFFFFFu;  // LDS offset of the last entry of this batch the pixel took
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(alive == 0.0f)) break;
             uint32_t jw[kGroup / 2];  // the next kGroup entries of this lane's list
@@ -708,10 +709,11 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 if (C > 2) acc[C > 2 ? 2 : 0] = acc[C > 2 ? 2 : 0] + rc[k].z * a_eff * Tr;
                 Dm = (Tr > 0.5f && test_T < 0.5f) ? rc[k].w : Dm;  // cannot hold for an entry that is not applied
                 Tr = stop ? Tr : test_T;
-                last_contributor = (a_eff > 0.0f) ? pos0 + (off >> 4) : last_contributor;
+                hit_off = (a_eff > 0.0f) ? off : hit_off;
                 alive = stop ? 0.0f : alive;
             }
         }
+        if (hit_off != 0xFFFFFFFFu) last_contributor = pos0 + (hit_off >> 4);  // list position (1-based) of that entry
         FNX_CLK(3)
     }
     if (inside) {
