@@ -242,6 +242,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         }
         const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
         const uint16_t *mylist = s_list[4 * w + row];
+        // entry q0 + slot lies in front of the pixel's last contributor <=> its LDS offset (16 slot) is below this bound
+        const uint32_t lim_off = last_contributor > q0 ? min(last_contributor - q0, 4096u) << 4 : 0u;
         // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
         // the pixel does not take has alpha = 0, which leaves T and the colour prefix exactly as they are (x * 1, + 0)
         // and zeroes every gradient term; the NULL record behind a list's end is such an entry for every pixel.
@@ -259,13 +261,13 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             }
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t slot = ((jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) >> 4;
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, slot = off >> 4;
                 const float dx = ra[k].x - pxf, dy = ra[k].y - pyf;
                 const float power = -0.5f * (ra[k].z * dx * dx + rb[k].x * dy * dy) - ra[k].w * dx * dy;
                 const float G = exp_fixed_in_range(fmaxf(power, -87.0f));
                 const float alpha = fminf(0.99f, rb[k].y * G);
                 // the forward's decision (blend_forward_kernel), for the entries in front of the pixel's last contributor
-                const bool active = !(power > 0.0f) && !(alpha < 1.0f / 255.0f) && (q0 + slot < last_contributor);
+                const bool active = !(power > 0.0f) && !(alpha < 1.0f / 255.0f) && (off < lim_off);
                 const bool wants = rb[k].w != 0.0f;  // uniform within a row
                 const float a = active ? alpha : 0.0f;
                 // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
