@@ -59,7 +59,7 @@ def test_split_equals_unsplit_full_size():
     _check_split(g, 3, 200_000, 100_000, 512, 512, S.arc_cameras(5, 512, 512, device="cuda"))
 
 
-def _check_split(g, channels, P_dyn, P_static, W, H, cams):
+def _check_split(g, channels, P_dyn, P_static, W, H, cams, strict=True):
     from fluidnexus_amd import _lib
     from fluidnexus_amd.rasterizer import GaussianRasterizerViews, StaticBin, ViewBatch
     dev = torch.device("cuda")
@@ -93,7 +93,7 @@ def _check_split(g, channels, P_dyn, P_static, W, H, cams):
     with torch.no_grad():
         sb = StaticBin(vb, B["means3D"][P_dyn:], B["opacities"][P_dyn:], P_dyn, colors_precomp=B["colors"][P_dyn:],
                        scales=B["scales"][P_dyn:], rotations=B["rotations"][P_dyn:], channels=channels)
-    assert min(sb.R) > 0 and sb.P == P_static
+    assert (min(sb.R) > 0 or not strict) and sb.P == P_static
     StaticBin.materialize_all = True
     try:
         im_b, ra_b, de_b, sc_b, bin_b, img_b = run(B, sb)
@@ -121,9 +121,9 @@ def _check_split(g, channels, P_dyn, P_static, W, H, cams):
         pa = _blob(bin_a[v * cap_a:(v + 1) * cap_a], 0, R, torch.int32)
         pb = _blob(bin_b[v * cap_b:(v + 1) * cap_b], 0, R, torch.int32)
         assert torch.equal(pa, pb), f"merged point_list of view {v}"
-    assert tot_static > 0
+    assert tot_static > 0 or not strict
     # gradients: leading splats agree, static rows are zero
-    assert float(A["means3D"].grad[:P_dyn].abs().max()) > 0
+    assert float(A["means3D"].grad[:P_dyn].abs().max()) > 0 or not strict
     for n in names:
         assert _close(B[n].grad[:P_dyn], A[n].grad[:P_dyn]), n
         assert float(B[n].grad[P_dyn:].abs().max()) == 0.0, n
@@ -135,6 +135,21 @@ def _check_split(g, channels, P_dyn, P_static, W, H, cams):
     assert torch.equal(im_a.view(torch.int32), im_c.view(torch.int32))
     for n in names:
         assert _close(C[n].grad[:P_dyn], A[n].grad[:P_dyn]), n
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FNX_RANDOM_CASES", "8"))))
+def test_split_equals_unsplit_random(seed):
+    """Seeded random splits: image sizes with partial tiles, 1-4 views, tiny and large dynamic / static sets, depth
+    ties between the two streams, thin (deep lists) and opaque (early saturation) splats."""
+    rng = np.random.RandomState(500 + seed)
+    channels = int(rng.choice([1, 3]))
+    P_dyn, P_static = int(rng.choice([1, 50, 1500, 6000])), int(rng.choice([1, 80, 2500, 7000]))
+    W, H, V = int(rng.randint(20, 180)), int(rng.randint(20, 180)), int(rng.randint(1, 5))
+    ties = int(min(P_dyn, P_static) * rng.choice([0.0, 0.0, 0.2]))
+    g = _scene(P_dyn, P_static, channels, seed=900 + seed, static_box=float(rng.uniform(0.08, 0.5)), ties=ties)
+    if rng.rand() < 0.5:  # thin: nothing saturates
+        g["opacities"] = rng.uniform(0.004, 0.05, size=g["opacities"].shape).astype(np.float32)
+    _check_split(g, channels, P_dyn, P_static, W, H, S.arc_cameras(V, W, H, device="cuda"), strict=False)
 
 
 def test_split_single_view_and_empty_streams():
