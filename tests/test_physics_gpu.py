@@ -345,3 +345,28 @@ def test_distance_loss_matches_reference_golden(tag):
     v = distance_loss(x, thr) * 3.0
     v.backward()
     assert np.abs(x.grad.cpu().numpy() - 3.0 * ref_g).max() <= 6e-5 * scale + 1e-12
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FNX_RANDOM_CASES", "6"))))
+def test_distance_loss_random_clouds_against_float64_dense(seed):
+    """fnx_distance_loss on random clouds (uniform + tight clusters + duplicates) against the reference's dense
+    expression (loss_utils.py:98-121) evaluated in float64 on the device."""
+    from fluidnexus_amd.physics import distance_loss_value_and_grad
+    rng = np.random.RandomState(70 + seed)
+    N = int(rng.randint(300, 4000))
+    thr = float(rng.choice([0.002, 0.00625, 0.02, 0.05]))
+    pts = rng.uniform(0, 1, size=(N, 3)) * rng.choice([0.05, 0.3, 1.0])
+    k = N // 4
+    pts[:k] = pts[rng.randint(k, N, size=k)] + rng.normal(size=(k, 3)) * thr * 0.3  # tight clusters
+    pts[k:k + 5] = pts[k + 5:k + 10]                                                # exact duplicates
+    x = torch.tensor(pts.astype(np.float32), device="cuda")
+    loss, grad = distance_loss_value_and_grad(x, thr)
+    x64 = x.double().requires_grad_(True)
+    d = torch.cdist(x64, x64, p=2)
+    mask = d < thr
+    mask.fill_diagonal_(False)
+    ref = ((thr - d) * mask.double()).clamp(min=0).pow(2).sum()
+    ref.backward()
+    assert abs(float(loss) - float(ref.detach())) <= 2e-5 * float(ref.detach()) + 1e-12, (seed, N, thr)
+    scale = float(x64.grad.abs().max()) + 1e-30
+    assert float((grad.double() - x64.grad).abs().max()) <= 2e-4 * scale, (seed, N, thr)
