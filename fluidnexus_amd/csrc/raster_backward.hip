@@ -638,7 +638,7 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// The grid is exactly the workgroups that are resident at a time (registers allow 5 per compute unit): a larger grid
+// The grid is exactly the workgroups that are resident at a time (the occupancy query: 4 per compute unit at the current register count): a larger grid
 // would run its surplus as a second, half-empty round.
 template <int C, int MODE, typename... A>
 static void launch_blend_backward_t(int n_cu, hipStream_t s, A... args) {
