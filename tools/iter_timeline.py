@@ -7,9 +7,16 @@ def nm(r):
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '')
     return n.split('(')[0][:60]
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), nm(r), r.get('Queue_Id', '')) for r in rows)
-vb = [e for e in ev if 'visual_backward' in e[2]]
+# anchor: a kernel that runs once per iteration (the loops differ: hidden<-visual backward, else the blend backward)
+vb = []
+for anchor in ('visual_backward', 'blend_backward_kernel<3, 1>', 'blend_backward_kernel<1, 1>', 'blend_backward_kernel<3, 0>'):
+    vb = [e for e in ev if anchor in e[2]]
+    if len(vb) > 2:
+        break
 gaps = [(vb[i + 1][0] - vb[i][0]) / 1e6 for i in range(len(vb) - 1)]
-i = min(range(len(gaps)), key=lambda k: gaps[k])
+# the replayed iterations are the bulk of the anchors: take the window with the MEDIAN spacing (the shortest one may
+# belong to the rasteriser-only timing the bench runs afterwards, the longest to an eager or capturing iteration)
+i = sorted(range(len(gaps)), key=lambda k: gaps[k])[len(gaps) // 2]
 w0, w1 = vb[i][1], vb[i + 1][1]
 win = [e for e in ev if e[0] >= w0 and e[1] <= w1]
 busy, last = 0, w0
