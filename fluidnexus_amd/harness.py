@@ -406,9 +406,9 @@ class HotLoop:
         use_dist = bool(mine) and c.get("lambda_current_distance", 0.0) > 0
         if mine:
             from . import rasterizer
-            fork_d = torch.cuda.Event()
+            fork_d, forked_d = torch.cuda.Event(), []
             if use_dist:
-                rasterizer.set_between_stages_hook(lambda: fork_d.record(torch.cuda.current_stream()))
+                rasterizer.set_between_stages_hook(lambda: (fork_d.record(torch.cuda.current_stream()), forked_d.append(1)))
             try:
                 pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                             GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
@@ -434,7 +434,10 @@ class HotLoop:
         if mine:
             if use_dist:
                 from .physics import distance_loss_value_and_grad
-                self.dist_stream.wait_event(fork_d)
+                if forked_d:
+                    self.dist_stream.wait_event(fork_d)
+                else:  # the forward did not pass the hook: order the branch behind everything enqueued so far
+                    self.dist_stream.wait_stream(main)
                 with torch.cuda.stream(self.dist_stream):
                     n_vis = gm._visual_xyz.shape[0]
                     self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
@@ -744,7 +747,7 @@ class FirstFrameLoop:
         self.capturable = capturable
         self.stream = torch.cuda.Stream(device=gm._visual_xyz.device) if capturable else None
         self.graph, self.graph_iterations, self._replay, self._reduce_buf = None, 1, False, None
-        self.itr, self.last, self._gt = 0, {}, None
+        self.itr, self.last, self._gt, self.dist_stream = 0, {}, None, None
 
     @property
     def multi(self):
@@ -782,25 +785,47 @@ class FirstFrameLoop:
         V = param.shape[0]
         terms = []
         if mine:
+            # distance_loss(visual positions) is the same for every view (tpp:141-144): evaluated once, on its own
+            # stream next to the rasteriser (it needs the leaf only), added once per local view
+            from . import rasterizer
+            gd, main = None, torch.cuda.current_stream()
+            use_dist = c.get("lambda_first_distance", 0.0) > 0
+            # the distance branch forks between the rasteriser's binning stage and its emit / blend stage (see HotLoop):
+            # next to the latency-bound depth sort its grid build stretches the critical path, next to the blend it is free
+            fork, forked = torch.cuda.Event(), []
+            if use_dist:
+                rasterizer.set_between_stages_hook(lambda: (fork.record(torch.cuda.current_stream()), forked.append(1)))
             cams = [self.cams[v] for v in mine]
-            if self.rd_pipe == "render_fluid":
-                means = param
-                pkg = render_fluid_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
-                                         pos_type="visual", means3D=means)
-            else:
-                means = gm.render_means_from_visual()
-                pkg = render_dynamics_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
-                                            pos_type="visual", scale=False, means3D=means)
+            try:
+                if self.rd_pipe == "render_fluid":
+                    means = param
+                    pkg = render_fluid_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
+                                             pos_type="visual", means3D=means)
+                else:
+                    means = gm.render_means_from_visual()
+                    pkg = render_dynamics_views(cams, gm, None, self.background, GRsetting=self.GRsetting,
+                                                GRzer=self.GRzer, pos_type="visual", scale=False, means3D=means)
+            finally:
+                rasterizer.set_between_stages_hook(None)
             loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine),
                                                              c["lambda_dssim"], 1.0, grey=self.grey)
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
             g, = torch.autograd.grad([pkg["render"]], [means], grad_outputs=[dimg])
             terms.append((g[:V], 1.0))
-            if c.get("lambda_first_distance", 0.0) > 0:
-                # the same for every view (tpp:141-144): evaluated once, added once per local view
+            if use_dist:
+                # enqueued AFTER the rasteriser chain (a captured graph keeps a node's first-enqueued successor on its
+                # hardware queue: the critical path must not be the branch that hops)
                 from .physics import distance_loss_value_and_grad
-                _, gd = distance_loss_value_and_grad(param.detach(), c["distance_threshold_visual"])
+                if self.dist_stream is None:
+                    self.dist_stream = torch.cuda.Stream(device=param.device)
+                if forked:
+                    self.dist_stream.wait_event(fork)
+                else:  # the forward did not pass the hook: order the branch behind everything enqueued so far
+                    self.dist_stream.wait_stream(main)
+                with torch.cuda.stream(self.dist_stream):
+                    _, gd = distance_loss_value_and_grad(param.detach(), c["distance_threshold_visual"])
+                main.wait_stream(self.dist_stream)
                 terms.append((gd, float(c["lambda_first_distance"]) * len(mine)))
         return terms
 
