@@ -384,6 +384,100 @@ void launch_l1_ssim_backward(int grey, dim3 grid, hipStream_t stream, A... args)
     else hipLaunchKernelGGL(l1_ssim_backward_kernel<false>, grid, dim3(256), 0, stream, args...);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Visual-particle stage (train_visual_particle.py:133-222): the leaves are the raw colour / opacity / scales /
+// rotation of the fluid Gaussians.  One kernel activates them into the leading rows of the concatenated
+// [fluid | background] arrays the rasteriser reads (gm_dynamics.py getters: identity x3, sigmoid, exp, normalize;
+// pipe_dynamics.py:88-148); one kernel turns the rasteriser's gradients with respect to those rows, plus the
+// view-independent terms of the loss (consistency MSE with the previous frame per attribute, scale-ratio
+// regulariser, tvp:161-194), into the gradients of the raw leaves -- instead of ~90 elementwise / reduction launches.
+__global__ void __launch_bounds__(256)
+level2_activate_kernel(const float *__restrict__ rc, const float *__restrict__ ro, const float *__restrict__ rs,
+                       const float *__restrict__ rr, int n, float *__restrict__ colors, float *__restrict__ opacity,
+                       float *__restrict__ scales, float *__restrict__ rot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float c = rc[i];
+    colors[3 * i] = colors[3 * i + 1] = colors[3 * i + 2] = c;
+    opacity[i] = 1.0f / (1.0f + expf(-ro[i]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) scales[3 * i + k] = expf(rs[3 * i + k]);
+    const float4 q = *reinterpret_cast<const float4 *>(rr + 4 * (size_t)i);
+    const float inv = 1.0f / fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);  // F.normalize
+    *reinterpret_cast<float4 *>(rot + 4 * (size_t)i) = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+
+struct Level2Args {
+    const float *raw[4], *prev[4], *g[4];  // colour [n,1] (g: [n,3]), opacity [n,1], scales [n,3], rotation [n,4]
+    float *d[4];
+    float lam[4], lam_reg, reg_thr, reg_count, scale;
+    int n, n_prev;
+};
+
+__global__ void __launch_bounds__(256) level2_backward_kernel(const Level2Args a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool has_prev = i < a.n_prev;
+    const float np = (float)a.n_prev;
+    // d mse(raw[:n_prev], prev) / d raw = 2 (raw - prev) / (n_prev * dim); counted reg_count (= local views) times
+    if (a.d[0]) {
+        const float r = a.raw[0][i];
+        float g = (a.g[0][3 * i] + a.g[0][3 * i + 1]) + a.g[0][3 * i + 2];
+        if (has_prev) g += a.reg_count * a.lam[0] * 2.0f * (r - a.prev[0][i]) / np;
+        a.d[0][i] = g * a.scale;
+    }
+    if (a.d[1]) {
+        const float r = a.raw[1][i], o = 1.0f / (1.0f + expf(-r));
+        float g = a.g[1][i] * (o * (1.0f - o));
+        if (has_prev) g += a.reg_count * a.lam[1] * 2.0f * (r - a.prev[1][i]) / np;
+        a.d[1][i] = g * a.scale;
+    }
+    if (a.d[2]) {
+        float r[3], s[3], g[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[k] = a.raw[2][3 * i + k];
+            s[k] = expf(r[k]);
+            g[k] = a.g[2][3 * i + k] * s[k];
+            if (has_prev) g[k] += a.reg_count * a.lam[2] * 2.0f * (r[k] - a.prev[2][3 * i + k]) / (3.0f * np);
+        }
+        if (a.lam_reg > 0.0f) {  // lam_reg * mean_i relu(max(s) / min(s) - thr): first maximal / minimal index, as torch
+            int hi = 0, lo = 0;
+#pragma unroll
+            for (int k = 1; k < 3; k++) {
+                if (s[k] > s[hi]) hi = k;
+                if (s[k] < s[lo]) lo = k;
+            }
+            if (s[hi] / s[lo] - a.reg_thr > 0.0f) {
+                const float w = a.reg_count * a.lam_reg / (float)a.n;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float dr = 0.0f;
+                    if (k == hi) dr += 1.0f / s[lo];
+                    if (k == lo) dr -= s[hi] / (s[lo] * s[lo]);
+                    g[k] += w * dr * s[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.d[2][3 * i + k] = g[k] * a.scale;
+    }
+    if (a.d[3]) {
+        const float4 q = *reinterpret_cast<const float4 *>(a.raw[3] + 4 * (size_t)i);
+        const float4 gq = *reinterpret_cast<const float4 *>(a.g[3] + 4 * (size_t)i);
+        const float nrm = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f), inv = 1.0f / nrm;
+        const float ux = q.x * inv, uy = q.y * inv, uz = q.z * inv, uw = q.w * inv;
+        const float dot = (ux * gq.x + uy * gq.y) + (uz * gq.z + uw * gq.w);
+        float g[4] = {(gq.x - ux * dot) * inv, (gq.y - uy * dot) * inv, (gq.z - uz * dot) * inv, (gq.w - uw * dot) * inv};
+        const float r[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (has_prev) g[k] += a.reg_count * a.lam[3] * 2.0f * (r[k] - a.prev[3][4 * i + k]) / (4.0f * np);
+            a.d[3][4 * i + k] = g[k] * a.scale;
+        }
+    }
+}
+
 thread_local char g_err[512] = "";
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -480,5 +574,40 @@ int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, 
 int fnx_l1_ssim_backward(const float *img, const float *gt, int C, int H, int W, int grey, const float *dmaps,
                          const float *g_l1, const float *g_ssim, float *dL_dimg, fnx_stream_t stream) {
     return fnx_l1_ssim_backward_batch(img, gt, 1, C, H, W, grey, dmaps, g_l1, g_ssim, dL_dimg, stream);
+}
+int fnx_level2_activate(const float *raw_color, const float *raw_opacity, const float *raw_scales, const float *raw_rotation,
+                        int n, float *colors, float *opacity, float *scales, float *rotations, fnx_stream_t stream) {
+    if (n < 0 || (n > 0 && (!raw_color || !raw_opacity || !raw_scales || !raw_rotation || !colors || !opacity || !scales ||
+                            !rotations)))
+        return fail(FNX_ERR_INVALID_ARG, "level2_activate: bad argument");
+    if (n == 0) return FNX_OK;
+    hipLaunchKernelGGL(level2_activate_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw_color,
+                       raw_opacity, raw_scales, raw_rotation, n, colors, opacity, scales, rotations);
+    return hip_check("level2_activate");
+}
+int fnx_level2_backward(const float *const raw[4], const float *const prev[4], const float *const g[4], float *const d[4],
+                        int n, int n_prev, const float lambdas[4], float lambda_reg, float reg_threshold, float reg_count,
+                        float scale, fnx_stream_t stream) {
+    if (n < 0 || n_prev < 0 || n_prev > n || !raw || !prev || !g || !d || !lambdas)
+        return fail(FNX_ERR_INVALID_ARG, "level2_backward: bad argument");
+    Level2Args a;
+    for (int k = 0; k < 4; k++) {
+        if (d[k] && (!raw[k] || !g[k] || (n_prev > 0 && !prev[k])))
+            return fail(FNX_ERR_INVALID_ARG, "level2_backward: attribute %d has an output but no input", k);
+        a.raw[k] = raw[k];
+        a.prev[k] = prev[k];
+        a.g[k] = g[k];
+        a.d[k] = d[k];
+        a.lam[k] = lambdas[k];
+    }
+    a.lam_reg = lambda_reg;
+    a.reg_thr = reg_threshold;
+    a.reg_count = reg_count;
+    a.scale = scale;
+    a.n = n;
+    a.n_prev = n_prev;
+    if (n == 0) return FNX_OK;
+    hipLaunchKernelGGL(level2_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_check("level2_backward");
 }
 }

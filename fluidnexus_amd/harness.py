@@ -548,11 +548,13 @@ class HotLoopLevelTwo:
     view, averaged over the batch (gm_dynamics.py:474-503) and applied with Adam(eps = 1e-15)."""
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, cfg=SMOKE_L2, image_loss="fused",
-                 log_scalars=False, batched_views=False, capturable=False, force_all_reduce=False):
+                 log_scalars=False, batched_views=False, capturable=False, force_all_reduce=False, fused_attributes=None):
         """batched_views: the views of the batch through ONE view-batched render / fused image loss / backward (all
         four attribute gradients out of the rasteriser's full backward, the static background binned once), the
         view-independent consistency terms evaluated once and counted once per view; capturable: device-side fused
-        Adam over the four attribute groups, so that capture() can record whole iterations as a hipGraph."""
+        Adam over the four attribute groups, so that capture() can record whole iterations as a hipGraph;
+        fused_attributes (default: with batched_views): activations, consistency / scale-ratio terms and the batch mean
+        in two kernels (fnx_level2_activate / fnx_level2_backward) instead of ~90 elementwise launches."""
         from .utils.loss_utils import l2_loss_consistency
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.view_subset = None
@@ -560,6 +562,9 @@ class HotLoopLevelTwo:
         self.image_loss, self.log_scalars = image_loss, log_scalars
         self.batched_views, self.capturable, self.force_all_reduce = bool(batched_views), bool(capturable), force_all_reduce
         assert not capturable or batched_views, "graph capture is implemented for the view-batched level-two loop"
+        self.fused_attributes = self.batched_views if fused_attributes is None else bool(fused_attributes)
+        assert not self.fused_attributes or (batched_views and gm._visual_color.shape[1] == 1)
+        self._attr = None
         self.background = torch.zeros(3, device=gm._visual_xyz.device)
         self.prev = {n: getattr(gm, f"_visual_{n}").detach().clone() for n in gm._L2}
         self._cons = l2_loss_consistency
@@ -601,7 +606,70 @@ class HotLoopLevelTwo:
             reg = reg + c["lambda_reg_scaling"] * torch.clamp_min(ratio - c["scaling_reg_ratio_threshold"], 0).mean()
         return reg
 
+    def _attribute_arrays(self):
+        """Persistent [fluid | background] attribute arrays for the fused path: the background rows (fixed in this
+        stage) are written once, the fluid rows by fnx_level2_activate every iteration."""
+        gm = self.gm
+        src = (gm._gs_opacity, gm._gs_scales, gm._gs_rotation, gm._gs_color)
+        key = tuple((t, t._version) for t in src) + (gm._visual_color.shape[0],)
+        if self._attr is None or len(self._attr[0]) != len(key) or any(
+                (a[0] is not b[0] or a[1] != b[1]) if isinstance(a, tuple) else a != b for a, b in zip(self._attr[0], key)):
+            n = gm._visual_color.shape[0]
+            with torch.no_grad():
+                dev = gm._visual_color.device
+                gs = dict(opacity=gm.get_gs_opacity, scales=gm.get_gs_scaling, rotation=gm.get_gs_rotation,
+                          color=gm.get_gs_color)
+                arrays = {}
+                for k, t in gs.items():
+                    a = torch.zeros((n + t.shape[0], t.shape[1]), device=dev, dtype=torch.float32)
+                    a[n:] = t.float()
+                    arrays[k] = a
+            self._attr = (key, arrays)
+        return self._attr[1]
+
+    def _body_fused(self):
+        from .losses import image_loss_value_and_grad, level2_activate, level2_backward
+        from .renderer.pipes import render_dynamics_views
+        gm, c = self.gm, self.cfg
+        gm.total_iterations += 1
+        batch = len(self.cams)
+        mine = self._mine(batch)
+        names = gm._l2_active()
+        raw = {n: getattr(gm, f"_visual_{n}") for n in gm._L2}
+        out = {}
+        for n in names:
+            p = raw[n]
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            out[n] = p.grad
+        if mine:
+            arrays = self._attribute_arrays()
+            level2_activate({k: t.detach() for k, t in raw.items()}, arrays)
+            leaves = {k: arrays[k].detach().requires_grad_() for k in gm._L2}
+            pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background, GRsetting=self.GRsetting,
+                                        GRzer=self.GRzer, pos_type="visual", scale=True, means3D=self._render_means(),
+                                        attributes=(leaves["opacity"], leaves["scales"], leaves["rotation"], leaves["color"]))
+            loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                                                             c["lambda_image"], grey=False)
+            if self.log_scalars:
+                self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
+            g = dict(zip(gm._L2, torch.autograd.grad([pkg["render"]], [leaves[k] for k in gm._L2], grad_outputs=[dimg])))
+            with torch.no_grad():
+                level2_backward({k: t.detach() for k, t in raw.items()}, self.prev, g, out,
+                                {k: c[f"lambda_consistency_{k}"] for k in gm._L2},
+                                c["lambda_reg_scaling"] if "scales" in names else 0.0, c["scaling_reg_ratio_threshold"],
+                                float(len(mine)), 1.0 / batch)
+        else:
+            for n in names:
+                out[n].zero_()
+        if self.multi:
+            for n in names:
+                dist.all_reduce(out[n], op=dist.ReduceOp.SUM)
+        gm.optimizer.step()  # set_batch_gradient_current_level_two (gm_dynamics.py:494-503) happened in the kernel
+
     def _body_batched(self):
+        if self.fused_attributes:
+            return self._body_fused()
         from .losses import image_loss_value_and_grad
         from .renderer.pipes import render_dynamics_views
         gm, c = self.gm, self.cfg

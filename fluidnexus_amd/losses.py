@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
            "fnx_l1_ssim_backward", "fnx_l1_ssim_forward_batch", "fnx_l1_ssim_backward_batch",
-           "fnx_image_loss_forward", "fnx_image_loss_backward", "fnx_image_loss_value_and_grad")
+           "fnx_image_loss_forward", "fnx_image_loss_backward", "fnx_image_loss_value_and_grad",
+           "fnx_level2_activate", "fnx_level2_backward")
 
 
 def lib():
@@ -37,6 +38,9 @@ def lib():
         L.fnx_image_loss_forward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p, p]
         L.fnx_image_loss_backward.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p]
         L.fnx_image_loss_value_and_grad.argtypes = [p, p, i, i, i, i, i, f, f, p, p, p, p, p, p, p]
+        L.fnx_level2_activate.argtypes = [p, p, p, p, i, p, p, p, p, p]
+        p4, f4 = C.c_void_p * 4, C.c_float * 4
+        L.fnx_level2_backward.argtypes = [p4, p4, p4, p4, i, i, f4, f, f, f, f, p]
         _LIB = L
     return _LIB
 
@@ -177,3 +181,44 @@ def fused_image_loss(img, gt, lambda_dssim, lambda_image=1.0, grey=True):
     Returns (loss, per_image) with per_image [N,2] = detached (L1_n, SSIM_n) for logging.  Three kernels."""
     return _ImageLoss.apply(img, gt, (1.0 - float(lambda_dssim)) * float(lambda_image),
                             float(lambda_dssim) * float(lambda_image), bool(grey))
+
+
+_L2_ORDER = ("color", "opacity", "scales", "rotation")
+_L2_WIDTH = {"color": 1, "opacity": 1, "scales": 3, "rotation": 4}
+
+
+def _l2_ptr(t, rows, width, what):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[0] >= rows
+            and t.shape[1] == width):
+        raise RuntimeError(f"level-two {what}: expected a contiguous float32 device tensor [>={rows}, {width}], got "
+                           f"{tuple(t.shape)} {t.dtype} on {t.device}")
+    return t.data_ptr()
+
+
+def level2_activate(raw, out):
+    """Visual-particle stage: activate the raw attributes of the n fluid Gaussians into the first n rows of the arrays
+    the rasteriser reads (gm_dynamics.py getters; pipe_dynamics.py:88-148).  raw / out: dicts keyed colour, opacity,
+    scales, rotation; out["color"] has 3 columns (the grey colour repeated)."""
+    n = raw["color"].shape[0]
+    args = [_l2_ptr(raw[k], n, _L2_WIDTH[k], f"raw {k}") for k in _L2_ORDER]
+    args += [_l2_ptr(out[k], n, 3 if k == "color" else _L2_WIDTH[k], f"activated {k}") for k in _L2_ORDER]
+    _check(lib().fnx_level2_activate(*args[:4], n, *args[4:], torch.cuda.current_stream().cuda_stream))
+
+
+def level2_backward(raw, prev, g, d, lambdas, lambda_reg, reg_threshold, reg_count, scale):
+    """Gradients of the raw attributes (d[k], None = not fitted) from the rasteriser's gradients with respect to the
+    activated rows (g[k]) plus reg_count x the view-independent terms of train_visual_particle.py:161-194, times scale
+    (include/fnx_losses.h)."""
+    n = raw["color"].shape[0]
+    n_prev = prev["color"].shape[0]
+    p4, f4 = C.c_void_p * 4, C.c_float * 4
+    lib().fnx_level2_backward.restype = C.c_int
+    _check(lib().fnx_level2_backward(
+        p4(*[_l2_ptr(raw[k], n, _L2_WIDTH[k], f"raw {k}") for k in _L2_ORDER]),
+        p4(*[_l2_ptr(prev[k], n_prev, _L2_WIDTH[k], f"previous {k}") for k in _L2_ORDER]),
+        p4(*[_l2_ptr(g[k], n, 3 if k == "color" else _L2_WIDTH[k], f"gradient {k}") for k in _L2_ORDER]),
+        p4(*[_l2_ptr(d.get(k), n, _L2_WIDTH[k], f"output {k}") for k in _L2_ORDER]),
+        n, n_prev, f4(*[float(lambdas[k]) for k in _L2_ORDER]), float(lambda_reg), float(reg_threshold), float(reg_count),
+        float(scale), torch.cuda.current_stream().cuda_stream))

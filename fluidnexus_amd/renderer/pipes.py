@@ -224,19 +224,21 @@ def _zero_scalar(like):
 
 def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                           GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
-                          gpf_only=False, gs_only=False, debug=False, means3D=None, **kwargs):
+                          gpf_only=False, gs_only=False, debug=False, means3D=None, attributes=None, **kwargs):
     """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
     reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
     per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
     [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3]); render[v] equals render_dynamics(camera v).
     `means3D`: positions [fluid | background] prepared by the caller (gm.render_means_from_nn()) instead of
-    the pos_type lookup + scaling + concatenation done here."""
+    the pos_type lookup + scaling + concatenation done here; `attributes`: (opacity, scales, rotations, colours) of
+    [fluid | background], activated by the caller (the visual-particle stage differentiates with respect to them)."""
     from ..rasterizer import GaussianRasterizerViews
     if means3D is not None:
         assert not (gpf_only or gs_only)
         n_fluid = means3D.shape[0] - gm.get_gs_xyz.shape[0]
         raw_render_xyz = render_xyz = means3D[:n_fluid]
-        opacity, scales, rotations, colors = _static_attributes(gm, pos_type, False)
+        opacity, scales, rotations, colors = (attributes if attributes is not None
+                                              else _static_attributes(gm, pos_type, False))
     else:
         raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
     if means3D is not None:

@@ -52,6 +52,21 @@ int fnx_image_loss_backward(const float *img, const float *gt, int N, int C, int
 int fnx_image_loss_value_and_grad(const float *img, const float *gt, int N, int C, int H, int W, int grey, float w_l1,
                                   float w_dssim, float *partials, float *dmaps, float *per_image, float *loss,
                                   const float *g_loss, float *dL_dimg, fnx_stream_t stream);
+/* Visual-particle stage (train_visual_particle.py:133-222): the leaves are the raw attributes of the n fluid Gaussians.
+ * fnx_level2_activate writes their activations (gm_dynamics.py getters: colour repeated to 3 channels, sigmoid(opacity),
+ * exp(scales), normalize(rotation)) into the first n rows of the arrays the rasteriser reads (pipe_dynamics.py:88-148). */
+int fnx_level2_activate(const float *raw_color, const float *raw_opacity, const float *raw_scales, const float *raw_rotation,
+                        int n, float *colors /* [.,3] */, float *opacity /* [.,1] */, float *scales /* [.,3] */,
+                        float *rotations /* [.,4] */, fnx_stream_t stream);
+/* d[k] = scale * ( d(rasteriser term)/d raw[k]  (from g[k], the gradient with respect to the activated rows)
+ *                + reg_count * ( lambdas[k] * d mse(raw[k][:n_prev], prev[k]) / d raw[k]            (tvp:161-186)
+ *                              + [k = scales] lambda_reg * d mean_i relu(max_i / min_i - reg_threshold) / d raw ) ),   (tvp:188-194)
+ * k = 0 colour [n,1] (g[0]: [n,3]), 1 opacity [n,1], 2 scales [n,3], 3 rotation [n,4]; d[k] NULL skips an attribute that
+ * is not fitted.  reg_count = the number of local views (every view's loss carries the view-independent terms once),
+ * scale = 1 / batch (gm_dynamics.py:494-503).  The four arrays of pointers and lambdas are read on the host. */
+int fnx_level2_backward(const float *const raw[4], const float *const prev[4], const float *const g[4], float *const d[4],
+                        int n, int n_prev, const float lambdas[4], float lambda_reg, float reg_threshold, float reg_count,
+                        float scale, fnx_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

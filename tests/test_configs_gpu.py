@@ -158,10 +158,10 @@ def test_level_two_batched_matches_per_view_loop():
     first moments after one step for all four attribute groups."""
     from fluidnexus_amd import harness as Hn
     res = {}
-    for mode in ("per_view", "batched"):
+    for mode in ("per_view", "batched", "fused"):
         gm, cams = Hn.build_smoke_frame(P_fluid=12000, P_background=4000, hidden_dims=(6, 10, 6), n_views=3, size=128, seed=4)
         cfg = dict(Hn.SMOKE_L2, lambda_reg_scaling=0.05, scaling_reg_ratio_threshold=1.2)
-        loop = Hn.HotLoopLevelTwo(gm, cams, cfg=cfg, batched_views=mode == "batched")
+        loop = Hn.HotLoopLevelTwo(gm, cams, cfg=cfg, batched_views=mode != "per_view", fused_attributes=mode == "fused")
         loop.make_targets()
         for n in gm._L2:  # away from the previous frame's values, so that the consistency terms have a gradient
             with torch.no_grad():
@@ -172,6 +172,8 @@ def test_level_two_batched_matches_per_view_loop():
         res[mode] = {n: _first_moment(gm, getattr(gm, f"_visual_{n}")) for n in gm._L2}
     for n in res["per_view"]:
         assert _close(res["batched"][n], res["per_view"][n], 1e-3), n
+        # the attribute kernels (fnx_level2_activate / fnx_level2_backward) against the same chain in torch ops
+        assert _close(res["fused"][n], res["batched"][n], 1e-4), n
 
 
 def test_level_two_graph_equals_eager():
