@@ -665,7 +665,14 @@ class HotLoopLevelTwo:
         if self.multi:
             for n in names:
                 dist.all_reduce(out[n], op=dist.ReduceOp.SUM)
-        gm.optimizer.step()  # set_batch_gradient_current_level_two (gm_dynamics.py:494-503) happened in the kernel
+        # set_batch_gradient_current_level_two (gm_dynamics.py:494-503) happened in the kernel; the step on the torch
+        # optimiser's own state, one launch per attribute group (torch's capturable fused Adam takes ~45 us per group)
+        if self.capturable:
+            from .physics import adam_step
+            for n in names:
+                adam_step(raw[n], gm.optimizer, [(out[n], 1.0)], 1.0)
+        else:
+            gm.optimizer.step()
 
     def _body_batched(self):
         if self.fused_attributes:

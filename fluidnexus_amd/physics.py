@@ -292,11 +292,14 @@ def distance_loss(positions, threshold):
 
 def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=None, scale=1.0):
     """Gradient mean + Adam step of `param` in one kernel (fnx_adam_step), on the state of `optimizer`
-    (a torch.optim.Adam with amsgrad = False, weight_decay = 0 whose only parameter is `param`).
+    (a torch.optim.Adam with amsgrad = False, weight_decay = 0; the hyper-parameters are those of the group that
+    holds `param`).
     terms: up to three (tensor, scale) pairs; the gradient is sum(tensor * scale) / batch_size.
     scaled_out: optional tensor like `param` that receives the updated param * scale."""
     lib = PL.physics()
-    group = optimizer.param_groups[0]
+    group = next((g for g in optimizer.param_groups if any(q is param for q in g["params"])), None)
+    if group is None:
+        raise RuntimeError("adam_step: the parameter does not belong to the optimiser")
     if group.get("amsgrad") or group.get("weight_decay") or group.get("maximize"):
         raise RuntimeError("adam_step: amsgrad / weight_decay / maximize are not supported")
     st = optimizer.state[param]

