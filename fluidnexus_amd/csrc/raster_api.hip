@@ -532,7 +532,8 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
     if (scales && (!rotations || !dL_dscale || !dL_drot))
         return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
-    if (geometry_only && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
+    if (geometry_only < 0 || geometry_only > 2) return fail(FNX_ERR_INVALID_ARG, "geometry_only must be 0, 1 or 2");
+    if (geometry_only == 1 && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
     if (binning_capacity < 0) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     fnx::ViewBatch vb;
     fnx::StaticRef st;
@@ -554,12 +555,12 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     const size_t cov3D_stride = cov3D_precomp ? 0 : vb.geom;
     {
         ProfScope ps(channels == 3 ? 1 : 6, s);
-        fnx::launch_blend_backward(channels, geometry_only ? 1 : 0, s, P_all, width, height, img.ranges, bin.point_list,
+        fnx::launch_blend_backward(channels, geometry_only, s, P_all, width, height, img.ranges, bin.point_list,
                                    background, g.blend_rec, img.final_T, img.n_contrib, img.acc_final, dL_dpix,
                                    dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
                                    (uint32_t)limit, V, vb, st);
     }
-    const int sum_appearance = (V > 1 && !geometry_only) ? 1 : 0;
+    const int sum_appearance = (V > 1 && geometry_only != 1) ? 1 : 0;
     fnx::launch_geom_backward(channels, s, P_all, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
                               cov3D_ptr, cov3D_stride, viewmatrix, projmatrix, campos, dL_dmean2D, dL_dconic,
                               dL_dopacity_views, dL_dcolor_views, dL_dopacity, shs ? nullptr : dL_dcolor, dL_dmean3D,

@@ -71,7 +71,9 @@ __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], floa
 // compacted list (block_mask_exact), the four rows walk four lists at once, and the per-entry sums are row
 // reductions; a block only receives entries in front of its own deepest contributor.
 // MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
-// MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients.
+// MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients;
+// MODE 2: fixed positions (conic.xyw | opacity | colour[C]) -- the caller does not need the gradient of the 2D means
+//         (the visual-particle stage: positions are not optimised).
 // Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
 #ifndef FNX_BWD_WAVES
 #define FNX_BWD_WAVES 4  // waves per SIMD the register allocation of the blend backward aims at
@@ -85,7 +87,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
                       float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
                       uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb) {
-    constexpr int NV = MODE == 0 ? 6 + C : 5;
+    constexpr bool kMeans = MODE != 2, kAppearance = MODE != 1;
+    constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums
+    constexpr int NV = kAppearance ? kCol + C : kOpac;
 #ifndef FNX_BWD_GROUP
 #define FNX_BWD_GROUP 4
 #endif
@@ -141,8 +145,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const float *dL_dpixels_v = dL_dpixels + (size_t)vw * C * H * W;
         float *dL_dmean2D_v = dL_dmean2D + (size_t)vw * P * 3;
         float *dL_dconic_v = dL_dconic + (size_t)vw * P * 4;
-        float *dL_dopacity_v = MODE == 0 ? dL_dopacity + (size_t)vw * P : nullptr;
-        float *dL_dcolors_v = MODE == 0 ? dL_dcolors + (size_t)vw * P * C : nullptr;
+        float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)vw * P : nullptr;
+        float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)vw * P * C : nullptr;
         // static-split mode: records of splats with id >= st.id0 live in the view's static blob
         const uint32_t id0 = st.base ? st.id0 : 0xFFFFFFFFu;
         const float4 *rec_static = st.base ? reinterpret_cast<const float4 *>(st.base + st.stride * vw + st.rec) : nullptr;
@@ -292,16 +296,18 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float wgt = Gm * dL_dG;
                 const float wx = wgt * dx, wy = wgt * dy;
                 float val[NV];
-                val[0] = wx;
-                val[1] = wy;
-                val[2] = wx * dx;
-                val[3] = wx * dy;
-                val[4] = wy * dy;
-                if (MODE == 0) {
-                    val[MODE == 0 ? 5 : 0] = Gm * dL_da;
+                if (kMeans) {
+                    val[0] = wx;
+                    val[kMeans ? 1 : 0] = wy;
+                }
+                val[kConic] = wx * dx;
+                val[kConic + 1] = wx * dy;
+                val[kConic + 2] = wy * dy;
+                if (kAppearance) {
+                    val[kAppearance ? kOpac : 0] = Gm * dL_da;
                     const float dchannel_dcolor = emits ? a * Tb : 0.0f;
 #pragma unroll
-                    for (int ch = 0; ch < C; ch++) val[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)] = dchannel_dcolor * dL_dpixel[ch];
+                    for (int ch = 0; ch < C; ch++) val[kAppearance ? kCol + ch : 0] = dchannel_dcolor * dL_dpixel[ch];
                 }
 #if FNX_ABLATE == 2
                 { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
@@ -325,16 +331,18 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 // -1/2 G (dx^2, dx dy, dy^2), each times dL/dG
                 const float4 ra = s_ra[tid];
                 const float cc = s_rb[tid].x;
-                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[1]) * ddelx_dx);
-                unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[1] + ra.w * a[0]) * ddely_dy);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[2]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[3]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[4]);
-                if (MODE == 0) {
-                    unsafeAtomicAdd(&dL_dopacity_v[id], a[MODE == 0 ? 5 : 0]);
+                if (kMeans) {
+                    unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
+                    unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
+                }
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
+                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
+                if (kAppearance) {
+                    unsafeAtomicAdd(&dL_dopacity_v[id], a[kAppearance ? kOpac : 0]);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++)
-                        unsafeAtomicAdd(&dL_dcolors_v[(size_t)id * C + ch], a[(MODE == 0 ? 6 : 0) + (MODE == 0 ? ch : 0)]);
+                        unsafeAtomicAdd(&dL_dcolors_v[(size_t)id * C + ch], a[kAppearance ? kCol + ch : 0]);
                 }
             }
         }
@@ -663,7 +671,9 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
     else if (C == 3) launch_blend_backward_t<3, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
     else if (mode == 0) launch_blend_backward_t<1, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
     else launch_blend_backward_t<1, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);

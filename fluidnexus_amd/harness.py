@@ -648,7 +648,8 @@ class HotLoopLevelTwo:
             leaves = {k: arrays[k].detach().requires_grad_() for k in gm._L2}
             pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background, GRsetting=self.GRsetting,
                                         GRzer=self.GRzer, pos_type="visual", scale=True, means3D=self._render_means(),
-                                        attributes=(leaves["opacity"], leaves["scales"], leaves["rotation"], leaves["color"]))
+                                        attributes=(leaves["opacity"], leaves["scales"], leaves["rotation"], leaves["color"]),
+                                        screen_grad=False)  # positions are fixed: no 2D-mean gradient sums
             loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
                                                              c["lambda_image"], grey=False)
             if self.log_scalars:

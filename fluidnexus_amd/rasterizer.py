@@ -153,6 +153,18 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings, channels, grad_splat_limit)
 
 
+
+def _gradient_mode(need, M):
+    """`geometry_only` of fnx_rasterize_backward_ex from autograd's needs_input_grad (means3D, means2D, sh, colors,
+    opacities, scales, rotations, cov3D, ...): 1 = nobody asked for opacity / colour / SH gradients, 2 = nobody asked
+    for the gradient of the positions (3D or screen-space), 0 = everything."""
+    if not (need[2] or need[3] or need[4]) and M == 0:
+        return 1
+    if not (need[0] or need[1]):
+        return 2
+    return 0
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -252,7 +264,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # skip what autograd would throw away: opacity / colour / SH gradients nobody asked for, and
             # splats the caller declared gradient-free (GaussianRasterizer.grad_splat_limit)
             need = ctx.needs_input_grad  # (means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, ...)
-            geometry_only = int(not (need[2] or need[3] or need[4]) and M == 0)
+            geometry_only = _gradient_mode(need, M)
             _lib.check(lib.fnx_rasterize_backward_ex(
                 Cn, P, int(rs.sh_degree), M, int(ctx.capacity), bg.data_ptr(), W, H, means3D.data_ptr(),
                 _ptr(sh), _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
@@ -532,15 +544,15 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         M = sh.shape[1] if sh.numel() else 0
         need = ctx.needs_input_grad
-        geometry_only = int(not (need[2] or need[3] or need[4]) and M == 0)
+        geometry_only = _gradient_mode(need, M)
         # per-view accumulators first, then the arrays summed over the views; one zero-filled slab
-        widths = [V * 3, V * 4] + ([] if geometry_only else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
+        widths = [V * 3, V * 4] + ([] if geometry_only == 1 else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
         flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)
         parts, off = [], 0
         for w in widths:
             parts.append(flat[off:off + P * w])
             off += P * w
-        if geometry_only:
+        if geometry_only == 1:
             g_means2D, g_conic, g_means3D, g_colors, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
             g_opacity_v, g_colors_v = g_opacity, g_colors  # never written in this mode
         else:
@@ -561,7 +573,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                 _lib.check(lib.fnx_rasterize_backward_views(*args, stream))
             else:  # the gradient arrays span all splats; rows of the static ones stay zero
                 _lib.check(lib.fnx_rasterize_backward_views_split(*args, sb.blob.data_ptr(), sb.P, sb.R_cap, stream))
-        if V == 1 and not geometry_only:  # a single view accumulates straight into its per-view arrays
+        if V == 1 and geometry_only != 1:  # a single view accumulates straight into its per-view arrays
             g_opacity, g_colors = g_opacity_v, g_colors_v
         return (g_means3D.view(P, 3), g_means2D.view(V, P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
                 g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None)

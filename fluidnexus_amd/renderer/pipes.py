@@ -224,14 +224,17 @@ def _zero_scalar(like):
 
 def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                           GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
-                          gpf_only=False, gs_only=False, debug=False, means3D=None, attributes=None, **kwargs):
+                          gpf_only=False, gs_only=False, debug=False, means3D=None, attributes=None, screen_grad=True,
+                          **kwargs):
     """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
     reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
     per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
     [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3]); render[v] equals render_dynamics(camera v).
     `means3D`: positions [fluid | background] prepared by the caller (gm.render_means_from_nn()) instead of
     the pos_type lookup + scaling + concatenation done here; `attributes`: (opacity, scales, rotations, colours) of
-    [fluid | background], activated by the caller (the visual-particle stage differentiates with respect to them)."""
+    [fluid | background], activated by the caller (the visual-particle stage differentiates with respect to them);
+    `screen_grad=False`: "viewspace_points" takes no gradient (a stage that neither optimises positions nor reads the
+    screen-space gradient lets the backward skip the 2D-mean sums)."""
     from ..rasterizer import GaussianRasterizerViews
     if means3D is not None:
         assert not (gpf_only or gs_only)
@@ -257,7 +260,9 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
     V = len(viewpoint_cameras)
     # zero "screen-space points" whose .grad receives the per-view 2D-mean gradients: a stride-0 view of one
     # zero (the rasteriser never reads the values), instead of filling V*P*3 floats every iteration
-    screen = _zero_scalar(means3D).expand((V,) + tuple(means3D.shape)).requires_grad_()
+    screen = _zero_scalar(means3D).expand((V,) + tuple(means3D.shape))
+    if screen_grad:
+        screen = screen.requires_grad_()
     rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
                                                      gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
     if not (gpf_only or gs_only) and not any(

@@ -106,8 +106,11 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
 /*
  * Extension of fnx_rasterize_backward for callers that discard part of the result (the reference
  * always computes everything): only splats with id < grad_splat_limit receive gradients (-1 = all;
- * the others still take part in the blending recurrences), and with geometry_only != 0 the
- * opacity / colour gradients are not produced (dL_dopacity, dL_dcolor stay as passed in).
+ * the others still take part in the blending recurrences); with geometry_only == 1 the
+ * opacity / colour gradients are not produced (dL_dopacity, dL_dcolor stay as passed in); with
+ * geometry_only == 2 ("fixed positions": the visual-particle stage, train_visual_particle.py:133-222, optimises
+ * appearance and shape only) the gradient with respect to the 2D means is not accumulated: dL_dmean2D stays as
+ * passed in and dL_dmean3D holds the covariance path's share only -- the caller must not use either.
  */
 int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,
                               const float *means3D, const float *shs, const float *colors_precomp, const float *scales,

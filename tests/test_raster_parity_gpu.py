@@ -129,6 +129,28 @@ def test_backward_extension_limit_and_geometry_only(oracle):
         r, got = ref[k].reshape(P, -1), part2[k].reshape(P, -1)
         assert np.abs(got[:lim] - r[:lim]).max() <= 2e-4 * np.abs(r).max(), k
         assert (got[lim:] == 0).all(), k
+    # geometry_only = 2 ("fixed positions"): appearance and shape gradients as the full backward's, the sums for the
+    # 2D means are not formed
+    part3 = h.backward(dL, grad_splat_limit=lim, geometry_only=2)
+    for k in ("dL_dopacity", "dL_dcolors", "dL_dconic", "dL_dscales", "dL_drotations", "dL_dcov3D"):
+        r, got = ref[k].reshape(P, -1), part3[k].reshape(P, -1)
+        assert np.abs(got[:lim] - r[:lim]).max() <= 2e-4 * np.abs(r).max(), k
+        assert (got[lim:] == 0).all(), k
+    assert (part3["dL_dmeans2D"] == 0).all()
+
+
+def test_fixed_positions_mode_ch1(oracle):
+    """geometry_only = 2 on the 1-channel rasteriser (all splats): opacity / colour / shape gradients against the oracle."""
+    P, W, H = 3000, 80, 64
+    g = S.random_gaussians(P, seed=32, channels=1, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    f, h = _run_pair(oracle, g, cam, W, H, np.array([0.1, 0.0, 0.0], np.float32), channels=1)
+    dL = np.random.RandomState(6).normal(size=(1, H, W)).astype(np.float32)
+    ref = oracle.backward(f, dL)
+    got = h.backward(dL, grad_splat_limit=-1, geometry_only=2)
+    for k in ("dL_dopacity", "dL_dcolors", "dL_dconic", "dL_dscales", "dL_drotations"):
+        assert np.abs(got[k].reshape(P, -1) - ref[k].reshape(P, -1)).max() <= 2e-4 * np.abs(ref[k]).max(), k
+    assert (got["dL_dmeans2D"] == 0).all()
 
 
 def test_edge_cases(oracle):
