@@ -211,3 +211,53 @@ def test_level_two_graph_equals_eager():
         # into steps of +-lr: a handful of such elements may differ between two runs of the same loop
         off = ((res["eager"][n] - res["graph"][n]).abs() > 0.02 * moved + 1e-6).sum().item()
         assert off <= max(2, res["eager"][n].numel() // 2000), (n, off)
+
+
+def test_config1_reference_cpu_case_end_to_end(oracle):
+    """BASELINE configs[0] / SURVEY 8(d) config 1 -- the one case the reference can run on a CPU: 10 000 random
+    Gaussians, one 256 x 256 view (FoV 0.8 rad, camera at distance 2 on +z), ch3, loss = L1 + 0.2 (1 - SSIM) against a
+    seeded U(0,1) target.  Through the plug-in API (`get_render_pipe` -> GaussianRasterizer, autograd) and the fused
+    image loss: the image is bit-identical to the CPU oracle's, the loss equals utils.loss_utils' (the reference's
+    functions, golden-pinned in test_golden_utils.py) on that image, and the gradients of all five inputs equal the
+    oracle's backward seeded with that loss's dL/dimage."""
+    from fluidnexus_amd import synthetic as S
+    from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
+    from fluidnexus_amd.losses import fused_l1_ssim
+    from fluidnexus_amd.utils.loss_utils import l1_loss, ssim
+    from tests.hip_harness import scene_kwargs
+    P, W, H = 10_000, 256, 256
+    dev = torch.device("cuda:0")
+    g = S.random_gaussians(P, seed=0)  # xyz U([-0.5, 0.5]^3), log-scale U(-5.5, -3.5), quat N(0,1) normalised, ...
+    cam = S.front_camera(W, H, device="cpu")
+    kw = scene_kwargs(g, cam, W, H, 0.8)
+    bg = np.zeros(3, np.float32)
+    target = np.random.RandomState(0).uniform(0, 1, size=(3, H, W)).astype(np.float32)
+
+    f = oracle.forward(kw["means3D"], kw["opacities"], bg, kw["view"], kw["proj"], kw["campos"], W, H, kw["tanx"], kw["tany"],
+                       colors_precomp=g["colors"], scales=g["scales"], rotations=g["rotations"])
+    img_ref = torch.tensor(f["color"], requires_grad=True)
+    loss_ref = 0.8 * l1_loss(img_ref, torch.tensor(target)) + 0.2 * (1.0 - ssim(img_ref, torch.tensor(target)))
+    loss_ref.backward()
+    grads_ref = oracle.backward(f, img_ref.grad.numpy())
+
+    _, Settings, Rasterizer = get_render_pipe("render_dynamics")
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    leaves = {k: t(g[k]).requires_grad_() for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+    screen = torch.zeros(P, 3, device=dev, requires_grad=True)
+    rs = Settings(image_height=H, image_width=W, tan_fov_x=kw["tanx"], tan_fov_y=kw["tany"], bg=t(bg), scale_modifier=1.0,
+                  view_matrix=t(kw["view"]), proj_matrix=t(kw["proj"]), sh_degree=0, campos=t(kw["campos"]), prefiltered=False)
+    image, radii, depth = Rasterizer(raster_settings=rs)(
+        means3D=leaves["means3D"], means2D=screen, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+        scales=leaves["scales"], rotations=leaves["rotations"])
+    assert torch.equal(image.detach().cpu().view(torch.int32), torch.tensor(f["color"]).view(torch.int32))
+    assert torch.equal(radii.cpu(), torch.tensor(f["radii"]))
+    l1_value, ssim_value = fused_l1_ssim(image, t(target))
+    loss = 0.8 * l1_value + 0.2 * (1.0 - ssim_value)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    loss.backward()
+    names = dict(means3D="dL_dmeans3D", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations",
+                 colors="dL_dcolors")
+    for k, rk in names.items():
+        ref = torch.tensor(grads_ref[rk]).reshape(leaves[k].shape)
+        assert _close(leaves[k].grad.cpu(), ref, 5e-4), k
+    assert _close(screen.grad.cpu(), torch.tensor(grads_ref["dL_dmeans2D"]), 5e-4)

@@ -50,7 +50,7 @@ for by in range(4):
     for bx in range(4):
         k_of[by * 4 + bx] = 4 * ((by >> 1) * 2 + (bx >> 1)) + ((by & 1) * 2 + (bx & 1))
 k_of = k_of.to(dev)
-tot = dict(entries=0, block_entries=0, present=0, new64=0, new128=0, new256=0)
+tot = dict(entries=0, block_entries=0, present=0, present_wg=0, new64=0, new128=0, new256=0)
 GROUP = 4
 for v in range(V):
     iv, bv = img[v * ib:(v + 1) * ib], binning[v * cap:(v + 1) * cap]
@@ -71,21 +71,25 @@ for v in range(V):
     tot["block_entries"] += int(bits.sum())
     nb = int(used.max().item() + 255) // 256 + 1
 
-    def iters(sub, lists_per_wave):
+    def iters(sub, lists_per_wave, whole_wg=False):
         per = 256 // sub
         idx = (tile * (nb * per) + q // sub)
         cnt = torch.zeros(T * nb * per, 16, dtype=torch.long, device=dev)
         cnt.index_add_(0, idx, bits.long())
         g = cnt.view(-1, 16 // lists_per_wave, lists_per_wave).amax(dim=2)  # per wave: its longest list
         g = (g + GROUP - 1) // GROUP * GROUP
+        if whole_wg:  # every wave of the workgroup stays until the slowest one reaches the batch's barrier
+            return int(g.amax(dim=1).sum()) * g.shape[1]
         return int(g.sum())
 
     tot["present"] += iters(256, 4)  # wave-iterations of 64 pixel-entries
+    tot["present_wg"] += iters(256, 4, whole_wg=True)
     tot["new64"] += iters(64, 16)    # wave-iterations of 256 pixel-entries
     tot["new128"] += iters(128, 16)
     tot["new256"] += iters(256, 16)
 print(tot)
 be = tot["block_entries"]
-print("present: lane efficiency", be / (tot["present"] * 4.0))
+print("present: lane efficiency", be / (tot["present"] * 4.0), " wave-slot efficiency with the per-batch barrier:",
+      tot["present"] / tot["present_wg"])
 for k in ("new64", "new128", "new256"):
     print(k, "lane efficiency", be / (tot[k] * 16.0), " wave-iterations x4 vs present:", tot[k] * 4.0 / tot["present"])
