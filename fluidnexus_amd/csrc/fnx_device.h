@@ -161,46 +161,47 @@ __device__ __forceinline__ int blend_pixel_y(int w, int lane) { return (w >> 1) 
 __device__ __forceinline__ uint32_t block_mask_exact(float x, float y, float a, float b, float c, float thr, float ex,
                                                      float ey, float tile_x0, float tile_y0) {
     if (ex < 0.0f) return 0u;
-    // The minimum of q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 over a block is 0 if the centre lies in it, otherwise
-    // the least of its four edge minima (1-D quadratics with clamped minimisers).  The edges lie on 8 vertical and 8 horizontal lines of
-    // the tile (block starts 0 4 8 12, block ends 3 7 11 15): the per-line terms are computed once, an edge then costs
-    // a clamp (v_med3), two fused multiply-adds and a min.  Culling arithmetic is free to fuse: its margins dwarf the
-    // rounding.
+    // The minimum of q(dx, dy) = a dx^2 + 2 b dx dy + c dy^2 over a block is 0 if the centre lies in it; otherwise it
+    // lies on an edge that FACES the centre (q is convex with its minimum at the centre: from any other point of the
+    // block a step towards the centre stays inside and lowers q).  Per column of blocks that is the vertical line
+    // nearer to the centre, per row the nearer horizontal line (for a column that straddles the centre the nearer
+    // line is no facing edge, but a point of the block all the same: it cannot undercut the minimum).  So a block
+    // costs two 1-D quadratics with clamped minimisers: a clamp (v_med3), two fused multiply-adds and a min each.
+    // Culling arithmetic is free to fuse: its margins dwarf the rounding.
     const float lim = (-2.0f * thr) * 1.001f + 0.01f;
     const float nbc = -b / c, nba = -b / a, b2 = 2.0f * b;
     const float ox = tile_x0 - x, oy = tile_y0 - y;
-    float LX[8], aXX[8], bX[8], sX[8], LY[8], cYY[8], bY[8], sY[8];
+    // in_x / in_y: 0 if the column / row of blocks straddles the centre, else huge; their sum is the "quadratic" of a
+    // block that holds the centre (0: kept, lim > 0) without a branch
+    float X0[4], X1[4], aXX[4], bX[4], sX[4], in_x[4], Y0[4], Y1[4], cYY[4], bY[4], sY[4], in_y[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {  // line i: block i / 2, its start (even i) or end (odd i)
-        const float off = (float)(4 * (i >> 1) + 3 * (i & 1));
-        LX[i] = ox + off;
-        aXX[i] = a * LX[i] * LX[i];
-        bX[i] = b2 * LX[i];
-        sX[i] = nbc * LX[i];  // minimiser in dy along the vertical line
-        LY[i] = oy + off;
-        cYY[i] = c * LY[i] * LY[i];
-        bY[i] = b2 * LY[i];
-        sY[i] = nba * LY[i];  // minimiser in dx along the horizontal line
+    for (int i = 0; i < 4; i++) {  // block column / row i: its first and last pixel line, and the one nearer the centre
+        X0[i] = ox + (float)(4 * i);
+        X1[i] = ox + (float)(4 * i + 3);
+        in_x[i] = fmaxf(X0[i], -X1[i]) <= 0.0f ? 0.0f : 3.0e38f;
+        const float LX = X0[i] > 0.0f ? X0[i] : X1[i];  // right of the centre: the left line; else the right line
+        aXX[i] = a * LX * LX;
+        bX[i] = b2 * LX;
+        sX[i] = nbc * LX;  // minimiser in dy along the vertical line
+        Y0[i] = oy + (float)(4 * i);
+        Y1[i] = oy + (float)(4 * i + 3);
+        in_y[i] = fmaxf(Y0[i], -Y1[i]) <= 0.0f ? 0.0f : 3.0e38f;
+        const float LY = Y0[i] > 0.0f ? Y0[i] : Y1[i];
+        cYY[i] = c * LY * LY;
+        bY[i] = b2 * LY;
+        sY[i] = nba * LY;  // minimiser in dx along the horizontal line
     }
     uint32_t m = 0u;
 #pragma unroll
     for (int cy = 0; cy < 4; cy++) {
-        const float Y0 = LY[2 * cy], Y1 = LY[2 * cy + 1];
-        const bool in_y = Y0 <= 0.0f && Y1 >= 0.0f;
 #pragma unroll
         for (int cx = 0; cx < 4; cx++) {
-            const float X0 = LX[2 * cx], X1 = LX[2 * cx + 1];
-            float q = 3.0e38f;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float dy = __builtin_amdgcn_fmed3f(sX[2 * cx + k], Y0, Y1);
-                q = fminf(q, __builtin_fmaf(dy, __builtin_fmaf(c, dy, bX[2 * cx + k]), aXX[2 * cx + k]));
-                const float dx = __builtin_amdgcn_fmed3f(sY[2 * cy + k], X0, X1);
-                q = fminf(q, __builtin_fmaf(dx, __builtin_fmaf(a, dx, bY[2 * cy + k]), cYY[2 * cy + k]));
-            }
-            const bool inside = in_y && X0 <= 0.0f && X1 >= 0.0f;
-            if (inside || !(q > lim))  // NaN keeps the block
-                m |= 1u << (4 * ((cy >> 1) * 2 + (cx >> 1)) + (cy & 1) * 2 + (cx & 1));
+            const float dy = __builtin_amdgcn_fmed3f(sX[cx], Y0[cy], Y1[cy]);
+            const float qv = __builtin_fmaf(dy, __builtin_fmaf(c, dy, bX[cx]), aXX[cx]);
+            const float dx = __builtin_amdgcn_fmed3f(sY[cy], X0[cx], X1[cx]);
+            const float qh = __builtin_fmaf(dx, __builtin_fmaf(a, dx, bY[cy]), cYY[cy]);
+            const float q = fminf(fminf(qv, qh), in_x[cx] + in_y[cy]);
+            m |= (q > lim) ? 0u : 1u << (4 * ((cy >> 1) * 2 + (cx >> 1)) + (cy & 1) * 2 + (cx & 1));
         }
     }
     return m;
