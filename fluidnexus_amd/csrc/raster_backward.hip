@@ -195,6 +195,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             pre_dot += pre[ch] * dL_dpixel[ch];
         }
         const float tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
+        // what lies behind the entry being processed, as one running value: (total - prefix) . dL + the background's
+        // share; an applied entry takes its own alpha T (c . dL) out of it (fused multiply-adds: the gradients are
+        // compared within fp32 summation tolerance, only power / alpha repeat the forward's arithmetic exactly)
+        float rest = (total_dot - pre_dot) + tail_dot;
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
@@ -280,12 +284,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
                 const float Tb = Tr;  // transmittance in front of the entry
                 const float col[3] = {rc[k].x, rc[k].y, rc[k].z};
-                float c_dot = 0.0f;
+                float c_dot = col[0] * dL_dpixel[0];
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) c_dot += col[ch] * dL_dpixel[ch];
-                pre_dot = pre_dot + (a * Tb) * c_dot;
+                for (int ch = 1; ch < C; ch++) c_dot = __builtin_fmaf(col[ch], dL_dpixel[ch], c_dot);
+                rest = __builtin_fmaf(-(a * Tb), c_dot, rest);
                 Tr = Tb * one_m;  // the forward's test_T
-                const float dL_dalpha = Tb * c_dot - ((total_dot - pre_dot) + tail_dot) * inv_1ma;
+                const float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
                 const bool emits = active && wants;
                 const float dL_da = emits ? dL_dalpha : 0.0f;
                 const float dL_dG = rb[k].y * dL_da;
