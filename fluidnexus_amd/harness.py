@@ -564,7 +564,7 @@ class HotLoopLevelTwo:
         assert not capturable or batched_views, "graph capture is implemented for the view-batched level-two loop"
         self.fused_attributes = self.batched_views if fused_attributes is None else bool(fused_attributes)
         assert not self.fused_attributes or (batched_views and gm._visual_color.shape[1] == 1)
-        self._attr = None
+        self._attr, self._flat_grad = None, None
         self.background = torch.zeros(3, device=gm._visual_xyz.device)
         self.prev = {n: getattr(gm, f"_visual_{n}").detach().clone() for n in gm._L2}
         self._cons = l2_loss_consistency
@@ -636,12 +636,17 @@ class HotLoopLevelTwo:
         mine = self._mine(batch)
         names = gm._l2_active()
         raw = {n: getattr(gm, f"_visual_{n}") for n in gm._L2}
-        out = {}
-        for n in names:
-            p = raw[n]
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            out[n] = p.grad
+        # the gradients of the fitted attributes live in ONE flat buffer (views of it are the parameters' .grad), so
+        # that a multi-rank step needs one all-reduce ("one fused flat buffer per iteration")
+        flat = self._flat_grad
+        sizes = [raw[n].numel() for n in names]
+        if flat is None or flat.numel() != sum(sizes) or any(raw[n].grad is None for n in names):
+            flat = self._flat_grad = torch.zeros(sum(sizes), device=raw["color"].device, dtype=torch.float32)
+            off = 0
+            for n, k in zip(names, sizes):
+                raw[n].grad = flat[off:off + k].view_as(raw[n])
+                off += k
+        out = {n: raw[n].grad for n in names}
         if mine:
             arrays = self._attribute_arrays()
             level2_activate({k: t.detach() for k, t in raw.items()}, arrays)
@@ -661,11 +666,9 @@ class HotLoopLevelTwo:
                                 c["lambda_reg_scaling"] if "scales" in names else 0.0, c["scaling_reg_ratio_threshold"],
                                 float(len(mine)), 1.0 / batch)
         else:
-            for n in names:
-                out[n].zero_()
+            flat.zero_()
         if self.multi:
-            for n in names:
-                dist.all_reduce(out[n], op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         # set_batch_gradient_current_level_two (gm_dynamics.py:494-503) happened in the kernel; the step on the torch
         # optimiser's own state, one launch per attribute group (torch's capturable fused Adam takes ~45 us per group)
         if self.capturable:

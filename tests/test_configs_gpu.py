@@ -261,3 +261,37 @@ def test_config1_reference_cpu_case_end_to_end(oracle):
         ref = torch.tensor(grads_ref[rk]).reshape(leaves[k].shape)
         assert _close(leaves[k].grad.cpu(), ref, 5e-4), k
     assert _close(screen.grad.cpu(), torch.tensor(grads_ref["dL_dmeans2D"]), 5e-4)
+
+
+def test_level_two_one_rank_process_group_matches_single_process():
+    """The visual-particle stage with a process group (views sharded, ONE all-reduce of the flat attribute gradient,
+    then the per-group Adam kernels) on a 1-rank RCCL group against the same loop without communication."""
+    import os
+    import torch.distributed as dist
+    from fluidnexus_amd import harness as Hn
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fnx_rccl_test_%h_%p.log")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    res = {}
+    try:
+        for use_dist in (False, True):
+            gm, cams = Hn.build_smoke_frame(P_fluid=8000, P_background=3000, hidden_dims=(6, 10, 6), n_views=3, size=96, seed=9)
+            loop = Hn.HotLoopLevelTwo(gm, cams, batched_views=True, capturable=True, force_all_reduce=use_dist)
+            loop.make_targets()
+            for n in gm._L2:  # anisotropic scales (else the rotation gradient is identically zero), consistency terms active
+                with torch.no_grad():
+                    p = getattr(gm, f"_visual_{n}")
+                    p.add_(0.01 * torch.randn(p.shape, device=p.device, generator=torch.Generator(p.device).manual_seed(11)))
+            loop.iteration()
+            torch.cuda.synchronize()
+            grads = torch.cat([getattr(gm, f"_visual_{n}").grad.flatten() for n in gm._L2])
+            assert loop._flat_grad is not None and torch.equal(grads, loop._flat_grad)  # one buffer behind the four .grad
+            res[use_dist] = {n: _first_moment(gm, getattr(gm, f"_visual_{n}")) for n in gm._L2}
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for n in res[False]:
+        assert _close(res[True][n], res[False][n], 1e-4), n
