@@ -390,9 +390,11 @@ def main():
     # HBM traffic / VALU instructions of the dominant kernel: separate rocprofv3 --pmc passes of this command
     # (tools/collect_profiles.sh -> profiles/<tag>_pmc_traffic.json, <tag>_sq_counters.json), null if absent
     full_bwd = a.unfused_physics or a.stage == "visual"
-    # backward modes (raster_backward.hip): 1 = geometry only (position stages), 2 = fixed positions (visual-particle
-    # stage: appearance + shape gradients), 0 = everything (per-view autograd physics)
-    bwd_mode = 2 if a.stage == "visual" else (0 if a.unfused_physics else 1)
+    # backward modes (raster_backward.hip): 3 = positions only (the position stages: the flush adds straight into
+    # dL/dmeans3D), 1 = geometry only (the same with FNX_SCREEN_GRAD=1), 2 = fixed positions (visual-particle stage:
+    # appearance + shape gradients), 0 = everything (per-view autograd physics)
+    bwd_mode = 2 if a.stage == "visual" else (0 if a.unfused_physics else
+                                              1 if os.environ.get("FNX_SCREEN_GRAD", "0") == "1" else 3)
     kname = f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}>"
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
     traffic = valu = None
@@ -492,7 +494,7 @@ def main():
             hot_loop_forward=sum(prof[k][0] for k in ("preprocess", "sort_and_counts", "emit", "blend_forward", "blend_forward_ch1")
                                  if k in prof) / max(prof["blend_forward"][1], 1) / max(views_per_launch, 1),
             **{"hot_loop_backward_blend_" + ("all_gradients" if bwd_mode == 0 else "geometry_only" if bwd_mode == 1 else
-                                             "appearance_and_shape"):
+                                             "appearance_and_shape" if bwd_mode == 2 else "positions_only"):
                bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)}),
     }
     if rank == 0:

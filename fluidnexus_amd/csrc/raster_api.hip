@@ -51,7 +51,8 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
                            float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                            const uint32_t *header, uint32_t capacity, uint32_t grad_limit, int V, const ViewBatch &vb,
-                           const StaticRef &st);
+                           const StaticRef &st, const float *means3D, const float *cov3Ds, size_t cov3D_stride,
+                           const float *viewmatrix, const float *projmatrix, float *dL_dmean3D);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -525,15 +526,17 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
                                        fnx_stream_t stream) {
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // rasterize_points.cu:160
-    if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix ||
-        !dL_dmean2D || !dL_dconic || !dL_dopacity_views || !dL_dcolor_views || !dL_dopacity || !dL_dmean3D ||
-        !dL_dcov3D)
+    if (geometry_only < 0 || geometry_only > 3) return fail(FNX_ERR_INVALID_ARG, "geometry_only must be 0, 1, 2 or 3");
+    const bool positions_only = geometry_only == 3;  // only dL_dmean3D is produced (and must come in zeroed)
+    if (!geom_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !dL_dpix || !dL_dmean3D)
         return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
-    if (shs && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
-    if (scales && (!rotations || !dL_dscale || !dL_drot))
+    if (!positions_only && (!dL_dmean2D || !dL_dconic || !dL_dopacity_views || !dL_dcolor_views || !dL_dopacity || !dL_dcov3D))
+        return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
+    if (shs && !positions_only && (!dL_dsh || !campos)) return fail(FNX_ERR_INVALID_ARG, "shs given but dL_dsh/campos NULL");
+    if (scales && !positions_only && (!rotations || !dL_dscale || !dL_drot))
         return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
-    if (geometry_only < 0 || geometry_only > 2) return fail(FNX_ERR_INVALID_ARG, "geometry_only must be 0, 1 or 2");
-    if (geometry_only == 1 && shs) return fail(FNX_ERR_INVALID_ARG, "geometry_only cannot be combined with SH colours");
+    if ((geometry_only == 1 || positions_only) && shs)
+        return fail(FNX_ERR_INVALID_ARG, "geometry_only = 1 / 3 cannot be combined with SH colours");
     if (binning_capacity < 0) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     fnx::ViewBatch vb;
     fnx::StaticRef st;
@@ -558,8 +561,10 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
         fnx::launch_blend_backward(channels, geometry_only, s, P_all, width, height, img.ranges, bin.point_list,
                                    background, g.blend_rec, img.final_T, img.n_contrib, img.acc_final, dL_dpix,
                                    dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
-                                   (uint32_t)limit, V, vb, st);
+                                   (uint32_t)limit, V, vb, st, means3D, cov3D_ptr, cov3D_stride, viewmatrix, projmatrix,
+                                   dL_dmean3D);
     }
+    if (positions_only) return hip_check("backward");  // the blend backward's flush went through the geometry itself
     const int sum_appearance = (V > 1 && geometry_only != 1) ? 1 : 0;
     fnx::launch_geom_backward(channels, s, P_all, D, M, means3D, rad, shs, g.clamped, scales, rotations, scale_modifier,
                               cov3D_ptr, cov3D_stride, viewmatrix, projmatrix, campos, dL_dmean2D, dL_dconic,

@@ -73,11 +73,18 @@ __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], floa
 // MODE 0: all screen-space gradients (mean2D.xy | conic.xyw | opacity | colour[C]);
 // MODE 1: geometry only (mean2D.xy | conic.xyw) -- the caller does not need opacity / colour gradients;
 // MODE 2: fixed positions (conic.xyw | opacity | colour[C]) -- the caller does not need the gradient of the 2D means
-//         (the visual-particle stage: positions are not optimised).
+//         (the visual-particle stage: positions are not optimised);
+// MODE 3: positions only -- the sums of MODE 1, but the flush carries them through the geometry backward of its
+//         (splat, view) (geom_backward_view: linear in them) and adds the result to dL/dmean3D, summed over the views:
+//         3 global atomics per (tile, batch, splat) instead of 5, no per-view arrays, no geometry kernel behind it.
 // Splats with id >= grad_limit still take part in the blend recurrences but produce no gradient.
 #ifndef FNX_BWD_WAVES
 #define FNX_BWD_WAVES 4  // waves per SIMD the register allocation of the blend backward aims at
 #endif
+__device__ inline void geom_backward_view(const float3 mean, const float *cov3D, const float *view, const float *proj,
+                                          float h_x, float h_y, float tan_fovx, float tan_fovy, float gc0, float gc1,
+                                          float gc2, float g0, float g1, float *gm, float *dcv);
+
 template <int C, int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWD_WAVES, FNX_BWD_WAVES)))
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
@@ -86,8 +93,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       const float *__restrict__ acc_final, const float *__restrict__ dL_dpixels,
                       float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
                       float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
-                      uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb) {
-    constexpr bool kMeans = MODE != 2, kAppearance = MODE != 1;
+                      uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb,
+                      const float *__restrict__ means3D, const float *__restrict__ cov3Ds, size_t cov3D_stride,
+                      const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
+                      float *__restrict__ dL_dmean3D) {
+    constexpr bool kMeans = MODE != 2, kAppearance = MODE == 0 || MODE == 2, kFusedGeom = MODE == 3;
     constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums
     constexpr int NV = kAppearance ? kCol + C : kOpac;
 #ifndef FNX_BWD_GROUP
@@ -395,13 +405,25 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 // -1/2 G (dx^2, dx dy, dy^2), each times dL/dG
                 const float4 ra = s_ra[tid];
                 const float cc = s_rb[tid].x;
-                if (kMeans) {
-                    unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
-                    unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
+                if (kFusedGeom) {
+                    const float3 mean = make_float3(means3D[3 * (size_t)id], means3D[3 * (size_t)id + 1], means3D[3 * (size_t)id + 2]);
+                    float gv[3], dv[6];
+                    geom_backward_view(mean, view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)id, viewmatrix + 16 * vw,
+                                       projmatrix + 16 * vw, vb.focal_x[vw], vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw],
+                                       -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2],
+                                       -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx,
+                                       -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy, gv, dv);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&dL_dmean3D[3 * (size_t)id + k], gv[k]);
+                } else {
+                    if (kMeans) {
+                        unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
+                        unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
+                    }
+                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
+                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
+                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
                 }
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
-                unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
                 if (kAppearance) {
                     unsafeAtomicAdd(&dL_dopacity_v[id], a[kAppearance ? kOpac : 0]);
 #pragma unroll
@@ -729,7 +751,9 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
                            float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
-                           uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st) {
+                           uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st, const float *means3D,
+                           const float *cov3Ds, size_t cov3D_stride, const float *viewmatrix, const float *projmatrix,
+                           float *dL_dmean3D) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
     static int n_cu = 0;
@@ -738,12 +762,14 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
-    else if (mode == 2) launch_blend_backward_t<1, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
-    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
-    else if (C == 3) launch_blend_backward_t<3, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
-    else if (mode == 0) launch_blend_backward_t<1, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
-    else launch_blend_backward_t<1, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb);
+    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 3) launch_blend_backward_t<1, 3>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3) launch_blend_backward_t<3, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else launch_blend_backward_t<1, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,

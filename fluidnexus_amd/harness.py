@@ -18,6 +18,7 @@ import math
 from types import SimpleNamespace
 
 import numpy as np
+import os
 import torch
 import torch.distributed as dist
 
@@ -110,6 +111,12 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
     gm._force = t(np.zeros((N, 3)))
     cams = (S.ring_cameras if ring else S.arc_cameras)(n_views, size, size, device=device)
     return gm, cams
+
+
+# The position stages read no screen-space gradient ("viewspace_points" feeds the background stage's densification
+# only): without it the rasteriser's backward adds straight into dL/dmeans3D (geometry_only = 3).  FNX_SCREEN_GRAD=1
+# keeps the reference's behaviour (the 2D-mean gradient is produced as well).
+_SCREEN_GRAD = os.environ.get("FNX_SCREEN_GRAD", "0") == "1"
 
 
 class HotLoop:
@@ -412,7 +419,7 @@ class HotLoop:
             try:
                 pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                             GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
-                                            scale=True, means3D=means3D)
+                                            scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
             finally:
                 rasterizer.set_between_stages_hook(None)
         if self.physics_per_view or self.rank == 0:
@@ -461,7 +468,7 @@ class HotLoop:
                 with torch.cuda.stream(self.ch1_stream):
                     pkg1 = render_fluid_views([self.cams[v] for v in mine], gm, None, self.background,
                                               GRsetting=self.GRsetting1, GRzer=self.GRzer1, pos_type="guess_visual_nn",
-                                              scale=True, means3D=means3D[:n_fluid])
+                                              scale=True, means3D=means3D[:n_fluid], screen_grad=_SCREEN_GRAD)
                     _, _, dimg1 = image_loss_value_and_grad(pkg1["render"].detach(), self._gt_stack(mine, "original_image_ch1"),
                                                             c["lambda_dssim"], c["lambda_image"], grey=False)
                 main.wait_stream(self.ch1_stream)
@@ -879,11 +886,12 @@ class FirstFrameLoop:
                 if self.rd_pipe == "render_fluid":
                     means = param
                     pkg = render_fluid_views(cams, gm, None, self.background, GRsetting=self.GRsetting, GRzer=self.GRzer,
-                                             pos_type="visual", means3D=means)
+                                             pos_type="visual", means3D=means, screen_grad=_SCREEN_GRAD)
                 else:
                     means = gm.render_means_from_visual()
                     pkg = render_dynamics_views(cams, gm, None, self.background, GRsetting=self.GRsetting,
-                                                GRzer=self.GRzer, pos_type="visual", scale=False, means3D=means)
+                                                GRzer=self.GRzer, pos_type="visual", scale=False, means3D=means,
+                                                screen_grad=_SCREEN_GRAD)
             finally:
                 rasterizer.set_between_stages_hook(None)
             loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine),

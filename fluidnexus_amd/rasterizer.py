@@ -156,9 +156,11 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 def _gradient_mode(need, M):
     """`geometry_only` of fnx_rasterize_backward_ex from autograd's needs_input_grad (means3D, means2D, sh, colors,
-    opacities, scales, rotations, cov3D, ...): 1 = nobody asked for opacity / colour / SH gradients, 2 = nobody asked
-    for the gradient of the positions (3D or screen-space), 0 = everything."""
+    opacities, scales, rotations, cov3D, ...): 3 = only the 3D positions, 1 = nobody asked for opacity / colour / SH
+    gradients, 2 = nobody asked for the gradient of the positions (3D or screen-space), 0 = everything."""
     if not (need[2] or need[3] or need[4]) and M == 0:
+        if need[0] and not (need[1] or need[5] or need[6] or need[7]):
+            return 3
         return 1
     if not (need[0] or need[1]):
         return 2
@@ -545,6 +547,22 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         M = sh.shape[1] if sh.numel() else 0
         need = ctx.needs_input_grad
         geometry_only = _gradient_mode(need, M)
+        if geometry_only == 3 and P != 0:
+            # positions only: the blend backward's flush runs the geometry backward itself and adds into this one array
+            g_means3D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+            dL = _f32c(grad_out_color)
+            args = (Cn, V, P - (sb.P if sb is not None else 0), int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H,
+                    means3D.data_ptr(), None, _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                    _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
+                    vbatch.tan_x, vbatch.tan_y, radii.data_ptr(), geom.data_ptr(), _ptr(binning), ctx.capacity,
+                    img.data_ptr(), dL.data_ptr(), None, None, None, None, None, None,
+                    g_means3D.data_ptr(), None, None, None, None, ctx.grad_splat_limit, 3)
+            stream = torch.cuda.current_stream().cuda_stream
+            if sb is None:
+                _lib.check(lib.fnx_rasterize_backward_views(*args, stream))
+            else:
+                _lib.check(lib.fnx_rasterize_backward_views_split(*args, sb.blob.data_ptr(), sb.P, sb.R_cap, stream))
+            return (g_means3D,) + (None,) * 11
         # per-view accumulators first, then the arrays summed over the views; one zero-filled slab
         widths = [V * 3, V * 4] + ([] if geometry_only == 1 else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
         flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)

@@ -297,11 +297,12 @@ def render_fluid(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=1.0
 
 def render_fluid_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                        GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, means3D=None,
-                       **kwargs):
+                       screen_grad=True, **kwargs):
     """render_fluid for all cameras of a training batch in one rasteriser call (extension, like
     render_dynamics_views): "render" [V,1,H,W], "radii" [V,P], "depth" [V,1,H,W], "viewspace_points" [V,P,3].
     `means3D`: positions prepared by the caller (a leaf to differentiate with respect to) instead of the pos_type
-    lookup and scaling."""
+    lookup and scaling; `screen_grad=False`: "viewspace_points" takes no gradient (with positions as the only leaf the
+    backward then adds straight into dL/dmeans3D, fnx_rasterize_backward_ex's geometry_only = 3)."""
     from ..rasterizer import GaussianRasterizerViews
     if means3D is None:
         raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
@@ -309,7 +310,9 @@ def render_fluid_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modif
         raw_render_xyz = render_xyz = means3D
     opacity, scales, rotations, colors = _fluid_attributes(gm, pos_type)
     V = len(viewpoint_cameras)
-    screen = _zero_scalar(render_xyz).expand((V,) + tuple(render_xyz.shape)).requires_grad_()
+    screen = _zero_scalar(render_xyz).expand((V,) + tuple(render_xyz.shape))
+    if screen_grad:
+        screen = screen.requires_grad_()
     rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
                                                      gm.active_sh_degree), channels=getattr(GRzer, "channels", 1))
     image, radii, depth = rasterizer(means3D=render_xyz.float(), means2D=screen, shs=None, colors_precomp=colors.float(),

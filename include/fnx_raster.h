@@ -110,7 +110,11 @@ int fnx_rasterize_backward(int channels, int P, int D, int M, int R, const float
  * opacity / colour gradients are not produced (dL_dopacity, dL_dcolor stay as passed in); with
  * geometry_only == 2 ("fixed positions": the visual-particle stage, train_visual_particle.py:133-222, optimises
  * appearance and shape only) the gradient with respect to the 2D means is not accumulated: dL_dmean2D stays as
- * passed in and dL_dmean3D holds the covariance path's share only -- the caller must not use either.
+ * passed in and dL_dmean3D holds the covariance path's share only -- the caller must not use either; with
+ * geometry_only == 3 ("positions only": the physical-particle and first-frame stages, train_physical_particle.py,
+ * optimise positions alone; colours_precomp, no SH) ONLY dL_dmean3D is produced: the blend backward carries its sums
+ * through the per-(splat, view) geometry backward itself and ADDS to dL_dmean3D, which the caller passes in zeroed;
+ * every other gradient pointer may be NULL.
  */
 int fnx_rasterize_backward_ex(int channels, int P, int D, int M, int R, const float *background, int width, int height,
                               const float *means3D, const float *shs, const float *colors_precomp, const float *scales,

@@ -362,3 +362,20 @@ def test_non_finite_colour_is_a_stated_deviation(oracle):
         assert (np.maximum(np.abs(ry - y), np.abs(rx - x)) <= 4).any(), (y, x)
     ok = ~nan_got
     assert (got[:, ok].view(np.uint32) == ref[:, ok].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("channels", [3, 1])
+def test_positions_only_mode(oracle, channels):
+    """geometry_only = 3: the blend backward's flush runs the per-(splat, view) geometry backward itself and adds into
+    dL/dmeans3D -- against the oracle's full backward, with and without a gradient limit."""
+    P, W, H = 4000, 96, 80
+    g = S.random_gaussians(P, seed=41, channels=channels, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    f, h = _run_pair(oracle, g, cam, W, H, np.array([0.2, 0.3, 0.4], np.float32), channels=channels)
+    dL = np.random.RandomState(8).normal(size=(channels, H, W)).astype(np.float32)
+    ref = oracle.backward(f, dL)["dL_dmeans3D"].reshape(P, 3)
+    for lim in (-1, 1500):
+        got = h.backward(dL, grad_splat_limit=lim, geometry_only=3)["dL_dmeans3D"].reshape(P, 3)
+        n = P if lim < 0 else lim
+        assert np.abs(got[:n] - ref[:n]).max() <= 2e-4 * np.abs(ref).max(), lim
+        assert (got[n:] == 0).all()
