@@ -672,21 +672,29 @@ distance_loss_kernel(const float *__restrict__ xyz, int N, float inv_cell, float
                                   c.z + ((sub & 4) ? (fz < 0.5f ? -1 : 1) : 0));
         const uint32_t h = cell_hash(cc, mask);
         const float thr2 = thr * thr;
-        for (uint32_t s = start[h], s1 = start[h + 1]; s < s1; s++) {
-            const float4 q = rec[s];
-            if ((int)__float_as_uint(q.w) == i) continue;
-            const float ex = px - q.x, ey = py - q.y, ez = pz - q.z;
-            const float r2 = ex * ex + ey * ey + ez * ez;
-            if (!(r2 < thr2)) continue;
-            const float d = sqrtf(r2);
-            const float t = thr - d;
-            if (!(t > 0.f)) continue;
-            acc += t * t;
-            if (d > 0.f) {
-                const float k = -4.0f * t / d;
-                ax += k * ex;
-                ay += k * ey;
-                az += k * ez;
+        // four records of the bucket per step, their loads in flight together (the kernel is pure latency, and it runs
+        // next to the rasteriser's blend forward: the shorter its waves live, the less they displace); the terms are
+        // added in bucket order, exactly as one by one
+        for (uint32_t s = start[h], s1 = start[h + 1]; s < s1; s += 4) {
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = rec[min(s + (uint32_t)k, s1 - 1u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (s + (uint32_t)k >= s1 || (int)__float_as_uint(q[k].w) == i) continue;
+                const float ex = px - q[k].x, ey = py - q[k].y, ez = pz - q[k].z;
+                const float r2 = ex * ex + ey * ey + ez * ez;
+                if (!(r2 < thr2)) continue;
+                const float d = sqrtf(r2);
+                const float t = thr - d;
+                if (!(t > 0.f)) continue;
+                acc += t * t;
+                if (d > 0.f) {
+                    const float kk = -4.0f * t / d;
+                    ax += kk * ex;
+                    ay += kk * ey;
+                    az += kk * ez;
+                }
             }
         }
     }
