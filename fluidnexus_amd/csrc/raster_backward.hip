@@ -205,7 +205,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     fetch_ids(cur);
     fetch_records(cur);
     for (uint32_t ticket = blockIdx.x;; ticket += gridDim.x) {
-        __syncthreads();  // the previous item is done with the LDS arrays
+        // no barrier here: before the next one (behind the block maxima) an item writes s_max only, and the previous
+        // item's last readers of s_max passed two barriers ago
         if (cur.item == kNoItem) break;
         const int vw = cur.vw;
         Fetched nx2;
