@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--scene", default="backdrop", choices=["backdrop", "r01"],
                     help="configs 3 / 4: background behind the plume (default), or the round-1 layout (a cloud AROUND "
                          "the plume that hides it from every camera: zero image gradient; for like-for-like comparisons)")
+    ap.add_argument("--blend-math", default="fast", choices=["fast", "exact"],
+                    help="arithmetic of the blend kernels (include/fnx_raster.h fnx_set_blend_math): fast = fused multiply-adds "
+                         "+ v_exp_f32, stated tolerance against the oracle (tests/test_fast_math_gpu.py); exact = the "
+                         "bit-reproducible sequence the oracle repeats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -239,6 +243,22 @@ def main():
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A bare `python bench.py --gpus N` IS an N-rank run: start one process per GPU under torch.distributed.run
+        # (RCCL over xGMI), rank 0 prints the one JSON line.  Never run fewer ranks than asked for.
+        import socket
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus and os.environ.get("FNX_SINGLE_DEVICE") != "1":
+            raise SystemExit(f"--gpus {a.gpus} but only {n_dev} device(s) visible (FNX_SINGLE_DEVICE=1 FNX_DIST_BACKEND=gloo "
+                             "runs every rank on device 0: a smoke test of the multi-rank path, not a measurement)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,7 +267,7 @@ def main():
     if os.environ.get("FNX_SINGLE_DEVICE") == "1":
         local = 0
     backend = os.environ.get("FNX_DIST_BACKEND", "nccl")
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -268,6 +288,7 @@ def main():
     from fluidnexus_amd.harness import shard_views
     from fluidnexus_amd.renderer import pipes
     _lib.raster()  # fail loudly if the HIP library is missing
+    rasterizer.set_blend_math(a.blend_math)
     if a.no_static_split:
         pipes.set_static_split(False)
 
@@ -461,7 +482,8 @@ def main():
         print(f"[bench] rasteriser-only timing failed: {type(e).__name__}: {e}", file=sys.stderr)
     out = {
         "metric": metric,
-        "value": value, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "iters/s", "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
+        "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": C["workload"] + stage_note, "baseline_config": cfg_id, "stage": a.stage,
@@ -471,6 +493,10 @@ def main():
                                    + (" (emulated: rank 0's share, no communication)" if a.emulate_world > 1 else "")
                                    + ", RCCL all-reduce of the leaf gradient"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
+                   "blend_math": {"fast": "fast: fused multiply-adds + v_exp_f32 in the two blend kernels; pixels within 2e-5 of the "
+                                          "bit-exact mode / oracle except counted threshold flips, binning bit-exact "
+                                          "(tests/test_fast_math_gpu.py)",
+                                  "exact": "exact: bit-reproducible blend arithmetic (equal to the CPU oracle bit for bit)"}[a.blend_math],
                    "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2),
                    "distance_loss": not a.no_distance, "scene": a.scene if cfg_id in (3, 4) else "backdrop",
                    "scene_note": ("background Gaussians BEHIND the plume: the fluid is visible to every camera and its image "

@@ -52,8 +52,12 @@ SYMBOLS = (
     "fnx_rasterize_backward_views",
     "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
-    "fnx_set_deep_threshold",
+    "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math",
 )
+
+# Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
+# scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
+ABI_VERSION = 2
 
 
 def raster_path() -> str:
@@ -74,6 +78,9 @@ def raster():
     lib = C.CDLL(path)
     p, i, f = c_void_p, c_int, c_float
     lib.fnx_abi_version.restype = i
+    if lib.fnx_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} exports C ABI version {lib.fnx_abi_version()}, this package needs {ABI_VERSION}: "
+                           "rebuild it (python -m fluidnexus_amd.build --force)")
     lib.fnx_last_error.restype = C.c_char_p
     lib.fnx_geom_bytes.restype = c_size_t
     lib.fnx_geom_bytes.argtypes = [i, i, i]
@@ -120,6 +127,9 @@ def raster():
     lib.fnx_forward_stage2_views_split.argtypes = [i, i, p, p, c_int64, p, i, i, i, p, p, p, p, p, i, c_int64, i, p, p]
     lib.fnx_set_deep_threshold.restype = i
     lib.fnx_set_deep_threshold.argtypes = [C.c_uint]
+    lib.fnx_set_blend_math.restype = i
+    lib.fnx_set_blend_math.argtypes = [i]
+    lib.fnx_get_blend_math.restype = i
     lib.fnx_rasterize_backward_views_split.restype = i
     lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]
     lib.fnx_binning_layout_split.argtypes = [c_int64, c_int64, C.POINTER(BinningLayout)]

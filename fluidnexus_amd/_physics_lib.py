@@ -7,6 +7,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+ABI_VERSION = 2  # include/fnx_physics.h FNX_PHYSICS_ABI_VERSION
+
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
@@ -26,6 +28,9 @@ def physics():
     lib = C.CDLL(path)
     p, i, f = C.c_void_p, C.c_int, C.c_float
     lib.fnx_physics_abi_version.restype = i
+    if lib.fnx_physics_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} exports C ABI version {lib.fnx_physics_abi_version()}, this package needs "
+                           f"{ABI_VERSION}: rebuild it (python -m fluidnexus_amd.build --force)")
     lib.fnx_physics_last_error.restype = C.c_char_p
     lib.fnx_grid_bytes.restype = C.c_size_t
     lib.fnx_grid_bytes.argtypes = [i]

@@ -1159,7 +1159,7 @@ inline float poly6_term1(float H) {  // gm_dynamics.py:130: 315 / (64 pi H^9), e
 
 extern "C" {
 
-int fnx_physics_abi_version(void) { return 1; }
+int fnx_physics_abi_version(void) { return FNX_PHYSICS_ABI_VERSION; }
 const char *fnx_physics_last_error(void) { return g_err; }
 size_t fnx_grid_bytes(int N) { return grid_bytes(N); }
 

@@ -44,7 +44,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb);
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -52,7 +52,7 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                            const uint32_t *header, uint32_t capacity, uint32_t grad_limit, int V, const ViewBatch &vb,
                            const StaticRef &st, const float *means3D, const float *cov3Ds, size_t cov3D_stride,
-                           const float *viewmatrix, const float *projmatrix, float *dL_dmean3D);
+                           const float *viewmatrix, const float *projmatrix, float *dL_dmean3D, int fast);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -217,6 +217,7 @@ struct ProfClass {
     size_t used = 0;
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
+int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
 bool g_prof_on = false;
 ProfClass g_prof[kProfClasses];
 
@@ -245,7 +246,7 @@ struct ProfScope {
 
 extern "C" {
 
-int fnx_abi_version(void) { return 1; }
+int fnx_abi_version(void) { return FNX_ABI_VERSION; }
 const char *fnx_last_error(void) { return g_err; }
 
 size_t fnx_geom_bytes(int P, int W, int H) {
@@ -426,7 +427,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb);
+                                  st, materialize_all, V, vb, g_blend_math);
     }
     return hip_check("stage2");
 }
@@ -562,7 +563,7 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
                                    background, g.blend_rec, img.final_T, img.n_contrib, img.acc_final, dL_dpix,
                                    dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
                                    (uint32_t)limit, V, vb, st, means3D, cov3D_ptr, cov3D_stride, viewmatrix, projmatrix,
-                                   dL_dmean3D);
+                                   dL_dmean3D, g_blend_math);
     }
     if (positions_only) return hip_check("backward");  // the blend backward's flush went through the geometry itself
     const int sum_appearance = (V > 1 && geometry_only != 1) ? 1 : 0;
@@ -632,6 +633,13 @@ int fnx_set_deep_threshold(unsigned int min_depth) {
     g_deep_min = min_depth ? min_depth : 1u;
     return FNX_OK;
 }
+
+int fnx_set_blend_math(int mode) {
+    if (mode != 0 && mode != 1) return fail(FNX_ERR_INVALID_ARG, "blend math mode must be 0 (exact) or 1 (fast)");
+    g_blend_math = mode;
+    return FNX_OK;
+}
+int fnx_get_blend_math(void) { return g_blend_math; }
 
 int fnx_profile_enable(int on) {
     g_prof_on = on != 0;

@@ -13,6 +13,14 @@
 #include "fnx_device.h"
 #include "fnx_state.h"
 
+#ifndef FNX_LDS_BARRIER
+#define FNX_LDS_BARRIER 1  // 0: plain __syncthreads() inside the item loop (timing experiments)
+#endif
+#if FNX_LDS_BARRIER
+#define FNX_LOOP_BARRIER() fnx::lds_barrier()
+#else
+#define FNX_LOOP_BARRIER() __syncthreads()
+#endif
 #ifndef FNX_ABLATE
 #define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
 #endif
@@ -85,7 +93,10 @@ __device__ inline void geom_backward_view(const float3 mean, const float *cov3D,
                                           float h_x, float h_y, float tan_fovx, float tan_fovy, float gc0, float gc1,
                                           float gc2, float g0, float g1, float *gm, float *dcv);
 
-template <int C, int MODE>
+// FAST: the arithmetic of the forward's fast mode (blend_forward_kernel: pre-scaled coefficients, log2(o) in the
+// exponent, one v_exp_f32), so that both passes see the same alphas; the per-entry sums of four consecutive entries are
+// folded together, one moment at a time (five 4-value folds per four entries instead of four 4 + 1 folds).
+template <int C, int MODE, bool FAST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWD_WAVES, FNX_BWD_WAVES)))
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                       int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
@@ -111,6 +122,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ float4 s_ra[257];  // x, y, conic a, conic b
     __shared__ float4 s_rb[257];  // conic c, opacity, -, 1.0 if the splat wants gradients (id < grad_limit) else 0.0
     __shared__ float4 s_rc[257];  // colour (C channels)
+    __shared__ float4 s_rd[FAST ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush (a, b, c, o)
     __shared__ float s_acc[NV][256];
     // per-block lists of LDS byte offsets (slot * 16), depth order; lists 4 w .. 4 w + 3 are built, padded and read by
     // wave w alone
@@ -123,7 +135,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
     if (tid == 0) {
         s_ra[256] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_rb[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rb[256] = FAST ? make_float4(0.f, -200.0f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // The work items of ALL views form one queue (view 0's first); workgroup b takes items b, b + grid, b + 2 grid, ...,
@@ -276,7 +288,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         uint32_t m = last_contributor;
         for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
         if ((lane & 15) == 0) s_max[4 * w + row] = m;
-        __syncthreads();
+        // LDS-only barriers in the item loop: the waves exchange nothing through global memory, and a plain
+        // __syncthreads() would also wait for the previous item's flush atomics and for the next item's prefetches
+        FNX_LOOP_BARRIER();
         uint32_t qmax = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) qmax = max(qmax, s_max[k]);
@@ -292,8 +306,16 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             for (int k = 0; k < 16; k++)
                 if (q >= s_max[k]) qm &= ~(1u << k);
             s_id[tid] = id;
-            s_ra[tid] = cur.ra;
-            s_rb[tid] = make_float4(cur.rbx, cur.rby, 0.f, id < grad_limit ? 1.0f : 0.0f);
+            if (FAST) {
+                constexpr float kL2e = 1.44269504088896341f;
+                s_ra[tid] = make_float4(cur.ra.x, cur.ra.y, (-0.5f * kL2e) * cur.ra.z, (-kL2e) * cur.ra.w);
+                s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), 0.f,
+                                        id < grad_limit ? 1.0f : 0.0f);
+                s_rd[FAST ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
+            } else {
+                s_ra[tid] = cur.ra;
+                s_rb[tid] = make_float4(cur.rbx, cur.rby, 0.f, id < grad_limit ? 1.0f : 0.0f);
+            }
             s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, 0.f);
         }
 #pragma unroll
@@ -304,7 +326,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
             for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
-        __syncthreads();
+        FNX_LOOP_BARRIER();
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's four lists
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -325,6 +347,86 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
         // the pixel does not take has alpha = 0, which leaves T and the colour prefix exactly as they are (x * 1, + 0)
         // and zeroes every gradient term; the NULL record behind a list's end is such an entry for every pixel.
+        if (FAST) {
+            static_assert(!FAST || kGroup == 4, "the fast walk folds the sums of four entries together");
+            const int vq = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1);  // entry of a step whose sums this lane's quad ends up with
+            const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+            for (uint32_t i0 = 0; i0 < (FNX_ABLATE == 3 ? 0u : n_w); i0 += 4) {
+                uint32_t jw[2];
+                jw[0] = reinterpret_cast<const uint32_t *>(mylist + i0)[0];
+                jw[1] = reinterpret_cast<const uint32_t *>(mylist + i0)[1];
+                float4 ra[4], rb[4], rc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    ra[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+                    rb[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+                    rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
+                }
+                float val[NV][4];
+                bool any_emit = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const float dx = ra[k].x - pxf, dy = ra[k].y - pyf;
+                    const float u = __builtin_fmaf(ra[k].z, dx, ra[k].w * dy);
+                    const float q = __builtin_fmaf(u, dx, (rb[k].x * dy) * dy);  // log2(e) * power
+                    const float e = __builtin_amdgcn_exp2f(q + rb[k].y);         // o G
+                    const float alpha = fminf(0.99f, e);
+                    const bool active = !(q > 0.0f) && !(alpha < 1.0f / 255.0f) && (off < lim_off);
+                    const bool emits = active && rb[k].w != 0.0f;
+                    const float a = active ? alpha : 0.0f;
+                    const float one_m = 1 - a;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
+                    const float Tb = Tr;
+                    float c_dot = rc[k].x * dL_dpixel[0];
+                    if (C > 1) c_dot = __builtin_fmaf(rc[k].y, dL_dpixel[C > 1 ? 1 : 0], c_dot);
+                    if (C > 2) c_dot = __builtin_fmaf(rc[k].z, dL_dpixel[C > 2 ? 2 : 0], c_dot);
+                    const float aT = a * Tb;
+                    rest = __builtin_fmaf(-aT, c_dot, rest);
+                    Tr = Tb * one_m;
+                    const float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
+                    // G dL/dG = G o dL/dalpha = (o G) dL/dalpha: the clamp at 0.99 has no mask in the reference (A.10)
+                    const float wgt = (emits ? e : 0.0f) * dL_dalpha;
+                    const float wx = wgt * dx, wy = wgt * dy;
+                    if (kMeans) {
+                        val[0][k] = wx;
+                        val[kMeans ? 1 : 0][k] = wy;
+                    }
+                    val[kConic][k] = wx * dx;
+                    val[kConic + 1][k] = wx * dy;
+                    val[kConic + 2][k] = wy * dy;
+                    if (kAppearance) {
+                        val[kAppearance ? kOpac : 0][k] = wgt;  // sum of (o G) dL/dalpha; the flush divides by o
+                        const float dchannel_dcolor = emits ? aT : 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) val[kAppearance ? kCol + ch : 0][k] = dchannel_dcolor * dL_dpixel[ch];
+                    }
+                    any_emit |= emits;
+                }
+#if FNX_ABLATE == 2
+                { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v][0] + val[v][1] + val[v][2] + val[v][3]; asm volatile("" ::"v"(sink)); }
+#else
+                if (__ballot(any_emit) != 0ull) {
+                    // this quad's target: the slot of entry vq of the step (row-uniform), the NULL slot's sums are dropped
+                    const uint32_t o01 = jw[0], o23 = jw[1];
+                    const uint32_t osel = (vq & 2) ? o23 : o01;
+                    const uint32_t slot = ((osel >> (16 * (vq & 1))) & 0xFFFFu) >> 4;
+                    const bool writer = (lane & 3) == 0 && slot < 256u;
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        const float a0 = val[v][0], b0 = val[v][1], c0 = val[v][2], d0 = val[v][3];
+                        const float s01 = (hi8 ? b0 : a0) + FNX_DPP((hi8 ? a0 : b0), 0x128, 0xf);
+                        const float s23 = (hi8 ? d0 : c0) + FNX_DPP((hi8 ? c0 : d0), 0x128, 0xf);
+                        float t = (hi4 ? s23 : s01) + FNX_DPP((hi4 ? s01 : s23), 0x141, 0xf);
+                        t += FNX_DPP(t, 0xb1, 0xf);
+                        t += FNX_DPP(t, 0x4e, 0xf);
+                        if (writer) atomicAdd(&s_acc[v][slot & 255u], t);
+                    }
+                }
+#endif
+            }
+        } else
         for (uint32_t i0 = 0; i0 < (FNX_ABLATE == 3 ? 0u : n_w); i0 += kGroup) {
             uint32_t jw[(kGroup + 1) / 2];
 #pragma unroll
@@ -391,7 +493,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             }
         }
         fetch_records(nxt);  // in flight while the accumulators are flushed
-        __syncthreads();
+        FNX_LOOP_BARRIER();
         if ((uint32_t)tid < cnt) {
             const uint32_t id = s_id[tid];
             float a[NV];
@@ -404,8 +506,15 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             if (any && FNX_ABLATE != 1) {
                 // moments -> gradients (backward.cu:512-533): dG/d(delta) = -G (a dx + b dy, c dy + b dx), conic terms
                 // -1/2 G (dx^2, dx dy, dy^2), each times dL/dG
-                const float4 ra = s_ra[tid];
-                const float cc = s_rb[tid].x;
+                float4 ra = s_ra[tid];
+                float cc = s_rb[tid].x;
+                if (FAST) {  // the entry's own conic (the staged coefficients are pre-scaled) and opacity
+                    const float4 rd = s_rd[FAST ? tid : 0];
+                    ra.z = rd.x;
+                    ra.w = rd.y;
+                    cc = rd.z;
+                    if (kAppearance) a[kAppearance ? kOpac : 0] = a[kAppearance ? kOpac : 0] / rd.w;
+                }
                 if (kFusedGeom) {
                     const float3 mean = make_float3(means3D[3 * (size_t)id], means3D[3 * (size_t)id + 1], means3D[3 * (size_t)id + 2]);
                     float gv[3], dv[6];
@@ -738,13 +847,18 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 // ---------------------------------------------------------------------------------------------
 // The grid is exactly the workgroups that are resident at a time (the occupancy query: 4 per compute unit at the current register count): a larger grid
 // would run its surplus as a second, half-empty round.
-template <int C, int MODE, typename... A>
-static void launch_blend_backward_t(int n_cu, hipStream_t s, A... args) {
+template <int C, int MODE, bool FAST, typename... A>
+static void launch_blend_backward_tf(int n_cu, hipStream_t s, A... args) {
     static int per_cu = 0;
-    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blend_backward_kernel<C, MODE>, 256, 0) != hipSuccess ||
+    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blend_backward_kernel<C, MODE, FAST>, 256, 0) != hipSuccess ||
                         per_cu <= 0))
         per_cu = 4;
-    hipLaunchKernelGGL((blend_backward_kernel<C, MODE>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+    hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+}
+template <int C, int MODE, typename... A>
+static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, A... args) {
+    if (fast) launch_blend_backward_tf<C, MODE, true>(n_cu, s, args...);
+    else launch_blend_backward_tf<C, MODE, false>(n_cu, s, args...);
 }
 
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
@@ -754,7 +868,7 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st, const float *means3D,
                            const float *cov3Ds, size_t cov3D_stride, const float *viewmatrix, const float *projmatrix,
-                           float *dL_dmean3D) {
+                           float *dL_dmean3D, int fast) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
     static int n_cu = 0;
@@ -763,14 +877,14 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 3) launch_blend_backward_t<1, 3>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 2) launch_blend_backward_t<1, 2>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3) launch_blend_backward_t<3, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 0) launch_blend_backward_t<1, 0>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else launch_blend_backward_t<1, 1>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,

@@ -28,6 +28,14 @@ extern "C" int fnx_debug_fwd_wg(unsigned long long *host, int n) {
 #else
 #define FNX_CLK(i)
 #endif
+#ifndef FNX_LDS_BARRIER
+#define FNX_LDS_BARRIER 1  // 0: plain __syncthreads() inside the batch loops (timing experiments)
+#endif
+#if FNX_LDS_BARRIER
+#define FNX_LOOP_BARRIER() fnx::lds_barrier()
+#else
+#define FNX_LOOP_BARRIER() __syncthreads()
+#endif
 #ifndef FNX_DEEP_PRIO
 #define FNX_DEEP_PRIO 3  // wave priority (0..3) of the tiles that went deep in the previous forward
 #endif
@@ -380,7 +388,14 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 #ifndef FNX_FWD_WAVES
 #define FNX_FWD_WAVES 4  // waves per SIMD the register allocation of the blend forward aims at (4: 469 us, 3: 486 us on config 3)
 #endif
-template <int C, bool SPLIT>
+//
+// FAST (fnx_set_blend_math(1), "stated-tolerance" arithmetic): the same lists, the same decisions, but per (pixel, entry)
+// the power is a chain of fused multiply-adds on coefficients pre-scaled by log2(e) at staging time, the opacity enters as
+// log2(o) inside the exponent, and the exponential is ONE v_exp_f32 (<= 1 ulp) instead of the 14-instruction fixed
+// sequence; T is updated as T - alpha T, the median depth is found from a per-batch count instead of per entry.
+// ~30 instead of ~54-65 VALU instructions per entry.  Pixels agree with the exact mode to ~1e-6 except where a rounding
+// moves an alpha across 1/255 or a T across 1e-4 (tests/test_fast_math_gpu.py states and checks the tolerance).
+template <int C, bool SPLIT, bool FAST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
@@ -437,6 +452,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];  //                ids
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
     __shared__ uint32_t s_qmax[4];
+    __shared__ uint32_t s_done[4];
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
     if (status_out && wg_rank == 0 && threadIdx.x < 8) status_out[8 * wg_view + threadIdx.x] = header[threadIdx.x];
@@ -452,7 +468,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     // channel (colours are assumed finite, like everywhere else).
     if (tid == 0) {
         s_ra[256] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_rb[256] = make_float4(0.f, 0.f, -87.0f, 0.f);
+        s_rb[256] = FAST ? make_float4(0.f, -200.0f, 0.f, 0.f) : make_float4(0.f, 0.f, -87.0f, 0.f);  // FAST: log2(o) = -200
         s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int row = lane >> 4;  // the wave's 4x4 block this lane belongs to (blend_pixel, fnx_device.h)
@@ -464,7 +480,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // 1 while the pixel is still blending, 0 once it has stopped (T would drop below 1e-4) or if it is outside the image:
-    // an arithmetic mask instead of a predicate, so that the recurrence below needs no lane-mask logic
+    // an arithmetic mask instead of a predicate, so that the recurrence below needs no lane-mask logic.
+    // FAST: `alive` is the WORKING transmittance (T while blending, 0 once stopped / outside), Tr the pixel's T.
     float alive = inside ? 1.0f : 0.0f;
     float Tr = 1.0f;
     uint32_t last_contributor = 0;
@@ -565,7 +582,14 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
     for (uint32_t base = r0; base < r1; base += 256) {
         FNX_CLK(0)
-        const bool all_done = __syncthreads_count(alive == 0.0f) == 256;
+        // barrier between the previous batch's walk and this batch's staging, and "has every pixel stopped?" in one:
+        // each wave leaves its own answer in LDS before the barrier.  LDS-only barriers in this loop (lds_barrier): a
+        // plain __syncthreads() also drains the wave's global stores (bstate, masks, point_list) and record prefetches,
+        // an L2 round trip on the critical path of every batch, although no wave reads another's global data here.
+        const uint32_t wave_done = __all(alive == 0.0f) ? 1u : 0u;  // a vote of all 64 lanes: taken outside the branch
+        if (lane == 0) s_done[w] = wave_done;
+        FNX_LOOP_BARRIER();
+        const bool all_done = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
         FNX_CLK(1)
         if (all_done) {
             if (!SPLIT || !materialize_all) break;
@@ -577,9 +601,22 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt && blending) {
             qm = block_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
-            s_ra[tid] = pa;
-            s_rb[tid] = pb;
-            s_rc[tid] = make_float4(pc.z, C > 1 ? pc.w : 0.f, C > 2 ? pd : 0.f, pb.w);
+            if (FAST) {
+                // log2(e) power = A dx^2 + B dx dy + C dy^2 with (A, B, C) = -log2(e) (a / 2, b, c / 2); alpha = 2^(that + log2 o)
+                constexpr float kL2e = 1.44269504088896341f;
+                s_ra[tid] = make_float4(pa.x, pa.y, (-0.5f * kL2e) * pa.z, (-kL2e) * pa.w);
+                const float lo = __builtin_amdgcn_logf(fmaxf(pb.y, 0.0f));  // v_log_f32; o = 0 -> -inf -> alpha = 0
+                if (C == 3) {
+                    s_rb[tid] = make_float4((-0.5f * kL2e) * pb.x, lo, pc.z, pc.w);
+                    s_rc[tid] = make_float4(pd, pb.w, 0.f, 0.f);  // colour 2, depth
+                } else {
+                    s_rb[tid] = make_float4((-0.5f * kL2e) * pb.x, lo, pc.z, pb.w);  // colour 0, depth
+                }
+            } else {
+                s_ra[tid] = pa;
+                s_rb[tid] = pb;
+                s_rc[tid] = make_float4(pc.z, C > 1 ? pc.w : 0.f, C > 2 ? pd : 0.f, pb.w);
+            }
         }
         if (SPLIT) {
             if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
@@ -602,7 +639,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
             for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
-        __syncthreads();
+        FNX_LOOP_BARRIER();
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
         // a block whose 16 pixels have all stopped gets an empty list: the wave's step count is its longest list, and a
         // finished block must not be the one that keeps it walking
@@ -623,7 +660,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             next_cnt = base + 256u < r1 ? min(256u, r1 - base - 256u) : 0u;
             next_id = merge_batch(next_cnt);
         }
-        __syncthreads();
+        FNX_LOOP_BARRIER();
         if (SPLIT) {
             if (next_cnt) {
                 const uint32_t a = s_adv;
@@ -659,6 +696,53 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (wg_rank == 0 && wg_view == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
 #endif
         uint32_t hit_off = 0xFFFFFFFFu;  // LDS offset of the last entry of this batch the pixel took
+        if (FAST) {
+            // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
+            // walk, and if T crosses 1/2 in this batch the entry that took it across is mylist[n_half] (forward.cu:351-354)
+            uint32_t n_half = 0;
+            const float T_in = Tr;
+            for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
+                if (__all(alive == 0.0f)) break;
+                uint32_t jw[kGroup / 2];
+#pragma unroll
+                for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
+                float a_h[kGroup], col[kGroup][3];
+#pragma unroll
+                for (int k = 0; k < kGroup; k++) {
+                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+                    const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+                    col[k][0] = rb.z;
+                    col[k][1] = rb.w;
+                    col[k][2] = C == 3 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off) : 0.f;
+                    const float dx = ra.x - pxf, dy = ra.y - pyf;
+                    const float u = __builtin_fmaf(ra.z, dx, ra.w * dy);
+                    const float q = __builtin_fmaf(u, dx, (rb.x * dy) * dy);  // log2(e) * power
+                    const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(q + rb.y));
+                    a_h[k] = (!(q > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < kGroup; k++) {
+                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const float wq = a_h[k] * alive;      // alpha T (0 for a stopped pixel: its working T is 0)
+                    const float t = alive - wq;           // test_T
+                    const bool stop = t < 0.0001f;        // also true for every entry behind the one that stopped the pixel
+                    const float wgt = stop ? 0.0f : wq;
+                    acc[0] = __builtin_fmaf(col[k][0], wgt, acc[0]);
+                    if (C > 1) acc[C > 1 ? 1 : 0] = __builtin_fmaf(col[k][1], wgt, acc[C > 1 ? 1 : 0]);
+                    if (C > 2) acc[C > 2 ? 2 : 0] = __builtin_fmaf(col[k][2], wgt, acc[C > 2 ? 2 : 0]);
+                    Tr = stop ? Tr : t;
+                    alive = stop ? 0.0f : t;
+                    n_half += (Tr >= 0.5f) ? 1u : 0u;
+                    hit_off = (wgt > 0.0f) ? off : hit_off;
+                }
+            }
+            if (T_in >= 0.5f && Tr < 0.5f) {
+                const uint32_t off = mylist[n_half];
+                Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
+                            : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
+            }
+        } else
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(alive == 0.0f)) break;
             uint32_t jw[kGroup / 2];  // the next kGroup entries of this lane's list
@@ -820,18 +904,24 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb) {
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
 #define FNX_LAUNCH_BF(CC, SS)                                                                                          \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,          \
+    if (fast)                                                                                                          \
+        FNX_LAUNCH_BF_(CC, SS, true);                                                                                  \
+    else                                                                                                               \
+        FNX_LAUNCH_BF_(CC, SS, false)
+#define FNX_LAUNCH_BF_(CC, SS, FF)                                                                                     \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,      \
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb)
-    if (C == 3 && st.base) FNX_LAUNCH_BF(3, true);
-    else if (C == 3) FNX_LAUNCH_BF(3, false);
-    else if (st.base) FNX_LAUNCH_BF(1, true);
-    else FNX_LAUNCH_BF(1, false);
+    if (C == 3 && st.base) { FNX_LAUNCH_BF(3, true); }
+    else if (C == 3) { FNX_LAUNCH_BF(3, false); }
+    else if (st.base) { FNX_LAUNCH_BF(1, true); }
+    else { FNX_LAUNCH_BF(1, false); }
 #undef FNX_LAUNCH_BF
+#undef FNX_LAUNCH_BF_
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

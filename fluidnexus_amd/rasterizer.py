@@ -49,6 +49,17 @@ def set_deep_variant(enabled: bool, min_depth: int | None = None):
         _lib.check(_lib.raster().fnx_set_deep_threshold(int(min_depth)))
 
 
+def set_blend_math(mode: str):
+    """Arithmetic of the blend kernels (library-wide, include/fnx_raster.h fnx_set_blend_math): "exact" = the
+    bit-reproducible sequence the oracle repeats (default), "fast" = fused multiply-adds + v_exp_f32, stated tolerance.
+    The forward and the backward of one render must run in the same mode."""
+    _lib.check(_lib.raster().fnx_set_blend_math({"exact": 0, "fast": 1}[mode]))
+
+
+def get_blend_math() -> str:
+    return ("exact", "fast")[_lib.raster().fnx_get_blend_math()]
+
+
 _between_stages_hook = None  # called (no arguments) between the binning stage and the emit / blend stage of a view batch
 
 

@@ -30,6 +30,8 @@ extern "C" {
 
 typedef void *fnx_stream_t;
 
+/* 2: fnx_adam_step gained `arrived` (before `stream`); compare with fnx_physics_abi_version() before anything else. */
+#define FNX_PHYSICS_ABI_VERSION 2
 int fnx_physics_abi_version(void);
 const char *fnx_physics_last_error(void);
 

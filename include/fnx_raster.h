@@ -43,6 +43,10 @@ typedef void *fnx_stream_t; /* hipStream_t */
  * [std::function<char*(size_t)>, rasterizer.h:31-33 / resizeFunctional, rasterize_points.cu:27-33]. */
 typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
 
+/* Version of this interface.  Bumped whenever a scratch-blob layout, a layout struct or an argument list changes
+ * (2: binning blob carries the forward -> backward hand-over, fnx_*_layout_t grew, fnx_set_blend_math added); a caller
+ * compares fnx_abi_version() with the FNX_ABI_VERSION it was compiled against before anything else. */
+#define FNX_ABI_VERSION 2
 int fnx_abi_version(void);
 const char *fnx_last_error(void);
 
@@ -235,6 +239,18 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char
  * the blend forward, at raised wave priority, because the launch ends when the longest sequential walk ends
  * (csrc/raster_forward.hip).  Purely a scheduling hint: results are bit-identical with any tile order. Zero-fill it once. */
 int fnx_set_deep_threshold(unsigned int min_depth);
+/* Arithmetic of the two blend kernels (process-wide, read at launch time; forward and backward of one render must run in
+ * the same mode).
+ *   0 (default): bit-reproducible -- every fp32 expression of forward.cu:319-345 as written, no contraction, exp() as one
+ *      fixed instruction sequence; pixels / depth / n_contrib equal the CPU oracle bit for bit.
+ *   1: fast, stated tolerance -- fused multiply-adds, log2(e) and log2(opacity) folded into per-entry coefficients,
+ *      exp as one v_exp_f32 (<= 1 ulp), T <- T - alpha T.  Same lists, same tests (power > 0, alpha < 1/255, T < 1e-4).
+ *      |pixel - exact| <= 2e-5 except where a rounding moves an alpha across 1/255 or a T across 1e-4 (a counted
+ *      <= 1e-4 fraction of pixels), gradients within 1e-3 relative + 2e-5 of the largest entry; tile / bin indices,
+ *      radii and ranges are computed before the blend and stay bit-exact.  This is the mode an nvcc build of the
+ *      reference (contraction on, libdevice expf) is closest to; tests/test_fast_math_gpu.py. */
+int fnx_set_blend_math(int mode);
+int fnx_get_blend_math(void);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
                                        const float *colors_precomp, const float *scales, float scale_modifier,

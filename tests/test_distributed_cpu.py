@@ -127,3 +127,158 @@ def test_hot_loop_sharded_equals_single_process():
     assert float((want - x0).abs().max()) > 1e-4  # the optimiser moved the particles
     assert (got[0] == got[1]).all()
     assert torch.allclose(torch.from_numpy(got[0]), want, rtol=0, atol=2e-6)
+
+
+# ---- the view-batched multi-rank path every real N-GPU run takes --------------------------------------------------
+# _iteration_body_batched(phase="local") -> all-reduce of HotLoop._reduce_buf -> _finish_step (harness.py).  On the host
+# the HIP-backed pieces are replaced by linear / smooth stand-ins (the hidden -> visual interpolation by a fixed matrix,
+# the view-batched render by a smooth map of the positions that depends on the camera, the fused image loss by its
+# torch expression, the fused physics stage by a quadratic) and the HIP stream objects by no-ops; the sharding, the
+# once-per-local-view physics term, the reduce buffer, the all-reduce, the 1/batch mean and the optimiser step are
+# the loop's own code.
+class _NoStream:
+    def wait_event(self, e):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _NoEvent:
+    def record(self, s=None):
+        pass
+
+
+def _batched_host_loop(rank, world, n_views):
+    from types import SimpleNamespace
+
+    import fluidnexus_amd.losses as losses
+    import fluidnexus_amd.physics as physics
+    import fluidnexus_amd.renderer.pipes as pipes
+    from fluidnexus_amd.harness import SMOKE, HotLoop
+
+    torch.cuda.current_stream = lambda *a, **k: _NoStream()
+    torch.cuda.Stream = lambda *a, **k: _NoStream()
+    torch.cuda.Event = lambda *a, **k: _NoEvent()
+    torch.cuda.stream = lambda s: _NoStream()
+
+    torch.manual_seed(0)
+    gm = GaussianModel(device="cpu")
+    gm.setup_constants()
+    N, V = 40, 24
+    gm._xyz = torch.randn(N, 3)
+    gm._estimate_xyz = gm._xyz + 0.1 * torch.randn(N, 3)
+    gm._visual_xyz = torch.randn(V, 3)
+    gm._gs_xyz = torch.randn(6, 3)
+    A = torch.randn(V, N, generator=torch.Generator().manual_seed(5)) * 0.2  # visual <- hidden interpolation
+    state = {}
+
+    def render_means_from_nn():
+        leaf = torch.cat([A @ gm._estimate_xyz_nn.detach(), gm._gs_xyz]).requires_grad_(True)
+        state["leaf"] = leaf
+        return leaf
+
+    def defer_render_means_gradient(g, extra=None):
+        assert extra is None
+        state["g"] = g[:V]
+
+    def flush_deferred_gradients():
+        g = state.pop("g", None)
+        if g is not None:
+            gm._estimate_xyz_nn_grad += A.t() @ g
+            gm._grad_cache_used = True
+
+    gm.render_means_from_nn = render_means_from_nn
+    gm.defer_render_means_gradient = defer_render_means_gradient
+    gm.flush_deferred_gradients = flush_deferred_gradients
+
+    def render_dynamics_views(cams, gm_, pipe_args, bg, means3D=None, **kw):
+        imgs = []
+        for cam in cams:
+            B = torch.randn(means3D.numel(), 3 * 8 * 8, generator=torch.Generator().manual_seed(100 + cam.uid)) * 0.3
+            imgs.append(torch.sigmoid(means3D.reshape(1, -1) @ B).reshape(3, 8, 8))
+        return {"render": torch.stack(imgs)}
+
+    def image_loss_value_and_grad(images, gts, lambda_dssim, lambda_image, grey=True):
+        x = images.detach().clone().requires_grad_(True)
+        per = ((x - gts) ** 2).mean(dim=(1, 2, 3))  # a smooth per-view image term (the fused kernel's is L1 + D-SSIM)
+        loss = per.sum() * lambda_image
+        g, = torch.autograd.grad(loss, x)
+        return loss.detach(), torch.stack([per.detach(), per.detach()], 1), g
+
+    def physical_stage_value_and_grad(gm_, l1, l2, l3, memo):
+        x = gm_._estimate_xyz_nn.detach()
+        return 0.5 * 0.01 * (x ** 2).sum(), 0.01 * x  # the same on every rank, like the real (view-independent) terms
+
+    pipes.render_dynamics_views = render_dynamics_views
+    losses.image_loss_value_and_grad = image_loss_value_and_grad
+    physics.physical_stage_value_and_grad = physical_stage_value_and_grad
+
+    cams = [SimpleNamespace(uid=v, original_image=torch.rand(3, 8, 8, generator=torch.Generator().manual_seed(v)))
+            for v in range(n_views)]
+    cfg = dict(SMOKE, lambda_current_distance=0.0)
+    loop = HotLoop(gm, cams, rank=rank, world=world, cfg=cfg, image_loss="fused", fused_physics=True,
+                   defer_visual_backward=True, batched_views=True, force_all_reduce=world == 1)
+    return gm, loop
+
+
+def _batched_step(loop, world):
+    """What HotLoop.iteration() does per replay in a multi-rank run (harness.py: graph replay of the local phase, the
+    all-reduce outside the graph, then the finish step)."""
+    if loop._reduce_buf is None:
+        loop._reduce_buf = torch.zeros_like(loop.gm._estimate_xyz_nn.detach())
+    loop._iteration_body_batched(phase="local")
+    dist.all_reduce(loop._reduce_buf, op=dist.ReduceOp.SUM)
+    loop._finish_step(len(loop.cams), grad=loop._reduce_buf)
+
+
+def _batched_worker(rank, world, port, n_views, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gm, loop = _batched_host_loop(rank, world, n_views)
+    for _ in range(steps):
+        _batched_step(loop, world)
+    q.put((rank, gm._estimate_xyz_nn.detach().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _serial_reference_worker(port, n_views, steps, q):
+    """One rank, the un-phased batched body (phase="all": in-line all-reduce over a 1-rank group)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    gm, loop = _batched_host_loop(0, 1, n_views)
+    x0 = gm._estimate_xyz_nn.detach().numpy().copy()
+    for _ in range(steps):
+        loop._iteration_body_batched(phase="all")
+    q.put(("ref", (x0, gm._estimate_xyz_nn.detach().numpy().copy())))
+    dist.destroy_process_group()
+
+
+def test_batched_local_phase_all_reduce_finish_step_equals_single_rank():
+    """5 views over 2 ranks (3 / 2) through `_iteration_body_batched(phase="local")` + all-reduce + `_finish_step`
+    against one rank running all 5 views through the un-phased body: same positions after three optimiser steps,
+    identical on both ranks (the physics term is added once per LOCAL view: 3 + 2 = 5 = the single rank's count)."""
+    n_views, world, steps = 5, 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    ref_p = ctx.Process(target=_serial_reference_worker, args=(port + 1, n_views, steps, q))
+    ref_p.start()
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, n_views, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world + 1))
+    for p in procs + [ref_p]:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x0, want = got["ref"]
+    assert float(abs(want - x0).max()) > 1e-4
+    assert (got[0] == got[1]).all()
+    assert abs(got[0] - want).max() <= 2e-6

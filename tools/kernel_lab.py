@@ -14,6 +14,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--views", type=int, default=5)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--no-backward", action="store_true")
+ap.add_argument("--math", default="exact", choices=["exact", "fast"])
 a = ap.parse_args()
 gm, cams = build_smoke_frame(n_views=a.views, size=a.size)
 gm.training_setup_current(__import__("types").SimpleNamespace(position_lr_init=1.6e-4, position_lr_final=1.6e-6,
@@ -21,6 +22,7 @@ gm.training_setup_current(__import__("types").SimpleNamespace(position_lr_init=1
 _, GRsetting, GRzer = get_render_pipe("render_dynamics")
 bg = torch.zeros(3, device="cuda")
 rasterizer.set_host_sync(False)
+rasterizer.set_blend_math(a.math)
 e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
 for it in range(a.iters + 2):
     if it == 2:
