@@ -225,6 +225,8 @@ def main():
                     help="arithmetic of the blend kernels (include/fnx_raster.h fnx_set_blend_math): fast = fused multiply-adds "
                          "+ v_exp_f32, stated tolerance against the oracle (tests/test_fast_math_gpu.py); exact = the "
                          "bit-reproducible sequence the oracle repeats")
+    ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
+                    help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -289,6 +291,8 @@ def main():
     from fluidnexus_amd.renderer import pipes
     _lib.raster()  # fail loudly if the HIP library is missing
     rasterizer.set_blend_math(a.blend_math)
+    if a.deep_kernel is not None:
+        _lib.check(_lib.raster().fnx_set_deep_kernel(a.deep_kernel))
     if a.no_static_split:
         pipes.set_static_split(False)
 

@@ -44,7 +44,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast);
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -217,6 +217,7 @@ struct ProfClass {
     size_t used = 0;
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
+int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
 int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
 bool g_prof_on = false;
 ProfClass g_prof[kProfClasses];
@@ -427,7 +428,7 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb, g_blend_math);
+                                  st, materialize_all, V, vb, g_blend_math, g_deep_kernel);
     }
     return hip_check("stage2");
 }
@@ -640,6 +641,11 @@ int fnx_set_blend_math(int mode) {
     return FNX_OK;
 }
 int fnx_get_blend_math(void) { return g_blend_math; }
+int fnx_set_deep_kernel(int mode) {
+    if (mode < 0 || mode > 2) return fail(FNX_ERR_INVALID_ARG, "deep kernel mode must be 0 (off), 1 (auto) or 2 (always)");
+    g_deep_kernel = mode;
+    return FNX_OK;
+}
 
 int fnx_profile_enable(int on) {
     g_prof_on = on != 0;

@@ -21,6 +21,11 @@
 #else
 #define FNX_LOOP_BARRIER() __syncthreads()
 #endif
+#ifdef FNX_EXP_WG_ATOMICS  // timing experiment: flush with workgroup-scope (XCD-local L2) atomics -- WRONG sums across XCDs
+#define FNX_FLUSH_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define FNX_FLUSH_ADD(p, v) unsafeAtomicAdd((p), (v))
+#endif
 #ifndef FNX_ABLATE
 #define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
 #endif
@@ -524,21 +529,21 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                                        -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx,
                                        -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy, gv, dv);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&dL_dmean3D[3 * (size_t)id + k], gv[k]);
+                    for (int k = 0; k < 3; k++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)id + k], gv[k]);
                 } else {
                     if (kMeans) {
-                        unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
-                        unsafeAtomicAdd(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
+                        FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
+                        FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
                     }
-                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
-                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
-                    unsafeAtomicAdd(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
+                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
+                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
+                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
                 }
                 if (kAppearance) {
-                    unsafeAtomicAdd(&dL_dopacity_v[id], a[kAppearance ? kOpac : 0]);
+                    FNX_FLUSH_ADD(&dL_dopacity_v[id], a[kAppearance ? kOpac : 0]);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++)
-                        unsafeAtomicAdd(&dL_dcolors_v[(size_t)id * C + ch], a[kAppearance ? kCol + ch : 0]);
+                        FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)id * C + ch], a[kAppearance ? kCol + ch : 0]);
                 }
             }
         }

@@ -241,6 +241,95 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     if (threadIdx.x == 0) key_min_blk[blockIdx.x] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Inner loops of the blend forward's FAST arithmetic (fnx_set_blend_math(1)), shared by the per-tile kernel and the
+// super-batch kernel for deep tiles.  `mylist`: the lane's block list (LDS byte offsets of staged entries, padded with
+// the NULL record), n_w: steps of the wave (its longest list).  Staged records: s_ra = (x, y, A, B), s_rb = (C, log2 o,
+// colour 0, colour 1 | depth), s_rc = (colour 2, depth) with (A, B, C) = -log2(e) (a / 2, b, c / 2) of the conic.
+template <int C>
+__device__ __forceinline__ float fast_alpha(const float4 ra, const float4 rb, float pxf, float pyf) {
+    const float dx = ra.x - pxf, dy = ra.y - pyf;
+    const float u = __builtin_fmaf(ra.z, dx, ra.w * dy);
+    const float q = __builtin_fmaf(u, dx, (rb.x * dy) * dy);  // log2(e) * power
+    const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(q + rb.y));
+    return (!(q > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;  // forward.cu:326-335
+}
+
+// Full walk: `alive` is the WORKING transmittance (T while the pixel blends, 0 once it has stopped or if it lies
+// outside the image), Tr the pixel's transmittance, acc its colour, hit_off the LDS offset of the last entry taken.
+template <int C>
+__device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
+                                          const float4 *s_rc, float pxf, float pyf, float (&acc)[C], float &Tr,
+                                          float &alive, float &Dm, uint32_t &hit_off) {
+    constexpr int kGroup = 4;
+    // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
+    // walk, and if T crosses 1/2 here the entry that took it across is mylist[n_half] (forward.cu:351-354)
+    uint32_t n_half = 0;
+    const float T_in = Tr;
+    for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
+        if (__all(alive == 0.0f)) break;
+        uint32_t jw[kGroup / 2];
+#pragma unroll
+        for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
+        float a_h[kGroup], col[kGroup][3];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+            const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+            col[k][0] = rb.z;
+            col[k][1] = rb.w;
+            col[k][2] = C == 3 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off) : 0.f;
+            a_h[k] = fast_alpha<C>(ra, rb, pxf, pyf);
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const float wq = a_h[k] * alive;      // alpha T (0 for a stopped pixel: its working T is 0)
+            const float t = alive - wq;           // test_T
+            const bool stop = t < 0.0001f;        // also true for every entry behind the one that stopped the pixel
+            const float wgt = stop ? 0.0f : wq;
+            acc[0] = __builtin_fmaf(col[k][0], wgt, acc[0]);
+            if (C > 1) acc[C > 1 ? 1 : 0] = __builtin_fmaf(col[k][1], wgt, acc[C > 1 ? 1 : 0]);
+            if (C > 2) acc[C > 2 ? 2 : 0] = __builtin_fmaf(col[k][2], wgt, acc[C > 2 ? 2 : 0]);
+            Tr = stop ? Tr : t;
+            alive = stop ? 0.0f : t;
+            n_half += (Tr >= 0.5f) ? 1u : 0u;
+            hit_off = (wgt > 0.0f) ? off : hit_off;
+        }
+    }
+    if (T_in >= 0.5f && Tr < 0.5f) {
+        const uint32_t off = mylist[n_half];
+        Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
+                    : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
+    }
+}
+
+// Transmittance only: the product of (1 - alpha) over the lane's list, without the stop rule (the caller applies it
+// to the running product between sub-batches, blend_forward_deep_kernel).
+template <int C>
+__device__ __forceinline__ float fast_walk_transmittance(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra,
+                                                         const float4 *s_rb, float pxf, float pyf) {
+    constexpr int kGroup = 4;
+    float P = 1.0f;
+    for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
+        uint32_t jw[kGroup / 2];
+#pragma unroll
+        for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
+        float a_h[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+            const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+            a_h[k] = fast_alpha<C>(ra, rb, pxf, pyf);
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) P = __builtin_fmaf(-a_h[k], P, P);
+    }
+    return P;
+}
+
 // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order, speed only), so
 // hand each XCD a contiguous band of tiles -> neighbouring tiles share splat records in one L2.
 __device__ __forceinline__ int xcd_tile(int bid, int T) {
@@ -261,8 +350,10 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  uint32_t *__restrict__ emit_items, size_t geom_stride, uint32_t *__restrict__ depth_hint,
                  uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
                  const StaticRef st) {
+    constexpr int kDeepSorted = 1024;
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_deep_n;
+    __shared__ uint2 s_deep[kDeepSorted];  // (depth hint, tile) of the deep tiles
     if (threadIdx.x == 0) s_deep_n = 0;
     tile_order = view_at(tile_order, img_stride, blockIdx.y);
     tile_deep = view_at(tile_deep, img_stride, blockIdx.y);
@@ -303,10 +394,30 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         // Tiles that went deep in the previous forward of this view (a list that does not saturate: thousands of
         // contributing entries per pixel) are handed to the first workgroups of the blend launch, at raised wave
         // priority: their sequential walks are the critical path of the launch and must not start last.
-        const bool deep = depth_hint && c && depth_hint[i] >= deep_min;
+        const uint32_t hint = depth_hint ? depth_hint[i] : 0u;
+        const bool deep = depth_hint && c && hint >= deep_min;
         tile_deep[i] = deep ? 1 : 0;
-        if (deep) tile_order[atomicAdd(&s_deep_n, 1u)] = (uint32_t)i;
+        if (deep) {
+            const uint32_t at = atomicAdd(&s_deep_n, 1u);
+            tile_order[at] = (uint32_t)i;
+            if (at < kDeepSorted) s_deep[at] = make_uint2(hint, (uint32_t)i);
+        }
         if (depth_hint) depth_hint[i] = 0u;  // the blend of this forward records the new depth
+    }
+    __syncthreads();
+    {
+        // deepest first (the deep-tile kernel hands them out in this order: longest jobs first); ties by tile index.
+        // Beyond kDeepSorted deep tiles the rest keep their arrival order.
+        const uint32_t nd = min(s_deep_n, (uint32_t)kDeepSorted);
+        for (uint32_t e = tid; e < nd; e += 1024) {
+            const uint2 me = s_deep[e];
+            uint32_t rank = 0;
+            for (uint32_t o = 0; o < nd; o++) {
+                const uint2 ot = s_deep[o];
+                rank += (ot.x > me.x || (ot.x == me.x && ot.y < me.y)) ? 1u : 0u;
+            }
+            tile_order[rank] = me.y;
+        }
     }
     __syncthreads();
     {
@@ -404,7 +515,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      uint32_t capacity, uint32_t *__restrict__ status_out, const uint32_t *__restrict__ tile_count,
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
-                     uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb) {
+                     uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
+                     int skip_deep) {
     const char *static_blob = nullptr;
     // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
     // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
@@ -461,7 +573,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
     // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
     const int tile = (int)tile_order[wg_rank];
-    if (tile_deep[tile]) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
+    if (tile_deep[tile]) {
+        if (skip_deep) return;  // blend_forward_deep_kernel takes the tiles that went deep in the previous forward
+        __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
+    }
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // The blend loop multiplies the colour of an entry a pixel does NOT take by alpha = 0 instead of selecting per
@@ -697,51 +812,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #endif
         uint32_t hit_off = 0xFFFFFFFFu;  // LDS offset of the last entry of this batch the pixel took
         if (FAST) {
-            // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
-            // walk, and if T crosses 1/2 in this batch the entry that took it across is mylist[n_half] (forward.cu:351-354)
-            uint32_t n_half = 0;
-            const float T_in = Tr;
-            for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
-                if (__all(alive == 0.0f)) break;
-                uint32_t jw[kGroup / 2];
-#pragma unroll
-                for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
-                float a_h[kGroup], col[kGroup][3];
-#pragma unroll
-                for (int k = 0; k < kGroup; k++) {
-                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                    const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
-                    const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
-                    col[k][0] = rb.z;
-                    col[k][1] = rb.w;
-                    col[k][2] = C == 3 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off) : 0.f;
-                    const float dx = ra.x - pxf, dy = ra.y - pyf;
-                    const float u = __builtin_fmaf(ra.z, dx, ra.w * dy);
-                    const float q = __builtin_fmaf(u, dx, (rb.x * dy) * dy);  // log2(e) * power
-                    const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(q + rb.y));
-                    a_h[k] = (!(q > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
-                }
-#pragma unroll
-                for (int k = 0; k < kGroup; k++) {
-                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                    const float wq = a_h[k] * alive;      // alpha T (0 for a stopped pixel: its working T is 0)
-                    const float t = alive - wq;           // test_T
-                    const bool stop = t < 0.0001f;        // also true for every entry behind the one that stopped the pixel
-                    const float wgt = stop ? 0.0f : wq;
-                    acc[0] = __builtin_fmaf(col[k][0], wgt, acc[0]);
-                    if (C > 1) acc[C > 1 ? 1 : 0] = __builtin_fmaf(col[k][1], wgt, acc[C > 1 ? 1 : 0]);
-                    if (C > 2) acc[C > 2 ? 2 : 0] = __builtin_fmaf(col[k][2], wgt, acc[C > 2 ? 2 : 0]);
-                    Tr = stop ? Tr : t;
-                    alive = stop ? 0.0f : t;
-                    n_half += (Tr >= 0.5f) ? 1u : 0u;
-                    hit_off = (wgt > 0.0f) ? off : hit_off;
-                }
-            }
-            if (T_in >= 0.5f && Tr < 0.5f) {
-                const uint32_t off = mylist[n_half];
-                Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
-                            : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
-            }
+            fast_walk<C>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off);
         } else
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
             if (__all(alive == 0.0f)) break;
@@ -837,6 +908,336 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #endif
 }
 
+// K5b: the blend forward of DEEP tiles (FAST arithmetic only).  A tile whose list does not saturate -- a semi-transparent
+// plume in front of a distant wall: thousands of contributing entries per pixel -- is a serial walk in K5, and the
+// launch ends when the deepest one ends (~10 us per 256-entry batch, 30 batches).  Here a workgroup of G x 256 threads
+// takes a SUPER-BATCH of G x 256 entries at a time: group g = threads [256 g, 256 g + 256) owns sub-batch g, every
+// group covers all 256 pixels of the tile (same pixel <-> lane map as K5).  Per super-batch:
+//   stage     all G x 256 entries at once (merge of the two streams, records, block masks, lists) -- the latency-bound
+//             part of a batch is paid once per super-batch instead of once per batch;
+//   pass A    groups 0 .. G-2 walk their sub-batch for the transmittance alone (fast_walk_transmittance: alpha and a
+//             running product, half the instructions of the full walk) -> P_g per pixel;
+//   T_in      sub-batch g starts from T_start * P_0 ... P_{g-1}; T only falls, so the pixel has stopped in front of g
+//             exactly if that running product fell below 1e-4 (forward.cu:336-340), up to the rounding of the product;
+//   pass B    every group walks its sub-batch in full from its own T_in (fast_walk, the same code as K5): colour,
+//             stop test, median depth, last contributor -- all four sub-batches at the same time;
+//   combine   group 0 (which owns the pixels' state) adds the groups' results in list order and writes the per-batch
+//             hand-over records of the backward pass (bstate) exactly as K5 does.
+// The deep tile's chain shrinks from G x (stage + walk) to stage + A + B per G batches; the price is pass A, ~1/3 more
+// work on the deep tiles.  Results differ from K5's by the association of T_in only (stated tolerance of the fast mode).
+#ifndef FNX_DEEP_GROUPS
+#define FNX_DEEP_GROUPS 4
+#endif
+template <int C, bool SPLIT>
+__global__ void __launch_bounds__(256 * FNX_DEEP_GROUPS) __attribute__((amdgpu_waves_per_eu(FNX_DEEP_GROUPS, FNX_DEEP_GROUPS)))
+blend_forward_deep_kernel(int T, int gx, const uint32_t *__restrict__ ranges_all, uint32_t *__restrict__ point_list_all,
+                          int W, int H, const float4 *__restrict__ blend_rec_all, const float *__restrict__ bg,
+                          float *__restrict__ final_T_all, uint32_t *__restrict__ n_contrib_all,
+                          float *__restrict__ out_color_all, float *__restrict__ out_depth_all,
+                          uint32_t *__restrict__ header_all, uint32_t capacity, const uint32_t *__restrict__ tile_count_all,
+                          const uint32_t *__restrict__ dyn_start_all, float *__restrict__ acc_final_all,
+                          const uint32_t *__restrict__ tile_order_all, uint32_t *__restrict__ depth_hint_all,
+                          const StaticRef st, int materialize_all, const ViewBatch vb, int n_views) {
+    constexpr int G = FNX_DEEP_GROUPS, NB = 256 * G, kGroup = 4;
+    constexpr int kListStride = (256 + kGroup + 7) & ~7;
+    constexpr uint32_t kNullOff = (uint32_t)NB * 16u;  // LDS offset of the NULL record (slot NB)
+    static_assert(NB * 16 <= 0xFFFF, "list entries are 16-bit LDS offsets");
+    __shared__ float4 s_ra[NB + 1];
+    __shared__ float4 s_rb[NB + 1];
+    __shared__ float4 s_rc[NB + 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[16 * G][kListStride];  // lists 16 g + 4 w .. + 3: wave (g, w)
+    __shared__ uint16_t s_mask[NB];
+    __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? NB : 1];
+    __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? NB : 1];
+    __shared__ uint32_t s_adv;
+    __shared__ uint32_t s_done[4], s_qmax[4], s_cnt[kMaxViews];
+    __shared__ float s_pT[256];      // working transmittance of every pixel at the start of the super-batch (0: stopped)
+    __shared__ float s_P[G][256];    // pass A: transmittance of sub-batch g per pixel
+    __shared__ float4 s_pa[G][256];  // pass B of groups >= 1: colour taken in the sub-batch, pixel T behind it
+    __shared__ float4 s_pb[G][256];  //                         working T behind it, last contributor, median depth, its flag
+    const int tid = threadIdx.x, g = tid >> 8, gt = tid & 255, lane = tid & 63, w = gt >> 6, row = lane >> 4;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (tid < n_views) {
+        const uint32_t *h = view_at(header_all, vb.img, tid);
+        s_cnt[tid] = h[HDR_NUM_RENDERED] > capacity ? 0u : h[HDR_DEEP_COUNT];
+    }
+    if (tid == 0) {
+        s_ra[NB] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rb[NB] = make_float4(0.f, -200.0f, 0.f, 0.f);
+        s_rc[NB] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    uint32_t most = 0;
+    for (int v = 0; v < n_views; v++) most = max(most, s_cnt[v]);
+    // deep tiles of all views, deepest first within a view (tile_scan_kernel), the views interleaved
+    for (uint32_t slot = blockIdx.x; slot < most * (uint32_t)n_views; slot += gridDim.x) {
+        __syncthreads();  // the previous tile is done with the LDS arrays
+        const int vw = (int)(slot % (uint32_t)n_views);
+        const uint32_t rank = slot / (uint32_t)n_views;
+        if (rank >= s_cnt[vw]) continue;
+        const uint32_t *ranges = view_at(ranges_all, vb.img, vw);
+        float *final_T = view_at(final_T_all, vb.img, vw);
+        uint32_t *n_contrib = view_at(n_contrib_all, vb.img, vw);
+        uint32_t *header = view_at(header_all, vb.img, vw);
+        uint32_t *point_list = view_at(point_list_all, vb.bin, vw);
+        const float4 *blend_rec = view_at(blend_rec_all, vb.geom, vw);
+        float *out_color = out_color_all + (size_t)vw * C * H * W;
+        float *out_depth = out_depth_all + (size_t)vw * H * W;
+        float *acc_final = view_at(acc_final_all, vb.img, vw);
+        const int tile = (int)view_at(tile_order_all, vb.img, vw)[rank];
+        const int tx = tile % gx, ty = tile / gx;
+        const int px = tx * FNX_TILE_X + blend_pixel_x(w, lane), py = ty * FNX_TILE_Y + blend_pixel_y(w, lane);
+        const bool inside = px < W && py < H;
+        const uint32_t pix_id = (uint32_t)W * py + px;
+        const float pxf = (float)px, pyf = (float)py;
+        const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        // pixel state: meaningful in group 0 (the other groups only ever hold the state of their own sub-batch)
+        float alive = inside ? 1.0f : 0.0f, Tr = 1.0f, Dm = 15.0f;
+        uint32_t last_contributor = 0;
+        float acc[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+        float pd = 0.f;
+        uint32_t id_ahead = 0;
+        const uint2 *sp = nullptr, *fp = nullptr;
+        const float4 *rec_s = nullptr;
+        uint32_t ns = 0, nf = 0, si = 0, fj = 0, my_id = 0;
+        uint2 ws = make_uint2(0u, 0u), wf = ws;
+        auto record_of = [&](uint32_t id) -> const float4 * {
+            return (SPLIT && id >= st.id0) ? rec_s + 4 * (size_t)(id - st.id0) : blend_rec + 4 * (size_t)id;
+        };
+        auto load_windows = [&]() {
+            ws = (si + (uint32_t)tid < ns) ? sp[si + tid] : make_uint2(0xFFFFFFFFu, 0u);
+            wf = (fj + (uint32_t)tid < nf) ? fp[fj + tid] : make_uint2(0xFFFFFFFFu, 0u);
+        };
+        auto store_windows = [&]() {
+            s_wk[0][SPLIT ? tid : 0] = ws.x;
+            s_wi[0][SPLIT ? tid : 0] = ws.y;
+            s_wk[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.x;
+            s_wi[SPLIT ? 1 : 0][SPLIT ? tid : 0] = wf.y;
+        };
+        auto merge_batch = [&](uint32_t cnt_next) -> uint32_t {  // merge path over the two windows (K5, NB entries wide)
+            uint32_t id = 0;
+            if ((uint32_t)tid < cnt_next) {
+                const uint32_t nsw = min((uint32_t)NB, ns - si), nfw = min((uint32_t)NB, nf - fj);
+                const uint32_t *ks = s_wk[0], *kf = s_wk[SPLIT ? 1 : 0];
+                const uint32_t t = (uint32_t)tid;
+                uint32_t lo = t > nfw ? t - nfw : 0u, hi = min(t, nsw);
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ks[mid] < kf[t - mid - 1]) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t i = lo, j = t - lo;
+                const bool from_static = !(j < nfw && (i >= nsw || kf[j] <= ks[i]));
+                id = from_static ? s_wi[0][i] : s_wi[SPLIT ? 1 : 0][j];
+                if (t == cnt_next - 1) s_adv = i + (from_static ? 1u : 0u);
+            }
+            return id;
+        };
+        auto fetch = [&](uint32_t id) {
+            const float4 *rec = record_of(id);
+            pa = rec[0];
+            pb = rec[1];
+            pc = rec[2];
+            if (C > 2) pd = rec[3].x;
+        };
+        if (SPLIT) {
+            const char *static_blob = st.base + st.stride * vw;
+            const uint32_t *starts = reinterpret_cast<const uint32_t *>(static_blob + st.starts);
+            const uint32_t s0 = starts[tile];
+            ns = starts[tile + 1] - s0;
+            sp = reinterpret_cast<const uint2 *>(static_blob + st.pairs) + s0;
+            rec_s = reinterpret_cast<const float4 *>(static_blob + st.rec);
+            nf = view_at(tile_count_all, vb.img, vw)[tile];
+            fp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(point_list) + vb.bin_pairs) +
+                 view_at(dyn_start_all, vb.img, vw)[tile];
+            load_windows();
+            store_windows();
+            __syncthreads();
+            const uint32_t cnt0 = min((uint32_t)NB, r1 - r0);
+            my_id = merge_batch(cnt0);
+            __syncthreads();
+            if (cnt0) {
+                const uint32_t a = s_adv;
+                si += a;
+                fj += cnt0 - a;
+            }
+            if ((uint32_t)tid < cnt0) fetch(my_id);
+            load_windows();
+        } else {
+            if (r0 + (uint32_t)tid < r1) fetch(point_list[r0 + tid]);
+            if (r0 + (uint32_t)NB + (uint32_t)tid < r1) id_ahead = point_list[r0 + NB + tid];
+        }
+        float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
+                         (size_t)(r0 >> 8) * 256 + gt;
+        uint16_t *masks_out = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks);
+        bool blending = true;
+        for (uint32_t base = r0; base < r1; base += NB) {
+            // group 0 publishes the pixels' working T; "has every pixel stopped?" through LDS as in K5
+            const uint32_t wave_done = __all(alive == 0.0f) ? 1u : 0u;
+            if (g == 0) {
+                if (lane == 0) s_done[w] = wave_done;
+                s_pT[gt] = alive;
+            }
+            FNX_LOOP_BARRIER();
+            const bool all_done = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
+            if (all_done) {
+                if (!SPLIT || !materialize_all) break;
+                blending = false;
+            }
+            // hand-over record in front of the super-batch's first sub-batch (the others: combine, below)
+            if (g == 0 && blending && base != r0)
+                bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
+            const uint32_t cnt = min((uint32_t)NB, r1 - base);
+            uint32_t qm = 0;
+            if ((uint32_t)tid < cnt && blending) {
+                qm = block_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
+                constexpr float kL2e = 1.44269504088896341f;
+                s_ra[tid] = make_float4(pa.x, pa.y, (-0.5f * kL2e) * pa.z, (-kL2e) * pa.w);
+                const float lo = __builtin_amdgcn_logf(fmaxf(pb.y, 0.0f));
+                if (C == 3) {
+                    s_rb[tid] = make_float4((-0.5f * kL2e) * pb.x, lo, pc.z, pc.w);
+                    s_rc[tid] = make_float4(pd, pb.w, 0.f, 0.f);
+                } else {
+                    s_rb[tid] = make_float4((-0.5f * kL2e) * pb.x, lo, pc.z, pb.w);
+                }
+            }
+            if (SPLIT) {
+                if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;
+                store_windows();
+            } else {
+                if (base + (uint32_t)NB + (uint32_t)tid < r1) fetch(id_ahead);
+                if (base + 2u * NB + (uint32_t)tid < r1) id_ahead = point_list[base + 2u * NB + tid];
+            }
+            s_mask[tid] = (uint16_t)qm;
+            if ((uint32_t)tid < cnt && blending) masks_out[base + tid] = (uint16_t)qm;
+            {  // this wave's four lists start out as NULL pointers from end to end
+                const uint32_t n2 = kNullOff | (kNullOff << 16);
+                const uint4 nul = make_uint4(n2, n2, n2, n2);
+                uint4 *mine = reinterpret_cast<uint4 *>(&s_list[16 * g + 4 * w][0]);
+                for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
+            }
+            FNX_LOOP_BARRIER();
+            uint32_t len[4] = {0u, 0u, 0u, 0u};
+            const unsigned long long live = __ballot(s_pT[gt] != 0.0f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int slot_e = 256 * g + 64 * k + lane;
+                const uint32_t mk = (uint32_t)s_mask[slot_e] >> (4 * w);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const bool bit = ((mk >> b) & 1u) && ((live >> (16 * b)) & 0xFFFFull) != 0ull;
+                    const unsigned long long m = __ballot(bit);
+                    if (bit) s_list[16 * g + 4 * w + b][len[b] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(slot_e * 16);
+                    len[b] += (uint32_t)__popcll(m);
+                }
+            }
+            uint32_t next_cnt = 0, next_id = 0;
+            if (SPLIT) {
+                next_cnt = base + (uint32_t)NB < r1 ? min((uint32_t)NB, r1 - base - (uint32_t)NB) : 0u;
+                next_id = merge_batch(next_cnt);
+            }
+            FNX_LOOP_BARRIER();
+            if (SPLIT) {
+                if (next_cnt) {
+                    const uint32_t a = s_adv;
+                    si += a;
+                    fj += next_cnt - a;
+                }
+                my_id = next_id;
+                if ((uint32_t)tid < next_cnt) fetch(my_id);
+                load_windows();
+                if (!blending) continue;
+            }
+            const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));
+            const uint16_t *mylist = s_list[16 * g + 4 * w + row];
+            // pass A: transmittance of the sub-batches that have a successor in this super-batch
+            if (g < G - 1) s_P[g][gt] = fast_walk_transmittance<C>(mylist, n_w, s_ra, s_rb, pxf, pyf);
+            FNX_LOOP_BARRIER();
+            // T in front of sub-batch g: the running product, with the stop rule applied between sub-batches
+            float T_in = s_pT[gt];
+#pragma unroll
+            for (int h = 0; h < G - 1; h++)
+                if (h < g) {
+                    const float tn = T_in * s_P[h][gt];
+                    T_in = tn < 0.0001f ? 0.0f : tn;
+                }
+            // pass B: the full walk of every sub-batch, from its own T_in (group 0: from the pixel state itself)
+            uint32_t hit_off = 0xFFFFFFFFu;
+            {
+                // one copy of the walk for all groups: group 0 runs it on the pixel state, the others on a fresh state
+                float acc_g[C], Tr_g = g == 0 ? Tr : T_in, alive_g = g == 0 ? alive : T_in, Dm_g = g == 0 ? Dm : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) acc_g[ch] = g == 0 ? acc[ch] : 0.f;
+                const float T_before = Tr_g;
+                fast_walk<C>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc_g, Tr_g, alive_g, Dm_g, hit_off);
+                const uint32_t hit = hit_off != 0xFFFFFFFFu ? (base - r0) + 1u + (hit_off >> 4) : 0u;
+                if (g == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) acc[ch] = acc_g[ch];
+                    Tr = Tr_g;
+                    alive = alive_g;
+                    Dm = Dm_g;
+                    last_contributor = hit ? hit : last_contributor;
+                } else {
+                    const bool crossed = T_before >= 0.5f && Tr_g < 0.5f;
+                    s_pa[g][gt] = make_float4(acc_g[0], acc_g[C > 1 ? 1 : 0], acc_g[C > 2 ? 2 : 0], Tr_g);
+                    s_pb[g][gt] = make_float4(alive_g, __uint_as_float(hit), Dm_g, crossed ? 1.0f : 0.0f);
+                }
+            }
+            FNX_LOOP_BARRIER();
+            // combine in list order: group 0 owns the pixel state and writes the backward pass's hand-over records
+            if (g == 0) {
+#pragma unroll
+                for (int h = 1; h < G; h++) {
+                    if (base + 256u * h >= r1) break;  // no such sub-batch
+                    bstate[(size_t)(((base - r0) >> 8) + h - 1) * 256] =
+                        make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
+                    const float4 ra_ = s_pa[h][gt], rb_ = s_pb[h][gt];
+                    if (alive != 0.0f) {  // a pixel that stopped in front of sub-batch h takes nothing from it
+                        acc[0] += ra_.x;
+                        if (C > 1) acc[C > 1 ? 1 : 0] += ra_.y;
+                        if (C > 2) acc[C > 2 ? 2 : 0] += ra_.z;
+                        Tr = rb_.x != 0.0f || ra_.w != 0.0f ? ra_.w : Tr;
+                        alive = rb_.x;
+                        const uint32_t hit = __float_as_uint(rb_.y);
+                        last_contributor = hit ? hit : last_contributor;
+                        Dm = rb_.w != 0.0f ? rb_.z : Dm;
+                    }
+                }
+            }
+        }
+        if (g == 0) {
+            if (inside) {
+                final_T[pix_id] = Tr;
+                n_contrib[pix_id] = last_contributor;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    out_color[(size_t)ch * H * W + pix_id] = acc[ch] + Tr * bg[ch];
+                    acc_final[(size_t)ch * H * W + pix_id] = acc[ch];
+                }
+                out_depth[pix_id] = Dm;
+            }
+            uint32_t m = last_contributor;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+            if (lane == 0) s_qmax[w] = m;
+        }
+        __syncthreads();
+        const uint32_t qmax = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
+        const uint32_t nb = (qmax + 255u) >> 8;
+        if (nb) {
+            if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
+            __syncthreads();
+            uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
+            for (uint32_t k = tid; k < nb; k += NB) items[k] = (uint32_t)tile | (k << 14);
+        }
+        if (depth_hint_all && tid == 0) (depth_hint_all + (size_t)vw * T)[tile] = qmax;
+    }
+}
+
 // rasterizer_impl.cu:52-63
 __global__ void __launch_bounds__(256)
 mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ view, uint8_t *__restrict__ present) {
@@ -904,8 +1305,41 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast) {
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
+    // Deep tiles (depth hints of the previous forward) go to the super-batch kernel; it exists for the fast arithmetic.
+    // A deep workgroup holds a whole compute unit at modest utilisation to cut the tile's LATENCY, which pays when the
+    // launch is bound by its longest walks -- few views per launch (a rank's share of a sharded batch) -- and costs
+    // throughput when thousands of other tiles wait for those compute units: deep = 1 (auto) uses it up to two views.
+    const int use_deep = (fast && depth_hint && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
+    // the two kernels touch disjoint tiles: the deep one runs on a helper stream beside the per-tile kernel
+    static hipStream_t helper = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t sd = s;
+    if (use_deep) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+            if (hipStreamCreateWithFlags(&helper, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+                helper = nullptr;
+        }
+        if (helper && hipEventRecord(ev_fork, s) == hipSuccess && hipStreamWaitEvent(helper, ev_fork, 0) == hipSuccess)
+            sd = helper;
+        (void)hipGetLastError();
+#define FNX_LAUNCH_BD(CC, SS)                                                                                          \
+    hipLaunchKernelGGL((blend_forward_deep_kernel<CC, SS>), dim3(n_cu), dim3(256 * FNX_DEEP_GROUPS), 0, sd, T, gx,     \
+                       ranges, point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header,      \
+                       capacity, tile_count, dyn_start, acc_final, tile_order, depth_hint, st, materialize_all, vb, V)
+        if (C == 3 && st.base) FNX_LAUNCH_BD(3, true);
+        else if (C == 3) FNX_LAUNCH_BD(3, false);
+        else if (st.base) FNX_LAUNCH_BD(1, true);
+        else FNX_LAUNCH_BD(1, false);
+#undef FNX_LAUNCH_BD
+    }
 #define FNX_LAUNCH_BF(CC, SS)                                                                                          \
     if (fast)                                                                                                          \
         FNX_LAUNCH_BF_(CC, SS, true);                                                                                  \
@@ -915,13 +1349,18 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,      \
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
-                       tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb)
+                       tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
+                       use_deep)
     if (C == 3 && st.base) { FNX_LAUNCH_BF(3, true); }
     else if (C == 3) { FNX_LAUNCH_BF(3, false); }
     else if (st.base) { FNX_LAUNCH_BF(1, true); }
     else { FNX_LAUNCH_BF(1, false); }
 #undef FNX_LAUNCH_BF
 #undef FNX_LAUNCH_BF_
+    if (use_deep && sd != s) {  // join
+        (void)hipEventRecord(ev_join, sd);
+        (void)hipStreamWaitEvent(s, ev_join, 0);
+    }
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present) {

@@ -117,6 +117,9 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
 # only): without it the rasteriser's backward adds straight into dL/dmeans3D (geometry_only = 3).  FNX_SCREEN_GRAD=1
 # keeps the reference's behaviour (the 2D-mean gradient is produced as well).
 _SCREEN_GRAD = os.environ.get("FNX_SCREEN_GRAD", "0") == "1"
+# Where the physics side branch is enqueued: behind the rasteriser forward (default) or right at its fork point, under
+# the latency-bound head of the iteration (interpolation, preprocess, depth sort, emission)
+_PHYSICS_EARLY = os.environ.get("FNX_PHYSICS_EARLY", "0") == "1"
 
 
 class HotLoop:
@@ -411,18 +414,10 @@ class HotLoop:
         fork = torch.cuda.Event()
         fork.record(main)
         use_dist = bool(mine) and c.get("lambda_current_distance", 0.0) > 0
-        if mine:
-            from . import rasterizer
-            fork_d, forked_d = torch.cuda.Event(), []
-            if use_dist:
-                rasterizer.set_between_stages_hook(lambda: (fork_d.record(torch.cuda.current_stream()), forked_d.append(1)))
-            try:
-                pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
-                                            GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
-                                            scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
-            finally:
-                rasterizer.set_between_stages_hook(None)
-        if self.physics_per_view or self.rank == 0:
+        def launch_physics():
+            nonlocal gp, n_phys
+            if not (self.physics_per_view or self.rank == 0):
+                return
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
                 # work items of the hidden-particle grid for the cell-by-cell hidden<-visual backward at the end
@@ -438,6 +433,22 @@ class HotLoop:
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
             n_phys = len(mine) if self.physics_per_view else batch
+
+        if _PHYSICS_EARLY:
+            launch_physics()
+        if mine:
+            from . import rasterizer
+            fork_d, forked_d = torch.cuda.Event(), []
+            if use_dist:
+                rasterizer.set_between_stages_hook(lambda: (fork_d.record(torch.cuda.current_stream()), forked_d.append(1)))
+            try:
+                pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
+                                            GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
+                                            scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
+            finally:
+                rasterizer.set_between_stages_hook(None)
+        if not _PHYSICS_EARLY:
+            launch_physics()
         if mine:
             if use_dist:
                 from .physics import distance_loss_value_and_grad

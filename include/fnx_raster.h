@@ -251,6 +251,17 @@ int fnx_set_deep_threshold(unsigned int min_depth);
  *      reference (contraction on, libdevice expf) is closest to; tests/test_fast_math_gpu.py. */
 int fnx_set_blend_math(int mode);
 int fnx_get_blend_math(void);
+/* Fast mode only: tiles that went at least fnx_set_deep_threshold() deep in the previous forward of their view (depth_hint)
+ * are blended by a second kernel that takes 1024 list entries at a time -- four 256-entry sub-batches walked
+ * concurrently, each from the transmittance a cheap pre-pass computed for it -- instead of one serial walk per tile
+ * (csrc/raster_forward.hip, blend_forward_deep_kernel), on a helper stream beside the per-tile kernel.  A deep
+ * workgroup holds a whole compute unit to cut the tile's latency: it pays when a launch is bound by its longest walks
+ * (one or two views per launch: a rank's share of a sharded batch) and costs throughput otherwise.
+ * mode 0 (default): never; 1: launches of at most two views; 2: always.
+ * Measured: a one-view forward alone 259 -> 171 us, but inside the replayed iteration the 1024-thread
+ * workgroups wait for an empty compute unit behind the per-tile kernel's workgroups and the iteration gets slower
+ * (config 3, 2 of 5 views: 1251 -> 1216 it/s), so it is opt-in. */
+int fnx_set_deep_kernel(int mode);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
                                        const float *colors_precomp, const float *scales, float scale_modifier,

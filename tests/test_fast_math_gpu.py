@@ -172,3 +172,85 @@ def test_fast_forward_is_deterministic_and_views_match_single_calls():
     for v in range(3):
         assert torch.equal(singles[v], again[v])
         assert torch.equal(singles[v], batch[v])
+
+
+def _views_render(g, cams, W, H, bg_np, channels, deep_kernel, min_depth=256, backward_seed=None, static_split=False):
+    """Two forwards of one view batch (the second one sees the depth hints of the first: deep tiles exist), fast mode."""
+    import math
+    import torch
+    from fluidnexus_amd import _lib, rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews, StaticBin
+    _lib.check(_lib.raster().fnx_set_deep_kernel(2 if deep_kernel else 0))
+    rasterizer.set_deep_variant(True, min_depth)
+    try:
+        t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+        bg = torch.from_numpy(bg_np).cuda()
+        tan = math.tan(0.4)
+        rs = [GaussianRasterizationSettings(H, W, tan, tan, bg, 1.0, c.world_view_transform.cuda(), c.full_proj_transform.cuda(),
+                                            0, c.camera_center.cuda(), False) for c in cams]
+        rz = GaussianRasterizerViews(rs, channels=channels)
+        P, V = t["means3D"].shape[0], len(cams)
+        if static_split:
+            n_dyn = static_split
+            rz.static_bin = StaticBin(rz.view_batch, t["means3D"][n_dyn:], t["opacities"][n_dyn:], colors_precomp=t["colors"][n_dyn:],
+                                      scales=t["scales"][n_dyn:], rotations=t["rotations"][n_dyn:], channels=channels,
+                                      id_offset=n_dyn)
+            rz.grad_splat_limit = n_dyn
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        out = None
+        for _ in range(2):
+            m2d = torch.zeros(V, P, 3, device="cuda", requires_grad=True)
+            out = rz(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                     scales=leaves["scales"], rotations=leaves["rotations"])
+        hint = rz.view_batch.depth_hint(channels)
+        grads = None
+        if backward_seed is not None:
+            dL = torch.from_numpy(np.random.RandomState(backward_seed).normal(size=tuple(out[0].shape)).astype(np.float32)).cuda()
+            gl = torch.autograd.grad([out[0]], [leaves["means3D"], leaves["opacities"], leaves["colors"], leaves["scales"],
+                                                leaves["rotations"]], grad_outputs=[dL])
+            grads = [x.detach().cpu().numpy() for x in gl]
+        torch.cuda.synchronize()
+        rasterizer.check_status()
+        return out[0].detach().cpu().numpy(), out[2].detach().cpu().numpy(), hint.cpu().numpy(), grads
+    finally:
+        _lib.check(_lib.raster().fnx_set_deep_kernel(0))
+        rasterizer.set_deep_variant(True, 1024)
+
+
+@pytest.mark.parametrize("channels,split", [(3, False), (1, False), (3, True)])
+def test_deep_tile_kernel_matches_per_tile_kernel_and_oracle(oracle, channels, split):
+    """blend_forward_deep_kernel (super-batches of 4 x 256 entries, transmittance pre-pass) against the per-tile kernel
+    and the oracle on a plume in front of a wall: colours within the fast mode's tolerance, the tiles' depths equal,
+    gradients (the backward reads the deep kernel's hand-over records) within the mixed bound."""
+    from tests.hip_harness import scene_kwargs
+    W = H = 160
+    n_dyn = 14_000
+    g = S.smoke_scene(n_dyn, 6_000, seed=9, channels=3, ring=True) if channels == 3 else S.plume_gaussians(n_dyn, seed=9, channels=1)
+    cams = S.ring_cameras(8, W, H, device="cpu")[3:5]
+    bg = np.array([0.05, 0.1, 0.2], np.float32)
+    sp = n_dyn if split else False
+    col_d, dep_d, hint_d, gr_d = _views_render(g, cams, W, H, bg, channels, True, backward_seed=4, static_split=sp)
+    col_r, dep_r, hint_r, gr_r = _views_render(g, cams, W, H, bg, channels, False, backward_seed=4, static_split=sp)
+    assert int((hint_r >= 256).sum()) > 10, "the scene must have deep tiles"
+    assert (hint_d == hint_r).all(), f"last-contributor depth of {int((hint_d != hint_r).sum())} tiles differs"
+    d = np.abs(col_d.astype(np.float64) - col_r).max(1)
+    print(f"[deep ch{channels} split={split}] deep tiles {int((hint_r >= 256).sum())}; max|deep - per-tile| {d.max():.2e}, "
+          f"pixels > {PIX_TOL:g}: {int((d > PIX_TOL).sum())}; depth differs on {int((dep_d != dep_r).sum())}")
+    assert int((d > PIX_TOL).sum()) <= max(2, int(1e-4 * d.size)) and d.max() <= FLIP_TOL
+    assert int((dep_d != dep_r).sum()) <= max(4, int(1e-3 * dep_r.size))
+    for v, cam in enumerate(cams):  # and against the oracle
+        kw = scene_kwargs(g, cam, W, H, 0.8)
+        f = oracle.forward(kw["means3D"], kw["opacities"], bg, kw["view"], kw["proj"], kw["campos"], W, H, kw["tanx"],
+                           kw["tany"], channels=channels, colors_precomp=g["colors"], scales=g["scales"],
+                           rotations=g["rotations"])
+        do = np.abs(col_d[v].astype(np.float64) - f["color"]).max(0)
+        assert int((do > PIX_TOL).sum()) <= max(2, int(1e-4 * do.size)) and do.max() <= FLIP_TOL, f"view {v}: {do.max():.2e}"
+    names = ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")
+    bad = []
+    for n, a, b in zip(names, gr_d, gr_r):
+        lim = n_dyn if split else a.shape[0]
+        ok, msg = mixed_bound_report(b[:lim], a[:lim])
+        print(f"[deep ch{channels} split={split}] {n}: {msg}")
+        if not ok:
+            bad.append(n + ": " + msg)
+    assert not bad, "\n".join(bad)

@@ -18,6 +18,7 @@ else:
     f = lambda: render_fluid_views(cams, gm, None, bg, GRsetting=S_, GRzer=Z_, pos_type="visual")
 bg = torch.zeros(3, device="cuda")
 rasterizer.set_host_sync(False)
+rasterizer.set_blend_math(os.environ.get("FNX_MATH", "exact"))
 with torch.no_grad():
     for _ in range(3):
         f()

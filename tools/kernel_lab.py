@@ -15,6 +15,10 @@ ap.add_argument("--views", type=int, default=5)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--no-backward", action="store_true")
 ap.add_argument("--math", default="exact", choices=["exact", "fast"])
+ap.add_argument("--no-deep", action="store_true")
+ap.add_argument("--deep", type=int, default=None)
+ap.add_argument("--deep-min", type=int, default=None)
+ap.add_argument("--no-split", action="store_true")
 a = ap.parse_args()
 gm, cams = build_smoke_frame(n_views=a.views, size=a.size)
 gm.training_setup_current(__import__("types").SimpleNamespace(position_lr_init=1.6e-4, position_lr_final=1.6e-6,
@@ -23,6 +27,17 @@ _, GRsetting, GRzer = get_render_pipe("render_dynamics")
 bg = torch.zeros(3, device="cuda")
 rasterizer.set_host_sync(False)
 rasterizer.set_blend_math(a.math)
+if a.no_split:
+    from fluidnexus_amd.renderer import pipes as _pp
+    _pp.set_static_split(False)
+if a.deep is not None:
+    from fluidnexus_amd import _lib as _l2
+    _l2.raster().fnx_set_deep_kernel(a.deep)
+if a.deep_min is not None:
+    rasterizer.set_deep_variant(True, a.deep_min)
+if a.no_deep:
+    from fluidnexus_amd import _lib as _l
+    _l.raster().fnx_set_deep_kernel(0)
 e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
 for it in range(a.iters + 2):
     if it == 2:
