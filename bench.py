@@ -203,6 +203,72 @@ def rasterise_timing(gm, cams, views, cfg_id, channels, bg, stage="physical"):
     return out
 
 
+def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
+    """The SH pipe's rasteriser on the configuration's Gaussians (row d3 of the scope table): colours as [P, 16, 3]
+    spherical-harmonics coefficients evaluated per view in the preprocess kernel (ch3 forward.cu:20-67) and
+    differentiated in the per-splat backward (backward.cu:20-132).  Returns per-view milliseconds of the forward and of
+    forward + backward with all gradients (SH coefficients included), the preprocess kernel's duration (HIP events in
+    the library) with its algorithmic bytes, and the MFMA statement north_star asks for."""
+    from fluidnexus_amd import _lib
+    from fluidnexus_amd.helpers.helper_pipe import get_render_pipe
+    from fluidnexus_amd.rasterizer import GaussianRasterizerViews
+    from fluidnexus_amd.renderer.pipes import _settings
+    xyz, opac, scales, rots, _ = scene_arrays(gm, cfg_id, stage)
+    dev = bg.device
+    _, GRsetting, _ = get_render_pipe("render_gs")
+    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, degree) for v in views], channels=3)
+    P, V = xyz.shape[0], len(views)
+    rng = np.random.RandomState(5)
+    shs = np.zeros((P, 16, 3), np.float32)
+    shs[:, 0] = rng.uniform(-1.0, 1.5, size=(P, 3))
+    shs[:, 1:] = rng.normal(size=(P, 15, 3)) * 0.25
+    L = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in
+         dict(means3D=xyz, opacities=opac, scales=scales, rotations=rots, shs=shs).items()}
+    dL = torch.ones(V, 3, SIZE, SIZE, device=dev)
+
+    def once(backward):
+        screen = torch.zeros(V, P, 3, device=dev, requires_grad=True)
+        im, radii, _ = rv(means3D=L["means3D"], means2D=screen, opacities=L["opacities"], shs=L["shs"],
+                          scales=L["scales"], rotations=L["rotations"])
+        if backward:
+            torch.autograd.grad([im], list(L.values()), grad_outputs=[dL])
+        return radii
+
+    out = {}
+    for name, bw in (("sh_forward", False), ("sh_forward_backward", True)):
+        once(bw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            once(bw)
+        e1.record()
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) / 5 / V
+    _lib.profile_enable(True)
+    for _ in range(5):
+        radii = once(False)
+    torch.cuda.synchronize()
+    pre_ms, pre_n = _lib.profile_read(3)
+    _lib.profile_enable(False)
+    p_vis = float((radii > 0).sum().item()) / V
+    # per splat and view: reads xyz 12 + scale 12 + rotation 16 + opacity 4 + SH 16 x 12 = 236 B; a visible splat writes
+    # the per-splat state of SURVEY 8(d) (60 B) + sort key 4 + rect 8 + blend record 64 + rgb 12 + clamped 3 = 151 B
+    bytes_launch = V * (P * 236 + p_vis * 151)
+    us = pre_ms / max(pre_n, 1) * 1e3
+    return {"degree": degree, "gaussians": P, "views_per_launch": V, "rasterise_ms_per_view": out,
+            "preprocess": {"avg_launch_us": us, "algorithmic_bytes_per_launch": int(bytes_launch),
+                           "GBps": bytes_launch / (us * 1e-6) / 1e9 if us > 0 else None,
+                           "frac_of_hbm_peak": bytes_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
+                           "bound": "hbm"},
+            "mfma_util": 0,
+            "why": "the SH contraction is a 1 x 16 . 16 x 3 product per (Gaussian, view) whose 16 x 3 operand is the "
+                   "Gaussian's own coefficients: no operand is shared between Gaussians, 192 B of coefficients feed 96 "
+                   "multiply-adds (0.5 flop/B against a machine balance of ~20), so the kernel is bound by reading the "
+                   "coefficients and the f32 matrix pipe has nothing to reuse; scalar FMAs in the preprocess kernel, "
+                   "no MFMA instruction in the library (DESIGN.md 4.6)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +293,9 @@ def main():
                          "bit-reproducible sequence the oracle repeats")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
+    ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="also time the SH pipe's rasteriser (colours as spherical-harmonics coefficients of this degree) "
+                         "on the configuration's Gaussians: record key `sh` (not part of the timed training step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -527,6 +596,11 @@ def main():
                                              "appearance_and_shape" if bwd_mode == 2 else "positions_only"):
                bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)}),
     }
+    if a.sh_degree >= 0 and loop_views and cfg_id != 2:
+        try:
+            out["sh"] = sh_timing(gm, cams, loop_views, cfg_id, loop.background, a.sh_degree, a.stage)
+        except Exception as e:
+            print(f"[bench] SH timing failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background, cfg_id, nominal_views, Cn, a.stage)

@@ -68,6 +68,8 @@ class GaussianModel:
         self._state_memos = {}
         self.defer_visual_backward = False  # opt-in: see flush_deferred_gradients
         self.fit_color = self.fit_opacity = self.fit_scales = self.fit_rotation = True
+        self.p0 = None  # setup_constants (train_physical_particle.py:488 reads / re-assigns it between frames)
+        self._velocity_nn = self._velocity_nn_grad = None  # cleared by the entry script after a frame (tpp:477-478)
         self.setup_functions()
 
     # defaults of arguments/__init__.py:298-345 for the fields setup_constants reads from `optim_args`
@@ -277,6 +279,52 @@ class GaussianModel:
                        total_tb_log_iterations=self.total_tb_log_iterations, particle_id_max=self._particle_id_max)
         with open(stem + "scalar_values.json", "w") as f:
             json.dump(scalars, f)
+
+    # -- per-frame / per-iteration position dumps of the entry scripts (gm_dynamics.py:1753-1831; called unconditionally at
+    #    train_physical_particle.py:91,200,227,325,435 and train_visual_particle.py:219): same file names, same scaling
+    def _dump(self, quantities_path, name, tensor, scaled):
+        import os
+        os.makedirs(quantities_path, exist_ok=True)
+        a = tensor.detach().clone().cpu().numpy()
+        np.save(os.path.join(quantities_path, name), a / self.scale_factor if scaled else a)
+
+    @torch.no_grad()
+    def save_particles_frame(self, quantities_path, frame_idx):
+        """:1754-1764"""
+        self._dump(quantities_path, f"frame_{frame_idx:03d}_xyz.npy", self._xyz, True)
+        if self._visual_xyz.shape[0] > 0:
+            self._dump(quantities_path, f"frame_{frame_idx:03d}_visual_xyz.npy", self._visual_xyz, True)
+
+    @torch.no_grad()
+    def save_particles_simulation(self, quantities_path, index):
+        """:1767-1781"""
+        self._dump(quantities_path, f"{index:03d}_xyz.npy", self._xyz, True)
+        self._dump(quantities_path, f"{index:03d}_estimated_xyz.npy", self._estimate_xyz, True)
+        if self._visual_xyz.shape[0] > 0:
+            self._dump(quantities_path, f"{index:03d}_visual_xyz.npy", self._visual_xyz, True)
+
+    @torch.no_grad()
+    def save_particles_simulation_guess(self, quantities_path, index):
+        """:1784-1789"""
+        self._dump(quantities_path, f"{index:03d}_guess_estimated_xyz.npy", self._estimate_xyz, True)
+
+    @torch.no_grad()
+    def save_particles_optimization_first(self, quantities_path, frame_idx, iteration):
+        """:1792-1798 (frame 0: the visual positions are in world units, not scaled)"""
+        self._dump(quantities_path, f"{frame_idx:03d}_{iteration:05d}_visual_xyz.npy", self._visual_xyz, False)
+
+    @torch.no_grad()
+    def save_particles_optimization(self, quantities_path, visual_xyz, frame_idx, iteration):
+        """:1801-1811 (_estimate_xyz_nn is the optimiser's own, unscaled variable)"""
+        self._dump(quantities_path, f"{frame_idx:03d}_{iteration:05d}_estimate_xyz_nn.npy", self._estimate_xyz_nn, False)
+        if visual_xyz.shape[0] > 0:
+            self._dump(quantities_path, f"{frame_idx:03d}_{iteration:05d}_visual_xyz.npy", visual_xyz, False)
+
+    @torch.no_grad()
+    def save_particles_optimization_level_two(self, quantities_path, frame_idx, iteration):
+        """:1814-1831"""
+        for name in ("color", "scales", "rotation", "opacity"):
+            self._dump(quantities_path, f"{frame_idx:03d}_{iteration:05d}_visual_{name}.npy", getattr(self, f"_visual_{name}"), False)
 
     @torch.no_grad()
     def save_visual(self, checkpoint_path, frame_idx, scale=True):
@@ -777,6 +825,19 @@ class GaussianModel:
         # state caches key on: drop them explicitly after every step
         self.optimizer.register_step_post_hook(lambda *_: self.invalidate_caches())
         self.xyz_scheduler_args = self._lr_schedule(optim_args)
+
+    @torch.no_grad()
+    def init_quantities_current_level_two(self, optim_args, prev_color, prev_opacity, prev_scales, prev_rotation):
+        """:399-414.  Start of a frame of the visual-particle stage: log-scales from the mean squared distance to the three
+        nearest visual particles (simple-knn's distCUDA2 -> fnx_knn_mean_dist2), clamped to [-10, 1]; then, attribute by
+        attribute, the previous frame's optimised values for the particles that already existed."""
+        if self.fit_scales and optim_args.init_scales_w_xyz_dist:
+            dist2 = torch.clamp_min(physics.knn_mean_dist2(self._visual_xyz.float()), 0.0000001)
+            scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+            self._visual_scales = torch.clamp(scales, -10, 1.0)
+        for name, prev in (("color", prev_color), ("opacity", prev_opacity), ("scales", prev_scales), ("rotation", prev_rotation)):
+            if getattr(self, f"fit_{name}") and prev is not None and getattr(optim_args, f"inherit_prev_{name}"):
+                getattr(self, f"_visual_{name}")[: prev.shape[0]] = prev.clone()
 
     def training_setup_current_level_two(self, optim_args, capturable=False):
         """Visual-particle stage: colour / opacity / scales / rotation of the visual particles become

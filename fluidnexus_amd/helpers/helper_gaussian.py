@@ -10,9 +10,8 @@ def get_model(model="gm_gs"):
     elif model == "gm_dynamics":
         from ..gaussian_splatting.gm_dynamics import GaussianModel
     elif model == "gm_gs":
-        # vanilla 3DGS with SH colour (gaussian_splatting/gaussian_model.py): not on any fluid pipe (SURVEY finding 3)
-        raise NotImplementedError("gm_gs (vanilla SH Gaussian model) is outside the hot-path scope; "
-                                  "use gm_dynamics / gm_fluid / gm_background")
+        # vanilla 3DGS with SH colour (gaussian_splatting/gaussian_model.py): the model behind the SH pipe (render_gs)
+        from ..gaussian_splatting.gaussian_model import GaussianModel
     else:
         raise ValueError(f"Model {model} not found")
     return GaussianModel

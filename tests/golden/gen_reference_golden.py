@@ -552,6 +552,93 @@ def gen_emitter():
         torch.Tensor.cuda = saved[-1]
 
 
+def gen_entry_surface():
+    """(1) NAMES ONLY of every `gaussians.<attr>` the reference's entry scripts touch (train_physical_particle.py,
+    train_visual_particle.py, train_background.py of entries_fluid_nexus / entries_scalar_real; lines that are comments
+    are skipped): entry_script_names.json.  (2) The per-frame / per-iteration position dumps those scripts call
+    unconditionally (gm_dynamics.py:1753-1831), written by the reference's own class from a small seeded state:
+    file names + arrays.  (3) init_quantities_current_level_two (gm_dynamics.py:399-414) on the reference's class with
+    simple-knn's distCUDA2 replaced by its definition (mean squared distance to the three nearest other points,
+    submodules/simple-knn/simple_knn.cu:134-165) evaluated by brute force in float64, .cuda() redirected."""
+    import glob
+    import json
+    import re
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    import gaussian_splatting.gm_dynamics as gmd
+    names = {}
+    for pth in sorted(glob.glob(os.path.join(REF, "entries_fluid_nexus", "train_*.py")) +
+                      glob.glob(os.path.join(REF, "entries_scalar_real", "train_*.py"))):
+        code = "\n".join(l for l in open(pth).read().splitlines() if not l.lstrip().startswith("#"))
+        names[os.path.relpath(pth, REF)] = sorted(set(re.findall(r"\bgaussians\.([A-Za-z_]\w*)", code)))
+    with open(os.path.join(OUT, "entry_script_names.json"), "w") as f:
+        json.dump(names, f, indent=0, sort_keys=True)
+
+    rng = np.random.RandomState(31)
+    f32 = lambda *s: torch.tensor(rng.normal(size=s).astype(np.float32))  # noqa: E731
+    gm = gmd.GaussianModel.__new__(gmd.GaussianModel)
+    N, V = 10, 7
+    gm.scale_factor = 100.0
+    gm._xyz, gm._estimate_xyz, gm._visual_xyz = f32(N, 3) * 30, f32(N, 3) * 30, f32(V, 3) * 30
+    gm._estimate_xyz_nn = f32(N, 3) * 0.3
+    gm._visual_color, gm._visual_scales = torch.tensor(rng.uniform(size=(V, 1)).astype(np.float32)), f32(V, 3)
+    gm._visual_rotation, gm._visual_opacity = f32(V, 4), f32(V, 1)
+    other_visual = f32(V, 3)
+    out = {k: getattr(gm, k).numpy().copy() for k in ("_xyz", "_estimate_xyz", "_visual_xyz", "_estimate_xyz_nn",
+                                                       "_visual_color", "_visual_scales", "_visual_rotation", "_visual_opacity")}
+    out["other_visual"] = other_visual.numpy().copy()
+    d = tempfile.mkdtemp()
+    try:
+        gm.save_particles_frame(d, 3)
+        gm.save_particles_simulation(d, 4)
+        gm.save_particles_simulation_guess(d, 5)
+        gm.save_particles_optimization_first(d, 0, 120)
+        gm.save_particles_optimization(d, other_visual, 6, 250)
+        gm.save_particles_optimization_level_two(d, 7, 999)
+        files = sorted(os.listdir(d))
+        out["files"] = np.array(files)
+        for fn in files:
+            out["file:" + fn] = np.load(os.path.join(d, fn))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    np.savez(os.path.join(OUT, "save_particles.npz"), **out)
+
+    def dist2_bruteforce(p):
+        d2 = torch.cdist(p.double(), p.double()) ** 2
+        d2.fill_diagonal_(float("inf"))
+        return d2.topk(3, dim=1, largest=False).values.mean(1).float()
+
+    saved = (gmd.distCUDA2, torch.Tensor.cuda)
+    gmd.distCUDA2 = dist2_bruteforce
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        out = {}
+        for case, flags in enumerate(((True, True, True, True, True), (False, True, False, True, False))):
+            V, Vp = 40, 25
+            gm = gmd.GaussianModel.__new__(gmd.GaussianModel)
+            gm.fit_color = gm.fit_opacity = gm.fit_scales = gm.fit_rotation = True
+            gm._visual_xyz = torch.tensor(rng.uniform(-3, 3, size=(V, 3)).astype(np.float32))
+            gm._visual_xyz[3] = gm._visual_xyz[4]  # coincident pair: the clamp_min at 1e-7 is not hit, log of a tiny mean is
+            gm._visual_color, gm._visual_opacity = torch.tensor(rng.uniform(size=(V, 1)).astype(np.float32)), f32(V, 1)
+            gm._visual_scales, gm._visual_rotation = f32(V, 3), f32(V, 4)
+            prev = dict(color=torch.tensor(rng.uniform(size=(Vp, 1)).astype(np.float32)), opacity=f32(Vp, 1),
+                        scales=f32(Vp, 3), rotation=f32(Vp, 4))
+            oa = SimpleNamespace(init_scales_w_xyz_dist=flags[0], inherit_prev_color=flags[1], inherit_prev_opacity=flags[2],
+                                 inherit_prev_scales=flags[3], inherit_prev_rotation=flags[4])
+            for k in ("xyz", "color", "opacity", "scales", "rotation"):
+                out[f"c{case}_in_{k}"] = getattr(gm, f"_visual_{k}").numpy().copy()
+            for k, v in prev.items():
+                out[f"c{case}_prev_{k}"] = v.numpy().copy()
+            out[f"c{case}_flags"] = np.array(flags)
+            gm.init_quantities_current_level_two(oa, prev["color"], prev["opacity"], prev["scales"], prev["rotation"])
+            for k in ("color", "opacity", "scales", "rotation"):
+                out[f"c{case}_out_{k}"] = getattr(gm, f"_visual_{k}").numpy().copy()
+        np.savez(os.path.join(OUT, "level_two_init.npz"), **out)
+    finally:
+        gmd.distCUDA2, torch.Tensor.cuda = saved
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only available in the build container"
     gen_graphics()
@@ -565,6 +652,7 @@ if __name__ == "__main__":
     gen_checkpoint()
     gen_background()
     gen_emitter()
+    gen_entry_surface()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
