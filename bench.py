@@ -163,8 +163,103 @@ def cpu_baseline(gm, cams, bg, cfg_id, views, channels, stage="physical"):
     t2 = time.perf_counter()
     per_view = t2 - t0
     return {"value": 1.0 / (views * per_view), "unit": "iters/s", "cores": cores, "kind": "port",
+            "scope": "rasteriser only (losses, physics terms and the optimiser step are not in this sample)",
             "sample": f"oracle/raster_oracle.c (OpenMP, {cores} threads), rasteriser only (ch{channels}): 1 of {views} views "
                       f"fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, R={f['num_rendered']}; value = 1/({views} x that)"}
+
+
+def cpu_baseline_config1(dev):
+    """BASELINE.md section 2, config 1 verbatim: 10k random Gaussians, one 256 x 256 view, forward + L1 / D-SSIM loss +
+    backward + Adam on the host cores (oracle/raster_oracle.c forward / backward, OpenMP over all cores; the loss and its
+    image gradient with the torch-CPU restatement of loss_utils.py; torch.optim.Adam, eps 1e-15, on all five attribute
+    groups), median of 5 iterations after 1 warm-up -- next to the SAME iteration through the HIP rasteriser on the GPU."""
+    import statistics
+    from oracle import raster_oracle as O
+    from fluidnexus_amd import rasterizer, synthetic as S
+    from fluidnexus_amd.utils.loss_utils import l1_loss, ssim
+    O.build()
+    # 256 tiles and a 256 x 256 image: beyond a few dozen threads the two OpenMP pools (the oracle's and torch's) only
+    # fight each other (measured on the 256-core GPU box: 12.8 s per iteration with 256 + 256 threads, the loss alone
+    # taking > 12 s); the sample uses at most 32 and says so
+    cores = min(os.cpu_count() or 1, 32)
+    O.set_threads(cores)
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    W = H = 256
+    tan = math.tan(0.4)
+    g = S.random_gaussians(10_000, seed=0, box=0.5, log_scale=(-5.5, -3.5))
+    cam = S.front_camera(W, H, device="cpu")
+    bg = np.zeros(3, np.float32)
+    target = torch.from_numpy(np.random.RandomState(0).uniform(size=(3, H, W)).astype(np.float32))
+    names = ("means3D", "opacities", "colors", "scales", "rotations")
+    lrs = dict(means3D=1.6e-4, opacities=0.05, colors=0.0025, scales=0.005, rotations=0.001)
+
+    def image_loss(img, tgt):
+        return 0.8 * l1_loss(img, tgt) + 0.2 * (1.0 - ssim(img, tgt))
+
+    # host
+    P = {k: torch.from_numpy(g[k].copy()).requires_grad_(True) for k in names}
+    opt = torch.optim.Adam([{"params": [P[k]], "lr": lrs[k]} for k in names], lr=0.0, eps=1e-15)
+    view, proj, campos = (cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), cam.camera_center.numpy())
+    t_iter, t_fwd, t_bwd = [], [], []
+    for it in range(6):
+        t0 = time.perf_counter()
+        a = {k: P[k].detach().numpy() for k in names}
+        f = O.forward(a["means3D"], a["opacities"], bg, view, proj, campos, W, H, tan, tan, colors_precomp=a["colors"],
+                      scales=a["scales"], rotations=a["rotations"], channels=3)
+        t1 = time.perf_counter()
+        img = torch.from_numpy(f["color"]).requires_grad_(True)
+        loss = image_loss(img, target)
+        dimg, = torch.autograd.grad(loss, img)
+        t2 = time.perf_counter()
+        go = O.backward(f, dimg.numpy())
+        t3 = time.perf_counter()
+        for k, gk in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("colors", "dL_dcolors"),
+                      ("scales", "dL_dscales"), ("rotations", "dL_drotations")):
+            P[k].grad = torch.from_numpy(np.ascontiguousarray(go[gk]).reshape(P[k].shape))
+        opt.step()
+        t4 = time.perf_counter()
+        if it:
+            t_iter.append(t4 - t0)
+            t_fwd.append(t1 - t0)
+            t_bwd.append(t3 - t2)
+    # the same iteration on the device (eager launches, exact blend arithmetic: the oracle's own)
+    from diff_gaussian_rasterization_ch3 import GaussianRasterizationSettings, GaussianRasterizer
+    mode = rasterizer.get_blend_math()
+    rasterizer.set_blend_math("exact")
+    try:
+        D = {k: torch.from_numpy(g[k].copy()).to(dev).requires_grad_(True) for k in names}
+        optd = torch.optim.Adam([{"params": [D[k]], "lr": lrs[k]} for k in names], lr=0.0, eps=1e-15)
+        camd = S.front_camera(W, H, device=dev)
+        rs = GaussianRasterizationSettings(H, W, tan, tan, torch.zeros(3, device=dev), 1.0, camd.world_view_transform,
+                                           camd.full_proj_transform, 0, camd.camera_center, False)
+        tgt = target.to(dev)
+        t_dev = []
+        for it in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m2d = torch.zeros(10_000, 3, device=dev, requires_grad=True)
+            img, _, _ = GaussianRasterizer(rs)(D["means3D"], m2d, D["opacities"], colors_precomp=D["colors"],
+                                               scales=D["scales"], rotations=D["rotations"])
+            image_loss(img, tgt).backward()
+            optd.step()
+            optd.zero_grad()
+            torch.cuda.synchronize()
+            if it:
+                t_dev.append(time.perf_counter() - t0)
+    finally:
+        rasterizer.set_blend_math(mode)
+        torch.set_num_threads(torch_threads)
+        O.set_threads(os.cpu_count() or 1)
+    med = statistics.median
+    return {"workload": "BASELINE configs[0] verbatim: 10k random Gaussians, one 256x256 view, forward + L1 / D-SSIM loss + "
+                        "backward + Adam (all five attribute groups)",
+            "host": {"iters_per_s": 1.0 / med(t_iter), "ms_per_iter": med(t_iter) * 1e3, "forward_ms": med(t_fwd) * 1e3,
+                     "backward_ms": med(t_bwd) * 1e3, "cores": cores, "cores_available": os.cpu_count(),
+                     "code": "oracle/raster_oracle.c (OpenMP) + torch-CPU losses + torch.optim.Adam", "statistic": "median of 5 after 1 warm-up"},
+            "mi355x": {"iters_per_s": 1.0 / med(t_dev), "ms_per_iter": med(t_dev) * 1e3,
+                       "code": "HIP rasteriser (exact arithmetic) + torch losses + torch.optim.Adam, eager launches, host-synchronised per iteration"},
+            "num_rendered": int(f["num_rendered"])}
 
 
 def rasterise_timing(gm, cams, views, cfg_id, channels, bg, stage="physical"):
@@ -604,6 +699,10 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gm, cams, loop.background, cfg_id, nominal_views, Cn, a.stage)
+            try:
+                out["cpu_baseline"]["config1"] = cpu_baseline_config1(dev)
+            except Exception as e:
+                print(f"[bench] config-1 CPU baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -4,9 +4,35 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/fnx_raster.h"
 
+#include <mutex>
+
 namespace fnx {
+
+// Host-side launch parameters that depend on the device (compute units, resident workgroups of a kernel variant):
+// looked up once per (device, slot) under a mutex -- a process may drive several devices, from several threads.
+constexpr int kMaxDevices = 64;
+template <typename F>
+inline int per_device_cached(int (&cache)[kMaxDevices], std::mutex &mu, F &&query) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) return query(dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache[dev] == 0) cache[dev] = query(dev);
+    return cache[dev];
+}
+inline int device_cu_count() {
+    static int cache[kMaxDevices];
+    static std::mutex mu;
+    return per_device_cached(cache, mu, [](int dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    });
+}
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
@@ -18,13 +44,20 @@ inline int tiles_y(int H) { return (H + 15) / 16; }
 // sort works on chunks of kSortChunk keys per workgroup.
 constexpr int kSplatBlock = 1024;
 constexpr int kSortChunk = 1024;
-constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB
+constexpr int kMaxTiles = 16384;  // LDS tile histogram: 64 KiB; also the tile field of a backward work item (kItemTileBits)
 // The blend kernels walk a tile's list in batches of kBlendBatch entries.  The forward leaves, for every batch b >= 1 it
 // blends, the per-pixel state in front of the batch (transmittance + accumulated colour, 16 bytes per pixel) in slot
 // (first list position of the tile) / kBlendBatch + b - 1 -- unique, because a tile owns ceil(len / 256) - 1 <=
 // floor(len / 256) such slots -- and one work item (tile | batch << 14) per batch that holds a contributor, so the
 // backward can run the batches of a tile as independent workgroups.
 constexpr int kBlendBatch = 256;
+// Backward work item = tile | batch << kItemTileBits: kMaxTiles tiles, 2^(32 - kItemTileBits) batches of kBlendBatch
+// entries per tile, i.e. a tile list of at most kMaxTileList entries.  A view's lists cannot be longer than its instance
+// capacity, so the forward rejects capacity + static instances above kMaxTileList (FNX_ERR_UNSUPPORTED).
+constexpr int kItemTileBits = 14;
+constexpr uint32_t kItemTileMask = (1u << kItemTileBits) - 1u;
+constexpr uint64_t kMaxTileList = (uint64_t)kBlendBatch << (32 - kItemTileBits);  // 2^26 entries
+static_assert(kMaxTiles <= (1 << kItemTileBits), "a backward work item holds the tile in kItemTileBits bits");
 constexpr size_t kBlendStateBytes = 256 * 16;
 inline size_t blend_state_slots(size_t list_capacity) { return list_capacity / kBlendBatch + 2; }
 // Depth sort digits: 9 bits.  Keys are sorted relative to the smallest visible key, so three passes order any
@@ -164,6 +197,9 @@ struct StaticRef {
 enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
 
 // header words inside the image blob
-enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4, HDR_DEEP_COUNT = 5 };
+// HDR_BIN_CAPACITY: the binning capacity stage 2 ran with (the binning blob's layout depends on it): the backward pass
+// refuses a view whose stored value differs from its own argument (status FNX_ERR_CAPACITY)
+enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4, HDR_DEEP_COUNT = 5,
+       HDR_BIN_CAPACITY = 6 };
 
 }  // namespace fnx

@@ -404,6 +404,10 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         return fail(FNX_ERR_INVALID_ARG, "a required pointer is NULL");
     if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     if ((binning_capacity > 0 || static_blobs) && !binning_buffer) return fail(FNX_ERR_INVALID_ARG, "binning_buffer is NULL");
+    if ((uint64_t)binning_capacity + (uint64_t)(static_blobs ? R_static_capacity : 0) > fnx::kMaxTileList)
+        return fail(FNX_ERR_UNSUPPORTED, "%lld instances per view > %llu: a tile list may not exceed 2^26 entries "
+                    "(backward work items hold the batch index in 18 bits)",
+                    (long long)(binning_capacity + (static_blobs ? R_static_capacity : 0)), (unsigned long long)fnx::kMaxTileList);
     fnx::ViewBatch vb;
     fnx::StaticRef st;
     if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
@@ -539,7 +543,7 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
         return fail(FNX_ERR_INVALID_ARG, "scales given but rotations/dL_dscale/dL_drot NULL");
     if ((geometry_only == 1 || positions_only) && shs)
         return fail(FNX_ERR_INVALID_ARG, "geometry_only = 1 / 3 cannot be combined with SH colours");
-    if (binning_capacity < 0) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
+    if (binning_capacity < 0 || binning_capacity > 0xFFFFFFFFll) return fail(FNX_ERR_INVALID_ARG, "bad capacity");
     fnx::ViewBatch vb;
     fnx::StaticRef st;
     if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
@@ -562,7 +566,8 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
         ProfScope ps(channels == 3 ? 1 : 6, s);
         fnx::launch_blend_backward(channels, geometry_only, s, P_all, width, height, img.ranges, bin.point_list,
                                    background, g.blend_rec, img.final_T, img.n_contrib, img.acc_final, dL_dpix,
-                                   dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header, 0xFFFFFFFFu,
+                                   dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header,
+                                   (uint32_t)binning_capacity,
                                    (uint32_t)limit, V, vb, st, means3D, cov3D_ptr, cov3D_stride, viewmatrix, projmatrix,
                                    dL_dmean3D, g_blend_math);
     }

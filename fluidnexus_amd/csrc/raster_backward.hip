@@ -153,7 +153,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         for (int v = 0; v < n_views; v++) {
             const uint32_t *h = view_at(header, vb.img, v);
             s_first[v] = run;
-            if (!(h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
+            // a view whose forward overflowed, or ran with another binning capacity than this call's (the blob's layout
+            // depends on it), contributes nothing; the mismatch is left in the view's status word (fnx_read_status)
+            const bool mismatch = h[HDR_BIN_CAPACITY] != capacity;
+            if (mismatch && blockIdx.x == 0) const_cast<uint32_t *>(h)[HDR_STATUS] = FNX_ERR_CAPACITY;
+            if (!(mismatch || h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
         }
         s_first[n_views] = run;
     }
@@ -183,7 +187,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     auto fetch_range = [&](Fetched &f) {
         f.r0 = f.r1 = 0;
         if (f.item != kNoItem) {
-            const uint2 rg = reinterpret_cast<const uint2 *>(view_at(ranges, vb.img, f.vw))[f.item & 0x3FFFu];
+            const uint2 rg = reinterpret_cast<const uint2 *>(view_at(ranges, vb.img, f.vw))[f.item & kItemTileMask];
             f.r0 = rg.x;
             f.r1 = rg.y;
         }
@@ -191,7 +195,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     auto fetch_ids = [&](Fetched &f) {
         f.id = 0;
         f.qm = 0;
-        const uint32_t pos = f.r0 + ((f.item >> 14) << 8) + (uint32_t)tid;
+        const uint32_t pos = f.r0 + ((f.item >> kItemTileBits) << 8) + (uint32_t)tid;
         if (f.item != kNoItem && pos < f.r1) {
             const uint32_t *pl = view_at(point_list, vb.bin, f.vw);
             f.id = pl[pos];
@@ -199,7 +203,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         }
     };
     auto fetch_records = [&](Fetched &f) {
-        const uint32_t pos = f.r0 + ((f.item >> 14) << 8) + (uint32_t)tid;
+        const uint32_t pos = f.r0 + ((f.item >> kItemTileBits) << 8) + (uint32_t)tid;
         if (f.item != kNoItem && pos < f.r1) {
             // static-split mode: records of splats with id >= st.id0 live in the view's static blob
             const float4 *rec = (st.base && f.id >= st.id0)
@@ -241,8 +245,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)vw * P * C : nullptr;
         const float4 *bstate_all = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(point_list_v) + vb.bin_bstate);
         const uint32_t item = cur.item;
-        const int tile = (int)(item & 0x3FFFu);
-        const uint32_t b = item >> 14;
+        const int tile = (int)(item & kItemTileMask);
+        const uint32_t b = item >> kItemTileBits;
         const int tx = tile % gx, ty = tile / gx;
         const int row = lane >> 4;
         const int px = tx * FNX_TILE_X + blend_pixel_x(w, lane), py = ty * FNX_TILE_Y + blend_pixel_y(w, lane);
@@ -854,10 +858,13 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 // would run its surplus as a second, half-empty round.
 template <int C, int MODE, bool FAST, typename... A>
 static void launch_blend_backward_tf(int n_cu, hipStream_t s, A... args) {
-    static int per_cu = 0;
-    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blend_backward_kernel<C, MODE, FAST>, 256, 0) != hipSuccess ||
-                        per_cu <= 0))
-        per_cu = 4;
+    static int cache[kMaxDevices];  // resident workgroups per compute unit of THIS kernel variant, per device
+    static std::mutex mu;
+    const int per_cu = per_device_cached(cache, mu, [](int) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_kernel<C, MODE, FAST>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        return n;
+    });
     hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
 }
 template <int C, int MODE, typename... A>
@@ -876,12 +883,7 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dmean3D, int fast) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_cu_count();
     if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
     else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
     else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);

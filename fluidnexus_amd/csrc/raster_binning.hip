@@ -709,20 +709,15 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
     const int TW = T < kEmitTileWindow ? T : kEmitTileWindow;
     const size_t lds = (size_t)TW * 4 * (kEmitMaskWords + 1);
     const void *kernel = pairs ? (const void *)emit_kernel<true> : (const void *)emit_kernel<false>;
-    // resident workgroups for this LDS size (host-side queries, cached per kernel variant)
-    static int n_cu = 0, wgs_cache[2][2] = {{0, 0}, {0, 0}};
+    // resident workgroups for this LDS size (host-side queries, cached per kernel variant and device)
     const bool large = lds > 40 * 1024;  // static + dynamic LDS exceeds the default 64 KiB limit
-    int &wgs = wgs_cache[pairs ? 1 : 0][large ? 1 : 0];
-    if (wgs == 0) {
+    static int cache[2][2][kMaxDevices];
+    static std::mutex mu;
+    const int n_cu = device_cu_count();
+    const int wgs = per_device_cached(cache[pairs ? 1 : 0][large ? 1 : 0], mu, [&](int) {
         if (large)
             (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kEmitTileWindow * 4 * (kEmitMaskWords + 1));
-        if (n_cu == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-        }
         int per_cu = 0;
         const size_t lds_max = (size_t)kEmitTileWindow * 4 * (kEmitMaskWords + 1);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kEmitThreads,
@@ -730,8 +725,8 @@ void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const
                 hipSuccess || per_cu <= 0)
             per_cu = 1;
         (void)hipGetLastError();
-        wgs = n_cu * per_cu;
-    }
+        return n_cu * per_cu;
+    });
     const int items_bound = splat_blocks(P) * V * kEmitBands;  // never more workgroups than items
     const dim3 grid(wgs < items_bound ? wgs : items_bound), block(kEmitThreads);
     if (pairs)

@@ -567,7 +567,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_done[4];
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
-    if (status_out && wg_rank == 0 && threadIdx.x < 8) status_out[8 * wg_view + threadIdx.x] = header[threadIdx.x];
+    if (wg_rank == 0 && threadIdx.x == 0) header[HDR_BIN_CAPACITY] = capacity;  // the backward checks its own against it
+    if (status_out && wg_rank == 0 && threadIdx.x < 8)
+        status_out[8 * wg_view + threadIdx.x] = threadIdx.x == HDR_BIN_CAPACITY ? capacity : header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity) return;
     // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
@@ -893,7 +895,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
         __syncthreads();
         uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
-        for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << 14);
+        for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << kItemTileBits);
     }
     if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: the next forward's tile order
 #ifdef FNX_EXP_CLOCK
@@ -1232,7 +1234,7 @@ blend_forward_deep_kernel(int T, int gx, const uint32_t *__restrict__ ranges_all
             if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
             __syncthreads();
             uint32_t *items = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(point_list) + vb.bin_items) + s_adv;
-            for (uint32_t k = tid; k < nb; k += NB) items[k] = (uint32_t)tile | (k << 14);
+            for (uint32_t k = tid; k < nb; k += NB) items[k] = (uint32_t)tile | (k << kItemTileBits);
         }
         if (depth_hint_all && tid == 0) (depth_hint_all + (size_t)vw * T)[tile] = qmax;
     }
@@ -1317,11 +1319,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t sd = s;
     if (use_deep) {
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        const int n_cu = device_cu_count();
+        if (!helper) {
             if (hipStreamCreateWithFlags(&helper, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)

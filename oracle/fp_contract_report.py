@@ -45,7 +45,7 @@ def run(g, cam, size, C):
 
 
 def main():
-    tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r02")
+    tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r03")
     quick = "--quick" in sys.argv
     O.set_threads(os.cpu_count() or 1)
     rows = []
@@ -80,6 +80,8 @@ def main():
         for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcolors"):
             a, b = ga[k].astype(np.float64), gb[k].astype(np.float64)
             row[f"{k}_max_rel_of_max"] = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30))
+            # the per-element mixed bound of the GPU tests (|err| <= 1e-3 |ref| + 2e-5 max|ref|): worst ratio err / bound
+            row[f"{k}_worst_mixed_ratio"] = float((np.abs(a - b) / (1e-3 * np.abs(a) + 2e-5 * np.abs(a).max() + 1e-300)).max())
         row["seconds"] = round(time.time() - t0, 1)
         rows.append(row)
         print(json.dumps(row), flush=True)
@@ -102,6 +104,11 @@ def main():
                     f"{r['depth_pixels_changed']} | {r['pixel_max_abs']:.2e} | {r['pixel_mean_abs']:.2e} | {r['pixels_over_2e5']} | "
                     + " / ".join(f"{r[k + '_max_rel_of_max']:.1e}" for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcolors"))
                     + " |\n")
+        f.write("\nWorst element of each gradient against the per-element bound the GPU tests use (|diff| <= 1e-3 |value| + 2e-5 max|value|; "
+                "ratio diff / bound, <= 1 passes):\n\n| scene | means3D | opacity | scales | rotations | colours |\n|---|---|---|---|---|---|\n")
+        for r in rows:
+            f.write(f"| {r['scene']} | " + " | ".join(f"{r[k + '_worst_mixed_ratio']:.2f}" for k in
+                    ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcolors")) + " |\n")
         f.write("\nReading: the integer state moves only where a fused rounding pushes `ceil(3 sqrt(lambda))` or a tile-rectangle "
                 "bound across an integer; every such splat changes its instances (point_list) and, if it contributes, a few "
                 "pixels.  The pixel and gradient differences elsewhere are fp32 rounding noise.\n")

@@ -47,14 +47,22 @@ def _assert_forward_exact(f, h):
     return it
 
 
-def _assert_grads_close(go, gh, rtol=2e-4):
+def _assert_grads_close(go, gh, rtol=2e-4, rel=1e-3, abs_of_max=2e-5):
+    """Two bounds per gradient array: the largest error against the largest entry (rtol), and PER ELEMENT
+    |err| <= rel |ref| + abs_of_max max|ref| -- an error of rtol * max on an entry a thousand times smaller than the
+    maximum would pass the first alone.  The worst element is named on failure."""
     for k, ref in go.items():
         if ref.size == 0:
             continue
-        got = gh[k].reshape(ref.shape)
-        scale = np.abs(ref).max() + 1e-20
-        err = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / scale
-        assert err < rtol, f"{k}: rel-to-max error {err:.3e}"
+        ref64 = ref.astype(np.float64)
+        got = gh[k].reshape(ref.shape).astype(np.float64)
+        scale = np.abs(ref64).max() + 1e-20
+        err = np.abs(got - ref64)
+        assert err.max() / scale < rtol, f"{k}: rel-to-max error {err.max() / scale:.3e}"
+        bound = rel * np.abs(ref64) + abs_of_max * scale
+        i = np.unravel_index(np.argmax(err / bound), ref.shape)
+        assert err[i] <= bound[i], (f"{k}: worst element {i}: ref {ref64[i]:.6e} got {got[i]:.6e} err {err[i]:.3e} > "
+                                    f"bound {bound[i]:.3e} (max|ref| {scale:.3e})")
 
 
 @pytest.mark.parametrize("P,W,H,seed", [(64, 32, 32, 0), (1000, 64, 48, 1), (10000, 256, 256, 2), (3000, 100, 70, 3)])
@@ -383,3 +391,35 @@ def test_positions_only_mode(oracle, channels):
         n = P if lim < 0 else lim
         assert np.abs(got[:n] - ref[:n]).max() <= 2e-4 * np.abs(ref).max(), lim
         assert (got[n:] == 0).all()
+
+
+def test_backward_refuses_a_capacity_that_is_not_the_forwards(oracle):
+    """The binning blob's layout depends on the capacity stage 2 ran with: a backward call that names
+    another one must not read the hand-over records at wrong offsets -- it produces no gradients and leaves
+    FNX_ERR_CAPACITY in the view's status word; the right capacity still works afterwards."""
+    from fluidnexus_amd import _lib
+    P, W, H = 800, 64, 64
+    g = S.random_gaussians(P, seed=41, log_scale=(-4.5, -2.5))
+    cam = S.front_camera(W, H, device="cpu")
+    f, h = _run_pair(oracle, g, cam, W, H, np.array([0.2, 0.3, 0.4], np.float32))
+    dL = np.random.RandomState(1).normal(size=(3, H, W)).astype(np.float32)
+    good_cap = h.cap
+    h.cap = good_cap + 256
+    bad = h.backward(dL)
+    assert all(not v.any() for v in bad.values()), "a mismatching capacity must produce no gradients"
+    assert h.status() == _lib.FNX_ERR_CAPACITY
+    # a fresh forward clears the status; the matching capacity gives the oracle's gradients
+    f, h = _run_pair(oracle, g, cam, W, H, np.array([0.2, 0.3, 0.4], np.float32))
+    assert h.cap == good_cap and h.status() == _lib.FNX_OK
+    _assert_grads_close(oracle.backward(f, dL), h.backward(dL))
+
+
+def test_forward_rejects_lists_longer_than_the_work_item_packing_allows():
+    """Backward work items hold the batch index in 18 bits: stage 2 refuses a capacity above 2^26 instances."""
+    import torch
+    from fluidnexus_amd import _lib
+    lib = _lib.raster()
+    z = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    rc = lib.fnx_forward_stage2(3, z.data_ptr(), z.data_ptr(), (1 << 26) + 1, z.data_ptr(), 10, 64, 64, z.data_ptr(),
+                                z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None)
+    assert rc == 5 and b"2^26" in lib.fnx_last_error()  # FNX_ERR_UNSUPPORTED
