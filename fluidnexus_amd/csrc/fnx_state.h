@@ -200,6 +200,6 @@ enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
 // HDR_BIN_CAPACITY: the binning capacity stage 2 ran with (the binning blob's layout depends on it): the backward pass
 // refuses a view whose stored value differs from its own argument (status FNX_ERR_CAPACITY)
 enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4, HDR_DEEP_COUNT = 5,
-       HDR_BIN_CAPACITY = 6 };
+       HDR_BIN_CAPACITY = 6, HDR_BWD_TICKET = 7, HDR_BWD_DONE = 8 };  // words 8 .. 63 of the header block are scratch
 
 }  // namespace fnx

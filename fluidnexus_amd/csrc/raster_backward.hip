@@ -219,19 +219,64 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         }
     };
     __syncthreads();  // s_first is written
+    // The forward appends a tile's batches as consecutive items.  A workgroup takes the queue in CHUNKS of kChunk
+    // consecutive items (chunk c of workgroup b: items (c grid + b) kChunk ...), so most of its items continue the tile of
+    // the one before: the pixels' state (final T, last contributor, dL/dpixel, what lies behind the whole list) then
+    // stays in registers, and the record in front of the next batch is prefetched under the walk.
+#ifndef FNX_BWD_DYNAMIC
+#define FNX_BWD_DYNAMIC 1
+#endif
+#ifndef FNX_BWD_CHUNK
+#define FNX_BWD_CHUNK 1  // measured on config 3 (mode 3): 1 -> 398 us, 2 -> 403, 4 -> 436, 8 -> 465, one contiguous range -> 483
+#endif
+    constexpr uint32_t kChunk = FNX_BWD_CHUNK;
+    (void)kChunk;
+#ifdef FNX_BWD_BLOCKED  // experiment: every workgroup takes ONE contiguous range of the queue
+    const uint32_t per_wg = (s_first[n_views] + gridDim.x - 1) / gridDim.x;
+    auto ticket_of = [&](uint32_t sidx) -> uint32_t { return sidx < per_wg ? blockIdx.x * per_wg + sidx : 0xFFFFFFF0u; };
+#elif FNX_BWD_DYNAMIC
+    // Items are handed out by a device counter (the first two per workgroup are fixed: b, b + grid), so a workgroup
+    // that drew light items takes more of them; ticket t is item (t * prime) mod n -- a bijection (the prime does not
+    // divide n) that keeps workgroups running at the same time on items far apart in the queue: neighbouring tiles'
+    // batches processed together meet on the same splats' accumulators (an unscrambled ticket measured 7 % slower than
+    // the fixed stride, this one 6 % faster: config 3, 399 -> 375 us).
+    __shared__ uint32_t s_tk;
+    const uint32_t n_all = max(s_first[n_views], 1u);
+    const unsigned long long mult = (n_all % 7919u) ? 7919ull : 7927ull;
+    auto scramble = [&](uint32_t t) -> uint32_t { return t < n_all ? (uint32_t)(((unsigned long long)t * mult) % n_all) : 0xFFFFFFF0u; };
+    uint32_t dyn_next = 0xFFFFFFF0u;  // the ticket drawn during the previous item
+    auto ticket_of = [&](uint32_t sidx) -> uint32_t {
+        return sidx < 2 ? scramble(blockIdx.x + sidx * gridDim.x) : scramble(dyn_next);
+    };
+#else
+    auto ticket_of = [&](uint32_t sidx) -> uint32_t { return ((sidx / kChunk) * gridDim.x + blockIdx.x) * kChunk + sidx % kChunk; };
+#endif
     Fetched cur, nxt;
-    fetch_item(blockIdx.x, cur);
-    fetch_item(blockIdx.x + gridDim.x, nxt);
+    fetch_item(ticket_of(0), cur);
+    fetch_item(ticket_of(1), nxt);
     fetch_range(cur);
     fetch_ids(cur);
     fetch_records(cur);
-    for (uint32_t ticket = blockIdx.x;; ticket += gridDim.x) {
+    // state of the tile the workgroup is on (valid while consecutive items stay on it)
+    uint32_t tile_key = 0xFFFFFFFFu;  // view << 16 | tile
+    uint32_t last_contributor = 0;
+    float dL_dpixel[C], total_dot = 0.f, tail_dot = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) dL_dpixel[ch] = 0.f;
+    float4 stt_ahead = make_float4(1.f, 0.f, 0.f, 0.f);  // hand-over record of the next item, if it continues this tile
+    bool stt_ahead_valid = false;
+    for (uint32_t sidx = 0;; sidx++) {
         // no barrier here: before the next one (behind the block maxima) an item writes s_max only, and the previous
         // item's last readers of s_max passed two barriers ago
-        if (cur.item == kNoItem) break;
+        if (cur.item == kNoItem) break;  // tickets only grow along a workgroup's sequence: nothing behind the queue's end
         const int vw = cur.vw;
         Fetched nx2;
-        fetch_item(ticket + 2 * gridDim.x, nx2);
+#if FNX_BWD_DYNAMIC
+        uint32_t drawn = 0;
+        if (tid == 0) drawn = 2u * gridDim.x + atomicAdd(const_cast<uint32_t *>(header) + HDR_BWD_TICKET, 1u);
+#else
+        fetch_item(ticket_of(sidx + 2), nx2);
+#endif
         fetch_range(nxt);
         // per-view scratch, pixel gradients and screen-space accumulators of the item's view
         const float *final_Ts_v = view_at(final_Ts, vb.img, vw);
@@ -256,37 +301,44 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const uint32_t r0 = cur.r0;
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
 
-        const float T_final = inside ? final_Ts_v[pix_id] : 0.f;
-        const uint32_t last_contributor = inside ? n_contrib_v[pix_id] : 0u;
-        float dL_dpixel[C], total[C], pre[C];
-        float Tr = 1.0f;
+        const uint32_t key = ((uint32_t)vw << 16) | (uint32_t)tile;
+        const bool same_tile = key == tile_key;
+        tile_key = key;
+        if (!same_tile) {
+            const float T_final = inside ? final_Ts_v[pix_id] : 0.f;
+            last_contributor = inside ? n_contrib_v[pix_id] : 0u;
+            float total[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-            dL_dpixel[ch] = inside ? dL_dpixels_v[(size_t)ch * H * W + pix_id] : 0.f;
-            total[ch] = inside ? acc_final_v[(size_t)ch * H * W + pix_id] : 0.f;
-            pre[ch] = 0.f;
+            for (int ch = 0; ch < C; ch++) {
+                dL_dpixel[ch] = inside ? dL_dpixels_v[(size_t)ch * H * W + pix_id] : 0.f;
+                total[ch] = inside ? acc_final_v[(size_t)ch * H * W + pix_id] : 0.f;
+            }
+            float bg_dot_dpixel = 0.f;
+            total_dot = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+                total_dot += total[ch] * dL_dpixel[ch];
+            }
+            tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
         }
+        float Tr = 1.0f, pre[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) pre[ch] = 0.f;
         if (b) {  // state in front of the batch, as the forward left it
-            const float4 stt = bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
+            const float4 stt = (same_tile && stt_ahead_valid) ? stt_ahead : bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
             Tr = stt.x;
             pre[0] = stt.y;
             if (C > 1) pre[C > 1 ? 1 : 0] = stt.z;
             if (C > 2) pre[C > 2 ? 2 : 0] = stt.w;
         }
-        float bg_dot_dpixel = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
         // Everything the gradient needs from the colour channels is their dot product with dL/dpixel:
         //   sum_ch dL_ch (c_ch T - S_ch / (1 - alpha)) = T (c . dL) - (S . dL) / (1 - alpha),
         //   S . dL = (total . dL) - (prefix . dL), and the prefix's dot product is itself a running sum of
         //   alpha_i T_i (c_i . dL): one scalar recurrence instead of one per channel.
-        float total_dot = 0.f, pre_dot = 0.f;
+        float pre_dot = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-            total_dot += total[ch] * dL_dpixel[ch];
-            pre_dot += pre[ch] * dL_dpixel[ch];
-        }
-        const float tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
+        for (int ch = 0; ch < C; ch++) pre_dot += pre[ch] * dL_dpixel[ch];
         // what lies behind the entry being processed, as one running value: (total - prefix) . dL + the background's
         // share; an applied entry takes its own alpha T (c . dL) out of it (fused multiply-adds: the gradients are
         // compared within fp32 summation tolerance, only power / alpha repeat the forward's arithmetic exactly)
@@ -294,9 +346,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
-        uint32_t m = last_contributor;
-        for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-        if ((lane & 15) == 0) s_max[4 * w + row] = m;
+        if (!same_tile) {  // the block maxima belong to the tile: they stay in LDS while the workgroup stays on it
+            uint32_t m = last_contributor;
+            for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+            if ((lane & 15) == 0) s_max[4 * w + row] = m;
+        }
         // LDS-only barriers in the item loop: the waves exchange nothing through global memory, and a plain
         // __syncthreads() would also wait for the previous item's flush atomics and for the next item's prefetches
         FNX_LOOP_BARRIER();
@@ -351,6 +405,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
         const uint16_t *mylist = s_list[4 * w + row];
         fetch_ids(nxt);  // in flight during the walk
+        {   // ... and, if the next item continues this tile, the pixels' record in front of its batch
+            const uint32_t nb_ = nxt.item >> kItemTileBits;
+            stt_ahead_valid = nxt.item != kNoItem && nxt.vw == vw && (nxt.item & kItemTileMask) == (uint32_t)tile && nb_ != 0u;
+            if (stt_ahead_valid) stt_ahead = bstate_all[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
+        }
         // entry q0 + slot lies in front of the pixel's last contributor <=> its LDS offset (16 slot) is below this bound
         const uint32_t lim_off = last_contributor > q0 ? min(last_contributor - q0, 4096u) << 4 : 0u;
         // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
@@ -502,7 +561,14 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             }
         }
         fetch_records(nxt);  // in flight while the accumulators are flushed
+#if FNX_BWD_DYNAMIC
+        if (tid == 0) s_tk = drawn;
+#endif
         FNX_LOOP_BARRIER();
+#if FNX_BWD_DYNAMIC
+        dyn_next = s_tk;
+        fetch_item(ticket_of(sidx + 2), nx2);
+#endif
         if ((uint32_t)tid < cnt) {
             const uint32_t id = s_id[tid];
             float a[NV];
@@ -555,6 +621,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         nxt.item = nx2.item;
         nxt.vw = nx2.vw;
     }
+#if FNX_BWD_DYNAMIC
+    // the last workgroup to run out of items re-arms the counters: another backward over the same forward (a second
+    // autograd pass, a test that calls it again) starts from ticket 0 like the first
+    if (tid == 0) {
+        uint32_t *h0 = const_cast<uint32_t *>(header);
+        if (atomicAdd(h0 + HDR_BWD_DONE, 1u) == gridDim.x - 1u) {
+            __hip_atomic_store(h0 + HDR_BWD_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(h0 + HDR_BWD_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -448,6 +448,8 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         header[HDR_CAPACITY] = 0u;
         header[HDR_NUM_STATIC] = st_starts ? st_starts[T] : 0u;
         header[HDR_BWD_ITEMS] = 0u;  // the blend forward appends the backward's work items
+        header[HDR_BWD_TICKET] = 0u;  // the backward's dynamic ticket counter (view 0's words)
+        header[HDR_BWD_DONE] = 0u;
     }
     // emission work items: exclusive prefix of the per-block band counts
     __syncthreads();

@@ -19,6 +19,7 @@ ap.add_argument("--no-deep", action="store_true")
 ap.add_argument("--deep", type=int, default=None)
 ap.add_argument("--deep-min", type=int, default=None)
 ap.add_argument("--no-split", action="store_true")
+ap.add_argument("--mode3", action="store_true", help="positions-only backward (screen_grad=False), as the bench runs it")
 a = ap.parse_args()
 gm, cams = build_smoke_frame(n_views=a.views, size=a.size)
 gm.training_setup_current(__import__("types").SimpleNamespace(position_lr_init=1.6e-4, position_lr_final=1.6e-6,
@@ -43,7 +44,8 @@ for it in range(a.iters + 2):
     if it == 2:
         torch.cuda.synchronize()
         e0.record()
-    pkg = render_dynamics_views(cams, gm, None, bg, GRsetting=GRsetting, GRzer=GRzer, pos_type="guess_visual_nn", scale=True)
+    pkg = render_dynamics_views(cams, gm, None, bg, GRsetting=GRsetting, GRzer=GRzer, pos_type="guess_visual_nn", scale=True,
+                                **({"screen_grad": False} if a.mode3 else {}))
     if not a.no_backward:
         pkg["render"].sum().backward()
         gm.optimizer.zero_grad()
