@@ -386,6 +386,8 @@ def main():
                     help="arithmetic of the blend kernels (include/fnx_raster.h fnx_set_blend_math): fast = fused multiply-adds "
                          "+ v_exp_f32, stated tolerance against the oracle (tests/test_fast_math_gpu.py); exact = the "
                          "bit-reproducible sequence the oracle repeats")
+    ap.add_argument("--full-geometry", action="store_true",
+                    help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
@@ -455,6 +457,7 @@ def main():
     from fluidnexus_amd.renderer import pipes
     _lib.raster()  # fail loudly if the HIP library is missing
     rasterizer.set_blend_math(a.blend_math)
+    rasterizer.set_lean_geometry(not a.full_geometry)
     if a.deep_kernel is not None:
         _lib.check(_lib.raster().fnx_set_deep_kernel(a.deep_kernel))
     if a.no_static_split:

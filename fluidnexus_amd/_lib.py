@@ -52,7 +52,7 @@ SYMBOLS = (
     "fnx_rasterize_backward_views",
     "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
-    "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel",
+    "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
@@ -131,6 +131,8 @@ def raster():
     lib.fnx_set_blend_math.argtypes = [i]
     lib.fnx_get_blend_math.restype = i
     lib.fnx_set_deep_kernel.restype = i
+    lib.fnx_set_lean_geometry.restype = i
+    lib.fnx_set_lean_geometry.argtypes = [i]
     lib.fnx_set_deep_kernel.argtypes = [i]
     lib.fnx_rasterize_backward_views_split.restype = i
     lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]

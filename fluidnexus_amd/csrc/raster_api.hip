@@ -20,7 +20,7 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb, const StaticRef &st);
+                       const ViewBatch &vb, const StaticRef &st, int lean);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
@@ -217,6 +217,7 @@ struct ProfClass {
     size_t used = 0;
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
+int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
 int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
 int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
 bool g_prof_on = false;
@@ -331,7 +332,8 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
-                           g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st);
+                           g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st,
+                           (g_lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0);
     }
     {
     ProfScope ps(2, s);
@@ -561,7 +563,8 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     Bin bin = carve_bin(binning_buffer, 0);
     const int *rad = radii ? radii : g.radii;
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
-    const size_t cov3D_stride = cov3D_precomp ? 0 : vb.geom;
+    // lean geometry (fnx_set_lean_geometry; must match the forward's setting): view 0's blob holds the one covariance array
+    const size_t cov3D_stride = (cov3D_precomp || (g_lean_geometry && V > 1)) ? 0 : vb.geom;
     {
         ProfScope ps(channels == 3 ? 1 : 6, s);
         fnx::launch_blend_backward(channels, geometry_only, s, P_all, width, height, img.ranges, bin.point_list,
@@ -646,6 +649,10 @@ int fnx_set_blend_math(int mode) {
     return FNX_OK;
 }
 int fnx_get_blend_math(void) { return g_blend_math; }
+int fnx_set_lean_geometry(int on) {
+    g_lean_geometry = on ? 1 : 0;
+    return FNX_OK;
+}
 int fnx_set_deep_kernel(int mode) {
     if (mode < 0 || mode > 2) return fail(FNX_ERR_INVALID_ARG, "deep kernel mode must be 0 (off), 1 (auto) or 2 (always)");
     g_deep_kernel = mode;

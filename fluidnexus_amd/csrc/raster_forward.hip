@@ -134,7 +134,10 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
-                  float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb) {
+                  float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb, int lean) {
+    // lean (fnx_set_lean_geometry): the copies of the reference's GeometryState that nothing in this library reads back
+    // (means2D, depths, conic_opacity, tiles_touched: the blend records carry the same numbers) are not written, and the
+    // world covariance -- the same for every view -- is written by view 0 only (the backward reads it at stride 0)
     __shared__ uint32_t s_min[4];
     const int vw = blockIdx.y;  // view of the batch: camera, radii and the geometry blob are per view
     radii += (size_t)vw * vb.radii_stride;
@@ -169,8 +172,14 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     if (idx < P) {
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         radii[idx] = 0;
-        tiles_touched[idx] = 0;
+        if (!lean) tiles_touched[idx] = 0;
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        if (lean && vw == 0) {  // the one covariance array of the batch: for every splat, whichever views see it
+            float c0[6];
+            cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, c0);
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov3Ds[(size_t)idx * 6 + k] = c0[k];
+        }
         const float3 p_view = xform4x3(p_orig, view);
         // near cull: only view-space z <= 0.2 (ch3 auxiliary.h:138)
         if (!(p_view.z <= 0.2f)) {
@@ -178,12 +187,16 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             const float p_w = 1.0f / (p_hom.w + 0.0000001f);
             const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
             const float *cov3D;
+            float c3[6];
             if (cov3D_precomp != nullptr) {
                 cov3D = cov3D_precomp + (size_t)idx * 6;
             } else {
-                cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx,
-                                     cov3Ds + (size_t)idx * 6);
-                cov3D = cov3Ds + (size_t)idx * 6;
+                cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, c3);
+                if (!lean) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) cov3Ds[(size_t)idx * 6 + k] = c3[k];
+                }
+                cov3D = c3;
             }
             const float3 cov = cov2d_ewa(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view);
             const float det = (cov.x * cov.z - cov.y * cov.y);
@@ -208,10 +221,12 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                         for (int ch = 0; ch < C; ch++) col[ch] = colors_precomp[(size_t)idx * C + ch];
                     }
                     const float opac = opacities[idx];
-                    depths[idx] = p_view.z;
                     radii[idx] = (int)my_radius;
-                    means2D[idx] = make_float2(px, py);
-                    conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opac);
+                    if (!lean) {
+                        depths[idx] = p_view.z;
+                        means2D[idx] = make_float2(px, py);
+                        conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opac);
+                    }
                     // packed record for the blend kernels (one 64-byte line per splat)
                     float thr, ex, ey;
                     splat_footprint(conic.x, conic.y, conic.z, opac, thr, ex, ey);
@@ -220,7 +235,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     rec[1] = make_float4(conic.z, opac, thr, p_view.z);
                     rec[2] = make_float4(ex, ey, col[0], col[1]);
                     rec[3] = make_float4(col[2], 0.f, 0.f, 0.f);
-                    tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+                    if (!lean) tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
                     key = __float_as_uint(p_view.z);
                 }
             }
@@ -1266,13 +1281,13 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 uint32_t *key_min_blk, uint2 *rect,
-                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st) {
+                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -1281,17 +1296,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
-                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st) {
+                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st);
+                               blend_rec, prefiltered, V, vb, st, lean);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st);
+                               blend_rec, prefiltered, V, vb, st, lean);
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,

@@ -56,6 +56,12 @@ def set_blend_math(mode: str):
     _lib.check(_lib.raster().fnx_set_blend_math({"exact": 0, "fast": 1}[mode]))
 
 
+def set_lean_geometry(enabled: bool):
+    """View batches only: do not write the per-view GeometryState copies nothing reads back, one world covariance for
+    all views (include/fnx_raster.h fnx_set_lean_geometry).  Forward and backward must run under the same setting."""
+    _lib.check(_lib.raster().fnx_set_lean_geometry(1 if enabled else 0))
+
+
 def get_blend_math() -> str:
     return ("exact", "fast")[_lib.raster().fnx_get_blend_math()]
 

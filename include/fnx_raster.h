@@ -262,6 +262,12 @@ int fnx_get_blend_math(void);
  * workgroups wait for an empty compute unit behind the per-tile kernel's workgroups and the iteration gets slower
  * (config 3, 2 of 5 views: 1251 -> 1216 it/s), so it is opt-in. */
 int fnx_set_deep_kernel(int mode);
+/* View-batched entry points (V > 1): 1 = the per-view copies of the reference's GeometryState that this library never
+ * reads back (means2D, depths, conic_opacity, tiles_touched: 32 of the 136 bytes a visible splat writes per view) are
+ * not written, and the world covariance -- identical for every view -- is written for view 0 only and read at stride 0
+ * by the backward.  Forward and backward of one render must run under the same setting.  Default 0 (everything written:
+ * fnx_geom_layout offsets stay meaningful for tools and tests). */
+int fnx_set_lean_geometry(int on);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
                                        const float *colors_precomp, const float *scales, float scale_modifier,

@@ -327,3 +327,41 @@ def test_image_loss_value_and_grad_matches_autograd_node():
     assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * abs(loss_a.item())
     assert (per_a - per_b).abs().max().item() <= 2e-6
     assert torch.equal(x.grad, g_b)
+
+
+def test_lean_geometry_gives_the_same_render_and_gradients():
+    """fnx_set_lean_geometry(1): a view batch that skips the unread GeometryState copies and keeps ONE world covariance
+    array (view 0's) equals the full one bit for bit in colour / depth / radii, and in the gradients up to the order of
+    the atomics -- including splats that view 0 does not see but another view does."""
+    import math
+    import torch
+    from fluidnexus_amd import rasterizer, synthetic as S
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews
+    W = H = 96
+    g = S.to_torch(S.random_gaussians(6000, seed=8, box=1.5, log_scale=(-4.0, -2.5)))  # box 1.5: splats behind some cameras
+    cams = S.ring_cameras(4, W, H, distance=1.2)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    tan = math.tan(0.4)
+    rs = [GaussianRasterizationSettings(H, W, tan, tan, bg, 1.0, c.world_view_transform, c.full_proj_transform, 0,
+                                        c.camera_center, False) for c in cams]
+    P = g["means3D"].shape[0]
+    dL = torch.randn(4, 3, H, W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    res = {}
+    for lean in (False, True):
+        rasterizer.set_lean_geometry(lean)
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in g.items()}
+            out = GaussianRasterizerViews(rs)(means3D=leaves["means3D"], means2D=torch.zeros(4, P, 3, device="cuda", requires_grad=True),
+                                              opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                                              scales=leaves["scales"], rotations=leaves["rotations"])
+            grads = torch.autograd.grad([out[0]], list(leaves.values()), grad_outputs=[dL])
+            res[lean] = (out, grads)
+        finally:
+            rasterizer.set_lean_geometry(False)
+    (o0, g0), (o1, g1) = res[False], res[True]
+    vis = o0[1] > 0
+    assert bool((vis[1:].any(0) & ~vis[0]).any()), "the scene must hold splats view 0 does not see"
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
