@@ -11,6 +11,7 @@
 // then across the tile's 16 blocks in LDS, and one set of atomics per (tile, batch, splat) reaches HBM:
 // ~256x fewer device-scope atomics, same sums up to fp32 association order.
 #include "fnx_device.h"
+#include "fnx_fold_asm.h"
 #include "fnx_state.h"
 
 #ifndef FNX_LDS_BARRIER
@@ -42,8 +43,8 @@ namespace fnx {
 // halves (row_ror:8), 8 -> 4 pairs the pairs across the half-row's quads (row_half_mirror), two quad permutes finish:
 // the quads of a row then hold the totals of a, c, b, d -- 11 VALU operations and ONE LDS atomic (4 lanes per row)
 // for four values instead of 4 x (5 + 1).
-template <int NV>
-__device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], float (*acc)[256], uint32_t slot, int lane,
+template <int NV, int STRIDE>
+__device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], float (*acc)[STRIDE], uint32_t slot, int lane,
                                                     bool row_active) {
     const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
     const int vq = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1);  // which value of a group this lane's quad ends up with
@@ -128,7 +129,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ float4 s_rb[257];  // conic c, opacity, -, 1.0 if the splat wants gradients (id < grad_limit) else 0.0
     __shared__ float4 s_rc[257];  // colour (C channels)
     __shared__ float4 s_rd[FAST ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush (a, b, c, o)
-    __shared__ float s_acc[NV][256];
+    // per-entry sums; FAST pads the rows so that the four values a quad adds at once fall into different banks
+    constexpr int kAccStride = FAST ? 272 : 256;
+    __shared__ float s_acc[NV][kAccStride];
     // per-block lists of LDS byte offsets (slot * 16), depth order; lists 4 w .. 4 w + 3 are built, padded and read by
     // wave w alone
     __shared__ __attribute__((aligned(16))) uint16_t s_list[16][kListStride];
@@ -372,14 +375,18 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             if (FAST) {
                 constexpr float kL2e = 1.44269504088896341f;
                 s_ra[tid] = make_float4(cur.ra.x, cur.ra.y, (-0.5f * kL2e) * cur.ra.z, (-kL2e) * cur.ra.w);
-                s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), 0.f,
-                                        id < grad_limit ? 1.0f : 0.0f);
+                // the walk is bound by LDS cycles: two 16-byte reads per entry (+ 8 bytes with three channels), no
+                // 12-byte reads (ds_read_b96 costs twice a ds_read_b128)
+                const float wants_f = id < grad_limit ? 1.0f : 0.0f;
+                s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), cur.rcz,
+                                        C == 3 ? cur.rcw : wants_f);
+                if (C == 3) s_rc[tid] = make_float4(cur.rdx, wants_f, 0.f, 0.f);
                 s_rd[FAST ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
             } else {
                 s_ra[tid] = cur.ra;
                 s_rb[tid] = make_float4(cur.rbx, cur.rby, 0.f, id < grad_limit ? 1.0f : 0.0f);
+                s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, 0.f);
             }
-            s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, 0.f);
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
@@ -419,20 +426,27 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             static_assert(!FAST || kGroup == 4, "the fast walk folds the sums of four entries together");
             const int vq = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1);  // entry of a step whose sums this lane's quad ends up with
             const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+            (void)hi8;
+            (void)hi4;
             for (uint32_t i0 = 0; i0 < (FNX_ABLATE == 3 ? 0u : n_w); i0 += 4) {
                 uint32_t jw[2];
                 jw[0] = reinterpret_cast<const uint32_t *>(mylist + i0)[0];
                 jw[1] = reinterpret_cast<const uint32_t *>(mylist + i0)[1];
-                float4 ra[4], rb[4], rc[4];
+                float val[NV][4];
+                bool any_emit = false;
+#ifndef FNX_BWD_LOAD_SPLIT
+#define FNX_BWD_LOAD_SPLIT 0  // 1: records of two entries at a time in registers instead of four
+#endif
+                float4 ra[4], rb[4];
+                float2 rc[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
                     ra[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
                     rb[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
-                    rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
+                    rc[k] = C == 3 ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(s_rc) + off)
+                                   : make_float2(0.f, 0.f);
                 }
-                float val[NV][4];
-                bool any_emit = false;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
@@ -442,14 +456,14 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     const float e = __builtin_amdgcn_exp2f(q + rb[k].y);         // o G
                     const float alpha = fminf(0.99f, e);
                     const bool active = !(q > 0.0f) && !(alpha < 1.0f / 255.0f) && (off < lim_off);
-                    const bool emits = active && rb[k].w != 0.0f;
+                    const bool emits = active && (C == 3 ? rc[k].y : rb[k].w) != 0.0f;
                     const float a = active ? alpha : 0.0f;
                     const float one_m = 1 - a;
                     const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
                     const float Tb = Tr;
-                    float c_dot = rc[k].x * dL_dpixel[0];
-                    if (C > 1) c_dot = __builtin_fmaf(rc[k].y, dL_dpixel[C > 1 ? 1 : 0], c_dot);
-                    if (C > 2) c_dot = __builtin_fmaf(rc[k].z, dL_dpixel[C > 2 ? 2 : 0], c_dot);
+                    float c_dot = rb[k].z * dL_dpixel[0];
+                    if (C > 1) c_dot = __builtin_fmaf(rb[k].w, dL_dpixel[C > 1 ? 1 : 0], c_dot);
+                    if (C > 2) c_dot = __builtin_fmaf(rc[k].x, dL_dpixel[C > 2 ? 2 : 0], c_dot);
                     const float aT = a * Tb;
                     rest = __builtin_fmaf(-aT, c_dot, rest);
                     Tr = Tb * one_m;
@@ -481,6 +495,25 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     const uint32_t osel = (vq & 2) ? o23 : o01;
                     const uint32_t slot = ((osel >> (16 * (vq & 1))) & 0xFFFFu) >> 4;
                     const bool writer = (lane & 3) == 0 && slot < 256u;
+#ifndef FNX_FOLD_ASM
+#define FNX_FOLD_ASM 1  // 0: the folds written with builtins (selects + DPP), as the exact path has them
+#endif
+#if FNX_FOLD_ASM
+                    fold_rows_asm<NV>(val);  // hand-scheduled DPP butterflies (fnx_fold_asm.h)
+                    (void)writer;
+                    // the four lanes of a quad hold the same totals: lane k of the quad adds value 4 j + k, so NV values
+                    // take ceil(NV / 4) LDS atomics instead of NV (the walk is bound by LDS cycles, not by instructions)
+                    const int kq = lane & 3;
+#pragma unroll
+                    for (int j = 0; j < (NV + 3) / 4; j++) {
+                        float t = val[4 * j][0];
+                        if (4 * j + 1 < NV) t = kq == 1 ? val[4 * j + 1 < NV ? 4 * j + 1 : 0][0] : t;
+                        if (4 * j + 2 < NV) t = kq == 2 ? val[4 * j + 2 < NV ? 4 * j + 2 : 0][0] : t;
+                        if (4 * j + 3 < NV) t = kq == 3 ? val[4 * j + 3 < NV ? 4 * j + 3 : 0][0] : t;
+                        const int v = 4 * j + kq;
+                        if (slot < 256u && v < NV) atomicAdd(&s_acc[0][0] + v * kAccStride + (slot & 255u), t);
+                    }
+#else
 #pragma unroll
                     for (int v = 0; v < NV; v++) {
                         const float a0 = val[v][0], b0 = val[v][1], c0 = val[v][2], d0 = val[v][3];
@@ -491,6 +524,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                         t += FNX_DPP(t, 0x4e, 0xf);
                         if (writer) atomicAdd(&s_acc[v][slot & 255u], t);
                     }
+#endif
                 }
 #endif
             }
@@ -556,7 +590,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #if FNX_ABLATE == 2
                 { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v]; asm volatile("" ::"v"(sink)); }
 #else
-                if (__ballot(emits) != 0ull) row_fold_accumulate<NV>(val, s_acc, slot & 255u, lane, wants);
+                if (__ballot(emits) != 0ull) row_fold_accumulate<NV, kAccStride>(val, s_acc, slot & 255u, lane, wants);
 #endif
             }
         }
