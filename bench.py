@@ -386,6 +386,8 @@ def main():
                     help="arithmetic of the blend kernels (include/fnx_raster.h fnx_set_blend_math): fast = fused multiply-adds "
                          "+ v_exp_f32, stated tolerance against the oracle (tests/test_fast_math_gpu.py); exact = the "
                          "bit-reproducible sequence the oracle repeats")
+    ap.add_argument("--sort-four-passes", action="store_true",
+                    help="always launch the fourth depth-sort pass (default: skipped once the warm-up has shown spans < 2^26 ulps)")
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
@@ -486,7 +488,10 @@ def main():
     for _ in range(max(a.warmup, 1)):  # at least one eager pass sizes the binning buffers before anything is captured
         loop.iteration()
     if not a.host_sync:
-        rasterizer.check_status()  # also records the binning high-water mark
+        rasterizer.check_status()  # also records the binning high-water mark and the views' depth-key spans
+        # three 9-bit passes order any view whose keys span < 2^27 ulps: the warm-up has shown how wide this scene's are
+        if 0 < rasterizer.max_sort_span_bits <= 25 and not a.sort_four_passes:
+            rasterizer.set_sort_narrow(True)  # a later view that needs the fourth pass fails the run (check_status)
     graph_mode = False
     if loop.capturable:
         try:
@@ -664,6 +669,9 @@ def main():
                                    + (" (emulated: rank 0's share, no communication)" if a.emulate_world > 1 else "")
                                    + ", RCCL all-reduce of the leaf gradient"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
+                   "depth_sort": f"9-bit passes; key span of the views <= 2^{rasterizer.max_sort_span_bits} ulps; fourth pass "
+                                 + ("not launched (device-checked)" if (0 < rasterizer.max_sort_span_bits <= 25 and not a.sort_four_passes
+                                                                        and not a.host_sync) else "launched"),
                    "blend_math": {"fast": "fast: fused multiply-adds + v_exp_f32 in the two blend kernels; pixels within 2e-5 of the "
                                           "bit-exact mode / oracle except counted threshold flips, binning bit-exact "
                                           "(tests/test_fast_math_gpu.py)",

@@ -69,7 +69,9 @@ constexpr int kKeyBlock = 256;  // splats per preprocess workgroup = per entry o
 struct SortScratch {
     size_t hist, hist_rel, totals, ctl, kmin_blk, kmax_blk, blk_total, emit_ctl, emit_items, words;
 };
-enum { SORT_CTL_KMIN = 0, SORT_CTL_WIDE = 1 };  // smallest visible key; 1 if the fourth pass is needed
+// smallest visible key; 1 if the fourth pass is needed (and will run); bit length of the view's key span; 1 if the span
+// needs a pass that was not launched (fnx_set_sort_narrow)
+enum { SORT_CTL_KMIN = 0, SORT_CTL_WIDE = 1, SORT_CTL_SPAN = 2, SORT_CTL_OVERFLOW = 3 };
 // Emission work items: a rank block with many instances (the nearest, largest splats) is split into up to
 // kEmitBands items, each a band of tile rows (a rectangle clipped to a band of rows is still a rectangle).
 #ifndef FNX_EMIT_BANDS

@@ -28,7 +28,7 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
-                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb);
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow);
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
                       uint32_t *blk_total, int V, const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
@@ -217,6 +217,7 @@ struct ProfClass {
     size_t used = 0;
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
+int g_sort_narrow = 0;       // the fourth depth-sort pass is not launched (fnx_set_sort_narrow)
 int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
 int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
 int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
@@ -339,7 +340,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
     ProfScope ps(2, s);
     // (key, id) pair buffers: sort_key0|sort_key1 and sort_val0|sort_val1 are adjacent P-word arrays
     fnx::launch_depth_sort(s, P, g.sort_key0, (uint2 *)g.sort_key0, (uint2 *)g.sort_val0, g.sort_hist, g.rect,
-                           g.rect_sorted, V, vb);
+                           g.rect_sorted, V, vb, g_sort_narrow);
     fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
@@ -649,6 +650,10 @@ int fnx_set_blend_math(int mode) {
     return FNX_OK;
 }
 int fnx_get_blend_math(void) { return g_blend_math; }
+int fnx_set_sort_narrow(int on) {
+    g_sort_narrow = on ? 1 : 0;
+    return FNX_OK;
+}
 int fnx_set_lean_geometry(int on) {
     g_lean_geometry = on ? 1 : 0;
     return FNX_OK;

@@ -35,7 +35,7 @@ template <typename CountT>
 __global__ void __launch_bounds__(1024)
 colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__restrict__ blk_rel,
                uint32_t *__restrict__ tile_count, size_t hist_stride, size_t count_stride,
-               const uint32_t *__restrict__ kmax_blk, uint32_t *__restrict__ ctl, int only_if_wide) {
+               const uint32_t *__restrict__ kmax_blk, uint32_t *__restrict__ ctl, int only_if_wide, int narrow) {
     __shared__ uint32_t s_band[16][64];
     if (ctl) {  // depth-sort passes
         ctl = view_at(ctl, hist_stride, blockIdx.y);
@@ -47,7 +47,12 @@ colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__r
             for (int b = threadIdx.x; b < NB; b += 64) m = max(m, kmax_blk[b]);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-            if (threadIdx.x == 0) ctl[SORT_CTL_WIDE] = (m >> (3 * kSortBits)) ? 1u : 0u;
+            if (threadIdx.x == 0) {
+                const uint32_t wide = (m >> (3 * kSortBits)) ? 1u : 0u;
+                ctl[SORT_CTL_WIDE] = narrow ? 0u : wide;  // narrow: the fourth pass is not launched
+                ctl[SORT_CTL_OVERFLOW] = narrow ? wide : 0u;
+                ctl[SORT_CTL_SPAN] = m ? 32u - (uint32_t)__clz((int)m) : 0u;
+            }
         }
     }
     blk_hist = view_at(blk_hist, hist_stride, blockIdx.y);
@@ -668,7 +673,7 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
                          uint32_t *tile_count, int V, const ViewBatch &vb) {
     hipLaunchKernelGGL((colscan_kernel<uint16_t>), dim3((T + 63) / 64, V), dim3(1024), 0, s, T, splat_blocks(P),
                        blk_hist, blk_rel, tile_count, vb.geom, vb.img, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                       0);
+                       0, 0);
 }
 
 // `raw_keys` holds the depth keys (preprocess), `scratch` the geometry blob's sort_hist region; pairs_a / pairs_b
@@ -676,18 +681,18 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
 // After the call the pairs in (depth bits, id) order are in pairs_b (three passes) or pairs_a (four: scratch ctl
 // word SORT_CTL_WIDE is 1).
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
-                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb) {
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow) {
     const int NSB = sort_blocks(P);
     const SortScratch L = sort_scratch(P);
     uint32_t *hist = scratch + L.hist, *hist_rel = scratch + L.hist_rel, *totals = scratch + L.totals,
              *ctl = scratch + L.ctl, *kmin_blk = scratch + L.kmin_blk, *kmax_blk = scratch + L.kmax_blk;
     uint2 *pin = pairs_a, *pout = pairs_b;
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < (narrow ? 3 : 4); pass++) {
         hipLaunchKernelGGL(sort_hist_kernel, dim3(NSB, V), dim3(256), 0, s, P, raw_keys, pin, pass, hist, kmin_blk,
                            kmax_blk, ctl, vb.geom);
         hipLaunchKernelGGL((colscan_kernel<uint32_t>), dim3(kSortRadix / 64, V), dim3(1024), 0, s, kSortRadix, NSB, hist,
                            hist_rel, totals, vb.geom, vb.geom, pass == SORT_FIRST ? kmax_blk : (const uint32_t *)nullptr,
-                           ctl, pass == SORT_FOURTH ? 1 : 0);
+                           ctl, pass == SORT_FOURTH ? 1 : 0, narrow);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, raw_keys, pin, pout, pass, hist_rel,
                            totals, ctl, rect, rect_sorted, vb.geom);
         uint2 *t = pin; pin = pout; pout = t;

@@ -364,7 +364,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
                  uint32_t *__restrict__ emit_items, size_t geom_stride, uint32_t *__restrict__ depth_hint,
                  uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
-                 const StaticRef st) {
+                 const StaticRef st, const uint32_t *__restrict__ sort_ctl) {
     constexpr int kDeepSorted = 1024;
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_deep_n;
@@ -455,11 +455,12 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
             if (!tile_deep[t]) tile_order[at++] = (uint32_t)t;
         }
         __syncthreads();
-        if (tid == 0) header[HDR_DEEP_COUNT] = nd;
+        // + the bit length of the view's depth-key span in the top byte (the host learns whether three sort passes suffice)
+        if (tid == 0) header[HDR_DEEP_COUNT] = min(nd, 0xFFFFFFu) | (view_at(sort_ctl, geom_stride, blockIdx.y)[SORT_CTL_SPAN] << 24);
     }
     if (tid == 1023) {
         header[HDR_NUM_RENDERED] = run;  // thread 1023 owns the last chunk of tiles: its running sum is the total
-        header[HDR_STATUS] = 0u;
+        header[HDR_STATUS] = view_at(sort_ctl, geom_stride, blockIdx.y)[SORT_CTL_OVERFLOW] ? (uint32_t)FNX_ERR_SORT_SPAN : 0u;
         header[HDR_CAPACITY] = 0u;
         header[HDR_NUM_STATIC] = st_starts ? st_starts[T] : 0u;
         header[HDR_BWD_ITEMS] = 0u;  // the blend forward appends the backward's work items
@@ -587,7 +588,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     if (wg_rank == 0 && threadIdx.x == 0) header[HDR_BIN_CAPACITY] = capacity;  // the backward checks its own against it
     if (status_out && wg_rank == 0 && threadIdx.x < 8)
         status_out[8 * wg_view + threadIdx.x] = threadIdx.x == HDR_BIN_CAPACITY ? capacity : header[threadIdx.x];
-    if (header[HDR_NUM_RENDERED] > capacity) return;
+    if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] == (uint32_t)FNX_ERR_SORT_SPAN) return;
     // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
     // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
@@ -978,7 +979,7 @@ blend_forward_deep_kernel(int T, int gx, const uint32_t *__restrict__ ranges_all
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (tid < n_views) {
         const uint32_t *h = view_at(header_all, vb.img, tid);
-        s_cnt[tid] = h[HDR_NUM_RENDERED] > capacity ? 0u : h[HDR_DEEP_COUNT];
+        s_cnt[tid] = (h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u) ? 0u : (h[HDR_DEEP_COUNT] & 0xFFFFFFu);
     }
     if (tid == 0) {
         s_ra[NB] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1316,7 +1317,8 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
     const SortScratch L = sort_scratch(P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
-                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, tile_order, tile_deep, st);
+                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, tile_order, tile_deep, st,
+                       sort_scratch_words + L.ctl);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,

@@ -35,6 +35,7 @@ _CAPTURED = 8192            # slots owned by captured forwards (rows _RING ... o
 _ring_next = 0
 _captured_next = 0
 last_num_rendered = -1      # updated by check_status(): instance count of the most recent forward
+max_sort_span_bits = 0      # updated by check_status(): largest bit length of a view's depth-key span seen so far
 
 
 _DEEP_VARIANT = True  # depth hints on: tiles whose lists went deep in the previous forward are scheduled first
@@ -54,6 +55,13 @@ def set_blend_math(mode: str):
     bit-reproducible sequence the oracle repeats (default), "fast" = fused multiply-adds + v_exp_f32, stated tolerance.
     The forward and the backward of one render must run in the same mode."""
     _lib.check(_lib.raster().fnx_set_blend_math({"exact": 0, "fast": 1}[mode]))
+
+
+def set_sort_narrow(enabled: bool):
+    """True: the fourth pass of the depth sort is not launched (include/fnx_raster.h fnx_set_sort_narrow).  Only after
+    check_status() has shown `max_sort_span_bits` <= 26 on the scene at hand; a view that needs the pass after all
+    raises FNX_ERR_SORT_SPAN at the next check_status()."""
+    _lib.check(_lib.raster().fnx_set_sort_narrow(1 if enabled else 0))
 
 
 def set_lean_geometry(enabled: bool):
@@ -134,7 +142,7 @@ def release_captured_status():
 def check_status():
     """Blocking: raise if any sync-free forward since the last call overflowed its binning capacity;
     also refreshes the binning high-water marks and `last_num_rendered`."""
-    global last_num_rendered
+    global last_num_rendered, max_sort_span_bits
     if not _pending_status and not _captured_status:
         return
     host = {d: r.cpu() for d, r in _status_ring.items()}  # one small D2H copy per device, synchronising
@@ -147,8 +155,12 @@ def check_status():
     for dev_index, slot, key in entries:
         n, status, cap = (int(x) for x in host[dev_index][slot][:3])
         _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n * _CAP_SLACK) + 1024)
+        max_sort_span_bits = max(max_sort_span_bits, (int(host[dev_index][slot][5]) >> 24) & 0xFF)
         if status == _lib.FNX_ERR_CAPACITY and err is None:
             err = _lib.FnxError(status, f"binning capacity {cap} < num_rendered {n}")
+        if status == _lib.FNX_ERR_SORT_SPAN and err is None:
+            err = _lib.FnxError(status, "set_sort_narrow(True) but a view's depth keys span 2^27 ulps or more: the fourth "
+                                        "sort pass was needed (set_sort_narrow(False) and render again)")
     if err is not None:
         raise err
 

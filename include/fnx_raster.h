@@ -36,6 +36,7 @@ extern "C" {
 #define FNX_ERR_HIP 3
 #define FNX_ERR_CAPACITY 4 /* binning buffer smaller than num_rendered */
 #define FNX_ERR_UNSUPPORTED 5 /* e.g. more than 16384 tiles (image larger than 2048x2048) */
+#define FNX_ERR_SORT_SPAN 6 /* fnx_set_sort_narrow(1) and a view's depth keys span 2^27 ulps or more: results invalid */
 
 typedef void *fnx_stream_t; /* hipStream_t */
 
@@ -268,6 +269,13 @@ int fnx_set_deep_kernel(int mode);
  * by the backward.  Forward and backward of one render must run under the same setting.  Default 0 (everything written:
  * fnx_geom_layout offsets stay meaningful for tools and tests). */
 int fnx_set_lean_geometry(int on);
+/* The depth sort runs 9-bit passes over keys taken relative to the view's nearest visible splat: three passes order any
+ * view whose depths span less than 2^27 ulps (far / near < ~2^4 at equal exponent ... 2^16 across exponents); the three
+ * kernels of the fourth pass are launched all the same and return at once when it is not needed (~14 us of launches on
+ * the critical path).  1 = the caller has seen (status word 5, bits 24-31 = bit length of the span; the Python layer
+ * keeps the maximum) that three passes suffice: the fourth is not launched, and a view that would have needed it sets
+ * FNX_ERR_SORT_SPAN in its status word instead of rendering.  Default 0. */
+int fnx_set_sort_narrow(int on);
 int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, int M, const float *background, int width,
                                        int height, const float *means3D, const float *shs,
                                        const float *colors_precomp, const float *scales, float scale_modifier,

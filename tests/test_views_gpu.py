@@ -365,3 +365,54 @@ def test_lean_geometry_gives_the_same_render_and_gradients():
         assert torch.equal(a, b)
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_sort_narrow_mode_is_exact_when_it_applies_and_reports_when_it_does_not():
+    """fnx_set_sort_narrow(1): without the fourth depth-sort pass a scene whose depth keys span < 2^27 ulps renders bit
+    for bit as before and reports its span; a scene spanning more raises FNX_ERR_SORT_SPAN at check_status()."""
+    import math
+    import torch
+    from fluidnexus_amd import _lib, rasterizer, synthetic as S
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews
+    W = H = 96
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    tan = math.tan(0.4)
+
+    def render(g, cams):
+        rs = [GaussianRasterizationSettings(H, W, tan, tan, bg, 1.0, c.world_view_transform, c.full_proj_transform, 0,
+                                            c.camera_center, False) for c in cams]
+        P = g["means3D"].shape[0]
+        out = GaussianRasterizerViews(rs)(means3D=g["means3D"], means2D=torch.zeros(len(cams), P, 3, device="cuda"),
+                                          opacities=g["opacities"], colors_precomp=g["colors"], scales=g["scales"],
+                                          rotations=g["rotations"])
+        torch.cuda.synchronize()
+        return out
+
+    rasterizer.set_host_sync(False, 2_000_000)
+    try:
+        near = S.to_torch(S.plume_gaussians(5000, seed=1, channels=3))  # depths 1.5 .. 1.7: ~2^21 ulps
+        cams = S.arc_cameras(2, W, H)
+        rasterizer.max_sort_span_bits = 0
+        ref = render(near, cams)
+        rasterizer.check_status()
+        assert 0 < rasterizer.max_sort_span_bits <= 25
+        rasterizer.set_sort_narrow(True)
+        got = render(near, cams)
+        rasterizer.check_status()
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        gw = S.random_gaussians(3000, seed=2, box=0.3, log_scale=(-4.0, -2.5))
+        gw["means3D"][:50, 2] = -4.0e6  # depths 1.7 .. 2.3 and 4e6: 21 binades apart, > 2^27 ulps of span
+        gw["scales"][:50] = 1.0e5
+        wide = S.to_torch(gw)
+        render(wide, [S.front_camera(W, H)])
+        with pytest.raises(_lib.FnxError) as e:
+            rasterizer.check_status()
+        assert e.value.code == _lib.FNX_ERR_SORT_SPAN
+        rasterizer.set_sort_narrow(False)
+        render(wide, [S.front_camera(W, H)])
+        rasterizer.check_status()
+        assert rasterizer.max_sort_span_bits >= 27
+    finally:
+        rasterizer.set_sort_narrow(False)
+        rasterizer.set_host_sync(True)
