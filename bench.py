@@ -45,9 +45,9 @@ import torch.distributed as dist  # noqa: E402
 
 SIZE = 512
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 4 * 1.0  # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
+VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 2 * 1.0  # 1024 SIMD-32s x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 VALU_MEASURED_WAVE_INSTR = 933e9                   # tools/micro/pk_rate.hip on this chip
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 CONFIGS = {
     2: dict(workload="BASELINE configs[1]: ScalarReal single frame, 100k grey Gaussians (gm_fluid / render_fluid / ch1), "
@@ -592,10 +592,10 @@ def main():
     # appearance + shape gradients), 0 = everything (per-view autograd physics)
     bwd_mode = 2 if a.stage == "visual" else (0 if a.unfused_physics else
                                               1 if os.environ.get("FNX_SCREEN_GRAD", "0") == "1" else 3)
-    kname = f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}>"
+    kname = f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {'true' if a.blend_math == 'fast' else 'false'}>"
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
     traffic = valu = None
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG,):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_traffic.json")) as f:
                 t = json.load(f).get("void " + kname)
@@ -626,8 +626,8 @@ def main():
         rate = valu["wave_instructions_per_launch"] / avg_s
         roofline["valu"] = dict(valu, wave_instructions_per_s=rate, frac_of_measured_issue_rate=rate / VALU_MEASURED_WAVE_INSTR,
                                 frac_of_spec_issue_rate=rate / VALU_SPEC_WAVE_INSTR,
-                                spec="1024 SIMDs x 1 wave64 VALU instruction / 4 cycles x 2.4 GHz = 614 G wave-instr/s "
-                                     "(78.6 T lane-FMA/s); measured on this chip 933 G/s (tools/micro/pk_rate.hip)")
+                                spec="1024 SIMD-32s x 1 wave64 VALU instruction / 2 cycles x 2.4 GHz = 1229 G wave-instr/s "
+                                     "(157 TFLOP/s fp32); measured on this chip 933 G/s (tools/micro/pk_rate.hip)")
     nominal_iters = (len(cams) / nominal_views) * a.steps  # weak scaling: N nominal batches per step
     value = nominal_iters / dt
     roofline["iteration_algorithmic"] = {"bytes": int(iter_bytes), "GBps": iter_bytes * a.steps / dt / 1e9,

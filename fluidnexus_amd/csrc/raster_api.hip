@@ -20,7 +20,7 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb, const StaticRef &st, int lean);
+                       const ViewBatch &vb, const StaticRef &st, int lean, float *zero3);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
@@ -217,6 +217,7 @@ struct ProfClass {
     size_t used = 0;
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
+float *g_zero_request = nullptr;  // fnx_request_zero3: zero-filled by the next stage 1 on its way
 int g_sort_narrow = 0;       // the fourth depth-sort pass is not launched (fnx_set_sort_narrow)
 int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
 int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
@@ -334,7 +335,8 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
                            g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st,
-                           (g_lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0);
+                           (g_lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0, g_zero_request);
+    g_zero_request = nullptr;  // one-shot
     }
     {
     ProfScope ps(2, s);
@@ -650,6 +652,10 @@ int fnx_set_blend_math(int mode) {
     return FNX_OK;
 }
 int fnx_get_blend_math(void) { return g_blend_math; }
+int fnx_request_zero3(float *rows3) {
+    g_zero_request = rows3;
+    return FNX_OK;
+}
 int fnx_set_sort_narrow(int on) {
     g_sort_narrow = on ? 1 : 0;
     return FNX_OK;

@@ -134,7 +134,8 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float *__restrict__ depths, float *__restrict__ cov3Ds, float *__restrict__ rgb,
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
-                  float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb, int lean) {
+                  float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb, int lean,
+                  float *__restrict__ zero3) {
     // lean (fnx_set_lean_geometry): the copies of the reference's GeometryState that nothing in this library reads back
     // (means2D, depths, conic_opacity, tiles_touched: the blend records carry the same numbers) are not written, and the
     // world covariance -- the same for every view -- is written by view 0 only (the backward reads it at stride 0)
@@ -147,7 +148,13 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
         const int nb_dyn = (P + 255) / 256;
         if ((int)blockIdx.x >= nb_dyn) {
             const int k = ((int)blockIdx.x - nb_dyn) * 256 + (int)threadIdx.x;
-            if (k < st.P) radii[(size_t)st.id0 + k] = reinterpret_cast<const int *>(st.base + st.stride * vw + st.radii)[k];
+            if (k < st.P) {
+                radii[(size_t)st.id0 + k] = reinterpret_cast<const int *>(st.base + st.stride * vw + st.radii)[k];
+                if (zero3 && vw == 0) {
+                    float *z = zero3 + 3 * ((size_t)st.id0 + k);
+                    z[0] = z[1] = z[2] = 0.f;
+                }
+            }
             return;
         }
     }
@@ -171,6 +178,11 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < P) {
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        if (zero3 && vw == 0) {  // the caller's [P_all, 3] accumulator of the positions-only backward, zeroed on the way
+            zero3[3 * (size_t)idx] = 0.f;
+            zero3[3 * (size_t)idx + 1] = 0.f;
+            zero3[3 * (size_t)idx + 2] = 0.f;
+        }
         radii[idx] = 0;
         if (!lean) tiles_touched[idx] = 0;
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -1282,13 +1294,14 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 int *radii, float2 *means2D, float *depths, float *cov3Ds, float *rgb,
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 uint32_t *key_min_blk, uint2 *rect,
-                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean) {
+                                float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
+                                float *zero3) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean, zero3);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -1297,17 +1310,18 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii,
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
-                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean) {
+                       float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
+                       float *zero3) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3);
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,

@@ -120,6 +120,8 @@ _SCREEN_GRAD = os.environ.get("FNX_SCREEN_GRAD", "0") == "1"
 # Where the physics side branch is enqueued: behind the rasteriser forward (default) or right at its fork point, under
 # the latency-bound head of the iteration (interpolation, preprocess, depth sort, emission)
 _PHYSICS_EARLY = os.environ.get("FNX_PHYSICS_EARLY", "0") == "1"
+# "hook": enqueued between the rasteriser's binning stage and its emit / blend stage, in front of the distance branch
+_PHYSICS_AT_HOOK = os.environ.get("FNX_PHYSICS_EARLY", "0") == "hook"
 
 
 class HotLoop:
@@ -439,15 +441,21 @@ class HotLoop:
         if mine:
             from . import rasterizer
             fork_d, forked_d = torch.cuda.Event(), []
-            if use_dist:
-                rasterizer.set_between_stages_hook(lambda: (fork_d.record(torch.cuda.current_stream()), forked_d.append(1)))
+            if use_dist or _PHYSICS_AT_HOOK:
+                def _hook():
+                    if _PHYSICS_AT_HOOK:
+                        launch_physics()
+                    if use_dist:
+                        fork_d.record(torch.cuda.current_stream())
+                        forked_d.append(1)
+                rasterizer.set_between_stages_hook(_hook)
             try:
                 pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                             GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                             scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
             finally:
                 rasterizer.set_between_stages_hook(None)
-        if not _PHYSICS_EARLY:
+        if not _PHYSICS_EARLY and not (_PHYSICS_AT_HOOK and mine):
             launch_physics()
         if mine:
             if use_dist:

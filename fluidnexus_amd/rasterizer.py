@@ -520,6 +520,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         radii = torch.empty(V, P_all, dtype=torch.int32, device=dev)
         hint = vbatch.depth_hint(Cn)
         hint_ptr = hint.data_ptr() if hint is not None else None
+        # positions-only backward ahead (geometry_only = 3): its accumulator is zero-filled by this forward's per-splat
+        # kernel instead of a fill launch between the image loss and the backward
+        ctx.g_means3D_zeroed = None
+        if _gradient_mode(ctx.needs_input_grad, M) == 3:
+            ctx.g_means3D_zeroed = torch.empty(P_all, 3, dtype=torch.float32, device=dev)
+            _lib.check(lib.fnx_request_zero3(ctx.g_means3D_zeroed.data_ptr()))
         _lib.check(lib.fnx_forward_stage1_views_split(
             Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
             _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
@@ -578,7 +584,10 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         geometry_only = _gradient_mode(need, M)
         if geometry_only == 3 and P != 0:
             # positions only: the blend backward's flush runs the geometry backward itself and adds into this one array
-            g_means3D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+            g_means3D = getattr(ctx, "g_means3D_zeroed", None)  # zero-filled by the forward (one use only)
+            ctx.g_means3D_zeroed = None
+            if g_means3D is None:
+                g_means3D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
             dL = _f32c(grad_out_color)
             args = (Cn, V, P - (sb.P if sb is not None else 0), int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H,
                     means3D.data_ptr(), None, _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),

@@ -269,6 +269,11 @@ int fnx_set_deep_kernel(int mode);
  * by the backward.  Forward and backward of one render must run under the same setting.  Default 0 (everything written:
  * fnx_geom_layout offsets stay meaningful for tools and tests). */
 int fnx_set_lean_geometry(int on);
+/* One-shot: the NEXT fnx_forward_stage1* call on this thread of control also zero-fills rows3[3 * (P_dyn + P_static)]
+ * floats (its per-splat kernel writes the zeros on the way).  For the positions-only backward (geometry_only = 3), whose
+ * dL_dmean3D accumulator must come in zeroed: the fill otherwise is a launch of its own on the critical path between
+ * the image loss and the backward.  NULL cancels. */
+int fnx_request_zero3(float *rows3);
 /* The depth sort runs 9-bit passes over keys taken relative to the view's nearest visible splat: three passes order any
  * view whose depths span less than 2^27 ulps (far / near < ~2^4 at equal exponent ... 2^16 across exponents); the three
  * kernels of the fourth pass are launched all the same and return at once when it is not needed (~14 us of launches on

@@ -4,7 +4,7 @@ default profiles/].  collect_profiles.sh runs it on the GPU box (the raw traces 
 import collections, csv, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ARGS = open(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")).read().strip() if os.path.exists(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")) else ""
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
