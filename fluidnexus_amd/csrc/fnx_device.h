@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define FNX_TILE_X 16  // ch3/cuda_rasterizer/config.h:16
 #define FNX_TILE_Y 16  // ch3/cuda_rasterizer/config.h:17
 #define FNX_TILE_PIX (FNX_TILE_X * FNX_TILE_Y)
@@ -15,9 +17,13 @@
 namespace fnx {
 
 // Slice of a per-view array: `stride_bytes` between consecutive views (see ViewBatch in fnx_state.h).
+// (pointer arithmetic on the pointer itself, not through an integer: a pointer rebuilt from a uintptr_t loses its
+// address space and every access through it becomes a FLAT instruction, which counts against BOTH vmcnt and lgkmcnt --
+// each LDS wait then also drains the global prefetches in flight)
 template <class T>
 __device__ __forceinline__ T *view_at(T *p, size_t stride_bytes, int v) {
-    return (T *)((uintptr_t)p + stride_bytes * (size_t)v);
+    using Byte = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+    return reinterpret_cast<T *>(reinterpret_cast<Byte *>(p) + stride_bytes * (size_t)v);
 }
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations, not for

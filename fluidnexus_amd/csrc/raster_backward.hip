@@ -31,6 +31,20 @@
 #define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
 #endif
 
+#ifdef FNX_EXP_BCLK  // developer timing: per-phase cycles of wave 0 / lane 0 of every workgroup, summed over the launch
+__device__ unsigned long long g_bwd_clock[16];
+extern "C" int fnx_debug_bwd_clock(unsigned long long *host, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_clock), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_clock), sizeof(g_bwd_clock));
+}
+#define FNX_BCLK(i) { const unsigned long long tn = clock64(); if (tid == 0) atomicAdd(&g_bwd_clock[i], tn - t_last); t_last = tn; }
+#else
+#define FNX_BCLK(i)
+#endif
+
 namespace fnx {
 
 // DPP row operations (gfx9 encodings): quad permutes 0xb1 / 0x4e, row_shr:4 / :8 = 0x114 / 0x118, row_ror:8 = 0x128,
@@ -136,7 +150,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     // wave w alone
     __shared__ __attribute__((aligned(16))) uint16_t s_list[16][kListStride];
     __shared__ uint16_t s_mask[256];
-    __shared__ uint32_t s_max[16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_max[16];
     __shared__ uint32_t s_first[kMaxViews + 1];  // ticket of every view's first work item; [n_views] = all items
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -260,15 +274,22 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     fetch_range(cur);
     fetch_ids(cur);
     fetch_records(cur);
-    // state of the tile the workgroup is on (valid while consecutive items stay on it)
-    uint32_t tile_key = 0xFFFFFFFFu;  // view << 16 | tile
-    uint32_t last_contributor = 0;
-    float dL_dpixel[C], total_dot = 0.f, tail_dot = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) dL_dpixel[ch] = 0.f;
-    float4 stt_ahead = make_float4(1.f, 0.f, 0.f, 0.f);  // hand-over record of the next item, if it continues this tile
-    bool stt_ahead_valid = false;
+    // The pixels' inputs of the NEXT item (final T, last contributor, dL/dpixel, the tile's accumulated colour, the
+    // hand-over record in front of its batch) are requested behind the walk of the current one, when the walk's registers
+    // are free, and arrive under the flush: an item then starts without a round trip to memory (~2-3 us of ~20 per item).
+    struct PixelsAhead {
+        bool valid;
+        float T_final;
+        uint32_t last_contributor;
+        float dL[C], total[C];
+        float4 stt;
+    } ahead;
+    ahead.valid = false;
+#ifdef FNX_EXP_BCLK
+    unsigned long long t_last = clock64();
+#endif
     for (uint32_t sidx = 0;; sidx++) {
+        FNX_BCLK(0)  // loop back-edge (flush of the previous item ends here)
         // no barrier here: before the next one (behind the block maxima) an item writes s_max only, and the previous
         // item's last readers of s_max passed two barriers ago
         if (cur.item == kNoItem) break;  // tickets only grow along a workgroup's sequence: nothing behind the queue's end
@@ -304,37 +325,39 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const uint32_t r0 = cur.r0;
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
 
-        const uint32_t key = ((uint32_t)vw << 16) | (uint32_t)tile;
-        const bool same_tile = key == tile_key;
-        tile_key = key;
-        if (!same_tile) {
-            const float T_final = inside ? final_Ts_v[pix_id] : 0.f;
+        float T_final, dL_dpixel[C], total[C];
+        uint32_t last_contributor;
+        float4 stt = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (ahead.valid) {
+            T_final = ahead.T_final;
+            last_contributor = ahead.last_contributor;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                dL_dpixel[ch] = ahead.dL[ch];
+                total[ch] = ahead.total[ch];
+            }
+            stt = ahead.stt;
+        } else {
+            T_final = inside ? final_Ts_v[pix_id] : 0.f;
             last_contributor = inside ? n_contrib_v[pix_id] : 0u;
-            float total[C];
 #pragma unroll
             for (int ch = 0; ch < C; ch++) {
                 dL_dpixel[ch] = inside ? dL_dpixels_v[(size_t)ch * H * W + pix_id] : 0.f;
                 total[ch] = inside ? acc_final_v[(size_t)ch * H * W + pix_id] : 0.f;
             }
-            float bg_dot_dpixel = 0.f;
-            total_dot = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
-                total_dot += total[ch] * dL_dpixel[ch];
-            }
-            tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
+            if (b) stt = bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];  // state in front of the batch, as the forward left it
         }
-        float Tr = 1.0f, pre[C];
+        float bg_dot_dpixel = 0.f, total_dot = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) pre[ch] = 0.f;
-        if (b) {  // state in front of the batch, as the forward left it
-            const float4 stt = (same_tile && stt_ahead_valid) ? stt_ahead : bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
-            Tr = stt.x;
-            pre[0] = stt.y;
-            if (C > 1) pre[C > 1 ? 1 : 0] = stt.z;
-            if (C > 2) pre[C > 2 ? 2 : 0] = stt.w;
+        for (int ch = 0; ch < C; ch++) {
+            bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+            total_dot += total[ch] * dL_dpixel[ch];
         }
+        const float tail_dot = T_final * bg_dot_dpixel;  // the background's share of what lies behind an entry
+        float Tr = b ? stt.x : 1.0f, pre[C];
+        pre[0] = b ? stt.y : 0.f;
+        if (C > 1) pre[C > 1 ? 1 : 0] = b ? stt.z : 0.f;
+        if (C > 2) pre[C > 2 ? 2 : 0] = b ? stt.w : 0.f;
         // Everything the gradient needs from the colour channels is their dot product with dL/dpixel:
         //   sum_ch dL_ch (c_ch T - S_ch / (1 - alpha)) = T (c . dL) - (S . dL) / (1 - alpha),
         //   S . dL = (total . dL) - (prefix . dL), and the prefix's dot product is itself a running sum of
@@ -349,17 +372,27 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
-        if (!same_tile) {  // the block maxima belong to the tile: they stay in LDS while the workgroup stays on it
-            uint32_t m = last_contributor;
-            for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-            if ((lane & 15) == 0) s_max[4 * w + row] = m;
-        }
+        uint32_t m = last_contributor;
+        for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if ((lane & 15) == 0) s_max[4 * w + row] = m;
+        FNX_BCLK(1)  // item head: pixel inputs, block maxima
         // LDS-only barriers in the item loop: the waves exchange nothing through global memory, and a plain
         // __syncthreads() would also wait for the previous item's flush atomics and for the next item's prefetches
         FNX_LOOP_BARRIER();
+        FNX_BCLK(2)  // wait at barrier A
+        // the 16 block maxima in registers (four 16-byte LDS reads instead of 2 x 16 scalar ones)
+        uint32_t bmax[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 m4 = reinterpret_cast<const uint4 *>(s_max)[k];
+            bmax[4 * k] = m4.x;
+            bmax[4 * k + 1] = m4.y;
+            bmax[4 * k + 2] = m4.z;
+            bmax[4 * k + 3] = m4.w;
+        }
         uint32_t qmax = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) qmax = max(qmax, s_max[k]);
+        for (int k = 0; k < 16; k++) qmax = max(qmax, bmax[k]);
         const uint32_t cnt = min(256u, qmax - min(qmax, q0));
 
         // stage entries q = q0 + t (slot t), zero the slot accumulators
@@ -370,7 +403,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             qm = cur.qm;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (q >= s_max[k]) qm &= ~(1u << k);
+                if (q >= bmax[k]) qm &= ~(1u << k);
             s_id[tid] = id;
             if (FAST) {
                 constexpr float kL2e = 1.44269504088896341f;
@@ -396,7 +429,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
             for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
+        FNX_BCLK(3)  // staging writes
         FNX_LOOP_BARRIER();
+        FNX_BCLK(4)  // wait at barrier B
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's four lists
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -412,11 +447,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const uint32_t n_w = max(max(len[0], len[1]), max(len[2], len[3]));  // steps of the wave = its longest list
         const uint16_t *mylist = s_list[4 * w + row];
         fetch_ids(nxt);  // in flight during the walk
-        {   // ... and, if the next item continues this tile, the pixels' record in front of its batch
-            const uint32_t nb_ = nxt.item >> kItemTileBits;
-            stt_ahead_valid = nxt.item != kNoItem && nxt.vw == vw && (nxt.item & kItemTileMask) == (uint32_t)tile && nb_ != 0u;
-            if (stt_ahead_valid) stt_ahead = bstate_all[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
-        }
+        FNX_BCLK(5)  // list build
         // entry q0 + slot lies in front of the pixel's last contributor <=> its LDS offset (16 slot) is below this bound
         const uint32_t lim_off = last_contributor > q0 ? min(last_contributor - q0, 4096u) << 4 : 0u;
         // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
@@ -594,15 +625,52 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #endif
             }
         }
-        fetch_records(nxt);  // in flight while the accumulators are flushed
+        FNX_BCLK(6)  // walk
 #if FNX_BWD_DYNAMIC
+        // the ticket drawn at the top has long arrived; published BEFORE the prefetches below are issued: s_waitcnt counts
+        // in order, so waiting for this atomic's return behind them would drain them all in front of the barrier
         if (tid == 0) s_tk = drawn;
 #endif
+        fetch_records(nxt);  // in flight while the accumulators are flushed
+        ahead.valid = nxt.item != kNoItem;
+        if (ahead.valid) {  // ... and so are the next item's pixels
+            const int nv = nxt.vw, ntile = (int)(nxt.item & kItemTileMask);
+            const uint32_t nb_ = nxt.item >> kItemTileBits;
+            const int npx = (ntile % gx) * FNX_TILE_X + blend_pixel_x(w, lane), npy = (ntile / gx) * FNX_TILE_Y + blend_pixel_y(w, lane);
+            const bool nin = npx < W && npy < H;
+            const uint32_t npix = (uint32_t)W * npy + npx;
+            ahead.T_final = nin ? view_at(final_Ts, vb.img, nv)[npix] : 0.f;
+            ahead.last_contributor = nin ? view_at(n_contrib, vb.img, nv)[npix] : 0u;
+            const float *nacc = view_at(acc_final, vb.img, nv), *ndl = dL_dpixels + (size_t)nv * C * H * W;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                ahead.dL[ch] = nin ? ndl[(size_t)ch * H * W + npix] : 0.f;
+                ahead.total[ch] = nin ? nacc[(size_t)ch * H * W + npix] : 0.f;
+            }
+            ahead.stt = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (nb_) {
+                const float4 *nbs = reinterpret_cast<const float4 *>(
+                    reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
+                ahead.stt = nbs[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
+            }
+        }
         FNX_LOOP_BARRIER();
+        FNX_BCLK(7)  // prefetches + wait at barrier C
 #if FNX_BWD_DYNAMIC
         dyn_next = s_tk;
         fetch_item(ticket_of(sidx + 2), nx2);
 #endif
+        // Flush: the values first, the global atomics last.  vmcnt counts loads, stores and atomics in order, and the
+        // atomics sit in a lane-divergent branch: whatever load is waited for behind them is waited for with vmcnt(0),
+        // i.e. until the atomics have retired (measured: 24 % of an item at the head of the NEXT one).  So every
+        // prefetched register is touched -- waited for -- in front of the atomics, and nothing needs a wait behind them
+        // until the next item's own loads return.
+        constexpr int kFl = kFusedGeom ? 3 : (kMeans ? 2 : 0) + 3 + (kAppearance ? 1 + C : 0);
+        float fl[kFl];
+#pragma unroll
+        for (int k = 0; k < kFl; k++) fl[k] = 0.f;
+        bool do_flush = false;
+        uint32_t fid = 0;
         if ((uint32_t)tid < cnt) {
             const uint32_t id = s_id[tid];
             float a[NV];
@@ -613,6 +681,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 any |= (a[v] != 0.f);
             }
             if (any && FNX_ABLATE != 1) {
+                do_flush = true;
+                fid = id;
                 // moments -> gradients (backward.cu:512-533): dG/d(delta) = -G (a dx + b dy, c dy + b dx), conic terms
                 // -1/2 G (dx^2, dx dy, dy^2), each times dL/dG
                 float4 ra = s_ra[tid];
@@ -624,30 +694,55 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     cc = rd.z;
                     if (kAppearance) a[kAppearance ? kOpac : 0] = a[kAppearance ? kOpac : 0] / rd.w;
                 }
+                const float g0 = kMeans ? -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx : 0.f;
+                const float g1 = kMeans ? -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy : 0.f;
                 if (kFusedGeom) {
                     const float3 mean = make_float3(means3D[3 * (size_t)id], means3D[3 * (size_t)id + 1], means3D[3 * (size_t)id + 2]);
                     float gv[3], dv[6];
                     geom_backward_view(mean, view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)id, viewmatrix + 16 * vw,
                                        projmatrix + 16 * vw, vb.focal_x[vw], vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw],
-                                       -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2],
-                                       -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx,
-                                       -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy, gv, dv);
+                                       -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, dv);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)id + k], gv[k]);
+                    for (int k = 0; k < 3; k++) fl[k < kFl ? k : 0] = gv[k];
                 } else {
+                    int o = 0;
                     if (kMeans) {
-                        FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)id + 0], -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx);
-                        FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)id + 1], -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy);
+                        fl[o++ < kFl ? o - 1 : 0] = g0;
+                        fl[o++ < kFl ? o - 1 : 0] = g1;
                     }
-                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 0], -0.5f * a[kConic]);
-                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 1], -0.5f * a[kConic + 1]);
-                    FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)id + 3], -0.5f * a[kConic + 2]);
-                }
-                if (kAppearance) {
-                    FNX_FLUSH_ADD(&dL_dopacity_v[id], a[kAppearance ? kOpac : 0]);
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic];
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 1];
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 2];
+                    if (kAppearance) {
+                        fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kOpac : 0];
 #pragma unroll
-                    for (int ch = 0; ch < C; ch++)
-                        FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)id * C + ch], a[kAppearance ? kCol + ch : 0]);
+                        for (int ch = 0; ch < C; ch++) fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kCol + ch : 0];
+                    }
+                }
+            }
+        }
+        asm volatile("" ::"v"(nxt.id), "v"(nxt.qm), "v"(nxt.ra.x), "v"(nxt.ra.y), "v"(nxt.ra.z), "v"(nxt.ra.w), "v"(nxt.rbx),
+                     "v"(nxt.rby), "v"(nxt.rcz), "v"(nxt.rcw), "v"(nxt.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                     "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
+                     "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
+                     "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nx2.item));
+        if (do_flush) {
+            if (kFusedGeom) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)fid + k], fl[k < kFl ? k : 0]);
+            } else {
+                int o = 0;
+                if (kMeans) {
+                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
+                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
+                }
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 3], fl[o++ < kFl ? o - 1 : 0]);
+                if (kAppearance) {
+                    FNX_FLUSH_ADD(&dL_dopacity_v[fid], fl[o++ < kFl ? o - 1 : 0]);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)fid * C + ch], fl[o++ < kFl ? o - 1 : 0]);
                 }
             }
         }
