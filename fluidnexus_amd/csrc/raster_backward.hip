@@ -240,6 +240,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     // consecutive items (chunk c of workgroup b: items (c grid + b) kChunk ...), so most of its items continue the tile of
     // the one before: the pixels' state (final T, last contributor, dL/dpixel, what lies behind the whole list) then
     // stays in registers, and the record in front of the next batch is prefetched under the walk.
+#ifndef FNX_EARLY_GATHER
+#define FNX_EARLY_GATHER 1
+#endif
 #ifndef FNX_BWD_DYNAMIC
 #define FNX_BWD_DYNAMIC 1
 #endif
@@ -296,8 +299,16 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const int vw = cur.vw;
         Fetched nx2;
 #if FNX_BWD_DYNAMIC
+        // The ticket for the item after next.  Written as an instruction, not as atomicAdd(): the compiler turns a
+        // uniform atomic add into a wave-aggregated one whose result it reads back at once (v_readfirstlane), i.e. with
+        // s_waitcnt vmcnt(0) HERE -- at the head of every item, behind the previous item's flush atomics (24 % of an
+        // item).  The returned value is only needed behind the walk; the wait for it is spelled out there.
         uint32_t drawn = 0;
-        if (tid == 0) drawn = 2u * gridDim.x + atomicAdd(const_cast<uint32_t *>(header) + HDR_BWD_TICKET, 1u);
+        if (tid == 0) {
+            uint32_t *tk = const_cast<uint32_t *>(header) + HDR_BWD_TICKET;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(tk), "v"(one) : "memory");
+        }
 #else
         fetch_item(ticket_of(sidx + 2), nx2);
 #endif
@@ -629,7 +640,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #if FNX_BWD_DYNAMIC
         // the ticket drawn at the top has long arrived; published BEFORE the prefetches below are issued: s_waitcnt counts
         // in order, so waiting for this atomic's return behind them would drain them all in front of the barrier
-        if (tid == 0) s_tk = drawn;
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not track the asm's return value
+            s_tk = 2u * gridDim.x + drawn;
+        }
 #endif
         fetch_records(nxt);  // in flight while the accumulators are flushed
         ahead.valid = nxt.item != kNoItem;
@@ -652,6 +666,19 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float4 *nbs = reinterpret_cast<const float4 *>(
                     reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
                 ahead.stt = nbs[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
+            }
+        }
+        // positions-only mode: the flush needs the splat's mean and world covariance; requested here, in front of the
+        // barrier (the waves wait for the slowest walk anyway), instead of as a round trip inside the flush
+        float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kFusedGeom && FNX_EARLY_GATHER && (uint32_t)tid < cnt) {
+            const uint32_t gid = s_id[tid];
+            if (gid < grad_limit) {
+                const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
+#pragma unroll
+                for (int k = 0; k < 3; k++) gmean[k] = means3D[3 * (size_t)gid + k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) gcov[k] = cv[k];
             }
         }
         FNX_LOOP_BARRIER();
@@ -697,9 +724,16 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float g0 = kMeans ? -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx : 0.f;
                 const float g1 = kMeans ? -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy : 0.f;
                 if (kFusedGeom) {
-                    const float3 mean = make_float3(means3D[3 * (size_t)id], means3D[3 * (size_t)id + 1], means3D[3 * (size_t)id + 2]);
+                    if (!FNX_EARLY_GATHER) {
+                        const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)id;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) gmean[k] = means3D[3 * (size_t)id + k];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) gcov[k] = cv[k];
+                    }
+                    const float3 mean = make_float3(gmean[0], gmean[1], gmean[2]);
                     float gv[3], dv[6];
-                    geom_backward_view(mean, view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)id, viewmatrix + 16 * vw,
+                    geom_backward_view(mean, gcov, viewmatrix + 16 * vw,
                                        projmatrix + 16 * vw, vb.focal_x[vw], vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw],
                                        -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, dv);
 #pragma unroll
