@@ -14,7 +14,8 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_physical_stage", "fnx_adam_step", "fnx_pbf_predict", "fnx_pbf_neighbor_counts", "fnx_pbf_project",
            "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
            "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials",
-           "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum")
+           "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum", "fnx_adam_step_grid",
+           "fnx_visual_interp_forward_cells_vel")
 
 
 def physics():
@@ -50,6 +51,11 @@ def physics():
     lib.fnx_visual_interp_forward_cells.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p]
     lib.fnx_visual_interp_forward_cells_div.restype = i
     lib.fnx_visual_interp_forward_cells_div.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p, f, p]
+    lib.fnx_visual_interp_forward_cells_vel.restype = i
+    lib.fnx_visual_interp_forward_cells_vel.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p, f, i, p]
+    lib.fnx_adam_step_grid.restype = i
+    lib.fnx_adam_step_grid.argtypes = [p, i, p, f, p, f, p, f, f, p, p, p, f, C.c_double, C.c_double, f, p, p, f, p,
+                                       f, p, p, f, p]
     lib.fnx_grid_cell_items_bytes.restype = C.c_size_t
     lib.fnx_grid_cell_items_bytes.argtypes = [i]
     lib.fnx_grid_cell_items.restype = i

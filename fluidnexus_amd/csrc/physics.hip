@@ -102,11 +102,11 @@ grid_count_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t
 // critical path of every iteration, before the first neighbour search): up to eight 4096-bucket chunks (coalesced
 // uint4 per thread) are loaded at once and scanned side by side, so the workgroup synchronises twice per 32768
 // buckets instead of twice per 4096, and the 16 wave totals are scanned with shuffles.
-__global__ void __launch_bounds__(1024)
-grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
-                 uint32_t *__restrict__ cursor) {
-    constexpr int K = 8;
-    __shared__ uint32_t s_wave[K][16];
+constexpr int kScanChunks = 8;
+__device__ __forceinline__ void grid_scan_block(uint32_t M, const uint32_t *__restrict__ count,
+                                                uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                                uint32_t (*s_wave)[16]) {
+    constexpr int K = kScanChunks;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < M; base += K * 4096u) {  // M is a power of two >= 4096
@@ -156,6 +156,13 @@ grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__res
         __syncthreads();  // s_wave is rewritten by the next round
     }
     if (tid == 0) start[M] = carry;
+}
+
+__global__ void __launch_bounds__(1024)
+grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
+                 uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_wave[kScanChunks][16];
+    grid_scan_block(M, count, start, cursor, s_wave);
 }
 
 __global__ void __launch_bounds__(256)
@@ -636,6 +643,79 @@ adam_step_kernel(float *__restrict__ x, int n, const float *__restrict__ g0, flo
             *arrived = 0;
         }
     }
+}
+
+// fnx_adam_step_grid, first launch: the same step, one thread per PARTICLE (three consecutive floats), which then counts
+// the particle into its bucket of the hash grid over the updated x * scale; the workgroup that arrives last also scans
+// the bucket counts (grid_scan_block) -- Adam, zero-fill, count and scan of the per-iteration grid build in one launch.
+// `count` is all zero on entry (the second launch leaves it so).
+__global__ void __launch_bounds__(1024)
+adam_count_scan_kernel(float *__restrict__ x, int N, const float *__restrict__ g0, float s0,
+                       const float *__restrict__ g1, float s1, const float *__restrict__ g2, float s2, float inv_batch,
+                       float *__restrict__ m, float *__restrict__ v, float *__restrict__ step, float lr, float b1,
+                       float b2, float omb1, float omb2, float eps, float *__restrict__ grad_out,
+                       float *__restrict__ scaled_out, float scale, unsigned int *__restrict__ arrived, float inv_cell,
+                       uint32_t M, uint32_t *__restrict__ count, uint32_t *__restrict__ start,
+                       uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_wave[kScanChunks][16];
+    __shared__ uint32_t s_last;
+    const int p = blockIdx.x * 1024 + threadIdx.x;
+    const float t = step[0] + 1.0f;
+    if (p < N) {
+        const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+        const float step_size = lr / bc1;
+        float sx[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = 3 * p + k;
+            float g = 0.f;
+            if (g0) g = g + g0[i] * s0;
+            if (g1) g = g + g1[i] * s1;
+            if (g2) g = g + g2[i] * s2;
+            g = g * inv_batch;
+            if (grad_out) grad_out[i] = g;
+            const float mi = m[i] + omb1 * (g - m[i]);
+            const float vi = b2 * v[i] + omb2 * g * g;
+            m[i] = mi;
+            v[i] = vi;
+            const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+            const float xn = x[i] - step_size * (mi / denom);
+            x[i] = xn;
+            sx[k] = xn * scale;
+            scaled_out[i] = sx[k];
+        }
+        atomicAdd(&count[cell_hash(cell_of(sx[0], sx[1], sx[2], inv_cell), M - 1)], 1u);
+    }
+    __syncthreads();  // every thread has read step[0] and issued its count
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (!(t < 0.5f) && atomicAdd(arrived, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        step[0] = t;
+        *arrived = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' counts (L2 atomics) before the loads below
+    grid_scan_block(M, count, start, cursor, s_wave);
+}
+
+// second launch: every particle takes its slot (position + id, and its velocity (x - prev) / secs for the
+// hidden -> visual interpolation), and the bucket counts are cleared for the next step
+__global__ void __launch_bounds__(256)
+grid_fill_velocity_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t M,
+                          const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, float4 *__restrict__ rec,
+                          const float *__restrict__ prev, float secs, float4 *__restrict__ u,
+                          uint32_t *__restrict__ count) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    for (uint32_t k = gid; k < M; k += gridDim.x * 256u) count[k] = 0u;
+    if (gid >= (uint32_t)N) return;
+    const float x = xyz[3 * gid], y = xyz[3 * gid + 1], z = xyz[3 * gid + 2];
+    const uint32_t h = cell_hash(cell_of(x, y, z, inv_cell), M - 1);
+    const uint32_t slot = start[h] + atomicAdd(&cursor[h], 1u);
+    rec[slot] = make_float4(x, y, z, __uint_as_float(gid));
+    if (prev) u[slot] = make_float4((x - prev[3 * gid]) / secs, (y - prev[3 * gid + 1]) / secs, (z - prev[3 * gid + 2]) / secs, 0.f);
 }
 
 // Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
@@ -1354,6 +1434,26 @@ int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, f
     return hip_check("adam_step");
 }
 
+int fnx_adam_step_grid(float *x, int N, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
+                       float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1_d,
+                       double beta2_d, float eps, float *grad_out, float *scaled_out, float scale, unsigned int *arrived,
+                       float cell, char *grid, const float *prev, float secs, fnx_stream_t stream) {
+    const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
+    if (N <= 0 || !x || !exp_avg || !exp_avg_sq || !step || !arrived || !(g0 || g1 || g2) || !scaled_out || !grid ||
+        cell <= 0.f || (prev && !(secs != 0.f)))
+        return fail(FNX_ERR_INVALID_ARG, "adam_step_grid: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    GridView g = carve(grid, N);
+    const float inv = 1.0f / cell;
+    hipLaunchKernelGGL(adam_count_scan_kernel, dim3((N + 1023) / 1024), dim3(1024), 0, s, x, N, g0, s0, g1, s1, g2, s2,
+                       inv_batch, exp_avg, exp_avg_sq, step, lr, beta1, beta2, (float)(1.0 - (double)beta1_d),
+                       (float)(1.0 - (double)beta2_d), eps, grad_out, scaled_out, scale, arrived, inv, g.M, g.count,
+                       g.start, g.cursor);
+    hipLaunchKernelGGL(grid_fill_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scaled_out, N, inv, g.M, g.start,
+                       g.cursor, g.rec, prev, secs, g.aux0, g.count);
+    return hip_check("adam_step_grid");
+}
+
 int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
                               float H, float secs, float eps, const char *hidden_grid, float *out, float *sum_w,
                               float *wvel, fnx_stream_t stream) {
@@ -1394,13 +1494,21 @@ int fnx_visual_interp_forward_cells_div(const float *visual, int V, const float 
                                         float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
                                         const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,
                                         float divisor, fnx_stream_t stream) {
+    return fnx_visual_interp_forward_cells_vel(visual, V, hidden, hidden_prev, N, H, secs, eps, hidden_grid, visual_grid,
+                                               visual_items, out, sum_w, wvel, out_div, divisor, 0, stream);
+}
+
+int fnx_visual_interp_forward_cells_vel(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                        float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                        const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,
+                                        float divisor, int velocity_ready, fnx_stream_t stream) {
     if (V == 0) return FNX_OK;
     if (V < 0 || N < 0 || !visual || !hidden_grid || !visual_grid || !visual_items || !out || !sum_w || !wvel ||
         (N > 0 && (!hidden || !hidden_prev)))
         return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward_cells: bad argument");
     GridView g = carve(const_cast<char *>(hidden_grid), N);
     GridView gv = carve(const_cast<char *>(visual_grid), V);
-    if (N > 0)
+    if (N > 0 && !velocity_ready)
         hipLaunchKernelGGL(slot_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec, N,
                            hidden_prev, secs, g.aux0);
     // one-wave workgroups that stride over the items; 20 of them fit a CU (8 KiB of LDS each)

@@ -297,11 +297,25 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
             }
     }
     __syncthreads();
-    for (int y = threadIdx.x; y < gy; y += 256) {  // running sum along the row
-        uint32_t run = 0;
-        for (int x = 0; x < gx; x++) {
-            run += s_hist[y * gx + x];
-            s_hist[y * gx + x] = run;
+    {  // running sum along every tile row: a half-wave (rows of <= 32 tiles: two rows per wave at a time) or a wave per
+       // row, 32 / 64 tiles per step with a shuffle scan (one thread per row walked the row through LDS serially)
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int seg = gx <= 32 ? 32 : 64, rows_at_once = 64 / seg;
+        const int sl = lane & (seg - 1), sub = lane / seg;
+        for (int y0 = w * rows_at_once; y0 < gy; y0 += 4 * rows_at_once) {
+            const int y = y0 + sub;
+            uint32_t carry = 0;
+            for (int x0 = 0; x0 < gx; x0 += seg) {
+                const int x = x0 + sl;
+                const bool in = y < gy && x < gx;
+                uint32_t v = in ? s_hist[y * gx + x] : 0u;
+                for (int off = 1; off < seg; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)v, off, seg);
+                    if (sl >= off) v += t;
+                }
+                if (in) s_hist[y * gx + x] = v + carry;
+                carry += (uint32_t)__shfl((int)v, seg - 1, seg);
+            }
         }
     }
     __syncthreads();

@@ -366,6 +366,26 @@ __device__ __forceinline__ int xcd_tile(int bid, int T) {
     return base + k;
 }
 
+// Inclusive prefix sum over the 1024 threads of a workgroup: shuffles inside the waves, the 16 wave totals through
+// LDS (two barriers; a Hillis-Steele scan through LDS takes twenty).  s_wave: 16 words, reusable after the call returns
+// (the trailing barrier).
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *s_wave) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) before += (k < w) ? s_wave[k] : 0u;
+    __syncthreads();
+    return inc + before;
+}
+
 // K2: per-tile counts -> [start,end) ranges (empty tiles keep (0,0) like the reference's memset,
 // rasterizer_impl.cu:292), total instance count -> header.  One 1024-thread block.  It also lays out the
 // emission work items of the view (raster_binning.hip): per rank block, 1..kEmitBands bands of tile rows
@@ -378,7 +398,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
                  const StaticRef st, const uint32_t *__restrict__ sort_ctl) {
     constexpr int kDeepSorted = 1024;
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_deep_n;
     __shared__ uint2 s_deep[kDeepSorted];  // (depth hint, tile) of the deep tiles
     if (threadIdx.x == 0) s_deep_n = 0;
@@ -400,16 +420,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
     const int b = tid * per, e = min(T, b + per);
     uint32_t sum = 0;
     for (int i = b; i < e; i++) sum += tile_count[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
+    uint32_t run = block_scan_1024(sum, s_wave) - sum;  // exclusive prefix of this thread's chunk (the barrier inside orders s_deep_n = 0)
     for (int i = b; i < e; i++) {
         const uint32_t cd = tile_count[i];
         const uint32_t s0 = st_starts ? st_starts[i] : 0u, cs = st_starts ? st_starts[i + 1] - s0 : 0u;
@@ -452,16 +463,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         const uint32_t nd = s_deep_n;
         uint32_t mine = 0;
         for (int k = b; k < e; k++) mine += tile_deep[xcd_tile(k, T)] ? 0u : 1u;
-        __syncthreads();
-        s_part[tid] = mine;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
-        }
-        uint32_t at = nd + s_part[tid] - mine;
+        uint32_t at = nd + block_scan_1024(mine, s_wave) - mine;
         for (int k = b; k < e; k++) {
             const int t = xcd_tile(k, T);
             if (!tile_deep[t]) tile_order[at++] = (uint32_t)t;
@@ -488,15 +490,8 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         const uint32_t inst = blk_total[i];
         if (inst) items += (uint32_t)max(1, min(min(kEmitBands, gy), (int)((inst + kEmitBandTarget - 1u) / kEmitBandTarget)));
     }
-    s_part[tid] = items;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t at = s_part[tid] - items;
+    const uint32_t items_inc = block_scan_1024(items, s_wave);
+    uint32_t at = items_inc - items;
     for (int i = bb; i < be; i++) {
         const uint32_t inst = blk_total[i];
         if (!inst) continue;  // a block without instances emits nothing
@@ -504,7 +499,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         for (uint32_t j = 0; j < nbands; j++) emit_items[at++] = emit_item_pack((uint32_t)i, j, nbands);
     }
     if (tid == 1023) {
-        view_at(emit_ctl, geom_stride, blockIdx.y)[EMIT_CTL_ITEMS] = s_part[1023];
+        view_at(emit_ctl, geom_stride, blockIdx.y)[EMIT_CTL_ITEMS] = items_inc;
         if (blockIdx.y == 0) emit_ctl[EMIT_CTL_TICKET] = 0u;  // one ticket counter for all views (view 0's word)
     }
 }

@@ -67,6 +67,7 @@ class GaussianModel:
         self._grad_cache_used = False
         self._state_memos = {}
         self.defer_visual_backward = False  # opt-in: see flush_deferred_gradients
+        self.fuse_step_grid = True  # fused_step_current also builds the next iteration's hidden-particle grid
         self.fit_color = self.fit_opacity = self.fit_scales = self.fit_rotation = True
         self.p0 = None  # setup_constants (train_physical_particle.py:488 reads / re-assigns it between frames)
         self._velocity_nn = self._velocity_nn_grad = None  # cleared by the entry script after a frame (tpp:477-478)
@@ -975,10 +976,21 @@ class GaussianModel:
         buf = getattr(self, "_est_scaled", None)
         if buf is None or buf[1].shape != est.shape or buf[1].device != est.device:
             buf = (None, torch.empty_like(est.detach()))
-        physics.adam_step(est, self.optimizer, terms, batch_size, scaled_out=buf[1], scale=self.scale_factor)
+        # ... and the hash grid over them (cell = H) with the per-slot velocities of the hidden -> visual interpolation:
+        # what the next iteration starts with (get_visual_xyz_from_nn), built by the step's own two launches
+        grid = None
+        if self.fuse_step_grid and est.dim() == 2 and est.shape[0] > 0 and est.shape[1] == 3:
+            grid = getattr(self, "_step_grid", None)
+            if grid is None or grid.N != est.shape[0] or grid.blob.device != est.device or grid.cell != float(self.H):
+                grid = self._step_grid = physics.HashGrid(buf[1], self.H, build=False, zeroed=True)
+        physics.adam_step(est, self.optimizer, terms, batch_size, scaled_out=buf[1], scale=self.scale_factor, grid=grid,
+                          prev=self._xyz if grid is not None else None, secs=self._secs)
         est.grad = None
         self.invalidate_caches()
-        self._est_scaled = ((id(est), est._version), buf[1])
+        key = (id(est), est._version)
+        self._est_scaled = (key, buf[1])
+        if grid is not None:
+            self._grid_cache["est"] = (key, grid)
 
     def set_batch_gradient_current(self, batch_size):
         self.flush_deferred_gradients()

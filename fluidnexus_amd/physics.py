@@ -26,12 +26,14 @@ def _req(t: torch.Tensor) -> torch.Tensor:
 class HashGrid:
     """Opaque uniform hash grid over a point cloud (cell edge = H)."""
 
-    def __init__(self, xyz: torch.Tensor, cell: float, build: bool = True):
+    def __init__(self, xyz: torch.Tensor, cell: float, build: bool = True, zeroed: bool = False):
         lib = PL.physics()
         xyz = _req(xyz.detach())
         self.N = xyz.shape[0]
         self.cell = float(cell)
-        self.blob = torch.empty(lib.fnx_grid_bytes(self.N), dtype=torch.uint8, device=xyz.device)
+        # zeroed=True: storage for fnx_adam_step_grid (its contract: bucket counts zero on entry, left zero)
+        self.blob = (torch.zeros if zeroed else torch.empty)(lib.fnx_grid_bytes(self.N), dtype=torch.uint8, device=xyz.device)
+        self.velocity_of = None  # (hidden_prev.data_ptr(), secs) whose per-slot velocities the payload holds, if any
         if build:  # build=False: storage only, a fused entry point fills it (fnx_physical_stage)
             PL.check(lib.fnx_grid_build(xyz.data_ptr() if self.N else None, self.N, self.cell, self.blob.data_ptr(),
                                         _stream()))
@@ -102,11 +104,14 @@ class _VisualFromHidden(torch.autograd.Function):
             # memo["out_div"] = (tensor [V,3], divisor): the caller also wants out / divisor (the rasteriser's units),
             # written by the same kernel; memo["out_div_done"] tells it that it was
             div = memo.get("out_div") if memo is not None else None
-            PL.check(lib.fnx_visual_interp_forward_cells_div(
+            # the fused optimiser step (fnx_adam_step_grid) leaves the per-slot velocities next to the grid it builds
+            ready = hgrid.velocity_of == (hidden_prev.data_ptr(), float(secs))
+            PL.check(lib.fnx_visual_interp_forward_cells_vel(
                 visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N, H, secs, eps, hgrid.blob.data_ptr(),
                 visual_grid.blob.data_ptr(), visual_grid.cell_items().data_ptr(), out.data_ptr(), sum_w.data_ptr(),
                 wvel.data_ptr(), div[0].data_ptr() if div is not None else None, float(div[1]) if div is not None else 1.0,
-                _stream()))
+                1 if ready else 0, _stream()))
+            hgrid.velocity_of = (hidden_prev.data_ptr(), float(secs))  # slot_velocity has run for this grid now
             if memo is not None:
                 memo.update(out=out, sum_w=sum_w, wvel=wvel, out_div_done=div is not None)
         if visual_grid is None:
@@ -290,12 +295,16 @@ def distance_loss(positions, threshold):
     return _DistanceLoss.apply(positions, float(threshold))
 
 
-def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=None, scale=1.0):
+def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=None, scale=1.0, grid=None, prev=None,
+              secs=None):
     """Gradient mean + Adam step of `param` in one kernel (fnx_adam_step), on the state of `optimizer`
     (a torch.optim.Adam with amsgrad = False, weight_decay = 0; the hyper-parameters are those of the group that
     holds `param`).
     terms: up to three (tensor, scale) pairs; the gradient is sum(tensor * scale) / batch_size.
-    scaled_out: optional tensor like `param` that receives the updated param * scale."""
+    scaled_out: optional tensor like `param` that receives the updated param * scale.
+    grid: a HashGrid(..., build=False, zeroed=True) over [N,3] points: the step also builds it over scaled_out
+    (fnx_adam_step_grid: two launches for step + grid build); prev / secs: leave the per-slot velocities
+    (scaled_out - prev) / secs in the grid for the hidden -> visual interpolation."""
     lib = PL.physics()
     group = next((g for g in optimizer.param_groups if any(q is param for q in g["params"])), None)
     if group is None:
@@ -320,6 +329,19 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=Non
     x = param.data
     assert x.is_contiguous() and x.dtype == torch.float32
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    if grid is not None:
+        if x.dim() != 2 or x.shape[1] != 3 or grid.N != x.shape[0] or scaled_out is None or x.shape[0] == 0:
+            raise RuntimeError("adam_step(grid=...): param must be [N,3] with N = grid.N > 0, and scaled_out given")
+        if prev is not None:
+            prev = _req(prev.detach())
+        PL.check(lib.fnx_adam_step_grid(x.data_ptr(), x.shape[0], ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
+                                        1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                        st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2),
+                                        float(group["eps"]), ptr(grad_out), ptr(scaled_out), float(scale),
+                                        st["fnx_arrived"].data_ptr(), float(grid.cell), grid.blob.data_ptr(), ptr(prev),
+                                        float(secs) if secs is not None else 1.0, _stream()))
+        grid.velocity_of = (prev.data_ptr(), float(secs)) if prev is not None else None
+        return
     PL.check(lib.fnx_adam_step(x.data_ptr(), x.numel(), ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
                                1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),

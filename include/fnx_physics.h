@@ -176,6 +176,27 @@ int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, f
                   float eps, float *grad_out, float *scaled_out, float scale, unsigned int *arrived,
                   fnx_stream_t stream);
 
+/* fnx_adam_step on N particles (x, exp_avg, exp_avg_sq, g*, grad_out, scaled_out: [N,3]) FOLLOWED BY the build of the
+ * hash grid (cell edge `cell`) over the updated positions in simulation units, scaled_out = x * scale -- what the next
+ * iteration's neighbour searches start with (gm_dynamics.py:1256, 1269-1294, 1453-1498) -- in two launches instead of
+ * six: [step + bucket count + scan by the last workgroup to arrive] and [slot fill + per-slot velocity + clearing of the
+ * counts].  Same arithmetic per element as fnx_adam_step; the grid equals fnx_grid_build(scaled_out, N, cell, grid) up to
+ * the order of the records inside a bucket (both fill by atomic cursor).  `prev` [N,3] (optional): the per-slot velocity
+ * (scaled_out - prev) / secs is left in the grid's payload, where fnx_visual_interp_forward_cells_vel(...,
+ * velocity_ready = 1, ...) finds it.
+ * CONTRACT: the bucket counts of `grid` (a blob of fnx_grid_bytes(N)) are zero on entry -- a zero-filled blob the first
+ * time; the call leaves them zero.  fnx_grid_build on the same blob breaks that (zero the blob again before reuse). */
+int fnx_adam_step_grid(float *x, int N, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,
+                       float inv_batch, float *exp_avg, float *exp_avg_sq, float *step, float lr, double beta1,
+                       double beta2, float eps, float *grad_out, float *scaled_out, float scale, unsigned int *arrived,
+                       float cell, char *grid, const float *prev, float secs, fnx_stream_t stream);
+/* fnx_visual_interp_forward_cells_div; velocity_ready != 0: the hidden grid's per-slot velocities were left by
+ * fnx_adam_step_grid for the same hidden_prev / secs (the slot-velocity launch is skipped). */
+int fnx_visual_interp_forward_cells_vel(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                        float H, float secs, float eps, const char *hidden_grid, const char *visual_grid,
+                                        const char *visual_items, float *out, float *sum_w, float *wvel, float *out_div,
+                                        float divisor, int velocity_ready, fnx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

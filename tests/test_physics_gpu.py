@@ -186,6 +186,68 @@ def test_adam_step_scaled_output_and_step_count():
             assert torch.equal(scaled, p.detach() * 100.0)
 
 
+def test_adam_step_grid_equals_step_then_grid_build():
+    """fnx_adam_step_grid (step + hash grid over the stepped positions in two launches) against fnx_adam_step followed
+    by fnx_grid_build: parameters, optimiser state and scaled positions bit-equal; the grid's bucket ranges equal, its
+    records equal as sets per bucket (both fill by atomic cursor); per-slot velocities = (x - prev) / secs of the record
+    in the slot; bucket counts left zero (the call's contract) over repeated steps; N below and above one workgroup."""
+    from fluidnexus_amd import physics
+    from fluidnexus_amd import _physics_lib as PL
+    lib = PL.physics()
+    dev = torch.device("cuda")
+    H, secs, scale = 2.0, 1.0 / 30.0, 100.0
+    for N in (300, 24_800):
+        gen = torch.Generator(device="cpu").manual_seed(N)
+        x0 = (torch.rand(N, 3, generator=gen) * 0.5).to(dev)
+        prev = (x0 * scale + torch.randn(N, 3, generator=gen).to(dev) * 0.1).contiguous()
+        pa, pb = torch.nn.Parameter(x0.clone()), torch.nn.Parameter(x0.clone())
+        oa = torch.optim.Adam([{"params": [pa], "lr": 1e-3, "name": "a"}], capturable=True, lr=0.0, eps=1e-15)
+        ob = torch.optim.Adam([{"params": [pb], "lr": 1e-3, "name": "b"}], capturable=True, lr=0.0, eps=1e-15)
+        sa, sb = torch.empty_like(x0), torch.empty_like(x0)
+        grid = physics.HashGrid(sb, H, build=False, zeroed=True)
+        for it in range(4):
+            g1 = torch.randn(N, 3, generator=gen).to(dev)
+            g2 = torch.randn(N, 3, generator=gen).to(dev)
+            physics.adam_step(pa, oa, [(g1, 2.0), (g2, 0.5)], 5, scaled_out=sa, scale=scale)
+            physics.adam_step(pb, ob, [(g1, 2.0), (g2, 0.5)], 5, scaled_out=sb, scale=scale, grid=grid, prev=prev, secs=secs)
+            torch.cuda.synchronize()
+            assert torch.equal(pa.detach(), pb.detach()) and torch.equal(sa, sb)
+            for k in ("exp_avg", "exp_avg_sq", "step"):
+                assert torch.equal(oa.state[pa][k], ob.state[pb][k])
+            ref = physics.HashGrid(sa, H)
+            torch.cuda.synchronize()
+            # blob layout (physics.hip carve): header 64 | count M | start M + 1 | cursor M | rec N x 16 | aux0 N x 16 | ...
+            M = 4096
+            while M < N:
+                M *= 2
+            al = lambda o: (o + 255) // 256 * 256  # noqa: E731
+
+            def parts(blob):
+                base = (blob.data_ptr() + 255) // 256 * 256 - blob.data_ptr()
+                b = blob[base:]
+                o_count = al(64)
+                o_start = al(o_count + 4 * M)
+                o_cursor = al(o_start + 4 * (M + 1))
+                o_rec = al(o_cursor + 4 * M)
+                o_aux = al(o_rec + 16 * N)
+                u32 = lambda o, n: b[o:o + 4 * n].view(torch.int32).cpu().numpy().astype(np.int64)  # noqa: E731
+                f4 = lambda o: b[o:o + 16 * N].view(torch.float32).view(N, 4).cpu().numpy()  # noqa: E731
+                return u32(o_count, M), u32(o_start, M + 1), f4(o_rec), f4(o_aux)
+            cnt, start, rec, vel = parts(grid.blob)
+            _, start_r, rec_r, _ = parts(ref.blob)
+            assert not cnt.any(), "bucket counts must be left zero"
+            assert np.array_equal(start, start_r) and start[-1] == N
+            ids, ids_r = rec[:, 3].view(np.uint32), rec_r[:, 3].view(np.uint32)
+            bucket = np.repeat(np.arange(M), np.diff(start))
+            order, order_r = np.lexsort((ids, bucket)), np.lexsort((ids_r, bucket))
+            assert np.array_equal(ids[order], ids_r[order_r]) and np.array_equal(rec[order], rec_r[order_r])
+            xs, pv = sb.cpu().numpy(), prev.cpu().numpy()
+            assert np.array_equal(rec[:, :3], xs[ids])
+            want = (xs[ids] - pv[ids]) / np.float32(secs)
+            assert np.allclose(vel[:, :3], want, rtol=2e-7, atol=0)
+        assert grid.velocity_of == (prev.data_ptr(), float(secs))
+
+
 def test_visual_forward_cells_equals_particle_walk():
     """The cell-by-cell visual interpolation (work items of the visual grid, hidden neighbourhood staged in LDS)
     against the particle-centric kernel: same neighbour sets, sums equal up to fp32 order.  Sparse rim cells,
