@@ -851,7 +851,10 @@ constexpr int kCellCand = 256;  // staged candidates per round (2 x 4 KiB of LDS
 // Work items of a grid for cell-by-cell kernels: every non-empty bucket becomes ceil(count / 64) items
 // (first slot, slots), so that one wave handles particles of ONE cell (up to hash collisions) -- a wave that
 // takes 64 consecutive slots instead spans up to dozens of sparse cells at the rim of the plume and becomes the
-// tail of the launch.  Item order is arbitrary (atomic append); nothing depends on it.
+// tail of the launch.  A bucket is cut into full items of 64 and ONE remainder: the interpolation kernel spreads a
+// short item's candidates over the idle lanes (64 / pow2ceil(slots) lanes per particle), so a remainder of 16 costs a
+// quarter of a full item, where two balanced halves of 40 would cost two.  Item order is arbitrary (atomic append);
+// nothing depends on it.
 __global__ void __launch_bounds__(256)
 grid_cell_items_kernel(uint32_t M, const uint32_t *__restrict__ start, uint2 *__restrict__ items,
                        uint32_t *__restrict__ n_items) {
@@ -859,11 +862,11 @@ grid_cell_items_kernel(uint32_t M, const uint32_t *__restrict__ start, uint2 *__
     if (h >= M) return;
     const uint32_t s0 = start[h], cnt = start[h + 1] - s0;
     if (cnt == 0) return;
-    const uint32_t k = (cnt + 63) / 64, each = (cnt + k - 1) / k;
+    const uint32_t k = (cnt + 63) / 64;
     const uint32_t at = atomicAdd(n_items, k);
     for (uint32_t j = 0; j < k; j++) {
-        const uint32_t b = j * each;
-        items[at + j] = make_uint2(s0 + b, min(each, cnt - b));
+        const uint32_t b = j * 64u;
+        items[at + j] = make_uint2(s0 + b, min(64u, cnt - b));
     }
 }
 
@@ -880,8 +883,14 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
     const uint32_t n_work = *n_items;
     for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
         const uint2 it = items[item];
-        const bool valid = (uint32_t)lane < it.y;
-        const float4 me = vrec[valid ? it.x + lane : it.x];
+        // a short item spreads over the wave: `spread` lanes per particle, lane = slice * group + particle, and a
+        // particle's lanes take every spread-th candidate each (their partial sums are added at the end)
+        uint32_t group = 64;  // pow2ceil(slots), at least 1
+        while ((group >> 1) >= it.y && group > 1) group >>= 1;
+        const uint32_t spread = 64u / group;
+        const uint32_t pi = (uint32_t)lane & (group - 1u), slice = (uint32_t)lane / group;
+        const bool valid = pi < it.y;
+        const float4 me = vrec[valid ? it.x + pi : it.x];
         const int3 c = cell_of(me.x, me.y, me.z, inv_cell);
         float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
         unsigned long long todo = __ballot(valid);
@@ -918,14 +927,17 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                 }
                 __syncthreads();  // one wave per workgroup: orders the LDS writes before the reads
                 if (mine) {
+                    const uint32_t steps = (n + spread - 1u) / spread;
 #pragma unroll 4
-                    for (uint32_t i = 0; i < n; i++) {
-                        const float4 q = s_pos[i];
-                        const float4 uj = s_vel[i];
+                    for (uint32_t k = 0; k < steps; k++) {
+                        const uint32_t i = k * spread + slice;
+                        const uint32_t ic = min(i, n - 1u);
+                        const float4 q = s_pos[ic];
+                        const float4 uj = s_vel[ic];
                         const float ex = me.x - q.x, ey = me.y - q.y, ez = me.z - q.z;
                         const float r2 = ex * ex + ey * ey + ez * ez;
                         const float t = H2 - r2;
-                        const float w = r2 < H2 ? term1 * (t * t * t) : 0.0f;  // +0 terms leave the sums unchanged
+                        const float w = (r2 < H2 && i < n) ? term1 * (t * t * t) : 0.0f;  // +0 terms leave the sums unchanged
                         S += w;
                         ax += uj.x * w;
                         ay += uj.y * w;
@@ -936,7 +948,13 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
             }
             todo &= ~__ballot(mine);
         }
-        if (valid) {
+        for (uint32_t step = group; step < 64u; step <<= 1) {  // add the slices' partial sums (wave-uniform trip count)
+            S += __shfl_xor(S, (int)step);
+            ax += __shfl_xor(ax, (int)step);
+            ay += __shfl_xor(ay, (int)step);
+            az += __shfl_xor(az, (int)step);
+        }
+        if (valid && slice == 0) {
             const uint32_t v = __float_as_uint(me.w);
             sum_w[v] = S;
             wvel[3 * v + 0] = ax;

@@ -199,6 +199,10 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
     const int shift = pass * kSortBits;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int base = blockIdx.x * kSortChunk + w * 256;
+    // the digit totals and this chunk's column prefixes are requested up front, with the keys (one round trip, not two)
+    static_assert(kSortRadix == 512, "two digits per thread");
+    const uint32_t t0 = digit_total[2 * tid], t1 = digit_total[2 * tid + 1];
+    const uint2 rel = *reinterpret_cast<const uint2 *>(hist_rel + (size_t)blockIdx.x * kSortRadix + 2 * tid);
 #pragma unroll
     for (int k = 0; k < 4; k++)
         for (int d = tid; d < kSortRadix; d += 256) s_cnt[k][d] = 0;
@@ -219,8 +223,6 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
     // thread = digit pair (2 tid, 2 tid + 1): global base of the digit (exclusive scan of the digit totals) +
     // keys of this digit in earlier chunks + earlier waves of this chunk
     {
-        static_assert(kSortRadix == 512, "two digits per thread");
-        const uint32_t t0 = digit_total[2 * tid], t1 = digit_total[2 * tid + 1];
         const uint32_t tot = t0 + t1;
         uint32_t inc = tot;
         for (int off = 1; off < 64; off <<= 1) {
@@ -231,7 +233,6 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
         __syncthreads();
         uint32_t dbase = inc - tot;
         for (int k = 0; k < w; k++) dbase += s_wtot[k];
-        const uint2 rel = *reinterpret_cast<const uint2 *>(hist_rel + (size_t)blockIdx.x * kSortRadix + 2 * tid);
         uint32_t run0 = dbase + rel.x, run1 = dbase + t0 + rel.y;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -383,9 +384,9 @@ struct InstanceWalk {
     }
     __device__ __forceinline__ int tile(int gx) const { return y * gx + x; }
     // position on instance number `target` (0-based over the whole block, window-restricted counts)
-    __device__ __forceinline__ void seek(const uint32_t *s_pre, const uint2 *s_rect, int l_lo, uint32_t target, int gx,
-                                         int tw0, int tw1, bool whole) {
-        int lo = l_lo, hi = kSplatBlock - 1;  // first splat whose inclusive prefix exceeds target
+    __device__ __forceinline__ void seek(const uint32_t *s_pre, const uint2 *s_rect, int l_lo, int l_hi, uint32_t target,
+                                         int gx, int tw0, int tw1, bool whole) {
+        int lo = l_lo, hi = l_hi;  // first splat whose inclusive prefix exceeds target (it lies in [l_lo, l_hi])
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (s_pre[mid] > target) hi = mid; else lo = mid + 1;
@@ -592,9 +593,13 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         for (int l0 = 0; done < total;) {
             // sub-batch [l0, l1): at most kEmitSpan ranks and kEmitStage instances
             int lo = l0, hi = min(kSplatBlock, l0 + kEmitSpan);  // l1 = first l with s_pre[l] - done > kEmitStage
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_pre[mid] - done > (uint32_t)kEmitStage) hi = mid; else lo = mid + 1;
+            if (s_pre[hi - 1] - done <= (uint32_t)kEmitStage) {
+                lo = hi;  // the usual case: the rank span ends the sub-batch, not the instance count (one LDS read, no search)
+            } else {
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pre[mid] - done > (uint32_t)kEmitStage) hi = mid; else lo = mid + 1;
+                }
             }
             const int l1 = lo;
             const uint32_t batch = s_pre[l1 - 1] - done;
@@ -609,7 +614,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
             if (batch > 0) {
                 InstanceWalk wk;
                 wk.load(s_rect, l0);
-                if (i0 < i1) wk.seek(s_pre, s_rect, l0, done + i0, gx, tw0, tw1, whole);
+                if (i0 < i1) wk.seek(s_pre, s_rect, l0, l1 - 1, done + i0, gx, tw0, tw1, whole);
 #pragma unroll
                 for (int k = 0; k < kEmitChunk; k++) {
                     ent[k] = 0xFFFFFFFFu;
@@ -633,8 +638,12 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
                     if (ent[k] != 0xFFFFFFFFu && FNX_EXP_EMIT != 11) {
                         const uint32_t t = ent[k] >> 10, l = ent[k] & 1023u, b = l - (uint32_t)l0;
                         const uint32_t bw = b >> 5;
-                        uint32_t r = __popc(s_mask[bw * TW + t] & ((1u << (b & 31u)) - 1u));
-                        for (uint32_t q = 0; q < bw; q++) r += __popc(s_mask[q * TW + t]);
+                        uint32_t r = 0;
+#pragma unroll
+                        for (uint32_t q = 0; q < (uint32_t)kEmitMaskWords; q++) {  // independent reads (words past nw are 0)
+                            const uint32_t m = s_mask[q * TW + t];
+                            r += q < bw ? __popc(m) : (q == bw ? __popc(m & ((1u << (b & 31u)) - 1u)) : 0u);
+                        }
                         if (FNX_EXP_EMIT == 12) {  // no scattered store
                             if (r == 0x7FFFFFFFu) point_list[0] = s_id[l];
                         } else if (FNX_EXP_EMIT == 13) {  // store, but lane-contiguous
@@ -649,12 +658,15 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
                 FNX_PH(5)
                 for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
                     uint32_t n = 0;
-                    for (int q = 0; q < nw; q++) n += __popc(s_mask[q * TW + i]);
+#pragma unroll
+                    for (int q = 0; q < kEmitMaskWords; q++) n += __popc(s_mask[q * TW + i]);  // words past nw are 0
                     if (n) {
                         s_cur[i] += n;
-                        for (int q = 0; q < nw; q++) s_mask[q * TW + i] = 0u;
+#pragma unroll
+                        for (int q = 0; q < kEmitMaskWords; q++) s_mask[q * TW + i] = 0u;
                     }
                 }
+                (void)nw;
                 lds_barrier();
                 FNX_PH(6)
             }
