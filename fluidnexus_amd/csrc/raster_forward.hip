@@ -2,6 +2,7 @@
 //
 // This file: per-splat preprocess (+ per-(splat block, tile) instance counts and depth-sort keys)
 // and the front-to-back blend.  The binning between them lives in raster_binning.hip.
+#include <mutex>
 #include "fnx_device.h"
 #include "fnx_state.h"
 
@@ -1343,16 +1344,43 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     // throughput when thousands of other tiles wait for those compute units: deep = 1 (auto) uses it up to two views.
     const int use_deep = (fast && depth_hint && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
     // the two kernels touch disjoint tiles: the deep one runs on a helper stream beside the per-tile kernel
-    static hipStream_t helper = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // (one helper per caller stream and device: two renders on two streams -- the 3-channel and the 1-channel one of a
+    // dual-channel iteration -- may be in flight, or being captured into two branches of a graph, at the same time)
+    struct Helper {
+        hipStream_t of;
+        int device;
+        hipStream_t stream;
+        hipEvent_t ev_fork, ev_join;
+    };
+    static Helper helpers[32];
+    static int n_helpers = 0;
+    static std::mutex helpers_mu;
+    hipStream_t helper = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t sd = s;
     if (use_deep) {
         const int n_cu = device_cu_count();
-        if (!helper) {
-            if (hipStreamCreateWithFlags(&helper, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-                helper = nullptr;
+        {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lock(helpers_mu);
+            int at = -1;
+            for (int i = 0; i < n_helpers; i++)
+                if (helpers[i].of == s && helpers[i].device == dev) at = i;
+            if (at < 0 && n_helpers < 32) {
+                Helper h{s, dev, nullptr, nullptr, nullptr};
+                if (hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) == hipSuccess) {
+                    at = n_helpers;
+                    helpers[n_helpers++] = h;
+                }
+            }
+            if (at >= 0) {
+                helper = helpers[at].stream;
+                ev_fork = helpers[at].ev_fork;
+                ev_join = helpers[at].ev_join;
+            }
         }
         if (helper && hipEventRecord(ev_fork, s) == hipSuccess && hipStreamWaitEvent(helper, ev_fork, 0) == hipSuccess)
             sd = helper;
