@@ -77,8 +77,9 @@ def test_deep_first_tile_order_changes_nothing(channels, split):
     finally:
         rasterizer.set_deep_variant(True, 1024)
     first, second, third = outs
-    assert all(v["header"][5] == 0 for v in first["views"])  # no history: the plain XCD-aware tile order
-    deep = [v["header"][5] for v in second["views"]]
+    # header word 5 = deep-tile count | bit length of the depth-key span << 24 (fnx_state.h HDR_DEEP_COUNT)
+    assert all(v["header"][5] & 0xFFFFFF == 0 for v in first["views"])  # no history: the plain XCD-aware tile order
+    deep = [v["header"][5] & 0xFFFFFF for v in second["views"]]
     assert min(deep) > 0 and max(deep) < T, deep           # history: the plume tiles are scheduled first
     assert int(first["hint"].max()) > 1000                 # ... because they went this deep
     for other in (second, third):
