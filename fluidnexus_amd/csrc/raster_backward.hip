@@ -474,11 +474,14 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 uint32_t jw[2];
                 jw[0] = reinterpret_cast<const uint32_t *>(mylist + i0)[0];
                 jw[1] = reinterpret_cast<const uint32_t *>(mylist + i0)[1];
-                float val[NV][4];
+                // per entry of the step only (w, dx, dy[, alpha T]) stay in registers; the NV values of an entry are formed
+                // from them block by block right in front of their fold (all NV x 4 at once spill with colour sums)
+                // (kLazy; with five values they are formed inside the loop: moving them behind it cost 5 % of the walk)
+                constexpr bool kLazy = NV > 5;
+                constexpr int kBlockA = NV <= 5 ? NV : 4, kBlockB = NV - kBlockA;
+                float w_[4], dx_[4], dy_[4], dc_[kAppearance ? 4 : 1];
+                float valA[kBlockA][4];
                 bool any_emit = false;
-#ifndef FNX_BWD_LOAD_SPLIT
-#define FNX_BWD_LOAD_SPLIT 0  // 1: records of two entries at a time in registers instead of four
-#endif
                 float4 ra[4], rb[4];
                 float2 rc[4];
 #pragma unroll
@@ -512,63 +515,86 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     const float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
                     // G dL/dG = G o dL/dalpha = (o G) dL/dalpha: the clamp at 0.99 has no mask in the reference (A.10)
                     const float wgt = (emits ? e : 0.0f) * dL_dalpha;
-                    const float wx = wgt * dx, wy = wgt * dy;
-                    if (kMeans) {
-                        val[0][k] = wx;
-                        val[kMeans ? 1 : 0][k] = wy;
-                    }
-                    val[kConic][k] = wx * dx;
-                    val[kConic + 1][k] = wx * dy;
-                    val[kConic + 2][k] = wy * dy;
-                    if (kAppearance) {
-                        val[kAppearance ? kOpac : 0][k] = wgt;  // sum of (o G) dL/dalpha; the flush divides by o
-                        const float dchannel_dcolor = emits ? aT : 0.0f;
+                    if constexpr (kLazy) {
+                        w_[k] = wgt;
+                        dx_[k] = dx;
+                        dy_[k] = dy;
+                        if (kAppearance) dc_[kAppearance ? k : 0] = emits ? aT : 0.0f;
+                    } else {
+                        const float wx = wgt * dx, wy = wgt * dy;
+                        if (kMeans) {
+                            valA[0][k] = wx;
+                            valA[kMeans ? 1 : 0][k] = wy;
+                        }
+                        valA[kConic][k] = wx * dx;
+                        valA[kConic + 1][k] = wx * dy;
+                        valA[kConic + 2][k] = wy * dy;
+                        if (kAppearance) {
+                            valA[kAppearance ? kOpac : 0][k] = wgt;
+                            const float dchannel_dcolor = emits ? aT : 0.0f;
 #pragma unroll
-                        for (int ch = 0; ch < C; ch++) val[kAppearance ? kCol + ch : 0][k] = dchannel_dcolor * dL_dpixel[ch];
+                            for (int ch = 0; ch < C; ch++) valA[kAppearance && kCol + ch < kBlockA ? kCol + ch : 0][k] = dchannel_dcolor * dL_dpixel[ch];
+                        }
                     }
                     any_emit |= emits;
                 }
-#if FNX_ABLATE == 2
-                { float sink = 0.f; _Pragma("unroll") for (int v = 0; v < NV; v++) sink += val[v][0] + val[v][1] + val[v][2] + val[v][3]; asm volatile("" ::"v"(sink)); }
-#else
-                if (__ballot(any_emit) != 0ull) {
+                if (FNX_ABLATE != 2 && __ballot(any_emit) != 0ull) {
                     // this quad's target: the slot of entry vq of the step (row-uniform), the NULL slot's sums are dropped
                     const uint32_t o01 = jw[0], o23 = jw[1];
                     const uint32_t osel = (vq & 2) ? o23 : o01;
                     const uint32_t slot = ((osel >> (16 * (vq & 1))) & 0xFFFFu) >> 4;
-                    const bool writer = (lane & 3) == 0 && slot < 256u;
-#ifndef FNX_FOLD_ASM
-#define FNX_FOLD_ASM 1  // 0: the folds written with builtins (selects + DPP), as the exact path has them
-#endif
-#if FNX_FOLD_ASM
-                    fold_rows_asm<NV>(val);  // hand-scheduled DPP butterflies (fnx_fold_asm.h)
-                    (void)writer;
-                    // the four lanes of a quad hold the same totals: lane k of the quad adds value 4 j + k, so NV values
-                    // take ceil(NV / 4) LDS atomics instead of NV (the walk is bound by LDS cycles, not by instructions)
                     const int kq = lane & 3;
+                    // value v of entry k: [w dx, w dy,] w dx dx, w dx dy, w dy dy [, w (the flush divides by o), alpha T dL_ch]
+                    auto value = [&](int v, int k) -> float {
+                        if (kMeans && v == 0) return w_[k] * dx_[k];
+                        if (kMeans && v == 1) return w_[k] * dy_[k];
+                        if (v == kConic) return (w_[k] * dx_[k]) * dx_[k];
+                        if (v == kConic + 1) return (w_[k] * dx_[k]) * dy_[k];
+                        if (v == kConic + 2) return (w_[k] * dy_[k]) * dy_[k];
+                        if (kAppearance && v == kOpac) return w_[k];
+                        return kAppearance ? dc_[kAppearance ? k : 0] * dL_dpixel[v - kCol < C && v >= kCol ? v - kCol : 0] : 0.0f;
+                    };
+                    // hand-scheduled DPP butterflies (fnx_fold_asm.h) over blocks of values; afterwards the four lanes of a
+                    // quad hold the same totals and lane k of the quad adds value 4 j + k: ceil(n / 4) LDS atomics per block
+                    // of n values instead of n (the walk is bound by LDS cycles, not by instructions)
+                    {
+                        float (&val)[kBlockA][4] = valA;
+                        if constexpr (kLazy) {
 #pragma unroll
-                    for (int j = 0; j < (NV + 3) / 4; j++) {
-                        float t = val[4 * j][0];
-                        if (4 * j + 1 < NV) t = kq == 1 ? val[4 * j + 1 < NV ? 4 * j + 1 : 0][0] : t;
-                        if (4 * j + 2 < NV) t = kq == 2 ? val[4 * j + 2 < NV ? 4 * j + 2 : 0][0] : t;
-                        if (4 * j + 3 < NV) t = kq == 3 ? val[4 * j + 3 < NV ? 4 * j + 3 : 0][0] : t;
-                        const int v = 4 * j + kq;
-                        if (slot < 256u && v < NV) atomicAdd(&s_acc[0][0] + v * kAccStride + (slot & 255u), t);
-                    }
-#else
+                            for (int v = 0; v < kBlockA; v++)
 #pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        const float a0 = val[v][0], b0 = val[v][1], c0 = val[v][2], d0 = val[v][3];
-                        const float s01 = (hi8 ? b0 : a0) + FNX_DPP((hi8 ? a0 : b0), 0x128, 0xf);
-                        const float s23 = (hi8 ? d0 : c0) + FNX_DPP((hi8 ? c0 : d0), 0x128, 0xf);
-                        float t = (hi4 ? s23 : s01) + FNX_DPP((hi4 ? s01 : s23), 0x141, 0xf);
-                        t += FNX_DPP(t, 0xb1, 0xf);
-                        t += FNX_DPP(t, 0x4e, 0xf);
-                        if (writer) atomicAdd(&s_acc[v][slot & 255u], t);
+                                for (int k = 0; k < 4; k++) val[v][k] = value(v, k);
+                        }
+                        fold_rows_asm<kBlockA>(val);
+#pragma unroll
+                        for (int j = 0; j < (kBlockA + 3) / 4; j++) {
+                            float t = val[4 * j][0];
+                            if (4 * j + 1 < kBlockA) t = kq == 1 ? val[4 * j + 1 < kBlockA ? 4 * j + 1 : 0][0] : t;
+                            if (4 * j + 2 < kBlockA) t = kq == 2 ? val[4 * j + 2 < kBlockA ? 4 * j + 2 : 0][0] : t;
+                            if (4 * j + 3 < kBlockA) t = kq == 3 ? val[4 * j + 3 < kBlockA ? 4 * j + 3 : 0][0] : t;
+                            const int v = 4 * j + kq;
+                            if (slot < 256u && v < kBlockA) atomicAdd(&s_acc[0][0] + v * kAccStride + (slot & 255u), t);
+                        }
                     }
-#endif
+                    if constexpr (kBlockB > 0) {
+                        float val[kBlockB][4];
+#pragma unroll
+                        for (int v = 0; v < kBlockB; v++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) val[v][k] = value(kBlockA + v, k);
+                        fold_rows_asm<kBlockB>(val);
+#pragma unroll
+                        for (int j = 0; j < (kBlockB + 3) / 4; j++) {
+                            float t = val[4 * j][0];
+                            if (4 * j + 1 < kBlockB) t = kq == 1 ? val[4 * j + 1 < kBlockB ? 4 * j + 1 : 0][0] : t;
+                            if (4 * j + 2 < kBlockB) t = kq == 2 ? val[4 * j + 2 < kBlockB ? 4 * j + 2 : 0][0] : t;
+                            if (4 * j + 3 < kBlockB) t = kq == 3 ? val[4 * j + 3 < kBlockB ? 4 * j + 3 : 0][0] : t;
+                            const int v = 4 * j + kq;
+                            if (slot < 256u && v < kBlockB)
+                                atomicAdd(&s_acc[0][0] + (kBlockA + v) * kAccStride + (slot & 255u), t);
+                        }
+                    }
                 }
-#endif
             }
         } else
         for (uint32_t i0 = 0; i0 < (FNX_ABLATE == 3 ? 0u : n_w); i0 += kGroup) {
