@@ -617,8 +617,9 @@ def main():
                 "kernel": kname, "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "views_per_launch": views_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (every instance read once) against "
-                        "HBM peak, as the contract defines them; the kernel is VALU-issue-bound: its lists saturate "
-                        "early and sit in L2, see hbm_traffic_frac and valu",
+                        "HBM peak, as the contract defines them; the kernel is bound by the compute units' VALU and LDS "
+                        "pipelines (profiles/<tag>_sq_counters.md: VALU busy ~65 % of the cycles incl. the quarter-rate "
+                        "exp / rcp; <tag>_lds_counters.md: LDS ~55 %), not by HBM: see hbm_traffic_frac and valu",
                 "traffic_source": traffic["source"] if traffic else None,
                 "hbm_traffic_frac": (traffic["bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_s > 0 else None,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}

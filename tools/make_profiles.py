@@ -103,4 +103,21 @@ with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
 json.dump({"_note": "per-launch averages of the SQ counter pass (see the .md of the same name)",
            **{k: dict(c, us=sum(dur[k]) / len(dur[k])) for k, c in sq.items() if "fnx::" in k or ("kernel" in k and "at::" not in k)}},
           open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
+# 6. LDS pipeline
+if os.path.exists(os.path.join(SRC, "pmc_lds", "r_counter_collection.csv")):
+    lds, dur = pmc("pmc_lds"), durations("pmc_lds")
+    with open(os.path.join(DST, f"{TAG}_lds_counters.md"), "w") as f:
+        f.write(f"# LDS pipeline per launch ({TAG}): rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES "
+                f"SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --kernel-trace -- python bench.py {ARGS} --no-cpu-baseline --no-graph --steps 5 "
+                "--warmup 2\n\n`lds busy %` = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (cycles the compute units' LDS pipelines "
+                "work, of the cycles the units are busy); `conflict %` = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
+                "`cycles / instr` = SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS.\n\n"
+                "| kernel | us | LDS instr M | lds busy % | conflict % | cycles / instr |\n|---|---|---|---|---|---|\n")
+        for k, c in sorted(lds.items(), key=lambda kv: -sum(dur[kv[0]]) / max(len(dur[kv[0]]), 1)):
+            us = sum(dur[k]) / len(dur[k])
+            if us < 8 or "at::" in k or "rocclr" in k or not c.get("SQ_INSTS_LDS"):
+                continue
+            act = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+            f.write(f"| `{k[:60]}` | {us:.1f} | {c['SQ_INSTS_LDS'] / 1e6:.2f} | {100 * act / max(c.get('SQ_BUSY_CU_CYCLES', 1), 1):.0f} | "
+                    f"{100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(act, 1):.0f} | {act / c['SQ_INSTS_LDS']:.1f} |\n")
 print("wrote", sorted(os.listdir(DST)))
