@@ -15,9 +15,13 @@ loop = Hn.HotLoop(gm, cams, image_loss="fused", fused_physics=True, defer_visual
                   batched_views=True, fused_step=True, cfg=dict(Hn.SMOKE))
 loop.make_targets()
 rasterizer.set_host_sync(False)
+rasterizer.set_blend_math("exact" if "exact" in sys.argv[2:] else "fast")  # the bench's settings
+rasterizer.set_lean_geometry(True)
 for _ in range(3):
     loop.iteration()
 rasterizer.check_status()
+if 0 < rasterizer.max_sort_span_bits <= 25:  # the bench's margin: two bits below what three passes order
+    rasterizer.set_sort_narrow(True)
 loop.log_scalars = True
 loop.iteration()
 first = dict(loop.last)
