@@ -77,6 +77,10 @@ def raster():
         raise RuntimeError(
             f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
             "fluidnexus_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64: loaded AFTER this library it would be a second HIP runtime in the process
+    # (this library bound to the system one), and device memory of one runtime is unknown to the other ("no
+    # ROCm-capable device is detected").  Loading torch first makes the dependency resolve to the runtime torch uses.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     p, i, f = c_void_p, c_int, c_float
     lib.fnx_abi_version.restype = i

@@ -26,6 +26,10 @@ def physics():
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
                            "fluidnexus_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64: loaded AFTER this library it would be a second HIP runtime in the process
+    # (this library bound to the system one), and device memory of one runtime is unknown to the other ("no
+    # ROCm-capable device is detected").  Loading torch first makes the dependency resolve to the runtime torch uses.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     p, i, f = C.c_void_p, C.c_int, C.c_float
     lib.fnx_physics_abi_version.restype = i
