@@ -186,6 +186,13 @@ __device__ __forceinline__ float wave_sum63(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
     return v;
 }
+// Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
+__device__ __forceinline__ float oct_sum7(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xa, false));
+    return v;
+}
 // Sum over a 16-lane row; the total lands in lane 15 of the row.
 __device__ __forceinline__ float row_sum15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
@@ -242,16 +249,24 @@ density_forward_kernel(const float *__restrict__ xyz, int N, const float *__rest
     if (sub == 15 && i < N) p_ratio[i] = acc / imass[i] / p0;
 }
 
+// Lanes per particle in the two kernels of the fused stage (a hidden bucket holds ~7 particles: with 16 lanes per
+// particle more than half of the lanes idle at every bucket and the per-bucket overhead is paid twice as often)
+#ifndef FNX_DENSITY_LANES
+#define FNX_DENSITY_LANES 8
+#endif
+constexpr int kDL = FNX_DENSITY_LANES, kDPerWg = 256 / kDL;
+__device__ __forceinline__ float density_lane_sum(float v) { return kDL == 16 ? row_sum15(v) : oct_sum7(v); }
+
 __global__ void __launch_bounds__(256)
 density_backward_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                         float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
                         const float4 *__restrict__ rec, const float *__restrict__ g, float gscale,
                         float *__restrict__ dL_dxyz) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int i = blockIdx.x * kDPerWg + (threadIdx.x / kDL), sub = threadIdx.x & (kDL - 1);
     const int ii = min(i, N - 1);
     const float Gi = (g[ii] * gscale) / imass[ii] / p0;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+    for_neighbours<kDL>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
                        [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
                            const float Gj = (g[j] * gscale) / imass[j] / p0;
                            const float t = H2 - r2;
@@ -261,10 +276,10 @@ density_backward_kernel(const float *__restrict__ xyz, int N, const float *__res
                            ay += k * ey;
                            az += k * ez;
                        });
-    ax = row_sum15(ax);
-    ay = row_sum15(ay);
-    az = row_sum15(az);
-    if (sub == 15 && i < N) {
+    ax = density_lane_sum(ax);
+    ay = density_lane_sum(ay);
+    az = density_lane_sum(az);
+    if (sub == kDL - 1 && i < N) {
         dL_dxyz[3 * i + 0] = ax;
         dL_dxyz[3 * i + 1] = ay;
         dL_dxyz[3 * i + 2] = az;
@@ -304,23 +319,22 @@ stage_points_kernel(const float *__restrict__ x_nn, int N, float sf, const float
     if (threadIdx.x == 0) terms[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-// d_i = p_ratio_i - 1 and per-workgroup sums of d_i^2 -> term[blockIdx.x].  16 lanes per particle (as
-// density_forward_kernel).
+// d_i = p_ratio_i - 1 and per-workgroup sums of d_i^2 -> term[blockIdx.x].  kDL lanes per particle.
 __global__ void __launch_bounds__(256)
 density_term_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                     float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
                     const float4 *__restrict__ rec, float *__restrict__ d_out, float *__restrict__ term) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int i = blockIdx.x * kDPerWg + (threadIdx.x / kDL), sub = threadIdx.x & (kDL - 1);
     const int ii = min(i, N - 1);
     float acc = 0.f;
-    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+    for_neighbours<kDL>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
                        [&](uint32_t, uint32_t, float, float, float, float r2) {
                            const float t = H2 - r2;
                            acc += term1 * (t * t * t);
                        });
-    acc = row_sum15(acc);
+    acc = density_lane_sum(acc);
     float d2 = 0.f;
-    if (sub == 15 && i < N) {
+    if (sub == kDL - 1 && i < N) {
         const float d = acc / imass[i] / p0 - 1.0f;
         d_out[i] = d;
         d2 = d * d;
@@ -341,7 +355,7 @@ stage_combine_kernel(int N, float sf, const float *__restrict__ x, const float *
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0) {  // add up the per-workgroup partial sums (fixed order), weighted loss
         __shared__ float s_r[256];
-        const int nb_e = (N + 255) / 256, nb_d = (N + 15) / 16;
+        const int nb_e = (N + 255) / 256, nb_d = (N + kDPerWg - 1) / kDPerWg;
         const float *part[3] = {partials, partials + nb_e, partials + nb_e + nb_d};
         const int cnt[3] = {nb_e, (lam_g > 0.f) ? nb_d : 0, (lam_n > 0.f) ? nb_d : 0};
         float tot[3];
@@ -718,13 +732,6 @@ grid_fill_velocity_kernel(const float *__restrict__ xyz, int N, float inv_cell, 
     if (prev) u[slot] = make_float4((x - prev[3 * gid]) / secs, (y - prev[3 * gid + 1]) / secs, (z - prev[3 * gid + 2]) / secs, 0.f);
 }
 
-// Sum over 8 consecutive lanes; totals land in lanes 7 and 15 of each 16-lane row.
-__device__ __forceinline__ float oct_sum7(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xa, false));
-    return v;
-}
 // Sum over 32 consecutive lanes; totals land in lanes 31 and 63.
 __device__ __forceinline__ float half_sum31(float v) {
     v = row_sum15(v);
@@ -1292,7 +1299,7 @@ int fnx_density_backward(const float *xyz, int N, const float *imass, float H, f
     if (N < 0 || !xyz || !imass || !grid || !dL_dp_ratio || !dL_dxyz)
         return fail(FNX_ERR_INVALID_ARG, "density_backward: bad argument");
     GridView g = carve(const_cast<char *>(grid), N);
-    hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N,
+    hipLaunchKernelGGL(density_backward_kernel, dim3((N + kDPerWg - 1) / kDPerWg), dim3(256), 0, (hipStream_t)stream, xyz, N,
                        imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, 1.0f, dL_dxyz);
     return hip_check("density_backward");
 }
@@ -1307,7 +1314,7 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
     hipStream_t s = (hipStream_t)stream;
     float *x = scratch, *xg = scratch + 3 * (size_t)N, *d1 = scratch + 6 * (size_t)N, *d2 = d1 + N;
     float *dx_est = d2 + N, *dg = dx_est + 3 * (size_t)N;
-    const int nb_e = (N + 255) / 256, nb_d = (N + 15) / 16;
+    const int nb_e = (N + 255) / 256, nb_d = (N + kDPerWg - 1) / kDPerWg;
     float *part_e = dg + 3 * (size_t)N, *part_g = part_e + nb_e, *part_n = part_g + nb_d;  // total <= 15 N + 64 floats
     hipLaunchKernelGGL(stage_points_kernel, dim3(nb_e), dim3(256), 0, s, x_nn, N, scale_factor, x_est, x_prev,
                        buoyancy, force, buoyancy_max_y, secs, x, xg, part_e);
@@ -1316,17 +1323,17 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
         if (build_est_grid)
             if (int rc = fnx_grid_build(x, N, H, est_grid, stream)) return rc;
         GridView g = carve(est_grid, N);
-        hipLaunchKernelGGL(density_term_kernel, dim3((N + 15) / 16), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+        hipLaunchKernelGGL(density_term_kernel, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d1, part_g);
-        hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+        hipLaunchKernelGGL(density_backward_kernel, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d1, 2.0f * lam_g / (float)N, dx_est);
     }
     if (lam_n > 0.f) {
         if (int rc = fnx_grid_build(xg, N, H, guess_grid, stream)) return rc;
         GridView g = carve(guess_grid, N);
-        hipLaunchKernelGGL(density_term_kernel, dim3((N + 15) / 16), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+        hipLaunchKernelGGL(density_term_kernel, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d2, part_n);
-        hipLaunchKernelGGL(density_backward_kernel, dim3((N + 15) / 16), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+        hipLaunchKernelGGL(density_backward_kernel, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d2, 2.0f * lam_n / (float)N, dg);
     }
     hipLaunchKernelGGL(stage_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, scale_factor, x, x_est, dx_est,
