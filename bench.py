@@ -112,7 +112,16 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
         view_mode = "serial"
     if cfg_id == 5 and view_mode != "batched":
         raise SystemExit("config 5 (both rasterisers per view) needs --views batched")
+    # view-independent terms (physics, distance): on every rank once per local view, or on ONE rank `batch` times -- by
+    # default the last rank of a multi-rank run (fewest views under round-robin sharding)
+    shard_n = a.emulate_world if a.emulate_world > 1 else world
+    shared_rank = None
+    # (an emulated share keeps the per-view form unless asked: without the all-reduce a rank that drops the terms would
+    # optimise a different objective, its particles drift and the timed workload is no longer the configuration's)
+    if a.shared_terms == "last-rank" or (a.shared_terms == "auto" and world > 1):
+        shared_rank = shard_n - 1
     loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once,
+                      shared_terms_rank=shared_rank,
                       image_loss="torch" if a.image_loss == "torch" else "fused", fused_physics=not a.unfused_physics,
                       defer_visual_backward=not a.unfused_physics, capturable=graph, cfg=cfg,
                       parallel_views=view_mode == "branches", batched_views=view_mode == "batched",
@@ -390,6 +399,11 @@ def main():
                     help="always launch the fourth depth-sort pass (default: skipped once the warm-up has shown spans < 2^26 ulps)")
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's share to time")
+    ap.add_argument("--shared-terms", default="auto", choices=["auto", "per-view", "last-rank"],
+                    help="who evaluates the view-independent terms (physics, distance loss) in a multi-rank run: every rank, "
+                         "once per local view (per-view: the reference's evaluation count, rank by rank), or only the last "
+                         "rank, `batch` times (last-rank; auto = last-rank when there is more than one rank)")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
@@ -480,7 +494,8 @@ def main():
     if a.emulate_world > 1:
         assert world == 1, "--emulate-world is a single-process mode"
         shard_world = a.emulate_world
-        loop_views = loop.view_subset = shard_views(len(cams), 0, shard_world)
+        loop_views = loop.view_subset = shard_views(len(cams), a.emulate_rank, shard_world)
+        loop.emulated = (a.emulate_rank, shard_world)
     loop.make_targets()
     if not a.host_sync:
         rasterizer.set_host_sync(False)
@@ -667,8 +682,12 @@ def main():
                    "views_this_rank": len(loop_views), "global_views_per_step": len(cams), "image": f"{SIZE}x{SIZE}",
                    "gaussians": P_total, "num_rendered_per_view": R_views, "visible_per_view": P_vis_views,
                    "parallelism": (f"views sharded round-robin over {shard_world} rank(s)"
-                                   + (" (emulated: rank 0's share, no communication)" if a.emulate_world > 1 else "")
+                                   + (f" (emulated: rank {a.emulate_rank}'s share, no communication)" if a.emulate_world > 1 else "")
                                    + ", RCCL all-reduce of the leaf gradient"),
+                   "shared_terms": ("physics terms + distance loss on every rank, added once per local view"
+                                    if getattr(loop, "shared_terms_rank", None) is None else
+                                    f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "
+                                    "the fewest views), added `batch` times; the all-reduce distributes the sum"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
                    "depth_sort": f"9-bit passes; key span of the views <= 2^{rasterizer.max_sort_span_bits} ulps; fourth pass "
                                  + ("not launched (device-checked)" if (0 < rasterizer.max_sort_span_bits <= 25 and not a.sort_four_passes

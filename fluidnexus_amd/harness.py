@@ -128,7 +128,7 @@ class HotLoop:
     """One frame's optimisation loop over `gm` and `cams` (physical-particle stage)."""
 
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
-                 physics_per_view=True, image_loss="torch", fused_physics=False, defer_visual_backward=False,
+                 physics_per_view=True, shared_terms_rank=None, image_loss="torch", fused_physics=False, defer_visual_backward=False,
                  force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False,
                  fused_step=False, dual_channel=False):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
@@ -142,6 +142,13 @@ class HotLoop:
             _, self.GRsetting1, self.GRzer1 = get_render_pipe("render_fluid")
         self.log_scalars = log_scalars
         self.physics_per_view = physics_per_view
+        # Multi-rank runs: the terms that do not depend on the view (physics terms, distance loss) are the same on every
+        # rank.  None: every rank evaluates them and adds them once per LOCAL view (the reference's per-view evaluation,
+        # tpp:365-404, rank by rank).  r: only rank r evaluates them and adds them `batch` times; the all-reduce hands the
+        # sum to everybody.  bench.py picks the LAST rank of a multi-rank run: round-robin sharding gives it
+        # the fewest views, so the extra work lands on the rank that would otherwise wait (view-batched loop only).
+        self.shared_terms_rank = shared_terms_rank
+        self.emulated = None  # (rank, world) of the run whose share `view_subset` is (bench.py --emulate-world)
         self.image_loss = image_loss
         self.fused_physics = fused_physics
         self.force_all_reduce = force_all_reduce
@@ -415,10 +422,19 @@ class HotLoop:
         gp, n_phys, gd = None, 0, None
         fork = torch.cuda.Event()
         fork.record(main)
-        use_dist = bool(mine) and c.get("lambda_current_distance", 0.0) > 0
+        # who evaluates the view-independent terms, and how many times their gradient counts (see __init__)
+        shared = self.shared_terms_rank if self.shared_terms_rank is not None else (None if self.physics_per_view else 0)
+        erank, eworld = self.emulated or (self.rank, self.world)
+        phys_here = shared is None or shared == erank
+        n_phys_weight = len(mine) if shared is None else batch
+        # the distance term needs a render on the rank that evaluates it (its gradient joins the rendered positions')
+        dist_shared = shared is not None and len(shard_views(batch, shared, eworld)) > 0
+        dist_here = (shared == erank) if dist_shared else True
+        n_dist_weight = batch if dist_shared else len(mine)
+        use_dist = bool(mine) and dist_here and c.get("lambda_current_distance", 0.0) > 0
         def launch_physics():
             nonlocal gp, n_phys
-            if not (self.physics_per_view or self.rank == 0):
+            if not phys_here:
                 return
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
@@ -434,7 +450,7 @@ class HotLoop:
                                                           gm.state_memo("physics_loss"))
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)
-            n_phys = len(mine) if self.physics_per_view else batch
+            n_phys = n_phys_weight
 
         if _PHYSICS_EARLY:
             launch_physics()
@@ -497,7 +513,7 @@ class HotLoop:
             extra = None
             if gd is not None:  # added inside the hidden<-visual backward instead of by a pass over g_means
                 main.wait_stream(self.dist_stream)
-                extra = (gd, float(c["lambda_current_distance"]) * len(mine))
+                extra = (gd, float(c["lambda_current_distance"]) * n_dist_weight)
             gm.defer_render_means_gradient(g_means, extra)  # -> the one hidden<-visual backward of the iteration
         if gp is not None:
             main.wait_stream(self.side_stream)

@@ -155,7 +155,7 @@ class _NoEvent:
         pass
 
 
-def _batched_host_loop(rank, world, n_views):
+def _batched_host_loop(rank, world, n_views, shared_rank=None):
     from types import SimpleNamespace
 
     import fluidnexus_amd.losses as losses
@@ -185,8 +185,7 @@ def _batched_host_loop(rank, world, n_views):
         return leaf
 
     def defer_render_means_gradient(g, extra=None):
-        assert extra is None
-        state["g"] = g[:V]
+        state["g"] = g[:V] if extra is None else g[:V] + float(extra[1]) * extra[0]
 
     def flush_deferred_gradients():
         g = state.pop("g", None)
@@ -216,15 +215,20 @@ def _batched_host_loop(rank, world, n_views):
         x = gm_._estimate_xyz_nn.detach()
         return 0.5 * 0.01 * (x ** 2).sum(), 0.01 * x  # the same on every rank, like the real (view-independent) terms
 
+    def distance_loss_value_and_grad(xyz, thr):  # a smooth view-independent term of the rendered positions
+        return 0.5 * (xyz ** 2).sum(), xyz.clone()
+
     pipes.render_dynamics_views = render_dynamics_views
     losses.image_loss_value_and_grad = image_loss_value_and_grad
     physics.physical_stage_value_and_grad = physical_stage_value_and_grad
+    physics.distance_loss_value_and_grad = distance_loss_value_and_grad
 
     cams = [SimpleNamespace(uid=v, original_image=torch.rand(3, 8, 8, generator=torch.Generator().manual_seed(v)))
             for v in range(n_views)]
-    cfg = dict(SMOKE, lambda_current_distance=0.0)
+    cfg = dict(SMOKE, lambda_current_distance=0.03)
     loop = HotLoop(gm, cams, rank=rank, world=world, cfg=cfg, image_loss="fused", fused_physics=True,
-                   defer_visual_backward=True, batched_views=True, force_all_reduce=world == 1)
+                   defer_visual_backward=True, batched_views=True, force_all_reduce=world == 1,
+                   shared_terms_rank=shared_rank)
     return gm, loop
 
 
@@ -238,10 +242,10 @@ def _batched_step(loop, world):
     loop._finish_step(len(loop.cams), grad=loop._reduce_buf)
 
 
-def _batched_worker(rank, world, port, n_views, steps, q):
+def _batched_worker(rank, world, port, n_views, steps, q, shared_rank=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    gm, loop = _batched_host_loop(rank, world, n_views)
+    gm, loop = _batched_host_loop(rank, world, n_views, shared_rank)
     for _ in range(steps):
         _batched_step(loop, world)
     q.put((rank, gm._estimate_xyz_nn.detach().numpy().copy()))
@@ -261,17 +265,23 @@ def _serial_reference_worker(port, n_views, steps, q):
     dist.destroy_process_group()
 
 
-def test_batched_local_phase_all_reduce_finish_step_equals_single_rank():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("shared_rank", [None, 1])
+def test_batched_local_phase_all_reduce_finish_step_equals_single_rank(shared_rank):
     """5 views over 2 ranks (3 / 2) through `_iteration_body_batched(phase="local")` + all-reduce + `_finish_step`
     against one rank running all 5 views through the un-phased body: same positions after three optimiser steps,
-    identical on both ranks (the physics term is added once per LOCAL view: 3 + 2 = 5 = the single rank's count)."""
+    identical on both ranks.  shared_rank None: the physics and distance terms are added once per LOCAL view on every rank
+    (3 + 2 = 5 = the single rank's count); 1: only rank 1 (the one with fewer views) evaluates them and adds them 5 times
+    (what bench.py does in a multi-rank run)."""
     n_views, world, steps = 5, 2, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + os.getpid() % 2000
     ref_p = ctx.Process(target=_serial_reference_worker, args=(port + 1, n_views, steps, q))
     ref_p.start()
-    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, n_views, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, n_views, steps, q, shared_rank)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=180) for _ in range(world + 1))
