@@ -112,13 +112,13 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
         view_mode = "serial"
     if cfg_id == 5 and view_mode != "batched":
         raise SystemExit("config 5 (both rasterisers per view) needs --views batched")
-    # view-independent terms (physics, distance): on every rank once per local view, or on ONE rank `batch` times -- by
-    # default the last rank of a multi-rank run (fewest views under round-robin sharding)
+    # view-independent terms (physics, distance): on every rank once per local view (default), or on ONE rank `batch`
+    # times: the last rank of a multi-rank run (fewest views under round-robin sharding)
     shard_n = a.emulate_world if a.emulate_world > 1 else world
     shared_rank = None
     # (an emulated share keeps the per-view form unless asked: without the all-reduce a rank that drops the terms would
     # optimise a different objective, its particles drift and the timed workload is no longer the configuration's)
-    if a.shared_terms == "last-rank" or (a.shared_terms == "auto" and world > 1):
+    if a.shared_terms == "last-rank":
         shared_rank = shard_n - 1
     loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once,
                       shared_terms_rank=shared_rank,
@@ -400,10 +400,11 @@ def main():
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's share to time")
-    ap.add_argument("--shared-terms", default="auto", choices=["auto", "per-view", "last-rank"],
+    ap.add_argument("--shared-terms", default="per-view", choices=["per-view", "last-rank"],
                     help="who evaluates the view-independent terms (physics, distance loss) in a multi-rank run: every rank, "
-                         "once per local view (per-view: the reference's evaluation count, rank by rank), or only the last "
-                         "rank, `batch` times (last-rank; auto = last-rank when there is more than one rank)")
+                         "once per local view (per-view, default: the reference's evaluation count, rank by rank), or only the "
+                         "last rank -- the one with the fewest views -- `batch` times (last-rank: same sum after the "
+                         "all-reduce, tests/test_distributed_cpu.py; not measured on multi-GPU hardware)")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],

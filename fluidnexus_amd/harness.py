@@ -145,8 +145,8 @@ class HotLoop:
         # Multi-rank runs: the terms that do not depend on the view (physics terms, distance loss) are the same on every
         # rank.  None: every rank evaluates them and adds them once per LOCAL view (the reference's per-view evaluation,
         # tpp:365-404, rank by rank).  r: only rank r evaluates them and adds them `batch` times; the all-reduce hands the
-        # sum to everybody.  bench.py picks the LAST rank of a multi-rank run: round-robin sharding gives it
-        # the fewest views, so the extra work lands on the rank that would otherwise wait (view-batched loop only).
+        # sum to everybody.  bench.py --shared-terms last-rank picks the LAST rank: round-robin sharding gives
+        # it the fewest views, so the extra work lands on the rank that would otherwise wait (view-batched loop only).
         self.shared_terms_rank = shared_terms_rank
         self.emulated = None  # (rank, world) of the run whose share `view_subset` is (bench.py --emulate-world)
         self.image_loss = image_loss
