@@ -884,8 +884,9 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                             const uint32_t *__restrict__ hstart, const float4 *__restrict__ hrec,
                             const float4 *__restrict__ u, float *__restrict__ out, float *__restrict__ sum_w,
                             float *__restrict__ wvel, float *__restrict__ out_div, float divisor) {
+    // a candidate = 24 bytes of LDS, read as 16 + 8 (position + u.x | u.y, u.z): the walk is bound by LDS cycles
     __shared__ float4 s_pos[kCellCand];
-    __shared__ float4 s_vel[kCellCand];
+    __shared__ float2 s_vel[kCellCand];
     const int lane = threadIdx.x;
     const uint32_t n_work = *n_items;
     for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x) {
@@ -929,8 +930,8 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                     float4 p0, v0, p1, v1;
                     if (in0) { p0 = hrec[s0 + j]; v0 = u[s0 + j]; }
                     if (in1) { p1 = hrec[s0 + j + 2]; v1 = u[s0 + j + 2]; }
-                    if (in0) { s_pos[i0 - base] = p0; s_vel[i0 - base] = v0; }
-                    if (in1) { s_pos[i1 - base] = p1; s_vel[i1 - base] = v1; }
+                    if (in0) { s_pos[i0 - base] = make_float4(p0.x, p0.y, p0.z, v0.x); s_vel[i0 - base] = make_float2(v0.y, v0.z); }
+                    if (in1) { s_pos[i1 - base] = make_float4(p1.x, p1.y, p1.z, v1.x); s_vel[i1 - base] = make_float2(v1.y, v1.z); }
                 }
                 __syncthreads();  // one wave per workgroup: orders the LDS writes before the reads
                 if (mine) {
@@ -940,15 +941,15 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                         const uint32_t i = k * spread + slice;
                         const uint32_t ic = min(i, n - 1u);
                         const float4 q = s_pos[ic];
-                        const float4 uj = s_vel[ic];
+                        const float2 uj = s_vel[ic];
                         const float ex = me.x - q.x, ey = me.y - q.y, ez = me.z - q.z;
                         const float r2 = ex * ex + ey * ey + ez * ez;
                         const float t = H2 - r2;
                         const float w = (r2 < H2 && i < n) ? term1 * (t * t * t) : 0.0f;  // +0 terms leave the sums unchanged
                         S += w;
-                        ax += uj.x * w;
-                        ay += uj.y * w;
-                        az += uj.z * w;
+                        ax += q.w * w;
+                        ay += uj.x * w;
+                        az += uj.y * w;
                     }
                 }
                 __syncthreads();
