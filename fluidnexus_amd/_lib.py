@@ -54,12 +54,12 @@ SYMBOLS = (
     "fnx_rasterize_backward_views",
     "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
-    "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3",
+    "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
 # scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def raster_path() -> str:
@@ -141,6 +141,8 @@ def raster():
     lib.fnx_set_sort_narrow.restype = i
     lib.fnx_request_zero3.restype = i
     lib.fnx_request_zero3.argtypes = [p]
+    lib.fnx_request_gradient_limit.restype = i
+    lib.fnx_request_gradient_limit.argtypes = [i]
     lib.fnx_set_sort_narrow.argtypes = [i]
     lib.fnx_set_lean_geometry.argtypes = [i]
     lib.fnx_set_deep_kernel.argtypes = [i]

@@ -137,7 +137,7 @@ inline void image_layout(int W, int H, fnx_image_layout_t *o) {
     size_t off = 0;
     o->header = off;      off = align_up(off + 32);
     o->final_T = off;     off = align_up(off + n * 4);
-    o->n_contrib = off;   off = align_up(off + n * 4);
+    o->n_contrib = off;   off = align_up(off + n * 4 * 2);  // [n_contrib | the limited backward's walking limit per pixel]
     o->ranges = off;      off = align_up(off + t * 8);
     o->tile_count = off;  off = align_up(off + t * 4);
     o->dyn_start = off;   off = align_up(off + t * 4);
@@ -202,6 +202,9 @@ enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
 // HDR_BIN_CAPACITY: the binning capacity stage 2 ran with (the binning blob's layout depends on it): the backward pass
 // refuses a view whose stored value differs from its own argument (status FNX_ERR_CAPACITY)
 enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 3, HDR_BWD_ITEMS = 4, HDR_DEEP_COUNT = 5,
-       HDR_BIN_CAPACITY = 6, HDR_BWD_TICKET = 7, HDR_BWD_DONE = 8 };  // words 8 .. 63 of the header block are scratch
+       HDR_BIN_CAPACITY = 6, HDR_BWD_TICKET = 7, HDR_BWD_DONE = 8,
+       // the forward's gradient limit: ids >= it were treated as gradient-free when the per-pixel walking limits of the
+       // backward (second half of n_contrib) and its work items were laid down; a backward with a larger limit is refused
+       HDR_DYN_LIMIT = 9 };  // words 10 .. 63 of the header block are scratch
 
 }  // namespace fnx

@@ -44,7 +44,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep);
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
+                          uint32_t dyn_limit);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -218,6 +219,7 @@ struct ProfClass {
 };
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
 float *g_zero_request = nullptr;  // fnx_request_zero3: zero-filled by the next stage 1 on its way
+uint32_t g_grad_limit_request = 0xFFFFFFFFu;  // fnx_request_gradient_limit: one-shot, for the next stage 2
 int g_sort_narrow = 0;       // the fourth depth-sort pass is not launched (fnx_set_sort_narrow)
 int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
 int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
@@ -395,6 +397,11 @@ int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_
     if (h[fnx::HDR_STATUS] == FNX_ERR_CAPACITY)
         return fail(FNX_ERR_CAPACITY, "binning capacity %u < num_rendered %u", h[fnx::HDR_CAPACITY],
                     h[fnx::HDR_NUM_RENDERED]);
+    if (h[fnx::HDR_STATUS] == FNX_ERR_INVALID_ARG)
+        return fail(FNX_ERR_INVALID_ARG, "a backward call asked for gradients beyond its forward's gradient limit "
+                                         "(fnx_request_gradient_limit)");
+    if (h[fnx::HDR_STATUS] == FNX_ERR_SORT_SPAN)
+        return fail(FNX_ERR_SORT_SPAN, "the view's depth keys need the fourth sort pass (fnx_set_sort_narrow)");
     return FNX_OK;
 }
 
@@ -437,7 +444,8 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb, g_blend_math, g_deep_kernel);
+                                  st, materialize_all, V, vb, g_blend_math, g_deep_kernel, g_grad_limit_request);
+        g_grad_limit_request = 0xFFFFFFFFu;  // one-shot
     }
     return hip_check("stage2");
 }
@@ -654,6 +662,10 @@ int fnx_set_blend_math(int mode) {
 int fnx_get_blend_math(void) { return g_blend_math; }
 int fnx_request_zero3(float *rows3) {
     g_zero_request = rows3;
+    return FNX_OK;
+}
+int fnx_request_gradient_limit(int grad_splat_limit) {
+    g_grad_limit_request = grad_splat_limit < 0 ? 0xFFFFFFFFu : (uint32_t)grad_splat_limit;
     return FNX_OK;
 }
 int fnx_set_sort_narrow(int on) {

@@ -172,8 +172,11 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             s_first[v] = run;
             // a view whose forward overflowed, or ran with another binning capacity than this call's (the blob's layout
             // depends on it), contributes nothing; the mismatch is left in the view's status word (fnx_read_status)
-            const bool mismatch = h[HDR_BIN_CAPACITY] != capacity;
-            if (mismatch && blockIdx.x == 0) const_cast<uint32_t *>(h)[HDR_STATUS] = FNX_ERR_CAPACITY;
+            // ... or whose forward laid the work items and walking limits down for a SMALLER gradient limit than this call's
+            // (fnx_request_gradient_limit; HDR_DYN_LIMIT): splats this call differentiates would be cut off
+            const bool cut = grad_limit > h[HDR_DYN_LIMIT];
+            const bool mismatch = h[HDR_BIN_CAPACITY] != capacity || cut;
+            if (mismatch && blockIdx.x == 0) const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
             if (!(mismatch || h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
         }
         s_first[n_views] = run;
@@ -315,7 +318,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         fetch_range(nxt);
         // per-view scratch, pixel gradients and screen-space accumulators of the item's view
         const float *final_Ts_v = view_at(final_Ts, vb.img, vw);
-        const uint32_t *n_contrib_v = view_at(n_contrib, vb.img, vw);
+        // the pixel's walking limit: the forward's last DYNAMIC contributor (second half of the n_contrib array; equal to the
+        // last contributor when the forward ran without a gradient limit) -- nothing behind it is differentiated
+        const uint32_t *n_contrib_v = view_at(n_contrib, vb.img, vw) + (size_t)W * H;
         const float *acc_final_v = view_at(acc_final, vb.img, vw);
         const uint32_t *point_list_v = view_at(point_list, vb.bin, vw);
         const float *dL_dpixels_v = dL_dpixels + (size_t)vw * C * H * W;
@@ -680,7 +685,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             const bool nin = npx < W && npy < H;
             const uint32_t npix = (uint32_t)W * npy + npx;
             ahead.T_final = nin ? view_at(final_Ts, vb.img, nv)[npix] : 0.f;
-            ahead.last_contributor = nin ? view_at(n_contrib, vb.img, nv)[npix] : 0u;
+            ahead.last_contributor = nin ? (view_at(n_contrib, vb.img, nv) + (size_t)W * H)[npix] : 0u;
             const float *nacc = view_at(acc_final, vb.img, nv), *ndl = dL_dpixels + (size_t)nv * C * H * W;
 #pragma unroll
             for (int ch = 0; ch < C; ch++) {

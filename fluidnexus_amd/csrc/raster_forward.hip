@@ -542,7 +542,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                      uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
-                     int skip_deep) {
+                     int skip_deep, uint32_t dyn_limit) {
     const char *static_blob = nullptr;
     // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
     // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
@@ -591,9 +591,14 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     __shared__ uint32_t s_adv;                                 // static entries among the batch just merged
     __shared__ uint32_t s_qmax[4];
     __shared__ uint32_t s_done[4];
+    __shared__ unsigned long long s_dynmask[4];  // per staging wave: which of its 64 slots hold dynamic entries
+    __shared__ uint32_t s_qdyn[4];
     // the view's header words (instance count, status, capacity) for the caller's deferred status check: the last
     // kernel of the forward copies them out, which saves the caller a strided device-to-device copy per call
-    if (wg_rank == 0 && threadIdx.x == 0) header[HDR_BIN_CAPACITY] = capacity;  // the backward checks its own against it
+    if (wg_rank == 0 && threadIdx.x == 0) {
+        header[HDR_BIN_CAPACITY] = capacity;  // the backward checks its own against it
+        header[HDR_DYN_LIMIT] = dyn_limit;    // ... and its gradient limit against this one
+    }
     if (status_out && wg_rank == 0 && threadIdx.x < 8)
         status_out[8 * wg_view + threadIdx.x] = threadIdx.x == HDR_BIN_CAPACITY ? capacity : header[threadIdx.x];
     if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] == (uint32_t)FNX_ERR_SORT_SPAN) return;
@@ -628,6 +633,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     float alive = inside ? 1.0f : 0.0f;
     float Tr = 1.0f;
     uint32_t last_contributor = 0;
+    // Splats with id >= dyn_limit take no gradient (the frozen background of the position stages).  A backward pass that
+    // differentiates only ids below it needs nothing from the entries BEHIND a pixel's last such ("dynamic") entry: what
+    // lies behind an entry enters its gradient only through (final colour - prefix) and final T, which the forward
+    // stores.  last_dyn: list position (1-based) of the last dynamic entry at or in front of the pixel's last
+    // contributor, 0 if none -- found per BATCH from a ballot of the staged entries' flags, not per entry.
+    uint32_t last_dyn = 0, dyn_before = 0;  // dyn_before (workgroup-uniform): last dynamic position of the earlier batches
     float acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
@@ -706,7 +717,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         load_windows();
     } else {
         if (r0 + (uint32_t)tid < r1) {
-            const float4 *rec = blend_rec + 4 * (size_t)point_list[r0 + tid];
+            my_id = point_list[r0 + tid];
+            const float4 *rec = blend_rec + 4 * (size_t)my_id;
             pa = rec[0];
             pb = rec[1];
             pc = rec[2];
@@ -742,6 +754,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
         const uint32_t cnt = min(256u, r1 - base);
         uint32_t qm = 0;
+        {  // which staged entries are dynamic: one ballot per wave (slot = thread), read back behind the walk
+            const unsigned long long dm = __ballot((uint32_t)tid < cnt && my_id < dyn_limit);
+            if (lane == 0) s_dynmask[w] = dm;
+        }
         if ((uint32_t)tid < cnt && blending) {
             qm = block_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
             if (FAST) {
@@ -766,6 +782,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             store_windows();
         } else {
             if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
+                my_id = id_ahead;
                 const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
                 pa = rec[0];
                 pb = rec[1];
@@ -896,12 +913,28 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 alive = stop ? 0.0f : alive;
             }
         }
-        if (hit_off != 0xFFFFFFFFu) last_contributor = pos0 + (hit_off >> 4);  // list position (1-based) of that entry
+        {
+            // highest dynamic slot of the batch at or below slot `upto` (0xFFFFFFFF: none); wave ws staged slots 64 ws ..
+            auto dyn_at_or_below = [&](uint32_t upto) -> uint32_t {
+                int ws = (int)(upto >> 6);
+                unsigned long long m = s_dynmask[ws] & ((2ull << (upto & 63u)) - 1ull);  // (2 << 63) wraps to 0: all ones
+                while (m == 0ull && ws > 0) m = s_dynmask[--ws];
+                return m ? (uint32_t)(64 * ws + 63 - __clzll((long long)m)) : 0xFFFFFFFFu;
+            };
+            if (hit_off != 0xFFFFFFFFu) {
+                last_contributor = pos0 + (hit_off >> 4);  // list position (1-based) of that entry
+                const uint32_t d = dyn_at_or_below(hit_off >> 4);
+                last_dyn = d != 0xFFFFFFFFu ? pos0 + d : dyn_before;
+            }
+            const uint32_t d_all = dyn_at_or_below(255u);  // workgroup-uniform
+            if (d_all != 0xFFFFFFFFu) dyn_before = pos0 + d_all;
+        }
         FNX_CLK(3)
     }
     if (inside) {
         final_T[pix_id] = Tr;
         n_contrib[pix_id] = last_contributor;
+        n_contrib[(size_t)W * H + pix_id] = last_dyn;  // second half of the array: what a limited backward walks to
 #pragma unroll
         for (int ch = 0; ch < C; ch++) {
             out_color[(size_t)ch * H * W + pix_id] = acc[ch] + Tr * bg[ch];
@@ -909,14 +942,21 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         out_depth[pix_id] = Dm;
     }
-    // one backward work item per batch that holds a contributor of some pixel of the tile
-    uint32_t m = last_contributor;
+    // one backward work item per batch that holds a DYNAMIC entry in front of some pixel's last contributor (the batches
+    // behind hold nothing a backward pass within the gradient limit needs); qmax: how deep the tile went
+    uint32_t m = last_contributor, md = last_dyn;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) s_qmax[w] = m;
+    for (int off = 32; off >= 1; off >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        md = max(md, (uint32_t)__shfl_xor((int)md, off));
+    }
+    if (lane == 0) {
+        s_qmax[w] = m;
+        s_qdyn[w] = md;
+    }
     __syncthreads();
     const uint32_t qmax = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
-    const uint32_t nb = (qmax + 255u) >> 8;
+    const uint32_t nb = (max(max(s_qdyn[0], s_qdyn[1]), max(s_qdyn[2], s_qdyn[3])) + 255u) >> 8;
     if (nb) {
         if (tid == 0) s_adv = atomicAdd(&header[HDR_BWD_ITEMS], nb);
         __syncthreads();
@@ -1241,6 +1281,7 @@ blend_forward_deep_kernel(int T, int gx, const uint32_t *__restrict__ ranges_all
             if (inside) {
                 final_T[pix_id] = Tr;
                 n_contrib[pix_id] = last_contributor;
+                n_contrib[(size_t)W * H + pix_id] = last_contributor;  // (this kernel does not track the dynamic limit: the conservative value)
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) {
                     out_color[(size_t)ch * H * W + pix_id] = acc[ch] + Tr * bg[ch];
@@ -1336,8 +1377,11 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           float *out_color, float *out_depth, uint32_t *header, uint32_t capacity,
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
-                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep) {
+                          const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
+                          uint32_t dyn_limit) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
+    // static splats never take gradients: in static-split mode the limit is at most the first static id
+    if (st.base && dyn_limit > st.id0) dyn_limit = st.id0;
     // Deep tiles (depth hints of the previous forward) go to the super-batch kernel; it exists for the fast arithmetic.
     // A deep workgroup holds a whole compute unit at modest utilisation to cut the tile's LATENCY, which pays when the
     // launch is bound by its longest walks -- few views per launch (a rank's share of a sharded batch) -- and costs
@@ -1405,7 +1449,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       use_deep)
+                       use_deep, dyn_limit)
     if (C == 3 && st.base) { FNX_LAUNCH_BF(3, true); }
     else if (C == 3) { FNX_LAUNCH_BF(3, false); }
     else if (st.base) { FNX_LAUNCH_BF(1, true); }

@@ -250,6 +250,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _capacity_hwm[key] = cap
                 num_rendered = -1
             binning = torch.empty(lib.fnx_binning_bytes(cap), **u8)
+            if grad_splat_limit is not None:  # the backward will stop behind every pixel's last splat below the limit
+                _lib.check(lib.fnx_request_gradient_limit(int(grad_splat_limit)))
             _lib.check(lib.fnx_forward_stage2(Cn, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H,
                                               bg.data_ptr(), _ptr(colors_precomp), radii.data_ptr(),
                                               color.data_ptr(), depth.data_ptr(), stream))
@@ -478,6 +480,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 ring, slot = _status_slots(dev, V, key)
                 status_ptr = ring[slot:slot + V].data_ptr()
+            if grad_splat_limit is not None:  # the backward will stop behind every pixel's last splat below the limit
+                _lib.check(lib.fnx_request_gradient_limit(int(grad_splat_limit)))
             _lib.check(lib.fnx_forward_stage2_views_split(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
                                                           P, W, H, vbatch.bg.data_ptr(), color.data_ptr(),
                                                           depth.data_ptr(), status_ptr, None, 0, 0, 0, hint_ptr, stream))
@@ -553,6 +557,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         if not synced:
             ring, slot = _status_slots(dev, V, key)
             status_ptr = ring[slot:slot + V].data_ptr()
+        if grad_splat_limit is not None:  # (in split mode the library already stops at the first static id)
+            _lib.check(lib.fnx_request_gradient_limit(int(grad_splat_limit)))
         _lib.check(lib.fnx_forward_stage2_views_split(
             Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
             color.data_ptr(), depth.data_ptr(), status_ptr, sb.blob.data_ptr(), sb.P, sb.R_cap,
