@@ -397,6 +397,10 @@ def main():
                          "bit-reproducible sequence the oracle repeats")
     ap.add_argument("--sort-four-passes", action="store_true",
                     help="always launch the fourth depth-sort pass (default: skipped once the warm-up has shown spans < 2^26 ulps)")
+    ap.add_argument("--sort", default="coherent", choices=["coherent", "radix"],
+                    help="depth sort of the per-call splats: coherent = one launch that repairs the previous iteration's order "
+                         "(verified on the device, in-launch full sort when the check fails: exact by construction, "
+                         "tests/test_coherent_sort_gpu.py); radix = the 9-bit LSD passes every call")
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's share to time")
@@ -475,8 +479,9 @@ def main():
     _lib.raster()  # fail loudly if the HIP library is missing
     rasterizer.set_blend_math(a.blend_math)
     rasterizer.set_lean_geometry(not a.full_geometry)
+    rasterizer.set_coherent_sort(a.sort == "coherent")
     if a.deep_kernel is not None:
-        _lib.check(_lib.raster().fnx_set_deep_kernel(a.deep_kernel))
+        rasterizer.set_deep_kernel(a.deep_kernel)
     if a.no_static_split:
         pipes.set_static_split(False)
 
@@ -506,7 +511,7 @@ def main():
     if not a.host_sync:
         rasterizer.check_status()  # also records the binning high-water mark and the views' depth-key spans
         # three 9-bit passes order any view whose keys span < 2^27 ulps: the warm-up has shown how wide this scene's are
-        if 0 < rasterizer.max_sort_span_bits <= 25 and not a.sort_four_passes:
+        if 0 < rasterizer.max_sort_span_bits <= rasterizer.SORT_NARROW_MAX_BITS and not a.sort_four_passes:
             rasterizer.set_sort_narrow(True)  # a later view that needs the fourth pass fails the run (check_status)
     graph_mode = False
     if loop.capturable:
@@ -664,6 +669,13 @@ def main():
         stage_note = (" -- FIRST-FRAME STAGE of this scene (entries_fluid_nexus/train_physical_particle.py:103-163): visual "
                       "particle positions optimised, grey-mean L1 + D-SSIM + distance loss; not the stage BASELINE's metric "
                       "is quoted on")
+    sort_fallbacks = None
+    try:  # how often the coherent sort had to fall back to its in-launch full sort (per view batch: [calls, fallbacks] per view)
+        from fluidnexus_amd.renderer.pipes import _VIEW_BATCH_CACHE
+        sort_fallbacks = [[list(c) for c in vb.sort_counters(*key)] for vb, _, _ in _VIEW_BATCH_CACHE.values()
+                          for key in list(vb._sort_state)]
+    except Exception as e:
+        print(f"[bench] sort counters unavailable: {type(e).__name__}: {e}", file=sys.stderr)
     knn = None
     if cfg_id != 2 and a.stage == "physical":
         knn = gm.knn_k_report()  # outside the timed region: are the reference's neighbour lists below their cap here?
@@ -690,9 +702,11 @@ def main():
                                     f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "
                                     "the fewest views), added `batch` times; the all-reduce distributes the sum"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
-                   "depth_sort": f"9-bit passes; key span of the views <= 2^{rasterizer.max_sort_span_bits} ulps; fourth pass "
-                                 + ("not launched (device-checked)" if (0 < rasterizer.max_sort_span_bits <= 25 and not a.sort_four_passes
-                                                                        and not a.host_sync) else "launched"),
+                   "depth_sort": (("coherent: one launch per call repairs the previous call's order, verified on the device "
+                                   f"(in-launch full sorts per view over the run: {sort_fallbacks}); first call: " if a.sort == "coherent" else "")
+                                  + f"9-bit radix passes; key span of the views <= 2^{rasterizer.max_sort_span_bits} ulps; fourth pass "
+                                  + ("not launched (device-checked)" if (0 < rasterizer.max_sort_span_bits <= rasterizer.SORT_NARROW_MAX_BITS
+                                                                         and not a.sort_four_passes and not a.host_sync) else "launched")),
                    "blend_math": {"fast": "fast: fused multiply-adds + v_exp_f32 in the two blend kernels; pixels within 2e-5 of the "
                                           "bit-exact mode / oracle except counted threshold flips, binning bit-exact "
                                           "(tests/test_fast_math_gpu.py)",

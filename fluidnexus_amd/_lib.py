@@ -26,7 +26,7 @@ FNX_ERR_SORT_SPAN = 6
 class GeomLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in
                 ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "sort_key0",
-                 "sort_key1", "sort_val0", "sort_val1", "rect", "rect_sorted", "sort_hist", "blk_hist", "blk_rel", "blend_rec", "total")]
+                 "sort_key1", "sort_val0", "sort_val1", "rect", "rect_sorted", "krec", "sort_hist", "blk_hist", "blk_rel", "blend_rec", "total")]
 
 
 class ImageLayout(C.Structure):
@@ -44,6 +44,26 @@ class StaticLayout(C.Structure):
 
 ALLOC_FN = C.CFUNCTYPE(c_void_p, c_size_t, c_void_p)
 
+FNX_OPT_DEFAULT = -2147483648
+FNX_SORT_FULL, FNX_SORT_NARROW, FNX_SORT_COHERENT = 0, 1, 2
+
+
+class RasterOpts(C.Structure):
+    """fnx_raster_opts_t (include/fnx_raster.h): the options of ONE call."""
+    _fields_ = [("size", C.c_uint32), ("blend_math", C.c_int32), ("lean_geometry", C.c_int32), ("sort_mode", C.c_int32),
+                ("deep_kernel", C.c_int32), ("grad_splat_limit", C.c_int32), ("deep_threshold", C.c_uint32),
+                ("reserved0", C.c_uint32), ("zero3", c_void_p), ("sort_state", c_void_p)]
+
+
+def make_opts(blend_math=0, lean_geometry=0, sort_mode=FNX_SORT_FULL, deep_kernel=0, grad_splat_limit=-1,
+              deep_threshold=0, zero3=None, sort_state=None) -> RasterOpts:
+    o = RasterOpts()
+    o.size = C.sizeof(RasterOpts)
+    o.blend_math, o.lean_geometry, o.sort_mode, o.deep_kernel = int(blend_math), int(lean_geometry), int(sort_mode), int(deep_kernel)
+    o.grad_splat_limit, o.deep_threshold = int(grad_splat_limit), int(deep_threshold)
+    o.zero3, o.sort_state = zero3, sort_state
+    return o
+
 # every symbol include/fnx_raster.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "fnx_abi_version", "fnx_last_error", "fnx_geom_bytes", "fnx_image_bytes", "fnx_binning_bytes",
@@ -55,11 +75,13 @@ SYMBOLS = (
     "fnx_static_bytes", "fnx_binning_bytes_split", "fnx_static_finalize_views", "fnx_forward_stage1_views_split",
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
     "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
+    "fnx_forward_stage1_views_split_opts", "fnx_forward_stage2_views_split_opts", "fnx_rasterize_backward_views_split_opts",
+    "fnx_sort_state_bytes", "fnx_sort_state_read",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
 # scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def raster_path() -> str:
@@ -148,6 +170,17 @@ def raster():
     lib.fnx_set_deep_kernel.argtypes = [i]
     lib.fnx_rasterize_backward_views_split.restype = i
     lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]
+    op = C.POINTER(RasterOpts)
+    lib.fnx_forward_stage1_views_split_opts.restype = i
+    lib.fnx_forward_stage1_views_split_opts.argtypes = lib.fnx_forward_stage1_views_split.argtypes[:-1] + [op, p]
+    lib.fnx_forward_stage2_views_split_opts.restype = i
+    lib.fnx_forward_stage2_views_split_opts.argtypes = lib.fnx_forward_stage2_views_split.argtypes[:-1] + [op, p]
+    lib.fnx_rasterize_backward_views_split_opts.restype = i
+    lib.fnx_rasterize_backward_views_split_opts.argtypes = lib.fnx_rasterize_backward_views_split.argtypes[:-1] + [p, op, p]
+    lib.fnx_sort_state_bytes.restype = c_size_t
+    lib.fnx_sort_state_bytes.argtypes = [i]
+    lib.fnx_sort_state_read.restype = i
+    lib.fnx_sort_state_read.argtypes = [p, i, i, p, C.POINTER(C.c_uint32)]
     lib.fnx_binning_layout_split.argtypes = [c_int64, c_int64, C.POINTER(BinningLayout)]
     lib.fnx_static_layout.argtypes = [i, i, i, c_int64, C.POINTER(StaticLayout)]
     lib.fnx_mark_visible.restype = i

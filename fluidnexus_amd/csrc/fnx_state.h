@@ -102,6 +102,42 @@ inline SortScratch sort_scratch(int P) {
     return o;
 }
 inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
+
+// Temporal-coherence depth sort (fnx_raster_opts_t.sort_mode = FNX_SORT_COHERENT, raster_binning.hip): the caller's
+// persistent per-view state.  Header words, the (key, id) bounds every repair workgroup publishes for its chunk of ranks
+// (first | last, u64 each), and inv[id] = depth rank of splat id in the previous call's order.
+enum { COH_MAGIC = 0, COH_EPOCH = 1, COH_ARRIVED = 2, COH_FAIL = 3, COH_FALLBACKS = 4, COH_REPAIRS = 5, COH_HDR_WORDS = 64 };
+struct SortStateLayout {
+    size_t hdr, bounds, inv, total;
+};
+inline SortStateLayout sort_state_layout(int P) {
+    const size_t p = (size_t)(P > 0 ? P : 0), nc = (p + kSplatBlock - 1) / kSplatBlock;
+    SortStateLayout o;
+    size_t off = 0;
+    o.hdr = off;    off = align_up(off + COH_HDR_WORDS * 4);
+    o.bounds = off; off = align_up(off + nc * 16);
+    o.inv = off;    off = align_up(off + p * 4);
+    o.total = off + kAlign;
+    return o;
+}
+// What the preprocess needs to leave its records in the previous depth order (state == nullptr: not in this mode)
+struct CohRef {
+    uint4 *krec;    // view 0's record array inside the geometry blob (stride: ViewBatch::geom)
+    char *state;    // aligned start of view 0's sort state
+    size_t stride;  // bytes between consecutive views' states
+    size_t hdr, inv;
+};
+// The blend forward refreshes inv[id] = rank from the sorted pairs on its way (pairs == nullptr: nothing to do): one
+// million scattered 4-byte stores disappear under a throughput-bound kernel instead of extending the sort's launch.
+struct InvUpdate {
+    const uint2 *pairs;  // view 0's (depth bits, id) pairs in rank order (stride: ViewBatch::geom)
+    char *state;         // aligned start of view 0's sort state
+    size_t stride, inv;
+    int P;
+};
+// the temporal-coherence records pack a tile rectangle into four bytes
+inline bool coherent_sort_supported(int W, int H) { return tiles_x(W) <= 255 && tiles_y(H) <= 255; }
+__host__ __device__ inline uint32_t coh_magic(int P) { return (0xC0DE0000u ^ ((uint32_t)P * 2654435761u)) | 1u; }
 inline int sort_blocks(int P) { return (P + kSortChunk - 1) / kSortChunk; }
 
 inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
@@ -125,6 +161,7 @@ inline void geom_layout(int P, int W, int H, fnx_geom_layout_t *o) {
     o->sort_val1 = off;     off = align_up(off + p * 4);
     o->rect = off;          off = align_up(off + p * 8);
     o->rect_sorted = off;   off = align_up(off + p * 8);
+    o->krec = off;          off = align_up(off + p * 16);
     o->sort_hist = off;     off = align_up(off + sort_scratch(P).words * 4);
     o->blk_hist = off;      off = align_up(off + nb * t * 2);
     o->blk_rel = off;       off = align_up(off + nb * t * 4);

@@ -20,7 +20,7 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb, const StaticRef &st, int lean, float *zero3);
+                       const ViewBatch &vb, const StaticRef &st, int lean, float *zero3, const CohRef &coh);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
@@ -28,7 +28,8 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
-                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow);
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow,
+                       char *coh_state, int coherent, const uint4 *krec);
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
                       uint32_t *blk_total, int V, const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
@@ -45,7 +46,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit);
+                          uint32_t dyn_limit, const InvUpdate &iu);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -53,7 +54,8 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                            const uint32_t *header, uint32_t capacity, uint32_t grad_limit, int V, const ViewBatch &vb,
                            const StaticRef &st, const float *means3D, const float *cov3Ds, size_t cov3D_stride,
-                           const float *viewmatrix, const float *projmatrix, float *dL_dmean3D, int fast);
+                           const float *viewmatrix, const float *projmatrix, float *dL_dmean3D, int fast,
+                           uint32_t *status_out);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -95,6 +97,7 @@ struct Geom {
     uint32_t *tiles_touched;
     uint32_t *sort_key0, *sort_key1, *sort_val0, *sort_val1, *sort_hist;
     uint2 *rect, *rect_sorted;
+    uint4 *krec;
     uint16_t *blk_hist;
     uint32_t *blk_rel;
     float4 *blend_rec;
@@ -119,6 +122,7 @@ Geom carve_geom(char *blob, int P, int W, int H) {
     g.sort_hist = (uint32_t *)(b + L.sort_hist);
     g.rect = (uint2 *)(b + L.rect);
     g.rect_sorted = (uint2 *)(b + L.rect_sorted);
+    g.krec = (uint4 *)(b + L.krec);
     g.blk_hist = (uint16_t *)(b + L.blk_hist);
     g.blk_rel = (uint32_t *)(b + L.blk_rel);
     g.blend_rec = (float4 *)(b + L.blend_rec);
@@ -217,13 +221,57 @@ struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t used = 0;
 };
+// Process-wide DEFAULTS of the per-call options (deprecated setters, include/fnx_raster.h): read when a call passes no
+// fnx_raster_opts_t or leaves a field at FNX_OPT_DEFAULT.
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
-float *g_zero_request = nullptr;  // fnx_request_zero3: zero-filled by the next stage 1 on its way
-uint32_t g_grad_limit_request = 0xFFFFFFFFu;  // fnx_request_gradient_limit: one-shot, for the next stage 2
 int g_sort_narrow = 0;       // the fourth depth-sort pass is not launched (fnx_set_sort_narrow)
 int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
 int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
 int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
+// Deprecated one-shot requests: per host thread, and TAKEN (cleared) at the top of the entry point they are meant for,
+// whatever that call then returns -- an early return can no longer leave a stale pointer or limit armed for an
+// unrelated later call.
+thread_local float *t_zero_request = nullptr;                  // fnx_request_zero3 -> next stage 1
+thread_local uint32_t t_grad_limit_request = 0xFFFFFFFFu;      // fnx_request_gradient_limit -> next stage 2
+
+// What a call runs with: its fnx_raster_opts_t, field by field, over the process-wide defaults.
+struct Opts {
+    int blend_math, lean_geometry, sort_mode, deep_kernel;
+    uint32_t grad_limit;  // 0xFFFFFFFF: none
+    uint32_t deep_min;
+    float *zero3;
+    char *sort_state;
+};
+int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pending_limit, Opts *out) {
+    out->blend_math = g_blend_math;
+    out->lean_geometry = g_lean_geometry;
+    out->sort_mode = g_sort_narrow ? FNX_SORT_NARROW : FNX_SORT_FULL;
+    out->deep_kernel = g_deep_kernel;
+    out->grad_limit = pending_limit;
+    out->deep_min = g_deep_min;
+    out->zero3 = pending_zero3;
+    out->sort_state = nullptr;
+    if (!o) return FNX_OK;
+    if (o->size != sizeof(fnx_raster_opts_t))
+        return fail(FNX_ERR_INVALID_ARG, "fnx_raster_opts_t.size is %u, this library's is %u (ABI %d)", o->size,
+                    (unsigned)sizeof(fnx_raster_opts_t), FNX_ABI_VERSION);
+    if (o->blend_math != FNX_OPT_DEFAULT) out->blend_math = o->blend_math;
+    if (o->lean_geometry != FNX_OPT_DEFAULT) out->lean_geometry = o->lean_geometry ? 1 : 0;
+    if (o->sort_mode != FNX_OPT_DEFAULT) out->sort_mode = o->sort_mode;
+    if (o->deep_kernel != FNX_OPT_DEFAULT) out->deep_kernel = o->deep_kernel;
+    // an options struct speaks for the whole call: pending one-shot requests are dropped, not merged
+    out->grad_limit = (o->grad_splat_limit == FNX_OPT_DEFAULT || o->grad_splat_limit < 0) ? 0xFFFFFFFFu
+                                                                                           : (uint32_t)o->grad_splat_limit;
+    if (o->deep_threshold) out->deep_min = o->deep_threshold;
+    out->zero3 = o->zero3;
+    out->sort_state = o->sort_state;
+    if (out->blend_math != 0 && out->blend_math != 1) return fail(FNX_ERR_INVALID_ARG, "blend_math must be 0 (exact) or 1 (fast)");
+    if (out->sort_mode < FNX_SORT_FULL || out->sort_mode > FNX_SORT_COHERENT) return fail(FNX_ERR_INVALID_ARG, "bad sort_mode");
+    if (out->sort_mode == FNX_SORT_COHERENT && !out->sort_state)
+        return fail(FNX_ERR_INVALID_ARG, "sort_mode FNX_SORT_COHERENT needs fnx_raster_opts_t.sort_state");
+    if (out->deep_kernel < 0 || out->deep_kernel > 2) return fail(FNX_ERR_INVALID_ARG, "deep_kernel must be 0, 1 or 2");
+    return FNX_OK;
+}
 bool g_prof_on = false;
 ProfClass g_prof[kProfClasses];
 
@@ -290,14 +338,18 @@ void fnx_static_layout(int P_static, int W, int H, int64_t R_static_capacity, fn
     fnx::static_layout(P_static, W, H, R_static_capacity, out);
 }
 
-int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M,
-                                   int width, int height, const float *means3D, const float *shs,
-                                   const float *colors_precomp, const float *opacities, const float *scales,
-                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                                   const float *viewmatrix, const float *projmatrix, const float *cam_pos,
-                                   const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
-                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   uint32_t *depth_hint, fnx_stream_t stream) {
+int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M,
+                                        int width, int height, const float *means3D, const float *shs,
+                                        const float *colors_precomp, const float *opacities, const float *scales,
+                                        float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                        const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                                        const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                                        const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                        uint32_t *depth_hint, const fnx_raster_opts_t *opts, fnx_stream_t stream) {
+    float *pending_zero3 = t_zero_request;
+    t_zero_request = nullptr;  // taken, whatever this call returns
+    Opts op;
+    if (int rc = resolve_opts(opts, pending_zero3, 0xFFFFFFFFu, &op)) return rc;
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P < 0 || width <= 0 || height <= 0) return fail(FNX_ERR_INVALID_ARG, "bad P/width/height");
     if (!image_buffer) return fail(FNX_ERR_INVALID_ARG, "image_buffer is NULL");
@@ -316,7 +368,7 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
         return fail(FNX_ERR_UNSUPPORTED, "%d tiles > %d (image larger than 2048x2048)", T, fnx::kMaxTiles);
     if (P == 0) {  // no kernels: zero instance count / status and empty ranges
         for (int v = 0; v < V; v++) {
-            (void)hipMemsetAsync((char *)img.header + v * vb.img, 0, 32, s);
+            (void)hipMemsetAsync((char *)img.header + v * vb.img, 0, 64, s);  // all 16 header words
             (void)hipMemsetAsync((char *)img.ranges + v * vb.img, 0, (size_t)T * 8, s);
         }
         return hip_check("stage1(P=0)");
@@ -331,27 +383,55 @@ int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char 
         return fail(FNX_ERR_INVALID_ARG, "neither cov3D_precomp nor scales+rotations given");
     Geom g = carve_geom(geom_buffer, P, width, height);
     int *rad = radii ? radii : g.radii;  // rasterizer_impl.cu:214-216
+    // temporal-coherence sort: only where a tile rectangle fits its packed record (else the radix passes, state left seeded)
+    char *sort_state = op.sort_state ? aligned(op.sort_state) : nullptr;
+    const bool coherent = op.sort_mode == FNX_SORT_COHERENT && fnx::coherent_sort_supported(width, height);
+    fnx::CohRef coh;
+    memset(&coh, 0, sizeof(coh));
+    if (coherent) {
+        const fnx::SortStateLayout SL = fnx::sort_state_layout(P);
+        coh.krec = g.krec;
+        coh.state = sort_state;
+        coh.stride = SL.total;
+        coh.hdr = SL.hdr;
+        coh.inv = SL.inv;
+    }
     {
     ProfScope ps(3, s);
     fnx::launch_preprocess(channels, s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, g.clamped,
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
                            g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st,
-                           (g_lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0, g_zero_request);
-    g_zero_request = nullptr;  // one-shot
+                           (op.lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0, op.zero3, coh);
     }
     {
     ProfScope ps(2, s);
     // (key, id) pair buffers: sort_key0|sort_key1 and sort_val0|sort_val1 are adjacent P-word arrays
     fnx::launch_depth_sort(s, P, g.sort_key0, (uint2 *)g.sort_key0, (uint2 *)g.sort_val0, g.sort_hist, g.rect,
-                           g.rect_sorted, V, vb, g_sort_narrow);
+                           g.rect_sorted, V, vb, op.sort_mode == FNX_SORT_NARROW ? 1 : 0, sort_state, coherent ? 1 : 0,
+                           g.krec);
     fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
                           vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
-                          g_deep_min, img.tile_order, img.tile_deep, V, vb, st);
+                          op.deep_min, img.tile_order, img.tile_deep, V, vb, st);
     }
     return hip_check("stage1");
+}
+
+int fnx_forward_stage1_views_split(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M,
+                                   int width, int height, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *opacities, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                   const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                                   const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   uint32_t *depth_hint, fnx_stream_t stream) {
+    return fnx_forward_stage1_views_split_opts(channels, V, geom_buffer, image_buffer, P, D, M, width, height, means3D,
+                                               shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                               cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                                               prefiltered, radii, static_blobs, P_static, R_static_capacity,
+                                               depth_hint, nullptr, stream);
 }
 
 int fnx_forward_stage1_views(int channels, int V, char *geom_buffer, char *image_buffer, int P, int D, int M, int width,
@@ -405,11 +485,16 @@ int fnx_read_status(const char *image_buffer, int width, int height, fnx_stream_
     return FNX_OK;
 }
 
-int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char *binning_buffer,
-                                   int64_t binning_capacity, char *image_buffer, int P, int width, int height,
-                                   const float *background, float *out_color, float *out_depth, uint32_t *status_out,
-                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                   int materialize_all, uint32_t *depth_hint, fnx_stream_t stream) {
+int fnx_forward_stage2_views_split_opts(int channels, int V, char *geom_buffer, char *binning_buffer,
+                                        int64_t binning_capacity, char *image_buffer, int P, int width, int height,
+                                        const float *background, float *out_color, float *out_depth,
+                                        uint32_t *status_out, const char *static_blobs, int P_static,
+                                        int64_t R_static_capacity, int materialize_all, uint32_t *depth_hint,
+                                        const fnx_raster_opts_t *opts, fnx_stream_t stream) {
+    const uint32_t pending_limit = t_grad_limit_request;
+    t_grad_limit_request = 0xFFFFFFFFu;  // taken, whatever this call returns
+    Opts op;
+    if (int rc = resolve_opts(opts, nullptr, pending_limit, &op)) return rc;
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // outputs stay as the caller zero-filled them (rasterize_points.cu:81)
     if (!geom_buffer || !image_buffer || !background || !out_color || !out_depth)
@@ -439,15 +524,34 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char 
                      g.rect_sorted, img.dyn_start, g.blk_rel, g.sort_hist + L.emit_ctl, g.sort_hist + L.emit_items,
                      bin.point_list, img.header, cap, st.base ? 1 : 0, V, vb);
     }
+    fnx::InvUpdate iu;
+    memset(&iu, 0, sizeof(iu));
+    if (op.sort_mode == FNX_SORT_COHERENT && op.sort_state && fnx::coherent_sort_supported(width, height)) {
+        const fnx::SortStateLayout SL = fnx::sort_state_layout(P);
+        iu.pairs = (const uint2 *)g.sort_val0;  // where the coherent sort leaves its (depth bits, id) pairs
+        iu.state = aligned(op.sort_state);
+        iu.stride = SL.total;
+        iu.inv = SL.inv;
+        iu.P = P;
+    }
     {
         ProfScope ps(channels == 3 ? 0 : 5, s);
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb, g_blend_math, g_deep_kernel, g_grad_limit_request);
-        g_grad_limit_request = 0xFFFFFFFFu;  // one-shot
+                                  st, materialize_all, V, vb, op.blend_math, op.deep_kernel, op.grad_limit, iu);
     }
     return hip_check("stage2");
+}
+
+int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffer, char *binning_buffer,
+                                   int64_t binning_capacity, char *image_buffer, int P, int width, int height,
+                                   const float *background, float *out_color, float *out_depth, uint32_t *status_out,
+                                   const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                   int materialize_all, uint32_t *depth_hint, fnx_stream_t stream) {
+    return fnx_forward_stage2_views_split_opts(channels, V, geom_buffer, binning_buffer, binning_capacity, image_buffer, P,
+                                               width, height, background, out_color, out_depth, status_out, static_blobs,
+                                               P_static, R_static_capacity, materialize_all, depth_hint, nullptr, stream);
 }
 
 int fnx_forward_stage2_views_status(int channels, int V, char *geom_buffer, char *binning_buffer,
@@ -530,19 +634,21 @@ int fnx_rasterize_forward(int channels, fnx_alloc_fn geometryBuffer, void *geom_
                               out_color, out_depth, stream);
 }
 
-int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M, const float *background, int width,
-                                       int height, const float *means3D, const float *shs,
-                                       const float *colors_precomp, const float *scales, float scale_modifier,
-                                       const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                                       const float *projmatrix, const float *campos, const float *tan_fovx,
-                                       const float *tan_fovy, const int *radii, char *geom_buffer,
-                                       char *binning_buffer, int64_t binning_capacity, char *image_buffer,
-                                       const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
-                                       float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
-                                       float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
-                                       float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
-                                       const char *static_blobs, int P_static, int64_t R_static_capacity,
-                                       fnx_stream_t stream) {
+int fnx_rasterize_backward_views_split_opts(int channels, int V, int P, int D, int M, const float *background,
+                                            int width, int height, const float *means3D, const float *shs,
+                                            const float *colors_precomp, const float *scales, float scale_modifier,
+                                            const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                            const float *projmatrix, const float *campos, const float *tan_fovx,
+                                            const float *tan_fovy, const int *radii, char *geom_buffer,
+                                            char *binning_buffer, int64_t binning_capacity, char *image_buffer,
+                                            const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                                            float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
+                                            float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                            float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                                            const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                            uint32_t *status_out, const fnx_raster_opts_t *opts, fnx_stream_t stream) {
+    Opts op;
+    if (int rc = resolve_opts(opts, nullptr, 0xFFFFFFFFu, &op)) return rc;
     if (!channels_ok(channels)) return fail(FNX_ERR_INVALID_ARG, "channels must be 1 or 3 (got %d)", channels);
     if (P == 0) return FNX_OK;  // rasterize_points.cu:160
     if (geometry_only < 0 || geometry_only > 3) return fail(FNX_ERR_INVALID_ARG, "geometry_only must be 0, 1, 2 or 3");
@@ -575,7 +681,7 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
     const int *rad = radii ? radii : g.radii;
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;      // rasterizer_impl.cu:390
     // lean geometry (fnx_set_lean_geometry; must match the forward's setting): view 0's blob holds the one covariance array
-    const size_t cov3D_stride = (cov3D_precomp || (g_lean_geometry && V > 1)) ? 0 : vb.geom;
+    const size_t cov3D_stride = (cov3D_precomp || (op.lean_geometry && V > 1)) ? 0 : vb.geom;
     {
         ProfScope ps(channels == 3 ? 1 : 6, s);
         fnx::launch_blend_backward(channels, geometry_only, s, P_all, width, height, img.ranges, bin.point_list,
@@ -583,7 +689,7 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
                                    dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header,
                                    (uint32_t)binning_capacity,
                                    (uint32_t)limit, V, vb, st, means3D, cov3D_ptr, cov3D_stride, viewmatrix, projmatrix,
-                                   dL_dmean3D, g_blend_math);
+                                   dL_dmean3D, op.blend_math, status_out);
     }
     if (positions_only) return hip_check("backward");  // the blend backward's flush went through the geometry itself
     const int sum_appearance = (V > 1 && geometry_only != 1) ? 1 : 0;
@@ -592,6 +698,27 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M,
                               dL_dopacity_views, dL_dcolor_views, dL_dopacity, shs ? nullptr : dL_dcolor, dL_dmean3D,
                               dL_dcov3D, dL_dsh, dL_dscale, dL_drot, limit, V, sum_appearance, vb);
     return hip_check("backward");
+}
+
+int fnx_rasterize_backward_views_split(int channels, int V, int P, int D, int M, const float *background, int width,
+                                       int height, const float *means3D, const float *shs,
+                                       const float *colors_precomp, const float *scales, float scale_modifier,
+                                       const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                       const float *projmatrix, const float *campos, const float *tan_fovx,
+                                       const float *tan_fovy, const int *radii, char *geom_buffer,
+                                       char *binning_buffer, int64_t binning_capacity, char *image_buffer,
+                                       const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
+                                       float *dL_dopacity_views, float *dL_dcolor_views, float *dL_dopacity,
+                                       float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                       float *dL_dscale, float *dL_drot, int grad_splat_limit, int geometry_only,
+                                       const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                       fnx_stream_t stream) {
+    return fnx_rasterize_backward_views_split_opts(
+        channels, V, P, D, M, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+        cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+        binning_capacity, image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, dL_dopacity,
+        dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, grad_splat_limit, geometry_only, static_blobs,
+        P_static, R_static_capacity, nullptr, nullptr, stream);
 }
 
 int fnx_rasterize_backward_views(int channels, int V, int P, int D, int M, const float *background, int width,
@@ -661,11 +788,24 @@ int fnx_set_blend_math(int mode) {
 }
 int fnx_get_blend_math(void) { return g_blend_math; }
 int fnx_request_zero3(float *rows3) {
-    g_zero_request = rows3;
+    t_zero_request = rows3;
     return FNX_OK;
 }
 int fnx_request_gradient_limit(int grad_splat_limit) {
-    g_grad_limit_request = grad_splat_limit < 0 ? 0xFFFFFFFFu : (uint32_t)grad_splat_limit;
+    t_grad_limit_request = grad_splat_limit < 0 ? 0xFFFFFFFFu : (uint32_t)grad_splat_limit;
+    return FNX_OK;
+}
+size_t fnx_sort_state_bytes(int P) { return fnx::sort_state_layout(P).total; }
+int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[2]) {
+    if (!sort_state || !out || P < 0 || view < 0) return fail(FNX_ERR_INVALID_ARG, "bad argument");
+    const fnx::SortStateLayout SL = fnx::sort_state_layout(P);
+    uint32_t h[fnx::COH_HDR_WORDS];
+    const char *src = aligned(sort_state) + SL.total * (size_t)view + SL.hdr;
+    hipError_t e = hipMemcpyAsync(h, src, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "sort_state_read: %s", hipGetErrorString(e));
+    out[0] = h[fnx::COH_REPAIRS];
+    out[1] = h[fnx::COH_FALLBACKS];
     return FNX_OK;
 }
 int fnx_set_sort_narrow(int on) {

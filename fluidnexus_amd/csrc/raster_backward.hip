@@ -127,7 +127,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb,
                       const float *__restrict__ means3D, const float *__restrict__ cov3Ds, size_t cov3D_stride,
                       const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
-                      float *__restrict__ dL_dmean3D) {
+                      float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out) {
     constexpr bool kMeans = MODE != 2, kAppearance = MODE == 0 || MODE == 2, kFusedGeom = MODE == 3;
     constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums
     constexpr int NV = kAppearance ? kCol + C : kOpac;
@@ -176,7 +176,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             // (fnx_request_gradient_limit; HDR_DYN_LIMIT): splats this call differentiates would be cut off
             const bool cut = grad_limit > h[HDR_DYN_LIMIT];
             const bool mismatch = h[HDR_BIN_CAPACITY] != capacity || cut;
-            if (mismatch && blockIdx.x == 0) const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+            if (mismatch && blockIdx.x == 0) {
+                const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+                // ... and in the caller's status row of the view, where a deferred check looks (a refused backward
+                // returns zero gradients: it must not pass unnoticed)
+                if (status_out) status_out[8 * v + HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+            }
             if (!(mismatch || h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
         }
         s_first[n_views] = run;
@@ -1151,18 +1156,18 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st, const float *means3D,
                            const float *cov3Ds, size_t cov3D_stride, const float *viewmatrix, const float *projmatrix,
-                           float *dL_dmean3D, int fast) {
+                           float *dL_dmean3D, int fast, uint32_t *status_out) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
     const int n_cu = device_cu_count();
-    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
-    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D);
+    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,

@@ -100,12 +100,22 @@ colscan_kernel(int T, int NB, const CountT *__restrict__ blk_hist, uint32_t *__r
 // ---------------------------------------------------------------------------------------------
 // Depth sort: LSD radix, kSortBits-bit digits, stable.  Workgroup = 256 threads = 4 waves over a chunk of
 // kSortChunk = 1024 keys; wave w owns keys [256 w, 256 w + 256) of the chunk in 4 steps of 64.
-// Pass 0 reads the raw keys and sorts key' = key - kmin (culled splats: 0; their rank is irrelevant, they emit
-// nothing), where kmin is the smallest visible key of the view; the later passes read key' as scattered.
+// Pass 0 reads the raw keys and sorts key' = key - kmin (culled splats: their own depth, clamped, see relative_key; their
+// rank is irrelevant, they emit nothing), where kmin is the smallest visible key of the view; the later passes read
+// key' as scattered.
 enum { SORT_FIRST = 0, SORT_MIDDLE = 1, SORT_THIRD = 2, SORT_FOURTH = 3 };
 
+// Culled splats carry bit 31 (visible depths are positive floats above 0.2: bit 31 clear) over their own depth bits: they
+// emit nothing, so any deterministic place in the order is correct, and keeping them AT THEIR DEPTH (clamped into the
+// range three passes order) means a splat that enters or leaves a view does not jump through the whole order -- the
+// temporal-coherence sort below relies on small displacements between consecutive calls.
+__device__ __forceinline__ bool key_culled(uint32_t key) { return (key & 0x80000000u) != 0u; }
 __device__ __forceinline__ uint32_t relative_key(uint32_t key, uint32_t kmin) {
-    return key == 0xFFFFFFFFu ? 0u : key - kmin;
+    if (key_culled(key)) {
+        const uint32_t d = key & 0x7FFFFFFFu;
+        return min(d > kmin ? d - kmin : 0u, (1u << (3 * kSortBits)) - 1u);
+    }
+    return key - kmin;
 }
 
 __global__ void __launch_bounds__(256)
@@ -146,8 +156,9 @@ sort_hist_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *__re
         if (i < P) {
             uint32_t key;
             if (pass == SORT_FIRST) {
-                key = relative_key(raw_keys[i], kmin);
-                kmax = max(kmax, key);
+                const uint32_t raw = raw_keys[i];
+                key = relative_key(raw, kmin);
+                if (!key_culled(raw)) kmax = max(kmax, key);  // the span that decides about the fourth pass: visible splats only
             } else {
                 key = pairs[i].x;
             }
@@ -176,7 +187,7 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
                     uint2 *__restrict__ pairs_out, int pass,
                     const uint32_t *__restrict__ hist_rel, const uint32_t *__restrict__ digit_total,
                     const uint32_t *__restrict__ ctl, const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted,
-                    size_t geom_stride) {
+                    size_t geom_stride, char *__restrict__ coh_state, size_t coh_stride, SortStateLayout SL) {
     __shared__ uint32_t s_cnt[4][kSortRadix];   // per-wave digit counts, then per-wave running offsets
     __shared__ uint32_t s_wtot[4];
     bool with_rect = false;
@@ -195,6 +206,15 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
         digit_total = view_at(digit_total, geom_stride, vw);
         rect = view_at(rect, geom_stride, vw);
         rect_sorted = view_at(rect_sorted, geom_stride, vw);
+        if (coh_state) coh_state += coh_stride * (size_t)vw;
+    }
+    // the pass that leaves the final order also seeds the caller's temporal-coherence state (rank of every splat)
+    uint32_t *__restrict__ coh_inv = (coh_state && with_rect) ? reinterpret_cast<uint32_t *>(coh_state + SL.inv) : nullptr;
+    if (coh_inv && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(coh_state + SL.hdr);
+        hdr[COH_MAGIC] = coh_magic(P);
+        hdr[COH_ARRIVED] = 0u;
+        hdr[COH_FAIL] = 0u;
     }
     const int shift = pass * kSortBits;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -259,9 +279,412 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
             const uint32_t pos = run_off[d] + r;
             pairs_out[pos] = kv[k];
             if (with_rect) rect_sorted[pos] = rect[kv[k].y];
+            if (coh_inv) coh_inv[kv[k].y] = pos;
         }
         // the wave's LDS reads above are issued before this write (in-order per wave)
         if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Temporal-coherence depth sort (sort_mode = FNX_SORT_COHERENT): ONE launch instead of nine, and no gather.
+//
+// Between two optimiser steps the positions move by ~1e-4 m, i.e. a splat's depth rank by a few hundred places in a
+// 200 k-splat plume (1e6 ranks per metre of depth).  The caller's persistent state holds inv[id] = the splat's rank in
+// the PREVIOUS call's depth order.  The preprocess kernel, which has the new depth and tile rectangle of splat id in
+// registers, writes them as one 16-byte record (depth bits, id, rectangle, call stamp) to slot inv[id] of a per-call
+// array: a scattered write that costs the bandwidth-bound kernel nothing measurable, and leaves the records in the
+// previous order.  Workgroup c of this kernel then reads the window of kCohWin consecutive records around its chunk of
+// kCohOut ranks with coalesced loads (measured before: gathering keys and rectangles by id cost 35 of 89 us), sorts
+// the window in LDS, and writes the middle kCohOut positions: that is the chunk of the globally sorted order whenever
+// no element has to travel further than kCohMargin ranks.
+//
+// The window sort is a sample sort: every 16th window element is a splitter (256 of them, ranked by counting), an
+// element's bucket is the number of splitters below it (binary search), a bucket holds ~16 elements in any order, and
+// the position inside the bucket is counted directly.  Its cost does not depend on how far the elements moved.  All
+// comparisons are on (depth bits, id) as one u64: ties in depth order by id, no limit on the key span.  Every phase is a
+// handful of dependent LDS round trips, so it is the number of waves in flight that sets the time (256 threads x 16
+// elements measured 42 us for the sort phases alone): kCohThreads threads per workgroup, two workgroups per unit.
+//
+// The result is VERIFIED, not assumed.  A record counts only if it carries this call's stamp and an id in range, i.e.
+// if the preprocess of THIS call wrote it (with the splat's current depth); every workgroup checks that its chunk is
+// strictly increasing in (depth bits, id) and publishes its first and last element; the workgroup that arrives last
+// checks the chunk boundaries.  N strictly increasing records of this call with ids in [0, P) are the sorted
+// permutation -- whatever the state held.  If a check fails (a new frame, a large move, an unseeded state) that same
+// workgroup sorts the view by itself from the preprocess' plain arrays (stable 8-bit LSD passes: ~2 ms for 200 k
+// splats, rare and counted), so the call is always exact; (depth bits, id) is a total order, hence point_list is
+// bit-identical to the radix path's (tests/test_coherent_sort_gpu.py).  Culled splats (bit 31 of the preprocess key)
+// are ordered by their own depth bits in this mode: they emit nothing, and a splat that enters or leaves a view
+// does not move in the order.
+constexpr int kCohOut = 2 * kSplatBlock;
+constexpr int kCohMargin = 1024;
+constexpr int kCohWin = kCohOut + 2 * kCohMargin;
+#ifndef FNX_COH_THREADS
+#define FNX_COH_THREADS 512
+#endif
+constexpr int kCohThreads = FNX_COH_THREADS;
+constexpr int kCohPer = kCohWin / kCohThreads;  // consecutive window positions per thread
+constexpr int kCohMaxBucket = 256;              // a bucket larger than this fails the call (cannot happen with distinct elements in practice)
+constexpr int kCohSampleThreads = 16 / kCohPer;  // threads per splitter: one splitter per 16 window positions
+constexpr int kCohParts = kCohThreads / 256;     // the 256 samples are ranked by kCohParts threads each
+static_assert(kCohPer * kCohSampleThreads == 16 && kCohParts * 256 == kCohThreads && kCohOut % kCohThreads == 0, "thread counts");
+typedef unsigned long long u64;
+#ifndef FNX_EXP_COH
+#define FNX_EXP_COH 0  // timing experiments (tools/build_variant.py; results wrong, verification off): 2 no rectangle / inv stores, 4 no window sort
+#endif
+// LDS layout of sort_repair_kernel: the output chunk | the bucketed window | splitters | bucket counts | starts | per
+// bucketed position: its bucket, then its final window position (the window itself lives in registers)
+constexpr size_t kCohLdsA = (size_t)kCohOut * 8;
+constexpr size_t kCohLdsT = (size_t)kCohWin * 8;
+constexpr size_t kCohLdsBytes = kCohLdsA + kCohLdsT + 256 * 8 + 2 * 272 * 4 + (size_t)kCohWin * 2;
+static_assert(kCohLdsBytes <= 64 * 1024, "static LDS");
+
+__device__ __forceinline__ uint32_t sort_key_bits(uint32_t raw) { return raw & 0x7FFFFFFFu; }  // depth bits, culled or not
+__device__ __forceinline__ uint2 unpack_rect8(uint32_t r) {
+    return make_uint2((r & 0xFFu) | (((r >> 8) & 0xFFu) << 16), ((r >> 16) & 0xFFu) | ((r >> 24) << 16));
+}
+
+// Whole-view stable LSD sort by the first 256 threads of ONE workgroup (the fallback above), on the absolute depth bits:
+// raw -> pb -> pa -> pb -> pa, then pa is copied to pb (pa aliases the raw keys, which only the first pass reads).
+// `lds`: >= 1288 words.
+__device__ void coh_fallback_sort(int P, const uint32_t *raw, uint2 *pa, uint2 *pb, uint32_t *inv, const uint2 *rect,
+                                  uint2 *rect_sorted, uint32_t *lds) {
+    uint32_t *s_base = lds;              // [256] next free position of every digit
+    uint32_t *s_cnt = lds + 256;         // [4][256] per-wave digit counts -> per-wave running offsets
+    uint32_t *s_wt = lds + 256 + 1024;   // [4]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nchunks = (P + 1023) / 1024;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        const uint2 *src = (pass & 1) ? pb : pa;
+        uint2 *dst = (pass & 1) ? pa : pb;
+        s_base[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < P; i += 256) {
+            const uint32_t key = pass == 0 ? sort_key_bits(raw[i]) : src[i].x;
+            atomicAdd(&s_base[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        {  // exclusive prefix over the 256 digits (thread = digit)
+            const uint32_t cnt = s_base[tid];
+            uint32_t inc = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += v;
+            }
+            if (lane == 63) s_wt[w] = inc;
+            __syncthreads();
+            uint32_t ex = inc - cnt;
+            for (int k = 0; k < w; k++) ex += s_wt[k];
+            __syncthreads();
+            s_base[tid] = ex;
+        }
+        for (int ch = 0; ch < nchunks; ch++) {
+            const int base = ch * 1024 + w * 256;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_cnt[k * 256 + tid] = 0u;
+            __syncthreads();
+            uint2 kv[4];
+            bool valid[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = base + k * 64 + lane;
+                valid[k] = i < P;
+                kv[k] = make_uint2(0u, 0u);
+                if (valid[k]) {
+                    kv[k] = pass == 0 ? make_uint2(sort_key_bits(raw[i]), (uint32_t)i) : src[i];
+                    atomicAdd(&s_cnt[w * 256 + ((kv[k].x >> shift) & 255u)], 1u);
+                }
+            }
+            __syncthreads();
+            {
+                uint32_t run = s_base[tid];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t c = s_cnt[k * 256 + tid];
+                    s_cnt[k * 256 + tid] = run;
+                    run += c;
+                }
+                s_base[tid] = run;
+            }
+            __syncthreads();
+            volatile uint32_t *run_off = s_cnt + w * 256;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = (kv[k].x >> shift) & 255u;
+                unsigned long long same = __ballot(valid[k]);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const unsigned long long m = __ballot((d >> b) & 1u);
+                    same &= ((d >> b) & 1u) ? m : ~m;
+                }
+                if (valid[k]) dst[run_off[d] + (uint32_t)__popcll(same & lt_mask)] = kv[k];
+                // the wave's LDS reads above are issued before this write (in-order per wave)
+                if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
+            }
+            __syncthreads();
+        }
+        // this workgroup reads back what it wrote: stores out to L2, stale L1 lines dropped
+        __threadfence();
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    for (int i = tid; i < P; i += 256) {
+        const uint2 kv = pa[i];
+        pb[i] = kv;
+        inv[kv.y] = (uint32_t)i;
+        rect_sorted[i] = rect[kv.y];
+    }
+}
+
+__global__ void __launch_bounds__(kCohThreads)  // two workgroups per unit (60 KiB of LDS each)
+sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__restrict__ krec,
+                   uint2 *__restrict__ pairs_tmp, uint2 *__restrict__ pairs_out, uint32_t *__restrict__ scratch,
+                   SortScratch L, const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted,
+                   char *__restrict__ state, size_t state_stride, SortStateLayout SL, size_t geom_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kCohLdsBytes];
+    u64 *s_out = reinterpret_cast<u64 *>(s_raw);                           // the output chunk is staged here
+    u64 *s_t = reinterpret_cast<u64 *>(s_raw + kCohLdsA);                  // bucketed copy of the window
+    u64 *s_split = reinterpret_cast<u64 *>(s_raw + kCohLdsA + kCohLdsT);   // [256] sorted sample of the window
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_raw + kCohLdsA + kCohLdsT + 256 * 8);  // [257] bucket sizes
+    uint32_t *s_start = s_cnt + 272;                                        // [257] bucket starts (before that: sample ranks)
+    uint16_t *s_bid = reinterpret_cast<uint16_t *>(s_start + 272);          // [kCohWin] bucket, then final position
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_flag, s_last;
+    const int vw = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = blockIdx.x, nc = gridDim.x;
+    raw_keys = view_at(raw_keys, geom_stride, vw);
+    krec = view_at(krec, geom_stride, vw);
+    pairs_tmp = view_at(pairs_tmp, geom_stride, vw);
+    pairs_out = view_at(pairs_out, geom_stride, vw);
+    scratch = view_at(scratch, geom_stride, vw);
+    rect = view_at(rect, geom_stride, vw);
+    rect_sorted = view_at(rect_sorted, geom_stride, vw);
+    state += state_stride * (size_t)vw;
+    uint32_t *ctl = scratch + L.ctl;
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(state + SL.hdr);
+    u64 *bounds = reinterpret_cast<u64 *>(state + SL.bounds);
+    uint32_t *__restrict__ inv = reinterpret_cast<uint32_t *>(state + SL.inv);
+    if (tid == 0) s_flag = 0u;
+    if (tid < 272) {
+        s_cnt[tid] = 0u;
+        s_start[tid] = 0u;
+    }
+    // a position nobody writes (impossible while every record is valid) must not pass for a splat: invalid id
+#pragma unroll
+    for (int k = 0; k < kCohOut / kCohThreads; k++) s_out[k * kCohThreads + tid] = ~0ull;
+    const uint32_t magic = coh_magic(P);
+    const bool seeded = hdr[COH_MAGIC] == magic;  // written only by the workgroup that arrives last, after everyone read it
+    const uint32_t epoch = hdr[COH_EPOCH];        // the stamp this call's preprocess put on its records
+    bool bad = false;
+    const int n_out = min(kCohOut, P - c * kCohOut);
+    if (seeded) {
+        // ---- the window: previous ranks [g0, g0 + kCohWin), thread t owns four consecutive ones.  Ranks outside the
+        // array take no part in the sort: the n_left window positions in front of rank 0 (chunk 0 only) shift every real
+        // element's position, the ones behind rank P - 1 lie behind every output.
+        const long long gt = (long long)c * kCohOut - kCohMargin + (long long)kCohPer * tid;
+        const int n_left = (int)max(0ll, (long long)kCohMargin - (long long)c * kCohOut);
+        uint4 rec[kCohPer];
+        bool real[kCohPer];
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++) {
+            const long long g = gt + k;
+            real[k] = g >= 0 && g < (long long)P;
+            rec[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (real[k]) rec[k] = krec[g];
+        }
+        u64 v[kCohPer];
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++) {
+            if (real[k] && (rec[k].w != epoch || rec[k].y >= (uint32_t)P)) {  // not written by this call's preprocess
+                bad = true;
+                real[k] = false;
+            }
+            v[k] = real[k] ? (((u64)rec[k].x << 32) | rec[k].y) : 0ull;
+        }
+        uint32_t at[kCohPer];  // where the element lies in the bucketed copy
+        if (FNX_EXP_COH & 4) {
+#pragma unroll
+            for (int k = 0; k < kCohPer; k++) {
+                at[k] = (uint32_t)(kCohPer * tid + k);
+                s_bid[at[k]] = (uint16_t)at[k];
+                const int o = kCohPer * tid + k - kCohMargin;
+                if (o >= 0 && o < kCohOut) s_out[o] = v[k];
+            }
+            __syncthreads();
+        } else {
+        // splitters: a REGULAR SAMPLE of the window (every 16th position), sorted by counting.  Consecutive sorted
+        // samples are ~16 window elements apart whatever the disorder (the longest of 256 gaps stays near 16 ln 256),
+        // so no bucket grows with the displacement.  A sample position without a real element contributes the largest
+        // value (empty buckets).
+        if (tid % kCohSampleThreads == 0) s_t[tid / kCohSampleThreads] = real[0] ? v[0] : ~0ull;  // s_t is free until the bucketed copy is written
+        __syncthreads();
+        {
+            constexpr int kSpan = 256 / kCohParts;
+            const int j = tid & 255, first = (tid >> 8) * kSpan;  // sample j against samples [first, first + kSpan)
+            const u64 mine = s_t[j];
+            uint32_t r = 0;
+#pragma unroll 2
+            for (int i0 = 0; i0 < kSpan; i0 += 8) {
+                u64 q[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = s_t[first + i0 + i];
+#pragma unroll
+                for (int i = 0; i < 8; i++) r += (q[i] < mine || (q[i] == mine && first + i0 + i < j)) ? 1u : 0u;
+            }
+            atomicAdd(&s_start[j], r);
+        }
+        __syncthreads();
+        if (tid < 256) s_split[s_start[tid]] = s_t[tid];
+        __syncthreads();
+        // bucket = number of splitters below the element: 0 .. 256
+        uint32_t bk[kCohPer];
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++) {
+            int lo = 0, hi = 256;
+#pragma unroll
+            for (int step = 0; step < 9; step++) {
+                const int mid = (lo + hi) >> 1;
+                if (lo < hi) {
+                    if (s_split[mid] < v[k]) lo = mid + 1;
+                    else hi = mid;
+                }
+            }
+            bk[k] = (uint32_t)lo;
+        }
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++) at[k] = real[k] ? atomicAdd(&s_cnt[bk[k]], 1u) : 0u;  // slot inside the bucket
+        __syncthreads();
+        uint32_t n_mine = 0, inc = 0;
+        if (tid < 256) {  // bucket starts: exclusive prefix of the sizes (thread = bucket)
+            n_mine = s_cnt[tid];
+            inc = n_mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t tu = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += tu;
+            }
+            if (lane == 63) s_wsum[w] = inc;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t ex = inc - n_mine;
+            for (int k = 0; k < w; k++) ex += s_wsum[k];
+            s_start[tid] = ex;
+            if (tid == 255) s_start[256] = ex + n_mine;  // elements above every splitter
+            if (n_mine > (uint32_t)kCohMaxBucket || s_cnt[256] > (uint32_t)kCohMaxBucket) bad = true;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++)
+            if (real[k]) {
+                at[k] += s_start[bk[k]];
+                s_t[at[k]] = v[k];
+                s_bid[at[k]] = (uint16_t)bk[k];
+            }
+        __syncthreads();
+        // Position of every bucketed element = n_left + bucket start + elements of its bucket below it; the middle
+        // kCohOut positions are the chunk.  Threads take the BUCKETED positions (lanes = consecutive positions: a wave
+        // spans four or five buckets, so its lanes loop about equally long and read the same LDS words: broadcasts).
+        const uint32_t n_real = s_start[256] + s_cnt[256];
+#pragma unroll
+        for (int k = 0; k < kCohPer; k++) {
+            const uint32_t p = (uint32_t)(k * kCohThreads + tid);
+            const bool on = p < n_real;
+            const uint32_t b = on ? s_bid[p] : 0u;
+            const u64 x = on ? s_t[p] : 0ull;
+            const uint32_t base = s_start[b], n = on ? min(s_cnt[b], (uint32_t)kCohMaxBucket) : 0u;
+            uint32_t below = 0;
+            for (uint32_t j = 0; j < n; j += 4) {
+                const u64 q0 = s_t[base + j], q1 = s_t[base + j + 1], q2 = s_t[base + j + 2], q3 = s_t[base + j + 3];
+                below += (q0 < x) ? 1u : 0u;
+                below += (j + 1 < n && q1 < x) ? 1u : 0u;
+                below += (j + 2 < n && q2 < x) ? 1u : 0u;
+                below += (j + 3 < n && q3 < x) ? 1u : 0u;
+            }
+            const int fw = n_left + (int)(base + below);  // final window position, < kCohWin
+            const int o = fw - kCohMargin;
+            if (on) {
+                s_bid[p] = (uint16_t)fw;  // for the element's owner (only this thread read the bucket stored here)
+                if (o >= 0 && o < kCohOut) s_out[o] = x;
+            }
+        }
+        __syncthreads();
+        }  // FNX_EXP_COH & 4
+        // the chunk, coalesced: (depth bits, id) pairs; strictly increasing?
+#pragma unroll
+        for (int k = 0; k < kCohOut / kCohThreads; k++) {
+            const int o = k * kCohThreads + tid;
+            if (o < n_out) {
+                const u64 x = s_out[o];
+                if ((uint32_t)x < (uint32_t)P) pairs_out[(size_t)c * kCohOut + o] = make_uint2((uint32_t)(x >> 32), (uint32_t)x);
+                else bad = true;
+                if (o + 1 < n_out && !(x < s_out[o + 1])) bad = true;
+            }
+        }
+        // every element's owner still has its rectangle in registers: it goes to the element's final position in LDS (the
+        // bucketed copy is dead by now), then out in rank order with coalesced stores.  (The splats' new ranks, inv[],
+        // are written by the blend forward on its way: InvUpdate.)
+        if (!(FNX_EXP_COH & 2)) {
+            uint32_t *s_orect = reinterpret_cast<uint32_t *>(s_t);
+#pragma unroll
+            for (int k = 0; k < kCohPer; k++) {
+                if (!real[k]) continue;
+                const int o = (int)s_bid[at[k]] - kCohMargin;
+                if (o >= 0 && o < n_out) s_orect[o] = rec[k].z;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kCohOut / kCohThreads; k++) {
+                const int o = k * kCohThreads + tid;
+                if (o < n_out) rect_sorted[(size_t)c * kCohOut + o] = unpack_rect8(s_orect[o]);
+            }
+        }
+        if (tid == 0) {
+            bounds[2 * c] = s_out[0];
+            bounds[2 * c + 1] = s_out[n_out - 1];
+        }
+    }
+    if (FNX_EXP_COH) bad = false;
+    if (bad) atomicOr(&s_flag, 1u);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_flag) atomicOr(&hdr[COH_FAIL], 1u);
+        __threadfence();
+        s_last = (atomicAdd(&hdr[COH_ARRIVED], 1u) == (uint32_t)nc - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || tid >= 256) return;  // the tail below is the work of four waves
+    // ---- the workgroup that arrives last: verify the chunk boundaries, repair by a full sort if need be, publish
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool fail = !seeded;
+    if (seeded) {
+        if (__hip_atomic_load(&hdr[COH_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) fail = true;
+        for (int b = tid; b + 1 < nc; b += 256)
+            if (!(bounds[2 * b + 1] < bounds[2 * b + 2])) fail = true;  // last of chunk b < first of chunk b + 1
+        if (FNX_EXP_COH) fail = false;
+    }
+    if (tid == 0) s_flag = 0u;
+    __syncthreads();
+    if (fail) atomicOr(&s_flag, 1u);
+    __syncthreads();
+    fail = s_flag != 0u;
+    if (fail) {
+        coh_fallback_sort(P, raw_keys, pairs_tmp, pairs_out, inv, rect, rect_sorted, reinterpret_cast<uint32_t *>(s_raw));
+        __threadfence();
+    }
+    if (tid == 0) {
+        ctl[SORT_CTL_KMIN] = 0u;      // this mode's pairs hold the depth bits themselves
+        ctl[SORT_CTL_WIDE] = 0u;      // emit reads the order from the three-pass buffer
+        ctl[SORT_CTL_OVERFLOW] = 0u;  // keys are compared whole: no span limit in this mode
+        ctl[SORT_CTL_SPAN] = 0u;      // not measured here (the radix call that seeded the state reported it)
+        hdr[COH_MAGIC] = magic;
+        hdr[COH_EPOCH] = epoch + 1u;
+        hdr[COH_ARRIVED] = 0u;
+        hdr[COH_FAIL] = 0u;
+        hdr[COH_REPAIRS] = hdr[COH_REPAIRS] + 1u;
+        if (fail) hdr[COH_FALLBACKS] = hdr[COH_FALLBACKS] + 1u;
     }
 }
 
@@ -706,10 +1129,20 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
 // are two P-entry (relative key, id) buffers (pairs_a may alias raw_keys: it is first written by the second pass).
 // After the call the pairs in (depth bits, id) order are in pairs_b (three passes) or pairs_a (four: scratch ctl
 // word SORT_CTL_WIDE is 1).
+// `coh_state` (may be NULL): the caller's persistent temporal-coherence state, V x sort_state_layout(P).total bytes.
+// coherent != 0: one launch of sort_repair_kernel over the records `krec` the preprocess left in the previous order;
+// otherwise the radix passes, which leave the state seeded when it is given.  (coh_state: already aligned.)
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
-                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow) {
+                       uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow,
+                       char *coh_state, int coherent, const uint4 *krec) {
     const int NSB = sort_blocks(P);
     const SortScratch L = sort_scratch(P);
+    const SortStateLayout SL = sort_state_layout(P);
+    if (coherent && coh_state) {
+        hipLaunchKernelGGL(sort_repair_kernel, dim3((P + kCohOut - 1) / kCohOut, V), dim3(kCohThreads), 0, s, P, raw_keys,
+                           krec, pairs_a, pairs_b, scratch, L, rect, rect_sorted, coh_state, SL.total, SL, vb.geom);
+        return;
+    }
     uint32_t *hist = scratch + L.hist, *hist_rel = scratch + L.hist_rel, *totals = scratch + L.totals,
              *ctl = scratch + L.ctl, *kmin_blk = scratch + L.kmin_blk, *kmax_blk = scratch + L.kmax_blk;
     uint2 *pin = pairs_a, *pout = pairs_b;
@@ -720,7 +1153,7 @@ void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pa
                            hist_rel, totals, vb.geom, vb.geom, pass == SORT_FIRST ? kmax_blk : (const uint32_t *)nullptr,
                            ctl, pass == SORT_FOURTH ? 1 : 0, narrow);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(NSB, V), dim3(256), 0, s, P, raw_keys, pin, pout, pass, hist_rel,
-                           totals, ctl, rect, rect_sorted, vb.geom);
+                           totals, ctl, rect, rect_sorted, vb.geom, coh_state, SL.total, SL);
         uint2 *t = pin; pin = pout; pout = t;
     }
 }

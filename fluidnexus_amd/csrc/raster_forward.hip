@@ -122,7 +122,8 @@ __device__ inline float3 cov2d_ewa(const float3 mean, float focal_x, float focal
 // ---------------------------------------------------------------------------------------------
 // K1: per-Gaussian preprocess (ch3 forward.cu:148-244), one thread per splat.  Besides the
 // reference's per-splat state it writes the packed 64-byte record the blend kernels read and
-//   sort_key[idx]: depth bits of visible splats, 0xFFFFFFFF for culled ones (raster_binning.hip),
+//   sort_key[idx]: depth bits of visible splats; bit 31 | depth bits for culled ones (they keep their place in depth so
+//                  that a splat entering / leaving a view does not jump through the sorted order, raster_binning.hip),
 //   key_min_blk[block]: the smallest key of the workgroup's splats (the sort works relative to the minimum).
 template <int C>
 __global__ void __launch_bounds__(256)
@@ -136,7 +137,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
                   float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb, int lean,
-                  float *__restrict__ zero3) {
+                  float *__restrict__ zero3, const CohRef coh) {
     // lean (fnx_set_lean_geometry): the copies of the reference's GeometryState that nothing in this library reads back
     // (means2D, depths, conic_opacity, tiles_touched: the blend records carry the same numbers) are not written, and the
     // world covariance -- the same for every view -- is written by view 0 only (the backward reads it at stride 0)
@@ -175,10 +176,11 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
     blend_rec = view_at(blend_rec, vb.geom, vw);
     const float tan_fovx = vb.tan_fovx[vw], tan_fovy = vb.tan_fovy[vw];
     const float focal_x = vb.focal_x[vw], focal_y = vb.focal_y[vw];
-    uint32_t key = 0xFFFFFFFFu;
+    uint32_t key = 0xFFFFFFFFu;  // bit 31 = culled (threads past the end included)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < P) {
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        bool visible = false;
         if (zero3 && vw == 0) {  // the caller's [P_all, 3] accumulator of the positions-only backward, zeroed on the way
             zero3[3 * (size_t)idx] = 0.f;
             zero3[3 * (size_t)idx + 1] = 0.f;
@@ -194,6 +196,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             for (int k = 0; k < 6; k++) cov3Ds[(size_t)idx * 6 + k] = c0[k];
         }
         const float3 p_view = xform4x3(p_orig, view);
+        key = 0x80000000u | (p_view.z > 0.0f ? (__float_as_uint(p_view.z) & 0x7FFFFFFFu) : 0u);  // culled until proven visible
         // near cull: only view-space z <= 0.2 (ch3 auxiliary.h:138)
         if (!(p_view.z <= 0.2f)) {
             const float4 p_hom = xform4x4(p_orig, proj);
@@ -249,18 +252,31 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     rec[2] = make_float4(ex, ey, col[0], col[1]);
                     rec[3] = make_float4(col[2], 0.f, 0.f, 0.f);
                     if (!lean) tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
-                    key = __float_as_uint(p_view.z);
+                    // a NaN depth passes the near cull as in the reference; its key keeps bit 31 out of the way of the flag
+                    key = __float_as_uint(p_view.z) & 0x7FFFFFFFu;
+                    visible = true;
                 }
             }
         } else if (prefiltered) {
             __builtin_trap();  // ch3 auxiliary.h:140-143
         }
         sort_key[idx] = key;
+        if (coh.state) {
+            // temporal-coherence sort (raster_binning.hip): the splat's record goes to the slot of its PREVIOUS depth rank,
+            // stamped with this call's number -- a record the repair kernel finds without that stamp was not written now
+            const char *stv = coh.state + coh.stride * (size_t)vw;
+            const uint32_t slot = reinterpret_cast<const uint32_t *>(stv + coh.inv)[idx];
+            if (slot < (uint32_t)P)
+                view_at(coh.krec, vb.geom, vw)[slot] =
+                    make_uint4(key & 0x7FFFFFFFu, (uint32_t)idx,
+                               visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
+                               reinterpret_cast<const uint32_t *>(stv + coh.hdr)[COH_EPOCH]);
+        }
         // tile rectangle for the binning kernels ((0, 0) = no instances)
-        rect[idx] = (key != 0xFFFFFFFFu) ? make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16))
-                                         : make_uint2(0u, 0u);
+        rect[idx] = visible ? make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16))
+                            : make_uint2(0u, 0u);
     }
-    // smallest key of the workgroup (0xFFFFFFFF if it holds no visible splat)
+    // smallest key of the workgroup (visible keys have bit 31 clear: they win against every culled one)
     uint32_t m = key;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
@@ -542,7 +558,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                      uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
-                     int skip_deep, uint32_t dyn_limit) {
+                     int skip_deep, uint32_t dyn_limit, const InvUpdate iu) {
     const char *static_blob = nullptr;
     // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
     // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
@@ -552,6 +568,17 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x, n_views = gridDim.y;
     const int wg_view = (wg_linear >> 3) % n_views, wg_rank = ((wg_linear >> 3) / n_views) * 8 + (wg_linear & 7);
     if (wg_rank >= T) return;  // gridDim.x is T rounded up to a multiple of 8
+    if (iu.pairs) {
+        // temporal-coherence depth sort (raster_binning.hip): the rank every splat has in this call's order, for the next
+        // call's preprocess.  The T workgroups of a view share the P ranks.
+        const uint2 *pr = view_at(iu.pairs, vb.geom, wg_view);
+        uint32_t *inv = reinterpret_cast<uint32_t *>(iu.state + iu.stride * (size_t)wg_view + iu.inv);
+        const int per = (iu.P + T - 1) / T, r1 = min(iu.P, (wg_rank + 1) * per);
+        for (int r = wg_rank * per + (int)threadIdx.x; r < r1; r += 256) {
+            const uint32_t id = pr[r].y;
+            if (id < (uint32_t)iu.P) inv[id] = (uint32_t)r;
+        }
+    }
     {
         const int vw = wg_view;
         ranges = view_at(ranges, vb.img, vw);
@@ -1332,13 +1359,13 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 uint32_t *key_min_blk, uint2 *rect,
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
-                                float *zero3) {
+                                float *zero3, const CohRef &coh) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean, zero3);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean, zero3, coh);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
@@ -1348,17 +1375,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
                        float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
-                       float *zero3) {
+                       float *zero3, const CohRef &coh) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean, zero3);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean, zero3);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh);
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
@@ -1378,7 +1405,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit) {
+                          uint32_t dyn_limit, const InvUpdate &iu) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // static splats never take gradients: in static-split mode the limit is at most the first static id
     if (st.base && dyn_limit > st.id0) dyn_limit = st.id0;
@@ -1449,7 +1476,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       use_deep, dyn_limit)
+                       use_deep, dyn_limit, iu)
     if (C == 3 && st.base) { FNX_LAUNCH_BF(3, true); }
     else if (C == 3) { FNX_LAUNCH_BF(3, false); }
     else if (st.base) { FNX_LAUNCH_BF(1, true); }

@@ -50,28 +50,74 @@ def set_deep_variant(enabled: bool, min_depth: int | None = None):
         _lib.check(_lib.raster().fnx_set_deep_threshold(int(min_depth)))
 
 
+# Module-level DEFAULTS of the per-call options (include/fnx_raster.h fnx_raster_opts_t).  The view-batched path hands
+# every call its own options struct -- these values overlaid with the rasteriser instance's `options` dict -- and the
+# backward of a render runs with the options its forward ran with (saved in the autograd context).  The setters also
+# forward to the library's deprecated process-wide setters, which only the single-view entry points still read.
+SORT_NARROW_MAX_BITS = 25   # widest depth-key span (bits) for which callers switch to the three-pass sort: two below the
+                            # 27 bits three 9-bit passes order
+_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0)
+
+
 def set_blend_math(mode: str):
-    """Arithmetic of the blend kernels (library-wide, include/fnx_raster.h fnx_set_blend_math): "exact" = the
-    bit-reproducible sequence the oracle repeats (default), "fast" = fused multiply-adds + v_exp_f32, stated tolerance.
-    The forward and the backward of one render must run in the same mode."""
-    _lib.check(_lib.raster().fnx_set_blend_math({"exact": 0, "fast": 1}[mode]))
+    """Arithmetic of the blend kernels: "exact" = the bit-reproducible sequence the oracle repeats (default), "fast" =
+    fused multiply-adds + v_exp_f32, stated tolerance (include/fnx_raster.h fnx_set_blend_math)."""
+    _OPTS["blend_math"] = {"exact": 0, "fast": 1}[mode]
+    _lib.check(_lib.raster().fnx_set_blend_math(_OPTS["blend_math"]))
 
 
 def set_sort_narrow(enabled: bool):
-    """True: the fourth pass of the depth sort is not launched (include/fnx_raster.h fnx_set_sort_narrow).  Only after
-    check_status() has shown `max_sort_span_bits` <= 26 on the scene at hand; a view that needs the pass after all
-    raises FNX_ERR_SORT_SPAN at the next check_status()."""
-    _lib.check(_lib.raster().fnx_set_sort_narrow(1 if enabled else 0))
+    """True: the fourth pass of the depth sort is not launched (FNX_SORT_NARROW).  Only after check_status() has shown
+    `max_sort_span_bits` <= SORT_NARROW_MAX_BITS on the scene at hand; a view that needs the pass after all raises
+    FNX_ERR_SORT_SPAN at the next check_status()."""
+    _OPTS["sort_narrow"] = 1 if enabled else 0
+    _lib.check(_lib.raster().fnx_set_sort_narrow(_OPTS["sort_narrow"]))
+
+
+def set_coherent_sort(enabled: bool):
+    """View batches: after the first call of a (camera batch, channel count, splat count) the depth order of the
+    PREVIOUS call is repaired in one launch instead of running the radix passes (FNX_SORT_COHERENT; the state lives on
+    the ViewBatch).  Exact by construction: the repaired order is verified on the device and a view that fails is
+    sorted from scratch inside the same launch (`ViewBatch.sort_counters()` reports how often)."""
+    _OPTS["coherent_sort"] = 1 if enabled else 0
 
 
 def set_lean_geometry(enabled: bool):
     """View batches only: do not write the per-view GeometryState copies nothing reads back, one world covariance for
-    all views (include/fnx_raster.h fnx_set_lean_geometry).  Forward and backward must run under the same setting."""
-    _lib.check(_lib.raster().fnx_set_lean_geometry(1 if enabled else 0))
+    all views (include/fnx_raster.h fnx_set_lean_geometry)."""
+    _OPTS["lean_geometry"] = 1 if enabled else 0
+    _lib.check(_lib.raster().fnx_set_lean_geometry(_OPTS["lean_geometry"]))
+
+
+def set_deep_kernel(mode: int):
+    _OPTS["deep_kernel"] = int(mode)
+    _lib.check(_lib.raster().fnx_set_deep_kernel(int(mode)))
 
 
 def get_blend_math() -> str:
-    return ("exact", "fast")[_lib.raster().fnx_get_blend_math()]
+    return ("exact", "fast")[_OPTS["blend_math"]]
+
+
+def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=None):
+    """(fnx_raster_opts_t, dict) of one view-batched forward: module defaults overlaid with the instance's overrides."""
+    o = dict(_OPTS)
+    if overrides:
+        unknown = set(overrides) - set(o)
+        if unknown:
+            raise ValueError(f"unknown rasteriser options: {sorted(unknown)}")
+        o.update(overrides)
+    sort_mode, state_ptr = (_lib.FNX_SORT_NARROW if o["sort_narrow"] else _lib.FNX_SORT_FULL), None
+    if o["coherent_sort"] and P > 0:
+        state, seeded = vbatch.sort_state(channels, P)
+        if state is not None:
+            state_ptr = state.data_ptr()
+            if seeded:
+                sort_mode = _lib.FNX_SORT_COHERENT  # else: this call's radix passes leave the state seeded
+    opts = _lib.make_opts(blend_math=o["blend_math"], lean_geometry=o["lean_geometry"], sort_mode=sort_mode,
+                          deep_kernel=o["deep_kernel"],
+                          grad_splat_limit=-1 if grad_splat_limit is None else int(grad_splat_limit),
+                          zero3=zero3, sort_state=state_ptr)
+    return opts, o
 
 
 _between_stages_hook = None  # called (no arguments) between the binning stage and the emit / blend stage of a view batch
@@ -338,6 +384,37 @@ class ViewBatch:
         self.tan_x = (C.c_float * self.V)(*[float(rs.tan_fov_x) for rs in settings_list])
         self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
         self._depth_hint = {}
+        self._sort_state = {}
+
+    def sort_state(self, channels, P):
+        """(u8 tensor [V * fnx_sort_state_bytes(P)], seeded) -- the persistent state of the temporal-coherence depth sort
+        for this camera batch, channel count and splat count (include/fnx_raster.h fnx_raster_opts_t.sort_state):
+        zero-filled once; `seeded` is False for the one call whose radix passes seed it.  (None, False) while a graph is
+        being captured before any eager call allocated it."""
+        key = (int(channels), int(P))
+        ent = self._sort_state.get(key)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None, False
+            if len(self._sort_state) > 8:  # splat counts of earlier frames
+                self._sort_state.clear()
+            n = _lib.raster().fnx_sort_state_bytes(int(P))
+            ent = self._sort_state[key] = torch.zeros(self.V * n, dtype=torch.uint8, device=self.view.device)
+            return ent, False  # this call's radix passes seed it
+        return ent, True
+
+    def sort_counters(self, channels, P):
+        """Per view (calls in coherent mode, of those: in-launch full sorts) -- blocking read-back."""
+        ent = self._sort_state.get((int(channels), int(P)))
+        if ent is None:
+            return []
+        out, lib = [], _lib.raster()
+        stream = torch.cuda.current_stream().cuda_stream
+        for v in range(self.V):
+            pair = (C.c_uint32 * 2)()
+            _lib.check(lib.fnx_sort_state_read(ent.data_ptr(), int(P), v, stream, pair))
+            out.append((int(pair[0]), int(pair[1])))
+        return out
 
     def depth_hint(self, channels):
         """u32 [V, T]: how deep every tile of every view went in the previous forward of this batch (per channel
@@ -404,9 +481,9 @@ class StaticBin:
 
 
 def rasterize_gaussians_views(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                              view_batch, channels=3, grad_splat_limit=None, static_bin=None):
+                              view_batch, channels=3, grad_splat_limit=None, static_bin=None, options=None):
     return _RasterizeGaussiansViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit, static_bin)
+                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit, static_bin, options)
 
 
 class _RasterizeGaussiansViews(torch.autograd.Function):
@@ -417,7 +494,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch,
-                channels, grad_splat_limit=None, static_bin=None):
+                channels, grad_splat_limit=None, static_bin=None, options=None):
         lib = _lib.raster()
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -430,7 +507,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         Cn = int(channels)
         if static_bin is not None:
             return _RasterizeGaussiansViews._forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations,
-                                                           cov3Ds_precomp, vbatch, Cn, grad_splat_limit, static_bin)
+                                                           cov3Ds_precomp, vbatch, Cn, grad_splat_limit, static_bin, options)
         means3D = _f32c(means3D)
         sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
@@ -441,6 +518,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         geom = torch.empty(V * gbytes, **u8)
         img = torch.empty(V * ibytes, **u8)
         cap = 0
+        ctx.status_ptr = None
+        opts, ctx.options = _call_options(vbatch, Cn, P, options, grad_splat_limit=grad_splat_limit)
         if P == 0:
             color = torch.zeros(V, Cn, H, W, dtype=torch.float32, device=dev)
             depth = torch.zeros(V, 1, H, W, dtype=torch.float32, device=dev)
@@ -452,11 +531,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             radii = torch.empty(V, P, dtype=torch.int32, device=dev)
             hint = vbatch.depth_hint(Cn)
             hint_ptr = hint.data_ptr() if hint is not None else None
-            _lib.check(lib.fnx_forward_stage1_views_split(
+            _lib.check(lib.fnx_forward_stage1_views_split_opts(
                 Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
                 _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
-                vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), None, 0, 0, hint_ptr, stream))
+                vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), None, 0, 0, hint_ptr,
+                C.byref(opts), stream))
             key = (dev.index, W, H, Cn, P)
             known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
             synced = _HOST_SYNC or not known
@@ -480,11 +560,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 ring, slot = _status_slots(dev, V, key)
                 status_ptr = ring[slot:slot + V].data_ptr()
-            if grad_splat_limit is not None:  # the backward will stop behind every pixel's last splat below the limit
-                _lib.check(lib.fnx_request_gradient_limit(int(grad_splat_limit)))
-            _lib.check(lib.fnx_forward_stage2_views_split(Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
-                                                          P, W, H, vbatch.bg.data_ptr(), color.data_ptr(),
-                                                          depth.data_ptr(), status_ptr, None, 0, 0, 0, hint_ptr, stream))
+            ctx.status_ptr = status_ptr
+            # (opts.grad_splat_limit: the backward will stop behind every pixel's last splat below the limit)
+            _lib.check(lib.fnx_forward_stage2_views_split_opts(Cn, V, geom.data_ptr(), binning.data_ptr(), cap,
+                                                               img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
+                                                               color.data_ptr(), depth.data_ptr(), status_ptr, None, 0, 0,
+                                                               0, hint_ptr, C.byref(opts), stream))
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
@@ -497,7 +578,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def _forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch, Cn,
-                       grad_splat_limit, sb):
+                       grad_splat_limit, sb, options=None):
         """Static-split forward: the trailing sb.P splats were binned once (StaticBin); this call preprocesses, sorts
         and bins only the leading ones and the blend kernel merges the two streams of every tile."""
         lib = _lib.raster()
@@ -529,13 +610,16 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         ctx.g_means3D_zeroed = None
         if _gradient_mode(ctx.needs_input_grad, M) == 3:
             ctx.g_means3D_zeroed = torch.empty(P_all, 3, dtype=torch.float32, device=dev)
-            _lib.check(lib.fnx_request_zero3(ctx.g_means3D_zeroed.data_ptr()))
-        _lib.check(lib.fnx_forward_stage1_views_split(
+        opts, ctx.options = _call_options(
+            vbatch, Cn, P, options, grad_splat_limit=grad_splat_limit,
+            zero3=ctx.g_means3D_zeroed.data_ptr() if ctx.g_means3D_zeroed is not None else None)
+        ctx.status_ptr = None
+        _lib.check(lib.fnx_forward_stage1_views_split_opts(
             Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
             _ptr(colors_precomp), opacities.data_ptr(), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
             _ptr(cov3Ds_precomp), vbatch.view.data_ptr(), vbatch.proj.data_ptr(), vbatch.campos.data_ptr(),
             vbatch.tan_x, vbatch.tan_y, int(bool(rs.prefiltered)), radii.data_ptr(), sb.blob.data_ptr(), sb.P, sb.R_cap,
-            hint_ptr, stream))
+            hint_ptr, C.byref(opts), stream))
         key = (dev.index, W, H, Cn, P, "split")
         known = _capacity_hwm.get(key) or _capacity_hwm.get("default")
         synced = _HOST_SYNC or not known
@@ -557,12 +641,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         if not synced:
             ring, slot = _status_slots(dev, V, key)
             status_ptr = ring[slot:slot + V].data_ptr()
-        if grad_splat_limit is not None:  # (in split mode the library already stops at the first static id)
-            _lib.check(lib.fnx_request_gradient_limit(int(grad_splat_limit)))
-        _lib.check(lib.fnx_forward_stage2_views_split(
+        ctx.status_ptr = status_ptr
+        # (opts.grad_splat_limit; in split mode the library already stops at the first static id)
+        _lib.check(lib.fnx_forward_stage2_views_split_opts(
             Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
             color.data_ptr(), depth.data_ptr(), status_ptr, sb.blob.data_ptr(), sb.P, sb.R_cap,
-            int(bool(StaticBin.materialize_all)), hint_ptr, stream))
+            int(bool(StaticBin.materialize_all)), hint_ptr, C.byref(opts), stream))
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
@@ -576,9 +660,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
         if grad_out_color is None:
-            return (None,) * 12
+            return (None,) * 13
         lib = _lib.raster()
         vbatch, Cn = ctx.vbatch, ctx.channels
+        # the backward runs with the options its forward ran with (blend arithmetic, lean geometry state)
+        bopts = _lib.make_opts(blend_math=ctx.options["blend_math"], lean_geometry=ctx.options["lean_geometry"])
+        static_args = (lambda sb: (sb.blob.data_ptr(), sb.P, sb.R_cap) if sb is not None else (None, 0, 0))
         rs = vbatch.settings[0]
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         dev = means3D.device
@@ -602,11 +689,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                     img.data_ptr(), dL.data_ptr(), None, None, None, None, None, None,
                     g_means3D.data_ptr(), None, None, None, None, ctx.grad_splat_limit, 3)
             stream = torch.cuda.current_stream().cuda_stream
-            if sb is None:
-                _lib.check(lib.fnx_rasterize_backward_views(*args, stream))
-            else:
-                _lib.check(lib.fnx_rasterize_backward_views_split(*args, sb.blob.data_ptr(), sb.P, sb.R_cap, stream))
-            return (g_means3D,) + (None,) * 11
+            _lib.check(lib.fnx_rasterize_backward_views_split_opts(*args, *static_args(sb), ctx.status_ptr,
+                                                                   C.byref(bopts), stream))
+            return (g_means3D,) + (None,) * 12
         # per-view accumulators first, then the arrays summed over the views; one zero-filled slab
         widths = [V * 3, V * 4] + ([] if geometry_only == 1 else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
         flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)
@@ -631,14 +716,13 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                     g_opacity.data_ptr(), g_colors.data_ptr(), g_means3D.data_ptr(), g_cov3D.data_ptr(),
                     g_sh.data_ptr() if M else None, g_scales.data_ptr(), g_rot.data_ptr(), ctx.grad_splat_limit,
                     geometry_only)
-            if sb is None:
-                _lib.check(lib.fnx_rasterize_backward_views(*args, stream))
-            else:  # the gradient arrays span all splats; rows of the static ones stay zero
-                _lib.check(lib.fnx_rasterize_backward_views_split(*args, sb.blob.data_ptr(), sb.P, sb.R_cap, stream))
+            # (split mode: the gradient arrays span all splats; rows of the static ones stay zero)
+            _lib.check(lib.fnx_rasterize_backward_views_split_opts(*args, *static_args(sb), ctx.status_ptr,
+                                                                   C.byref(bopts), stream))
         if V == 1 and geometry_only != 1:  # a single view accumulates straight into its per-view arrays
             g_opacity, g_colors = g_opacity_v, g_colors_v
         return (g_means3D.view(P, 3), g_means2D.view(V, P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
-                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None)
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -717,12 +801,15 @@ class GaussianRasterizerViews(nn.Module):
     channels = 3
     grad_splat_limit = None
     static_bin = None  # a StaticBin over the trailing splats of the arrays passed to forward (static-split mode)
+    options = None     # per-instance overrides of the module-level option defaults (keys of rasterizer._OPTS)
 
-    def __init__(self, raster_settings_list, channels=None):
+    def __init__(self, raster_settings_list, channels=None, options=None):
         super().__init__()
         self.view_batch = raster_settings_list if isinstance(raster_settings_list, ViewBatch) else ViewBatch(raster_settings_list)
         if channels is not None:
             self.channels = int(channels)
+        if options is not None:
+            self.options = dict(options)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
@@ -741,4 +828,4 @@ class GaussianRasterizerViews(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians_views(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                          cov3D_precomp, self.view_batch, self.channels, self.grad_splat_limit,
-                                         self.static_bin)
+                                         self.static_bin, self.options)

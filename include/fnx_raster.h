@@ -36,7 +36,7 @@ extern "C" {
 #define FNX_ERR_HIP 3
 #define FNX_ERR_CAPACITY 4 /* binning buffer smaller than num_rendered */
 #define FNX_ERR_UNSUPPORTED 5 /* e.g. more than 16384 tiles (image larger than 2048x2048) */
-#define FNX_ERR_SORT_SPAN 6 /* fnx_set_sort_narrow(1) and a view's depth keys span 2^27 ulps or more: results invalid */
+#define FNX_ERR_SORT_SPAN 6 /* sort_mode FNX_SORT_NARROW and a view's depth keys span 2^27 ulps or more: results invalid */
 
 typedef void *fnx_stream_t; /* hipStream_t */
 
@@ -46,11 +46,53 @@ typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
 
 /* Version of this interface.  Bumped whenever a scratch-blob layout, a layout struct or an argument list changes
  * (2: binning blob carries the forward -> backward hand-over, fnx_*_layout_t grew, fnx_set_blend_math added; 3: the image
- * blob's n_contrib array doubled -- its second half is the backward's per-pixel walking limit, fnx_request_gradient_limit); a caller
- * compares fnx_abi_version() with the FNX_ABI_VERSION it was compiled against before anything else. */
-#define FNX_ABI_VERSION 3
+ * blob's n_contrib array doubled -- its second half is the backward's per-pixel walking limit, fnx_request_gradient_limit;
+ * 4: per-call options fnx_raster_opts_t and the *_opts entry points, the process-wide setters and one-shot requests are
+ * deprecated shims; culled splats keep their depth in the sort keys; image header grew to 16 words with the walked-entry
+ * counters); a caller compares fnx_abi_version() with the FNX_ABI_VERSION it was compiled against before anything else. */
+#define FNX_ABI_VERSION 4
 int fnx_abi_version(void);
 const char *fnx_last_error(void);
+
+
+/*
+ * Per-call options (ABI 4).  The reference's interface is a set of stateless static functions (rasterizer.h:18-84); the
+ * tuning knobs this library adds are therefore ARGUMENTS of a call, not process state: two rasteriser instances with
+ * different options may be driven from different streams or host threads of one process.  Pass a pointer to the *_opts
+ * entry points; NULL means "all defaults" and is what the entry points without the suffix pass.
+ *
+ * Integer fields take FNX_OPT_DEFAULT to defer to the deprecated process-wide setter of the same name (kept for one
+ * round for ABI-3 callers: fnx_set_blend_math, fnx_set_lean_geometry, fnx_set_sort_narrow, fnx_set_deep_kernel,
+ * fnx_set_deep_threshold); a zero-initialised struct with `size` set selects the library defaults (exact arithmetic,
+ * full geometry state, four sort passes, no deep kernel, no gradient limit, no extras).
+ */
+#define FNX_OPT_DEFAULT (-2147483647 - 1)
+#define FNX_SORT_FULL 0     /* 9-bit LSD radix passes; the fourth runs only when the key span needs it            */
+#define FNX_SORT_NARROW 1   /* the fourth pass is not launched; a view that needed it reports FNX_ERR_SORT_SPAN */
+#define FNX_SORT_COHERENT 2 /* one launch: repair of the previous call's order held in `sort_state` (see below) */
+typedef struct fnx_raster_opts {
+    uint32_t size;            /* sizeof(fnx_raster_opts_t) of the caller (checked)                                  */
+    int32_t blend_math;       /* 0 exact / 1 fast (see fnx_set_blend_math); forward and backward must agree          */
+    int32_t lean_geometry;    /* see fnx_set_lean_geometry; forward and backward must agree                          */
+    int32_t sort_mode;        /* FNX_SORT_*; stage 1                                                                 */
+    int32_t deep_kernel;      /* see fnx_set_deep_kernel; stage 2                                                    */
+    int32_t grad_splat_limit; /* stage 2: the backward will differentiate ids < limit only (< 0: all), see
+                                 fnx_request_gradient_limit                                                          */
+    uint32_t deep_threshold;  /* 0: default (1024), see fnx_set_deep_threshold; stage 1                              */
+    uint32_t reserved0;
+    float *zero3;             /* stage 1: [3 (P_dyn + P_static)] floats zero-filled on the way (fnx_request_zero3)    */
+    char *sort_state;         /* stage 1: V * fnx_sort_state_bytes(P_dyn) bytes owned by the caller and kept across the
+                                 calls of one (camera batch, splat count); ZERO-FILLED ONCE before its first use.  With
+                                 FNX_SORT_COHERENT the depth order of the previous call is repaired instead of sorting
+                                 from scratch (csrc/raster_binning.hip): exact by construction -- the result is verified
+                                 as a strictly increasing (depth bits, id) sequence on the device and a view that fails
+                                 (new frame, large move, unseeded state) is sorted from scratch inside the same launch.
+                                 With the other modes the radix sort leaves the state seeded.  NULL: no state.       */
+} fnx_raster_opts_t;
+size_t fnx_sort_state_bytes(int P);
+/* Host read-back (blocking) of a view's counters in a sort state: out[0] = calls in coherent mode, out[1] = of those,
+ * calls that fell back to the in-launch full sort. */
+int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[2]);
 
 /* Scratch sizes [required<GeometryState>(P), required<ImageState>(W*H), required<BinningState>(R),
  * rasterizer_impl.cu:210,222,266]. */
@@ -235,6 +277,21 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char
                                    const float *background, float *out_color, float *out_depth, uint32_t *status_out,
                                    const char *static_blobs, int P_static, int64_t R_static_capacity,
                                    int materialize_all, uint32_t *depth_hint, fnx_stream_t stream);
+/* The same three calls with per-call options (opts may be NULL = defaults). */
+int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffers, char *image_buffers, int P_dyn, int D,
+                                        int M, int width, int height, const float *means3D, const float *shs,
+                                        const float *colors_precomp, const float *opacities, const float *scales,
+                                        float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                        const float *viewmatrices, const float *projmatrices, const float *cam_pos,
+                                        const float *tan_fovx, const float *tan_fovy, int prefiltered, int *radii,
+                                        const char *static_blobs, int P_static, int64_t R_static_capacity,
+                                        uint32_t *depth_hint, const fnx_raster_opts_t *opts, fnx_stream_t stream);
+int fnx_forward_stage2_views_split_opts(int channels, int V, char *geom_buffers, char *binning_buffers,
+                                        int64_t binning_capacity, char *image_buffers, int P_dyn, int width, int height,
+                                        const float *background, float *out_color, float *out_depth,
+                                        uint32_t *status_out, const char *static_blobs, int P_static,
+                                        int64_t R_static_capacity, int materialize_all, uint32_t *depth_hint,
+                                        const fnx_raster_opts_t *opts, fnx_stream_t stream);
 /* depth_hint (may be NULL): u32[V, T] owned by the caller and kept across calls with the same cameras.  Stage 2 records
  * in it how deep (list position of the last contributor) every tile of every view went; stage 1 of the NEXT call reads
  * it (and clears it for that call's stage 2): the tiles that went at least fnx_set_deep_threshold() deep (default 1024)
@@ -242,8 +299,8 @@ int fnx_forward_stage2_views_split(int channels, int V, char *geom_buffers, char
  * the blend forward, at raised wave priority, because the launch ends when the longest sequential walk ends
  * (csrc/raster_forward.hip).  Purely a scheduling hint: results are bit-identical with any tile order. Zero-fill it once. */
 int fnx_set_deep_threshold(unsigned int min_depth);
-/* Arithmetic of the two blend kernels (process-wide, read at launch time; forward and backward of one render must run in
- * the same mode).
+/* DEPRECATED process-wide default of fnx_raster_opts_t.blend_math (used when opts is NULL or the field is
+ * FNX_OPT_DEFAULT).  Arithmetic of the two blend kernels (forward and backward of one render must run in the same mode).
  *   0 (default): bit-reproducible -- every fp32 expression of forward.cu:319-345 as written, no contraction, exp() as one
  *      fixed instruction sequence; pixels / depth / n_contrib equal the CPU oracle bit for bit.
  *   1: fast, stated tolerance -- fused multiply-adds, log2(e) and log2(opacity) folded into per-entry coefficients,
@@ -271,12 +328,14 @@ int fnx_set_deep_kernel(int mode);
  * by the backward.  Forward and backward of one render must run under the same setting.  Default 0 (everything written:
  * fnx_geom_layout offsets stay meaningful for tools and tests). */
 int fnx_set_lean_geometry(int on);
-/* One-shot: the NEXT fnx_forward_stage1* call on this thread of control also zero-fills rows3[3 * (P_dyn + P_static)]
+/* DEPRECATED (fnx_raster_opts_t.zero3).  One-shot, per host thread, consumed -- used or not -- by the next stage-1 entry on
+ * that thread whatever it returns: the NEXT fnx_forward_stage1* call also zero-fills rows3[3 * (P_dyn + P_static)]
  * floats (its per-splat kernel writes the zeros on the way).  For the positions-only backward (geometry_only = 3), whose
  * dL_dmean3D accumulator must come in zeroed: the fill otherwise is a launch of its own on the critical path between
  * the image loss and the backward.  NULL cancels. */
 int fnx_request_zero3(float *rows3);
-/* One-shot: the NEXT stage 2 (fnx_forward_stage2*, fnx_rasterize_forward) is told that only splats with id <
+/* DEPRECATED (fnx_raster_opts_t.grad_splat_limit).  One-shot, per host thread, consumed by the next stage-2 entry on that
+ * thread whatever it returns: the NEXT stage 2 (fnx_forward_stage2*, fnx_rasterize_forward) is told that only splats with id <
  * grad_splat_limit will be differentiated (< 0: all; the same value the backward entry points take).  The forward then
  * records, per pixel, the list position of the last such splat at or in front of the pixel's last contributor (second
  * half of the image blob's n_contrib array) and lays down backward work items only for the batches up to it: a backward
@@ -308,6 +367,24 @@ int fnx_rasterize_backward_views_split(int channels, int V, int P_dyn, int D, in
                                        const char *static_blobs, int P_static, int64_t R_static_capacity,
                                        fnx_stream_t stream);
 
+/* status_out (may be NULL): as in stage 2 -- the header words of every view are copied there behind the backward, so that a
+ * refused backward (FNX_ERR_INVALID_ARG: gradient limit beyond the forward's; FNX_ERR_CAPACITY: blob of another capacity)
+ * reaches a caller that checks its status rows instead of returning zero gradients silently. */
+int fnx_rasterize_backward_views_split_opts(int channels, int V, int P_dyn, int D, int M, const float *background,
+                                            int width, int height, const float *means3D, const float *shs,
+                                            const float *colors_precomp, const float *scales, float scale_modifier,
+                                            const float *rotations, const float *cov3D_precomp,
+                                            const float *viewmatrices, const float *projmatrices, const float *campos,
+                                            const float *tan_fovx, const float *tan_fovy, const int *radii,
+                                            char *geom_buffers, char *binning_buffers, int64_t binning_capacity,
+                                            char *image_buffers, const float *dL_dpix, float *dL_dmean2D,
+                                            float *dL_dconic, float *dL_dopacity_views, float *dL_dcolor_views,
+                                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
+                                            float *dL_dsh, float *dL_dscale, float *dL_drot, int grad_splat_limit,
+                                            int geometry_only, const char *static_blobs, int P_static,
+                                            int64_t R_static_capacity, uint32_t *status_out,
+                                            const fnx_raster_opts_t *opts, fnx_stream_t stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-25): present[i] = view-space z > 0.2 (auxiliary.h:138). */
 int fnx_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                      fnx_stream_t stream);
@@ -334,7 +411,7 @@ typedef struct {
     size_t conic_opacity; /* f32[4P]                                                */
     size_t rgb;           /* f32[3P]  SH colours                                    */
     size_t tiles_touched; /* u32[P]                                                 */
-    size_t sort_key0;     /* u32[P]   depth bits (0xFFFFFFFF if culled) as written by the preprocess; with
+    size_t sort_key0;     /* u32[P]   depth bits (culled splats: bit 31 | their depth bits) as written by the preprocess; with
                              sort_key1 one (key - nearest key, id) pair buffer uint2[P] of the depth sort */
     size_t sort_key1;     /* u32[P]   second half of that pair buffer                */
     size_t sort_val0;     /* u32[P]   with sort_val1 the other pair buffer uint2[P]; it holds the pairs in
@@ -342,6 +419,8 @@ typedef struct {
     size_t sort_val1;     /* u32[P]                                                 */
     size_t rect;          /* u32[2P]  tile rectangle of each splat: x0 | x1 << 16, y0 | y1 << 16 (0, 0 if invisible) */
     size_t rect_sorted;   /* u32[2P]  the same in depth-rank order                  */
+    size_t krec;          /* u32[4P]  FNX_SORT_COHERENT: (depth bits, id, rectangle as 4 bytes, call stamp) of every splat,
+                             written by the preprocess at the splat's PREVIOUS depth rank                            */
     size_t sort_hist;     /* u32[...] sort scratch: 512-digit chunk histograms + prefixes, digit totals, control
                              words (nearest key, fourth-pass flag), key minima / maxima per block, instances per
                              rank block, emission work items (csrc/fnx_state.h: sort_scratch)                  */
@@ -352,8 +431,12 @@ typedef struct {
     size_t total;
 } fnx_geom_layout_t;
 typedef struct {
-    size_t header;      /* u32[8]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split),
-                           [4] backward work items, [5] tiles scheduled first ("deep")                      */
+    size_t header;      /* u32[16]: [0] num_rendered, [1] status, [2] capacity seen, [3] static instances (split),
+                           [4] backward work items, [5] tiles scheduled first ("deep") | bit length of the depth-key
+                           span << 24, [6] binning capacity stage 2 ran with, [7] / [8] backward ticket / arrival
+                           counters, [9] the forward's gradient limit, [10] list entries the blend forward staged
+                           (batches x 256 clipped to the lists), [11] list entries the blend backward walked (work items
+                           x their batch length), [12..15] reserved                                                  */
     size_t final_T;     /* f32[H*W]                                                 */
     size_t n_contrib;   /* u32[2*H*W]: last contributor per pixel | the limited backward's walking limit per pixel
                            (fnx_request_gradient_limit; equal to the first half without a limit) */

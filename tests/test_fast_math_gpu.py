@@ -180,7 +180,7 @@ def _views_render(g, cams, W, H, bg_np, channels, deep_kernel, min_depth=256, ba
     import torch
     from fluidnexus_amd import _lib, rasterizer
     from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews, StaticBin
-    _lib.check(_lib.raster().fnx_set_deep_kernel(2 if deep_kernel else 0))
+    rasterizer.set_deep_kernel(2 if deep_kernel else 0)
     rasterizer.set_deep_variant(True, min_depth)
     try:
         t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
@@ -213,7 +213,7 @@ def _views_render(g, cams, W, H, bg_np, channels, deep_kernel, min_depth=256, ba
         rasterizer.check_status()
         return out[0].detach().cpu().numpy(), out[2].detach().cpu().numpy(), hint.cpu().numpy(), grads
     finally:
-        _lib.check(_lib.raster().fnx_set_deep_kernel(0))
+        rasterizer.set_deep_kernel(0)
         rasterizer.set_deep_variant(True, 1024)
 
 

@@ -49,12 +49,13 @@ def test_limited_forward_changes_no_gradient_and_no_output(channels, math_mode, 
     IL = _lib.image_layout(W, H)
     ib = lib.fnx_image_bytes(W, H)
     rasterizer.set_blend_math(math_mode)
-    real_request = lib.fnx_request_gradient_limit
+    real_options = rasterizer._call_options
     res = {}
     try:
         for name in ("limited", "full"):
-            if name == "full":  # the same calls with the request suppressed: the backward walks to the last contributor
-                monkeypatch.setattr(lib, "fnx_request_gradient_limit", lambda limit: 0)
+            if name == "full":  # the same calls with the forward's limit suppressed: the backward walks to the last contributor
+                monkeypatch.setattr(rasterizer, "_call_options",
+                                    lambda *a, **k: real_options(*a, **dict(k, grad_splat_limit=None)))
             vb = ViewBatch(settings)
             L = {n: torch.tensor(g[n], device=dev, requires_grad=True) for n in g}
             rv = GaussianRasterizerViews(vb, channels=channels)
@@ -76,7 +77,7 @@ def test_limited_forward_changes_no_gradient_and_no_output(channels, math_mode, 
                              grads={n: (L[n].grad.detach().clone() if L[n].grad is not None else None) for n in L},
                              m2d=m2d.grad.detach().clone() if screen else None)
     finally:
-        monkeypatch.setattr(lib, "fnx_request_gradient_limit", real_request)
+        monkeypatch.setattr(rasterizer, "_call_options", real_options)
         rasterizer.set_blend_math("exact")
     a, b = res["limited"], res["full"]
     assert torch.equal(a["im"].view(torch.int32), b["im"].view(torch.int32))

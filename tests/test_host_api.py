@@ -24,7 +24,7 @@ def test_raster_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     for n in names:
         getattr(lib, n)
-    assert lib.fnx_abi_version() == _lib.ABI_VERSION == 3  # include/fnx_raster.h FNX_ABI_VERSION
+    assert lib.fnx_abi_version() == _lib.ABI_VERSION == 4  # include/fnx_raster.h FNX_ABI_VERSION
 
 
 def test_physics_and_losses_libraries_export_every_declared_symbol():
@@ -45,7 +45,7 @@ def test_scratch_layouts():
     lib = _lib.raster()
     g = _lib.geom_layout(300000, 512, 512)
     offs = [g.depths, g.clamped, g.radii, g.means2D, g.cov3D, g.conic_opacity, g.rgb, g.tiles_touched, g.sort_key0,
-            g.sort_key1, g.sort_val0, g.sort_val1, g.rect, g.rect_sorted, g.sort_hist, g.blk_hist, g.blk_rel, g.total]
+            g.sort_key1, g.sort_val0, g.sort_val1, g.rect, g.rect_sorted, g.krec, g.sort_hist, g.blk_hist, g.blk_rel, g.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert lib.fnx_geom_bytes(300000, 512, 512) == g.total
     assert lib.fnx_geom_bytes(0, 512, 512) <= lib.fnx_geom_bytes(1000, 512, 512) < lib.fnx_geom_bytes(2000, 512, 512)

@@ -33,12 +33,12 @@ if a.no_split:
     _pp.set_static_split(False)
 if a.deep is not None:
     from fluidnexus_amd import _lib as _l2
-    _l2.raster().fnx_set_deep_kernel(a.deep)
+    rasterizer.set_deep_kernel(a.deep)
 if a.deep_min is not None:
     rasterizer.set_deep_variant(True, a.deep_min)
 if a.no_deep:
     from fluidnexus_amd import _lib as _l
-    _l.raster().fnx_set_deep_kernel(0)
+    rasterizer.set_deep_kernel(0)
 e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
 for it in range(a.iters + 2):
     if it == 2:
