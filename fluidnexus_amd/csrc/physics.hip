@@ -1421,6 +1421,159 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
     return hip_check("knn_mean_dist2");
 }
 
+// ---- the same loss on per-bucket LINKED LISTS (fnx_distance_loss_lists) ---------------------------------------
+// The grid version above is five dependent launches (zero, count, scan by one workgroup, fill, search with eight lanes
+// per point = 25 000 waves for 200 k points); next to the rasteriser's blend forward those waves take registers the
+// forward's workgroups are waiting for, and the branch cost the iteration ~60 us wherever it was placed.  Here a bucket
+// is a list threaded through the points: two launches, ONE thread per point, and a bucket table large enough that a
+// list holds about one point.
+//   build   old = atomicExch(head[bucket], call stamp | i); node i = (x, y, z, next = old's index if old carries this
+//           call's stamp).  The table is never cleared: an entry of an earlier call fails the stamp test.
+//   search  the eight buckets a point's threshold ball can touch (the 2 x 2 x 2 cells on the point's side of its own
+//           cell: eight different buckets, see cell_hash), their lists walked side by side (eight loads in flight);
+//           value and gradient as above; per-workgroup sums, added up in workgroup order by the workgroup that arrives
+//           last (deterministic given the lists; the order inside a list is the arrival order of the atomics, as the
+//           slot order of the grid version is).
+// `table`: caller-owned, persistent, zero-filled once (fnx_distance_table_bytes): header | head u64[M] | nodes float4[N] |
+// partial sums.
+struct DistTable {
+    uint32_t *hdr;  // [0] call stamp, [1] arrival counter
+    unsigned long long *head;
+    float4 *node;
+    float *partial;
+    uint32_t M;
+};
+inline uint32_t dist_buckets_for(int N) {
+    uint32_t m = 4096;
+    while (m < (1u << 20) && m < 2u * (uint32_t)(N > 0 ? N : 1)) m <<= 1;
+    return m;
+}
+inline size_t dist_table_bytes(int N) {
+    const size_t n = (size_t)(N > 0 ? N : 0);
+    size_t off = align_up(256);
+    off = align_up(off + (size_t)dist_buckets_for(N) * 8);
+    off = align_up(off + n * 16);
+    off = align_up(off + ((n + 255) / 256 + 1) * 4);
+    return off + kAlign;
+}
+inline DistTable carve_dist(char *blob, int N) {
+    char *b = (char *)(((uintptr_t)blob + kAlign - 1) / kAlign * kAlign);
+    const size_t n = (size_t)(N > 0 ? N : 0);
+    DistTable t;
+    t.M = dist_buckets_for(N);
+    size_t off = 0;
+    t.hdr = (uint32_t *)(b + off);            off = align_up(off + 256);
+    t.head = (unsigned long long *)(b + off); off = align_up(off + (size_t)t.M * 8);
+    t.node = (float4 *)(b + off);             off = align_up(off + n * 16);
+    t.partial = (float *)(b + off);
+    return t;
+}
+constexpr uint32_t kDistNone = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256)
+distance_build_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask, const uint32_t *__restrict__ hdr,
+                      unsigned long long *__restrict__ head, float4 *__restrict__ node) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t stamp = hdr[0] + 1u;  // never 0: a zero-filled table entry belongs to no call
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const uint32_t h = cell_hash(cell_of(x, y, z, inv_cell), mask);
+    const unsigned long long old = atomicExch(&head[h], ((unsigned long long)stamp << 32) | (uint32_t)i);
+    const uint32_t next = ((uint32_t)(old >> 32) == stamp && (uint32_t)old < (uint32_t)N) ? (uint32_t)old : kDistNone;
+    node[i] = make_float4(x, y, z, __uint_as_float(next));
+}
+
+__global__ void __launch_bounds__(256)
+distance_lists_kernel(int N, float inv_cell, float thr, uint32_t mask, uint32_t *__restrict__ hdr,
+                      const unsigned long long *__restrict__ head, const float4 *__restrict__ node,
+                      float *__restrict__ partial, float *__restrict__ grad, float *__restrict__ loss_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stamp = hdr[0] + 1u;
+    float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < N) {
+        const float4 me = node[i];
+        const float px = me.x, py = me.y, pz = me.z;
+        const int3 c = cell_of(px, py, pz, inv_cell);
+        const float fx = px * inv_cell - (float)c.x, fy = py * inv_cell - (float)c.y, fz = pz * inv_cell - (float)c.z;
+        const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
+        const float thr2 = thr * thr;
+        uint32_t cur[8];
+        {
+            unsigned long long hd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                hd[k] = head[cell_hash(make_int3(c.x + ((k & 1) ? sx : 0), c.y + ((k & 2) ? sy : 0), c.z + ((k & 4) ? sz : 0)), mask)];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                cur[k] = ((uint32_t)(hd[k] >> 32) == stamp && (uint32_t)hd[k] < (uint32_t)N) ? (uint32_t)hd[k] : kDistNone;
+        }
+        for (int guard = 0; guard < N; guard++) {  // one node of every list per round (a list cannot be longer than N)
+            bool any = false;
+            float4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cur[k] != kDistNone) {
+                    q[k] = node[cur[k]];
+                    any = true;
+                }
+            }
+            if (!any) break;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (cur[k] == kDistNone) continue;
+                const bool self = cur[k] == (uint32_t)i;
+                const uint32_t nx = __float_as_uint(q[k].w);
+                cur[k] = nx < (uint32_t)N ? nx : kDistNone;
+                if (self) continue;
+                const float ex = px - q[k].x, ey = py - q[k].y, ez = pz - q[k].z;
+                const float r2 = ex * ex + ey * ey + ez * ez;
+                if (!(r2 < thr2)) continue;
+                const float d = sqrtf(r2);
+                const float t = thr - d;
+                if (!(t > 0.f)) continue;
+                acc += t * t;
+                if (d > 0.f) {
+                    const float kk = -4.0f * t / d;
+                    ax += kk * ex;
+                    ay += kk * ey;
+                    az += kk * ez;
+                }
+            }
+        }
+        if (grad) {
+            grad[3 * i + 0] = ax;
+            grad[3 * i + 1] = ay;
+            grad[3 * i + 2] = az;
+        }
+    }
+    __shared__ float s_w[4];
+    __shared__ uint32_t s_last;
+    acc = wave_sum63(acc);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        __threadfence();
+        s_last = atomicAdd(&hdr[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the workgroup that arrives last: the loss (partial sums in workgroup order), the next call's stamp
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float tot = 0.f;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) tot += partial[b];
+    tot = wave_sum63(tot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        hdr[1] = 0u;
+        hdr[0] = stamp;  // the next call stamps its entries stamp + 1
+    }
+}
+
 int fnx_distance_loss_partials(int N) { return N > 0 ? (N + 31) / 32 : 0; }
 
 int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, float *partials, float *grad,
@@ -1443,6 +1596,26 @@ int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, floa
     hipLaunchKernelGGL(distance_loss_kernel, dim3((N + 31) / 32), dim3(256), 0, s, xyz, N, inv, threshold, M - 1,
                        g.start, g.rec, partials, grad);
     return hip_check("distance_loss");
+}
+
+size_t fnx_distance_table_bytes(int N) { return dist_table_bytes(N); }
+
+int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,
+                            fnx_stream_t stream) {
+    if (N < 0 || !loss_out || (N > 0 && (!xyz || !table)) || !(threshold > 0.f))
+        return fail(FNX_ERR_INVALID_ARG, "distance_loss_lists: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t *>(loss_out), (size_t)1);
+        return hip_check("distance_loss_lists");
+    }
+    DistTable t = carve_dist(table, N);
+    const float inv = 1.0f / (2.0f * threshold);
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(distance_build_kernel, dim3(nb), dim3(256), 0, s, xyz, N, inv, t.M - 1, t.hdr, t.head, t.node);
+    hipLaunchKernelGGL(distance_lists_kernel, dim3(nb), dim3(256), 0, s, N, inv, threshold, t.M - 1, t.hdr, t.head, t.node,
+                       t.partial, grad, loss_out);
+    return hip_check("distance_loss_lists");
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,

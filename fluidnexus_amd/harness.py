@@ -122,6 +122,10 @@ _SCREEN_GRAD = os.environ.get("FNX_SCREEN_GRAD", "0") == "1"
 _PHYSICS_EARLY = os.environ.get("FNX_PHYSICS_EARLY", "0") == "1"
 # "hook": enqueued between the rasteriser's binning stage and its emit / blend stage, in front of the distance branch
 _PHYSICS_AT_HOOK = os.environ.get("FNX_PHYSICS_EARLY", "0") == "hook"
+# Where the distance-loss branch forks: "hook" = between the rasteriser's binning stage and its emit / blend stage,
+# "early" = as soon as the rendered positions exist (under preprocess / sort), "loss" = behind the image loss (under the
+# blend backward)
+_DIST_AT = os.environ.get("FNX_DIST_AT", "hook")
 
 
 class HotLoop:
@@ -457,11 +461,14 @@ class HotLoop:
         if mine:
             from . import rasterizer
             fork_d, forked_d = torch.cuda.Event(), []
-            if use_dist or _PHYSICS_AT_HOOK:
+            if use_dist and _DIST_AT == "early":
+                fork_d.record(main)
+                forked_d.append(1)
+            if (use_dist and _DIST_AT == "hook") or _PHYSICS_AT_HOOK:
                 def _hook():
                     if _PHYSICS_AT_HOOK:
                         launch_physics()
-                    if use_dist:
+                    if use_dist and _DIST_AT == "hook":
                         fork_d.record(torch.cuda.current_stream())
                         forked_d.append(1)
                 rasterizer.set_between_stages_hook(_hook)
@@ -474,6 +481,13 @@ class HotLoop:
         if not _PHYSICS_EARLY and not (_PHYSICS_AT_HOOK and mine):
             launch_physics()
         if mine:
+            dimg_ready = None
+            if use_dist and _DIST_AT == "loss":  # the image term first: the distance branch forks behind it
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                                                                 c["lambda_image"])
+                dimg_ready = (loss, per_view, dimg)
+                fork_d.record(main)
+                forked_d.append(1)
             if use_dist:
                 from .physics import distance_loss_value_and_grad
                 if forked_d:
@@ -486,8 +500,11 @@ class HotLoop:
                                                                           c["distance_threshold_visual"])
             # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
             # that saves the ones seed and its copies), then back through the rasteriser
-            loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
-                                                             c["lambda_image"])
+            if dimg_ready is not None:
+                loss, per_view, dimg = dimg_ready
+            else:
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                                                                 c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
             outs, seeds = [pkg["render"]], [dimg]

@@ -7,6 +7,8 @@ Both fuse the neighbour search; see the header for the neighbour rule and the KN
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _physics_lib as PL
@@ -269,6 +271,24 @@ class _DistanceLoss(torch.autograd.Function):
         return grad * g, None
 
 
+_DIST_TABLES: dict = {}  # (device, stream, N) -> persistent bucket table of fnx_distance_loss_lists
+_DIST_LISTS = os.environ.get("FNX_DIST_GRID", "0") != "1"  # FNX_DIST_GRID=1: the counted / scanned / filled grid version
+
+
+def _distance_table(dev, N):
+    """The zero-filled-once table of the linked-list distance loss for the CURRENT stream (one call at a time per table;
+    allocated outside graph capture: a captured iteration reuses the table its warm-up iterations created)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(N))
+    t = _DIST_TABLES.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if len(_DIST_TABLES) > 16:
+            _DIST_TABLES.clear()
+        t = _DIST_TABLES[key] = torch.zeros(PL.physics().fnx_distance_table_bytes(int(N)), dtype=torch.uint8, device=dev)
+    return t
+
+
 def distance_loss_value_and_grad(positions, threshold, need_grad=True):
     """(loss, d loss / d positions [N,3]) of utils/loss_utils.distance_loss(positions, threshold)
     (loss_utils.py:98-121: every pair closer than `threshold` pays (threshold - distance)^2, counted in both
@@ -282,9 +302,15 @@ def distance_loss_value_and_grad(positions, threshold, need_grad=True):
     if N == 0:
         z = torch.zeros((), dtype=torch.float32, device=x.device)
         return z, torch.zeros_like(x)
+    grad = torch.empty_like(x) if need_grad else None
+    table = _distance_table(x.device, N) if _DIST_LISTS else None
+    if table is not None:  # two launches, one thread per point (csrc/physics.hip fnx_distance_loss_lists)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        PL.check(lib.fnx_distance_loss_lists(x.data_ptr(), N, float(threshold), table.data_ptr(),
+                                             grad.data_ptr() if need_grad else None, loss.data_ptr(), _stream()))
+        return loss[0], grad
     grid = torch.empty(lib.fnx_grid_bytes(N), dtype=torch.uint8, device=x.device)
     partials = torch.empty(lib.fnx_distance_loss_partials(N), dtype=torch.float32, device=x.device)
-    grad = torch.empty_like(x) if need_grad else None
     PL.check(lib.fnx_distance_loss(x.data_ptr(), N, float(threshold), grid.data_ptr(), partials.data_ptr(),
                                    grad.data_ptr() if need_grad else None, _stream()))
     return partials.sum(), grad

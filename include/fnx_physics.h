@@ -159,6 +159,15 @@ int fnx_knn_mean_dist2(const float *xyz, int N, float cell, char *grid, float *m
 int fnx_distance_loss_partials(int N);
 int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, float *partials, float *grad,
                       fnx_stream_t stream);
+/* The same loss on per-bucket linked lists instead of a counted / scanned / filled grid: two launches (build, search) and
+ * one thread per point -- an eighth of the waves, which is what the branch costs the rasteriser's blend forward it runs
+ * beside (csrc/physics.hip).  `table`: fnx_distance_table_bytes(N) bytes owned by the caller, PERSISTENT across calls
+ * with the same N and ZERO-FILLED ONCE (entries carry the number of the call that wrote them, so the table is never
+ * cleared); one call at a time per table.  loss_out[0] = the loss (partial sums added in workgroup order by the
+ * workgroup that arrives last); grad as above (may be NULL). */
+size_t fnx_distance_table_bytes(int N);
+int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,
+                            fnx_stream_t stream);
 
 /* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
  * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
