@@ -373,6 +373,120 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
                    "no MFMA instruction in the library (DESIGN.md 4.7)"}
 
 
+def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
+    """BASELINE config 3 as what it names: a multi-FRAME sequence.  Per frame the reference's boundary in its call order
+    (entries_fluid_nexus/train_physical_particle.py:283-302: remove_invalid_particles -> emit_new_particles ->
+    guess_hidden_particles -> update_solver_counts x solver_iterations -> project_gas_constraints x solver_iterations ->
+    training_setup_current -> prepare_visual_particles_for_rendering), then n optimisation iterations (tpp:329-432),
+    then the hand-over (tpp:456-458: confirm_guess_hidden_particles_from_nn -> update_visual_xyz_from_nn ->
+    confirm_guess_hidden_particles_wo_velocity).  The emitter changes the particle counts every frame, so the static
+    background is re-binned, the binning high-water mark and the sort state start over and the hipGraph is re-captured
+    -- all inside the timed region.  Dataset I/O (the frame's target images) is not part of the path: the targets of the
+    first frame are kept."""
+    from fluidnexus_amd import harness as Hn, rasterizer
+    K, n = int(a.frames), int(a.iters_per_frame)
+    gm, cams, loop = build_workload(cfg_id, CONFIGS[cfg_id]["views"], dev, rank, world, a, use_dist)
+    loop.make_targets()
+    # a synthetic emitter at the foot of the plume (world units, like prepare_emitter_points leaves them): one lattice
+    # layer of hidden particles and a disc of visual particles per frame
+    rng = np.random.RandomState(11)
+    cx, cz = 0.34, -0.225
+    hx, hz = np.meshgrid(np.arange(-4, 5) * 0.01, np.arange(-4, 5) * 0.01, indexing="ij")
+    keep = (hx ** 2 + hz ** 2) <= 0.045 ** 2
+    hid = np.stack([cx + hx[keep], np.full(keep.sum(), -0.025), cz + hz[keep]], 1)
+    ang, rad = rng.uniform(0, 2 * np.pi, 600), 0.09 * np.sqrt(rng.uniform(0, 1, 600))
+    vis = np.stack([cx + rad * np.cos(ang), rng.uniform(-0.02, -0.015, 600), cz + rad * np.sin(ang)], 1)
+    gm.hidden_emitter_points = torch.tensor(hid, dtype=torch.float32, device=dev)
+    gm.visual_emitter_points = torch.tensor(vis, dtype=torch.float32, device=dev)
+    gm.emit_ratio_hidden, gm.emit_ratio_visual, gm.extra_visual_ratio, gm.extra_visual_num = 1.0, 1.0, 0.0, 0
+    N0 = gm._xyz.shape[0]
+    gm._particle_id = torch.arange(N0, device=dev).unsqueeze(1)
+    gm._particle_id_max = N0
+    gm._counts = torch.zeros(N0, 1, dtype=torch.float32, device=dev)
+    solver_iterations = 3  # configs/fluid_nexus_smoke_dynamics.json
+    optim = loop.optim_args
+    graph = loop.capturable
+    gi = max(1, min(int(a.graph_iters), n))
+    seg = dict(simulate=0.0, setup=0.0, optimise=0.0, accept=0.0)
+    counts, sort_switched = [], []
+
+    def tick():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def one_frame(timed):
+        nonlocal loop
+        t0 = tick()
+        gm.remove_invalid_particles()
+        gm.emit_new_particles()
+        gm.guess_hidden_particles()
+        for _ in range(solver_iterations):
+            gm.update_solver_counts()
+        for _ in range(solver_iterations):
+            gm.project_gas_constraints()
+        t1 = tick()
+        # training_setup_current + the loop object of the frame (its warm-up iterations are optimisation iterations)
+        gm.prepare_visual_particles_for_rendering()
+        rasterizer.release_captured_status()
+        loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=loop.physics_per_view,
+                          shared_terms_rank=loop.shared_terms_rank, image_loss=loop.image_loss, fused_physics=loop.fused_physics,
+                          defer_visual_backward=True, capturable=graph, cfg=loop.cfg, batched_views=loop.batched_views,
+                          fused_step=loop.fused_step, dual_channel=loop.dual_channel)
+        done = 0
+        rasterizer.set_coherent_sort(a.sort == "coherent")
+        c0 = rasterizer.coherent_sort_counters()
+        # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
+        # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
+        for _ in range(4 if a.sort == "coherent" else 2):
+            loop.iteration()
+            done += 1
+        rasterizer.check_status()
+        if a.sort == "coherent":
+            c1 = rasterizer.coherent_sort_counters()
+            if c1[1] - c0[1] > 0:
+                rasterizer.set_coherent_sort(False)
+                sort_switched.append(len(counts))
+        if graph and n - done - 1 >= gi:
+            loop.capture(warmup=1, iterations=gi)
+            done += 1
+        t2 = tick()
+        while done < n:
+            if loop.iterations_per_call > n - done:
+                loop.use_graph(False)
+            done += loop.iterations_per_call
+            loop.iteration()
+        rasterizer.check_status()
+        t3 = tick()
+        gm.confirm_guess_hidden_particles_from_nn()
+        gm.update_visual_xyz_from_nn()
+        gm.confirm_guess_hidden_particles_wo_velocity()
+        t4 = tick()
+        if timed:
+            seg["simulate"] += t1 - t0
+            seg["setup"] += t2 - t1
+            seg["optimise"] += t3 - t2
+            seg["accept"] += t4 - t3
+            counts.append((int(gm._xyz.shape[0]), int(gm._visual_xyz.shape[0])))
+        return t4 - t0
+
+    one_frame(False)  # untimed: first-use allocations of every stage
+    sort_switched.clear()
+    total = sum(one_frame(True) for _ in range(K))
+    rasterizer.set_coherent_sort(a.sort == "coherent")
+    per_frame = total / K
+    return {"frames": K, "iters_per_frame": n, "seq_iters_per_s": K * n / total, "ms_per_frame": per_frame * 1e3,
+            "frame_boundary_ms": (per_frame - n * steady_ms * 1e-3) * 1e3,
+            "vs_steady_state": (K * n / total) / (1e3 / steady_ms),
+            "segments_ms_per_frame": {k: v / K * 1e3 for k, v in seg.items()},
+            "particles_last_frame": {"hidden": counts[-1][0], "visual": counts[-1][1]},
+            "emitted_per_frame": {"hidden": int(hid.shape[0]), "visual": int(vis.shape[0])},
+            "frames_on_radix_sort": len(sort_switched),
+            "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, two eager "
+                    "iterations, static background re-binned, hipGraph re-captured (setup: its iterations count towards n) | "
+                    "replayed iterations | confirm + advect + confirm; frame_boundary_ms = ms_per_frame - n x the steady-state "
+                    "ms_per_step of this record; a host sync at each segment boundary (4 per frame)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,6 +528,12 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="also time the SH pipe's rasteriser (colours as spherical-harmonics coefficients of this degree) "
                          "on the configuration's Gaussians: record key `sh` (not part of the timed training step)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="also time a sequence of this many frames (config 3 / 5, physical stage): the reference's frame "
+                         "boundary in its call order + --iters-per-frame optimisation iterations per frame, record key "
+                         "`sequence` (seq_iters_per_s, frame_boundary_ms); 0 = off")
+    ap.add_argument("--iters-per-frame", type=int, default=1000,
+                    help="optimisation iterations per frame of --frames (configs/fluid_nexus_smoke_dynamics.json: 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -513,6 +633,14 @@ def main():
         # three 9-bit passes order any view whose keys span < 2^27 ulps: the warm-up has shown how wide this scene's are
         if 0 < rasterizer.max_sort_span_bits <= rasterizer.SORT_NARROW_MAX_BITS and not a.sort_four_passes:
             rasterizer.set_sort_narrow(True)  # a later view that needs the fourth pass fails the run (check_status)
+    sort_note = None
+    if a.sort == "coherent":
+        # the coherent sort is exact whatever the scene does, but a scene whose splats jump further than its repair window
+        # pays a full in-launch sort per call: look at the warm-up's counters before committing to it
+        calls, falls = rasterizer.coherent_sort_counters()
+        if calls and falls > 0.02 * calls:
+            rasterizer.set_coherent_sort(False)
+            sort_note = f"coherent sort switched off after the warm-up: {falls} in-launch full sorts in {calls} view calls"
     graph_mode = False
     if loop.capturable:
         try:
@@ -702,7 +830,7 @@ def main():
                                     f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "
                                     "the fewest views), added `batch` times; the all-reduce distributes the sum"),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
-                   "depth_sort": (("coherent: one launch per call repairs the previous call's order, verified on the device "
+                   "depth_sort": sort_note or (("coherent: one launch per call repairs the previous call's order, verified on the device "
                                    f"(in-launch full sorts per view over the run: {sort_fallbacks}); first call: " if a.sort == "coherent" else "")
                                   + f"9-bit radix passes; key span of the views <= 2^{rasterizer.max_sort_span_bits} ulps; fourth pass "
                                   + ("not launched (device-checked)" if (0 < rasterizer.max_sort_span_bits <= rasterizer.SORT_NARROW_MAX_BITS
@@ -737,6 +865,13 @@ def main():
                                              "appearance_and_shape" if bwd_mode == 2 else "positions_only"):
                bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)}),
     }
+    if a.frames > 0 and cfg_id != 2 and a.stage == "physical" and a.emulate_world <= 1:
+        try:
+            out["sequence"] = sequence_timing(a, dev, cfg_id, rank, world, use_dist, dt / a.steps * 1e3)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] sequence timing failed: {type(e).__name__}: {e}", file=sys.stderr)
     if a.sh_degree >= 0 and loop_views and cfg_id != 2:
         try:
             out["sh"] = sh_timing(gm, cams, loop_views, cfg_id, loop.background, a.sh_degree, a.stage)

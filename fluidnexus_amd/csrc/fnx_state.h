@@ -106,7 +106,9 @@ inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
 // Temporal-coherence depth sort (fnx_raster_opts_t.sort_mode = FNX_SORT_COHERENT, raster_binning.hip): the caller's
 // persistent per-view state.  Header words, the (key, id) bounds every repair workgroup publishes for its chunk of ranks
 // (first | last, u64 each), and inv[id] = depth rank of splat id in the previous call's order.
-enum { COH_MAGIC = 0, COH_EPOCH = 1, COH_ARRIVED = 2, COH_FAIL = 3, COH_FALLBACKS = 4, COH_REPAIRS = 5, COH_HDR_WORDS = 64 };
+enum { COH_MAGIC = 0, COH_EPOCH = 1, COH_ARRIVED = 2, COH_FAIL = 3, COH_FALLBACKS = 4, COH_REPAIRS = 5,
+       COH_WHY = 6,  // sticky: why calls fell back (1 record not of this call, 2 bucket overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded)
+       COH_HDR_WORDS = 64 };
 struct SortStateLayout {
     size_t hdr, bounds, inv, total;
 };

@@ -796,7 +796,7 @@ int fnx_request_gradient_limit(int grad_splat_limit) {
     return FNX_OK;
 }
 size_t fnx_sort_state_bytes(int P) { return fnx::sort_state_layout(P).total; }
-int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[2]) {
+int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[3]) {
     if (!sort_state || !out || P < 0 || view < 0) return fail(FNX_ERR_INVALID_ARG, "bad argument");
     const fnx::SortStateLayout SL = fnx::sort_state_layout(P);
     uint32_t h[fnx::COH_HDR_WORDS];
@@ -806,6 +806,7 @@ int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t st
     if (e != hipSuccess) return fail(FNX_ERR_HIP, "sort_state_read: %s", hipGetErrorString(e));
     out[0] = h[fnx::COH_REPAIRS];
     out[1] = h[fnx::COH_FALLBACKS];
+    out[2] = h[fnx::COH_WHY];
     return FNX_OK;
 }
 int fnx_set_sort_narrow(int on) {

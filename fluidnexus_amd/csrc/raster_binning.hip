@@ -478,7 +478,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     const uint32_t magic = coh_magic(P);
     const bool seeded = hdr[COH_MAGIC] == magic;  // written only by the workgroup that arrives last, after everyone read it
     const uint32_t epoch = hdr[COH_EPOCH];        // the stamp this call's preprocess put on its records
-    bool bad = false;
+    uint32_t bad = 0;  // COH_WHY bits
     const int n_out = min(kCohOut, P - c * kCohOut);
     if (seeded) {
         // ---- the window: previous ranks [g0, g0 + kCohWin), thread t owns four consecutive ones.  Ranks outside the
@@ -499,7 +499,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
 #pragma unroll
         for (int k = 0; k < kCohPer; k++) {
             if (real[k] && (rec[k].w != epoch || rec[k].y >= (uint32_t)P)) {  // not written by this call's preprocess
-                bad = true;
+                bad |= 1u;
                 real[k] = false;
             }
             v[k] = real[k] ? (((u64)rec[k].x << 32) | rec[k].y) : 0ull;
@@ -573,7 +573,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             for (int k = 0; k < w; k++) ex += s_wsum[k];
             s_start[tid] = ex;
             if (tid == 255) s_start[256] = ex + n_mine;  // elements above every splitter
-            if (n_mine > (uint32_t)kCohMaxBucket || s_cnt[256] > (uint32_t)kCohMaxBucket) bad = true;
+            if (n_mine > (uint32_t)kCohMaxBucket || s_cnt[256] > (uint32_t)kCohMaxBucket) bad |= 2u;
         }
         __syncthreads();
 #pragma unroll
@@ -619,8 +619,8 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             if (o < n_out) {
                 const u64 x = s_out[o];
                 if ((uint32_t)x < (uint32_t)P) pairs_out[(size_t)c * kCohOut + o] = make_uint2((uint32_t)(x >> 32), (uint32_t)x);
-                else bad = true;
-                if (o + 1 < n_out && !(x < s_out[o + 1])) bad = true;
+                else bad |= 4u;
+                if (o + 1 < n_out && !(x < s_out[o + 1])) bad |= 4u;
             }
         }
         // every element's owner still has its rectangle in registers: it goes to the element's final position in LDS (the
@@ -646,11 +646,11 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             bounds[2 * c + 1] = s_out[n_out - 1];
         }
     }
-    if (FNX_EXP_COH) bad = false;
-    if (bad) atomicOr(&s_flag, 1u);
+    if (FNX_EXP_COH) bad = 0;
+    if (bad) atomicOr(&s_flag, bad);
     __syncthreads();
     if (tid == 0) {
-        if (s_flag) atomicOr(&hdr[COH_FAIL], 1u);
+        if (s_flag) atomicOr(&hdr[COH_FAIL], s_flag);
         __threadfence();
         s_last = (atomicAdd(&hdr[COH_ARRIVED], 1u) == (uint32_t)nc - 1u) ? 1u : 0u;
     }
@@ -658,18 +658,18 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     if (!s_last || tid >= 256) return;  // the tail below is the work of four waves
     // ---- the workgroup that arrives last: verify the chunk boundaries, repair by a full sort if need be, publish
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    bool fail = !seeded;
+    uint32_t why = seeded ? 0u : 16u;
     if (seeded) {
-        if (__hip_atomic_load(&hdr[COH_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) fail = true;
+        why |= __hip_atomic_load(&hdr[COH_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int b = tid; b + 1 < nc; b += 256)
-            if (!(bounds[2 * b + 1] < bounds[2 * b + 2])) fail = true;  // last of chunk b < first of chunk b + 1
-        if (FNX_EXP_COH) fail = false;
+            if (!(bounds[2 * b + 1] < bounds[2 * b + 2])) why |= 8u;  // last of chunk b < first of chunk b + 1
+        if (FNX_EXP_COH) why = 0u;
     }
     if (tid == 0) s_flag = 0u;
     __syncthreads();
-    if (fail) atomicOr(&s_flag, 1u);
+    if (why) atomicOr(&s_flag, why);
     __syncthreads();
-    fail = s_flag != 0u;
+    const bool fail = s_flag != 0u;
     if (fail) {
         coh_fallback_sort(P, raw_keys, pairs_tmp, pairs_out, inv, rect, rect_sorted, reinterpret_cast<uint32_t *>(s_raw));
         __threadfence();
@@ -684,7 +684,10 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         hdr[COH_ARRIVED] = 0u;
         hdr[COH_FAIL] = 0u;
         hdr[COH_REPAIRS] = hdr[COH_REPAIRS] + 1u;
-        if (fail) hdr[COH_FALLBACKS] = hdr[COH_FALLBACKS] + 1u;
+        if (fail) {
+            hdr[COH_FALLBACKS] = hdr[COH_FALLBACKS] + 1u;
+            hdr[COH_WHY] = hdr[COH_WHY] | s_flag;
+        }
     }
 }
 

@@ -82,6 +82,23 @@ def set_coherent_sort(enabled: bool):
     _OPTS["coherent_sort"] = 1 if enabled else 0
 
 
+_VIEW_BATCHES = None  # weak set of the ViewBatch objects that hold a sort state
+
+
+def coherent_sort_counters():
+    """(calls in coherent mode, of those: in-launch full sorts) summed over every live sort state -- blocking.  A caller
+    that sees the second number grow (a scene whose splats jump further than the repair window between calls: e.g.
+    particles at the fringe of the velocity field's support) switches back with set_coherent_sort(False): the mode is
+    exact either way, a fallback only costs time (~2 ms per view and call)."""
+    calls = falls = 0
+    for vb in list(_VIEW_BATCHES or ()):
+        for (ch, P) in list(vb._sort_state):
+            for c in vb.sort_counters(ch, P):
+                calls += c[0]
+                falls += c[1]
+    return calls, falls
+
+
 def set_lean_geometry(enabled: bool):
     """View batches only: do not write the per-view GeometryState copies nothing reads back, one world covariance for
     all views (include/fnx_raster.h fnx_set_lean_geometry)."""
@@ -400,20 +417,26 @@ class ViewBatch:
                 self._sort_state.clear()
             n = _lib.raster().fnx_sort_state_bytes(int(P))
             ent = self._sort_state[key] = torch.zeros(self.V * n, dtype=torch.uint8, device=self.view.device)
+            global _VIEW_BATCHES
+            if _VIEW_BATCHES is None:
+                import weakref
+                _VIEW_BATCHES = weakref.WeakSet()
+            _VIEW_BATCHES.add(self)
             return ent, False  # this call's radix passes seed it
         return ent, True
 
-    def sort_counters(self, channels, P):
-        """Per view (calls in coherent mode, of those: in-launch full sorts) -- blocking read-back."""
+    def sort_counters(self, channels, P, why=False):
+        """Per view (calls in coherent mode, of those: in-launch full sorts[, why: fnx_sort_state_read's bit mask]) --
+        blocking read-back."""
         ent = self._sort_state.get((int(channels), int(P)))
         if ent is None:
             return []
         out, lib = [], _lib.raster()
         stream = torch.cuda.current_stream().cuda_stream
         for v in range(self.V):
-            pair = (C.c_uint32 * 2)()
+            pair = (C.c_uint32 * 3)()
             _lib.check(lib.fnx_sort_state_read(ent.data_ptr(), int(P), v, stream, pair))
-            out.append((int(pair[0]), int(pair[1])))
+            out.append((int(pair[0]), int(pair[1])) + ((int(pair[2]),) if why else ()))
         return out
 
     def depth_hint(self, channels):

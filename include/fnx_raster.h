@@ -91,8 +91,10 @@ typedef struct fnx_raster_opts {
 } fnx_raster_opts_t;
 size_t fnx_sort_state_bytes(int P);
 /* Host read-back (blocking) of a view's counters in a sort state: out[0] = calls in coherent mode, out[1] = of those,
- * calls that fell back to the in-launch full sort. */
-int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[2]);
+ * calls that fell back to the in-launch full sort, out[2] = why they did, OR-ed over the calls (1: a record not written
+ * by the call's preprocess, 2: a sample-sort bucket overflowed, 4: a chunk not strictly increasing, 8: a chunk boundary out
+ * of order = an element moved further than the window margin, 16: unseeded state). */
+int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[3]);
 
 /* Scratch sizes [required<GeometryState>(P), required<ImageState>(W*H), required<BinningState>(R),
  * rasterizer_impl.cu:210,222,266]. */

@@ -43,7 +43,7 @@ class _Views:
     def counters(self, P):
         out = []
         for v in range(self.V):
-            pair = (C.c_uint32 * 2)()
+            pair = (C.c_uint32 * 3)()
             self._lib.check(self.lib.fnx_sort_state_read(self.state[P].data_ptr(), P, v,
                                                          torch.cuda.current_stream().cuda_stream, pair))
             out.append((int(pair[0]), int(pair[1])))
