@@ -47,7 +47,7 @@ SIZE = 512
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 2 * 1.0  # 1024 SIMD-32s x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 VALU_MEASURED_WAVE_INSTR = 933e9                   # tools/micro/pk_rate.hip on this chip
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 CONFIGS = {
     2: dict(workload="BASELINE configs[1]: ScalarReal single frame, 100k grey Gaussians (gm_fluid / render_fluid / ch1), "
@@ -373,6 +373,53 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
                    "no MFMA instruction in the library (DESIGN.md 4.7)"}
 
 
+def drop_in_timing(a, dev, cfg_id, steps=8):
+    """What a FluidNexus user gets from `PYTHONPATH=<this repo>` alone: the reference's own op sequence
+    through the plug-in seam -- one GaussianRasterizer autograd node per view (train_physical_particle.py:338-405), the
+    image / physics / distance terms as separate autograd nodes, gm.cache_gradient_current per view, torch.optim.Adam,
+    the per-forward host sync of rasterizer_impl.cu:264, bit-exact blend arithmetic, no static split, no graph, no
+    view batching.  Everything faster than this needs fluidnexus_amd.harness (or the entry script edited to call the
+    view-batched pipe)."""
+    from types import SimpleNamespace
+    from fluidnexus_amd import rasterizer
+    from fluidnexus_amd.renderer import pipes
+    keep = dict(rasterizer._OPTS)
+    keep_sync, keep_split, keep_cudnn = rasterizer._HOST_SYNC, pipes._STATIC_SPLIT, torch.backends.cudnn.enabled
+    try:
+        rasterizer.set_blend_math("exact")
+        rasterizer.set_lean_geometry(False)
+        rasterizer.set_sort_narrow(False)
+        rasterizer.set_coherent_sort(False)
+        rasterizer.set_host_sync(True)
+        pipes.set_static_split(False)
+        torch.backends.cudnn.enabled = False  # utils.loss_utils.ssim's conv2d on ATen's own kernels (MIOpen's cold find step, DESIGN 4.5)
+        b = SimpleNamespace(**vars(a))
+        b.no_graph, b.host_sync, b.image_loss, b.unfused_physics, b.torch_adam, b.views = True, True, "torch", True, True, "serial"
+        gm, cams, loop = build_workload(cfg_id, CONFIGS[cfg_id]["views"], dev, 0, 1, b, False)
+        loop.make_targets()
+        for _ in range(2):
+            loop.iteration()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loop.iteration()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"drop_in_iters_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                "what": "reference op sequence through the plug-in seam: per-view rasteriser autograd nodes, torch image / "
+                        "physics / distance terms, per-view gradient cache, torch.optim.Adam, host sync per forward, exact "
+                        "blend arithmetic, no static split / view batching / graph (bench.py --views serial --no-graph "
+                        "--image-loss torch --torch-adam --unfused-physics --host-sync --blend-math exact --no-static-split)"}
+    finally:
+        rasterizer.set_blend_math(("exact", "fast")[keep["blend_math"]])
+        rasterizer.set_lean_geometry(bool(keep["lean_geometry"]))
+        rasterizer.set_sort_narrow(bool(keep["sort_narrow"]))
+        rasterizer.set_coherent_sort(bool(keep["coherent_sort"]))
+        rasterizer.set_host_sync(keep_sync)
+        pipes.set_static_split(keep_split)
+        torch.backends.cudnn.enabled = keep_cudnn
+
+
 def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     """BASELINE config 3 as what it names: a multi-FRAME sequence.  Per frame the reference's boundary in its call order
     (entries_fluid_nexus/train_physical_particle.py:283-302: remove_invalid_particles -> emit_new_particles ->
@@ -528,6 +575,10 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="also time the SH pipe's rasteriser (colours as spherical-harmonics coefficients of this degree) "
                          "on the configuration's Gaussians: record key `sh` (not part of the timed training step)")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="skip the `drop_in` leg (the reference's op sequence through the plug-in seam, ~1 s)")
+    ap.add_argument("--no-exact-leg", action="store_true",
+                    help="skip the `exact_mode` leg (the same loop re-captured with the bit-exact blend arithmetic, ~1 s)")
     ap.add_argument("--frames", type=int, default=0,
                     help="also time a sequence of this many frames (config 3 / 5, physical stage): the reference's frame "
                          "boundary in its call order + --iters-per-frame optimisation iterations per frame, record key "
@@ -691,9 +742,12 @@ def main():
         if hasattr(loop, "parallel_views"):
             loop.parallel_views = False  # kernels one at a time, so the event pairs time single kernels
         _lib.profile_enable(True)
+        rasterizer.keep_last_blobs(True)
         for _ in range(5):
             loop.iteration()
         torch.cuda.synchronize()
+    walked = rasterizer.walked_entries()  # the blend kernels' own counts of the list entries they read (last eager iteration)
+    rasterizer.keep_last_blobs(False)
     prof = {name: _lib.profile_read(i) for i, name in enumerate(("blend_forward", "blend_backward", "sort_and_counts",
                                                                  "preprocess", "emit", "blend_forward_ch1",
                                                                  "blend_backward_ch1"))}
@@ -724,60 +778,110 @@ def main():
     R = sum(R_views) / max(len(R_views), 1)
     P_vis = sum(P_vis_views) / max(len(P_vis_views), 1)
     bwd_ms, bwd_n = prof["blend_backward"]
-    # blend backward reads per instance id 4 + xy 8 + conic_opacity 16 + depth 4 + colour 4C,
-    # per pixel dL_dpix C + final_T + n_contrib, and writes per visible splat 2+3+1+C accumulated gradients;
-    # a view-batched launch processes all of the rank's views
-    alg_bytes = int(views_per_launch * (R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)))
-    avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
+    fwd_ms, fwd_n = prof["blend_forward"]
+    fwd_s, bwd_s = (fwd_ms / max(fwd_n, 1)) * 1e-3, (bwd_ms / max(bwd_n, 1)) * 1e-3
+    # SURVEY 8(d), per view: the blend FORWARD reads per instance id 4 + xy 8 + conic_opacity 16 + depth 4 + colour 4C and
+    # writes per pixel colour C + depth + final_T + n_contrib; the blend BACKWARD reads the same per instance, per pixel
+    # dL_dpix C + final_T + n_contrib, and writes per visible splat 2+3+1+C accumulated gradients.  A view-batched launch
+    # processes all of the rank's views.
+    alg = {"blend_forward": int(views_per_launch * (R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 3))),
+           "blend_backward": int(views_per_launch * (R * (32 + 4 * Cn) + SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn)))}
+    # ... and what the kernels actually read: both stop early (saturated pixels, the gradient limit), so the lists they walk
+    # are shorter than R.  Counted by the kernels (header words 10 / 11), one eager iteration outside the timed region.
+    touched = None
+    if walked is not None and view_mode == "batched":
+        fw, bw = sum(walked[0]), walked[1]
+        touched = {"blend_forward": int(fw * (32 + 4 * Cn) + views_per_launch * SIZE * SIZE * 4 * (Cn + 3)),
+                   "blend_backward": int(bw * (32 + 4 * Cn) + views_per_launch * (SIZE * SIZE * 4 * (Cn + 2) + P_vis * 4 * (6 + Cn))),
+                   "entries": {"blend_forward": int(fw), "blend_backward": int(bw), "instances": int(R * views_per_launch)}}
+    # the dominant kernel is the one that takes longer, measured
+    dom = "blend_forward" if fwd_s >= bwd_s else "blend_backward"
+    avg_s = fwd_s if dom == "blend_forward" else bwd_s
+    alg_bytes = alg[dom]
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     # whole-iteration algorithmic bytes (B_view = 324 P + 132 R + 44 HW for ch3, 308 P + 116 R + 28 HW for ch1)
     per_view = (324 * P_total + 132 * R + 44 * SIZE * SIZE) if Cn == 3 else (308 * P_total + 116 * R + 28 * SIZE * SIZE)
     iter_bytes = per_view * len(cams)
-    # HBM traffic / VALU instructions of the dominant kernel: separate rocprofv3 --pmc passes of this command
+    # HBM traffic / VALU instructions of the two kernels: separate rocprofv3 --pmc passes of this command
     # (tools/collect_profiles.sh -> profiles/<tag>_pmc_traffic.json, <tag>_sq_counters.json), null if absent
-    full_bwd = a.unfused_physics or a.stage == "visual"
     # backward modes (raster_backward.hip): 3 = positions only (the position stages: the flush adds straight into
     # dL/dmeans3D), 1 = geometry only (the same with FNX_SCREEN_GRAD=1), 2 = fixed positions (visual-particle stage:
     # appearance + shape gradients), 0 = everything (per-view autograd physics)
     bwd_mode = 2 if a.stage == "visual" else (0 if a.unfused_physics else
                                               1 if os.environ.get("FNX_SCREEN_GRAD", "0") == "1" else 3)
-    kname = f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {'true' if a.blend_math == 'fast' else 'false'}>"
+    fast_s = 'true' if a.blend_math == 'fast' else 'false'
+    split_s = 'true' if (pipes._STATIC_SPLIT and cfg_id != 2 and a.stage != "first") else 'false'
+    knames = {"blend_forward": f"fnx::blend_forward_kernel<{Cn}, {split_s}, {fast_s}>",
+              "blend_backward": f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}>"}
+    kname = knames[dom]
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
-    traffic = valu = None
-    for tag in (PROFILE_TAG,):
+    counters = {}
+    for which, kn in knames.items():
+        ent = {}
         try:
-            with open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_traffic.json")) as f:
-                t = json.load(f).get("void " + kname)
-            if t and traffic is None:
-                traffic = {"bytes_per_launch": t["fetch_bytes"] + t["write_bytes"],
-                           "source": f"profiles/{tag}{suffix}_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{suffix}_pmc_traffic.json")) as f:
+                t = json.load(f).get("void " + kn)
+            if t:
+                ent["hbm_bytes_per_launch"] = t["fetch_bytes"] + t["write_bytes"]
         except OSError:
             pass
         try:
-            with open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_sq_counters.json")) as f:
-                t = json.load(f).get("void " + kname)
-            if t and valu is None:
-                valu = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "counter_run_launch_us": t["us"],
-                        "source": f"profiles/{tag}{suffix}_sq_counters.json (separate rocprofv3 --pmc SQ_INSTS_VALU pass)"}
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{suffix}_sq_counters.json")) as f:
+                t = json.load(f).get("void " + kn)
+            if t:
+                ent["valu_wave_instructions_per_launch"] = t["SQ_INSTS_VALU"]
+                ent["counter_run_launch_us"] = t["us"]
+                for src, dst in (("valu_busy", "valu_busy"), ("lds_busy", "lds_busy"), ("wait_frac", "wave_wait_frac")):
+                    if src in t:
+                        ent[dst] = t[src]
         except OSError:
             pass
-    roofline = {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes_per_launch"] if traffic else None,
-                "kernel": kname, "avg_launch_us": avg_s * 1e6, "launches": bwd_n, "views_per_launch": views_per_launch,
+        counters[which] = ent
+    cdom = counters[dom]
+    traffic = cdom.get("hbm_bytes_per_launch")
+    src_note = (f"profiles/{PROFILE_TAG}{suffix}_pmc_traffic.json / _sq_counters.json: separate rocprofv3 --pmc passes of this "
+                "command on the builder's box (tools/collect_profiles.sh), NOT collected in this run")
+    frac = achieved / HBM_PEAK_GBS
+    roofline = {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                "traffic": traffic, "kernel": kname, "avg_launch_us": avg_s * 1e6,
+                "launches": fwd_n if dom == "blend_forward" else bwd_n, "views_per_launch": views_per_launch,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (every instance read once) against "
-                        "HBM peak, as the contract defines them; the kernel is bound by the compute units' VALU and LDS "
-                        "pipelines (profiles/<tag>_sq_counters.md: VALU busy ~65 % of the cycles incl. the quarter-rate "
-                        "exp / rcp; <tag>_lds_counters.md: LDS ~55 %), not by HBM: see hbm_traffic_frac and valu",
-                "traffic_source": traffic["source"] if traffic else None,
-                "hbm_traffic_frac": (traffic["bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_s > 0 else None,
+                "kernel_chosen_by": f"measured launch time: blend forward {fwd_s * 1e6:.1f} us, blend backward {bwd_s * 1e6:.1f} us",
+                "note": "achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (every instance read once) against HBM "
+                        "peak, as the contract defines them.  The blends stop early (saturated pixels, gradient limit), so the "
+                        "bytes they must touch are fewer: see `touched` (the kernels' own entry counts).  Neither kernel is "
+                        "bound by HBM: the primary bound is the compute units' VALU / LDS pipelines, see `primary_bound`",
+                "traffic_source": src_note if traffic else None,
+                "hbm_traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_s > 0 else None,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
-    if valu and avg_s > 0:
-        rate = valu["wave_instructions_per_launch"] / avg_s
-        roofline["valu"] = dict(valu, wave_instructions_per_s=rate, frac_of_measured_issue_rate=rate / VALU_MEASURED_WAVE_INSTR,
-                                frac_of_spec_issue_rate=rate / VALU_SPEC_WAVE_INSTR,
-                                spec="1024 SIMD-32s x 1 wave64 VALU instruction / 2 cycles x 2.4 GHz = 1229 G wave-instr/s "
-                                     "(157 TFLOP/s fp32); measured on this chip 933 G/s (tools/micro/pk_rate.hip)")
+    if touched:
+        tb = touched[dom]
+        roofline["touched"] = {"algorithmic_bytes_touched": tb, "GBps": tb / avg_s / 1e9 if avg_s > 0 else None,
+                               "frac": tb / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else None,
+                               "list_entries": touched["entries"],
+                               "traffic_over_touched": (traffic / tb) if traffic else None}
+        if frac > 1.0:  # the formula prices bytes the kernel never reads (e.g. a scene whose tiles saturate early)
+            roofline["frac_of_formula"], roofline["achieved_of_formula"] = frac, achieved
+            roofline["frac"], roofline["achieved"] = roofline["touched"]["frac"], roofline["touched"]["GBps"]
+            roofline["note"] += "; the 8(d) formula gave a fraction above 1 on this scene: frac / achieved are the TOUCHED bytes'"
+    elif frac > 1.0:
+        roofline["frac_of_formula"], roofline["frac"] = frac, None
+    if cdom.get("valu_wave_instructions_per_launch") and avg_s > 0:
+        rate = cdom["valu_wave_instructions_per_launch"] / avg_s
+        roofline["primary_bound"] = {"valu_busy": cdom.get("valu_busy"), "lds_busy": cdom.get("lds_busy"),
+                                     "wave_wait_frac": cdom.get("wave_wait_frac"),
+                                     "valu_wave_instructions_per_launch": cdom["valu_wave_instructions_per_launch"],
+                                     "frac_of_measured_issue_rate": rate / VALU_MEASURED_WAVE_INSTR,
+                                     "frac_of_spec_issue_rate": rate / VALU_SPEC_WAVE_INSTR,
+                                     "source": src_note,
+                                     "spec": "1024 SIMDs x 1 wave64 VALU instruction / 2 cycles x 2.4 GHz = 1229 G wave-instr/s "
+                                             "(157 TFLOP/s fp32); measured on this chip 933 G/s (tools/micro/pk_rate.hip)"}
+    other = "blend_backward" if dom == "blend_forward" else "blend_forward"
+    o_s = bwd_s if dom == "blend_forward" else fwd_s
+    roofline["second_kernel"] = {"kernel": knames[other], "avg_launch_us": o_s * 1e6, "algorithmic_bytes_per_launch": alg[other],
+                                 "frac": alg[other] / o_s / 1e9 / HBM_PEAK_GBS if o_s > 0 else None,
+                                 "touched_frac": (touched[other] / o_s / 1e9 / HBM_PEAK_GBS) if touched and o_s > 0 else None,
+                                 "traffic": counters[other].get("hbm_bytes_per_launch")}
     nominal_iters = (len(cams) / nominal_views) * a.steps  # weak scaling: N nominal batches per step
     value = nominal_iters / dt
     roofline["iteration_algorithmic"] = {"bytes": int(iter_bytes), "GBps": iter_bytes * a.steps / dt / 1e9,
@@ -865,6 +969,38 @@ def main():
                                              "appearance_and_shape" if bwd_mode == 2 else "positions_only"):
                bwd_ms / max(bwd_n, 1) / max(views_per_launch, 1)}),
     }
+    # top-level switches of the number above (one record must not mix modes silently)
+    out["modes"] = {"blend_math": a.blend_math, "lean_geometry": not a.full_geometry,
+                    "depth_sort": "radix" if (a.sort == "radix" or sort_note) else "coherent",
+                    "sort_narrow_max_bits": rasterizer.SORT_NARROW_MAX_BITS, "graph": bool(graph_mode),
+                    "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2)}
+    if (a.blend_math == "fast" and graph_mode and not a.no_exact_leg and world == 1 and a.emulate_world <= 1
+            and hasattr(loop, "capture")):
+        try:  # the same loop with the bit-exact blend arithmetic (what the oracle parity tests run), re-captured
+            rasterizer.set_blend_math("exact")
+            loop.capture(warmup=1, iterations=loop.graph_iterations)
+            loop.iteration()
+            torch.cuda.synchronize()
+            n_calls = max(1, 100 // loop.iterations_per_call)
+            t0 = time.perf_counter()
+            for _ in range(n_calls):
+                loop.iteration()
+            torch.cuda.synchronize()
+            e_dt = (time.perf_counter() - t0) / (n_calls * loop.iterations_per_call)
+            rasterizer.check_status()
+            out["exact_mode"] = {"iters_per_s": 1.0 / e_dt, "ms_per_step": e_dt * 1e3, "steps": n_calls * loop.iterations_per_call,
+                                 "what": "the same configuration with --blend-math exact (bit-equal to the CPU oracle), re-captured"}
+        except Exception as e:
+            print(f"[bench] exact-mode leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+        finally:
+            rasterizer.set_blend_math(a.blend_math)
+    if not a.no_drop_in and cfg_id != 2 and a.stage == "physical" and world == 1 and a.emulate_world <= 1:
+        try:
+            out["drop_in"] = drop_in_timing(a, dev, cfg_id)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] drop-in leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     if a.frames > 0 and cfg_id != 2 and a.stage == "physical" and a.emulate_world <= 1:
         try:
             out["sequence"] = sequence_timing(a, dev, cfg_id, rank, world, use_dist, dt / a.steps * 1e3)

@@ -244,6 +244,9 @@ enum { HDR_NUM_RENDERED = 0, HDR_STATUS = 1, HDR_CAPACITY = 2, HDR_NUM_STATIC = 
        HDR_BIN_CAPACITY = 6, HDR_BWD_TICKET = 7, HDR_BWD_DONE = 8,
        // the forward's gradient limit: ids >= it were treated as gradient-free when the per-pixel walking limits of the
        // backward (second half of n_contrib) and its work items were laid down; a backward with a larger limit is refused
-       HDR_DYN_LIMIT = 9 };  // words 10 .. 63 of the header block are scratch
+       HDR_DYN_LIMIT = 9,
+       // list entries the blend forward staged (batches it blended, clipped to the lists) and the blend backward walked
+       // (its work items' batches): what the two kernels actually read, for the roofline record (one atomic per workgroup)
+       HDR_FWD_ENTRIES = 10, HDR_BWD_ENTRIES = 11 };  // words 12 .. 63 of the header block are scratch
 
 }  // namespace fnx

@@ -279,6 +279,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #else
     auto ticket_of = [&](uint32_t sidx) -> uint32_t { return ((sidx / kChunk) * gridDim.x + blockIdx.x) * kChunk + sidx % kChunk; };
 #endif
+    uint32_t walked[1] = {0u};  // list entries of this workgroup's items (thread 0)
     Fetched cur, nxt;
     fetch_item(ticket_of(0), cur);
     fetch_item(ticket_of(1), nxt);
@@ -345,6 +346,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const float pxf = (float)px, pyf = (float)py;
         const uint32_t r0 = cur.r0;
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
+        walked[0] += min(256u, cur.r1 - r0 - q0);
 
         float T_final, dL_dpixel[C], total[C];
         uint32_t last_contributor;
@@ -820,6 +822,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         nxt.item = nx2.item;
         nxt.vw = nx2.vw;
     }
+    // (all views' entries are counted in view 0's word: the items of a workgroup come from every view)
+    if (tid == 0 && walked[0]) atomicAdd(const_cast<uint32_t *>(header) + HDR_BWD_ENTRIES, walked[0]);
 #if FNX_BWD_DYNAMIC
     // the last workgroup to run out of items re-arms the counters: another backward over the same forward (a second
     // autograd pass, a test that calls it again) starts from ticket 0 like the first

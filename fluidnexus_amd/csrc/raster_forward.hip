@@ -497,6 +497,8 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         header[HDR_BWD_ITEMS] = 0u;  // the blend forward appends the backward's work items
         header[HDR_BWD_TICKET] = 0u;  // the backward's dynamic ticket counter (view 0's words)
         header[HDR_BWD_DONE] = 0u;
+        header[HDR_FWD_ENTRIES] = 0u;
+        header[HDR_BWD_ENTRIES] = 0u;
     }
     // emission work items: exclusive prefix of the per-block band counts
     __syncthreads();
@@ -762,6 +764,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     if (wg_rank == 0 && wg_view == 0 && lane == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[16 * w + i] = 0; g_fwd_clock[16 * w + 15] = r1 - r0; }
 #endif
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
+    uint32_t staged = 0;   // list entries of the batches this tile blended
     for (uint32_t base = r0; base < r1; base += 256) {
         FNX_CLK(0)
         // barrier between the previous batch's walk and this batch's staging, and "has every pixel stopped?" in one:
@@ -780,6 +783,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (blending && base != r0)
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
         const uint32_t cnt = min(256u, r1 - base);
+        if (blending) staged += cnt;
         uint32_t qm = 0;
         {  // which staged entries are dynamic: one ballot per wave (slot = thread), read back behind the walk
             const unsigned long long dm = __ballot((uint32_t)tid < cnt && my_id < dyn_limit);
@@ -991,6 +995,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         for (uint32_t k = tid; k < nb; k += 256) items[k] = (uint32_t)tile | (k << kItemTileBits);
     }
     if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: the next forward's tile order
+    if (tid == 0 && staged) atomicAdd(&header[HDR_FWD_ENTRIES], staged);
 #ifdef FNX_EXP_CLOCK
     if (tid == 0) {
         const int wg = wg_view * T + wg_rank;

@@ -82,6 +82,32 @@ def set_coherent_sort(enabled: bool):
     _OPTS["coherent_sort"] = 1 if enabled else 0
 
 
+_KEEP_LAST = False   # keep_last_blobs(): remember the image blobs of the most recent view-batched forward
+_last_blobs = None
+
+
+def keep_last_blobs(enabled: bool):
+    """Measurement aid (bench.py): keep a reference to the image blobs of the latest view-batched forward so that
+    walked_entries() can read the blend kernels' own counters after an eager iteration."""
+    global _KEEP_LAST, _last_blobs
+    _KEEP_LAST = bool(enabled)
+    if not enabled:
+        _last_blobs = None
+
+
+def walked_entries():
+    """(list entries the blend forward staged, per view; list entries the blend backward walked, all views) of the most
+    recent view-batched forward / backward pair -- header words 10 / 11 of the image blobs (include/fnx_raster.h),
+    counted by the kernels themselves, one atomic per workgroup.  Blocking.  None without keep_last_blobs(True)."""
+    if _last_blobs is None:
+        return None
+    img, ibytes, V = _last_blobs
+    torch.cuda.synchronize()
+    al = (-img.data_ptr()) % 256
+    words = [img[v * ibytes + al: v * ibytes + al + 64].view(torch.int32).cpu().tolist() for v in range(V)]
+    return [w[10] & 0xFFFFFFFF for w in words], sum(w[11] & 0xFFFFFFFF for w in words)
+
+
 _VIEW_BATCHES = None  # weak set of the ViewBatch objects that hold a sort state
 
 
@@ -589,6 +615,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                                                                img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
                                                                color.data_ptr(), depth.data_ptr(), status_ptr, None, 0, 0,
                                                                0, hint_ptr, C.byref(opts), stream))
+        if _KEEP_LAST and P and not torch.cuda.is_current_stream_capturing():
+            global _last_blobs
+            _last_blobs = (img, ibytes, V)
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
@@ -670,6 +699,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             Cn, V, geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, W, H, vbatch.bg.data_ptr(),
             color.data_ptr(), depth.data_ptr(), status_ptr, sb.blob.data_ptr(), sb.P, sb.R_cap,
             int(bool(StaticBin.materialize_all)), hint_ptr, C.byref(opts), stream))
+        if _KEEP_LAST and not torch.cuda.is_current_stream_capturing():
+            global _last_blobs
+            _last_blobs = (img, ibytes, V)
         ctx.vbatch = vbatch
         ctx.capacity = cap
         ctx.channels = Cn
