@@ -571,7 +571,7 @@ def main():
                          "last rank -- the one with the fewest views -- `batch` times (last-rank: same sum after the "
                          "all-reduce, tests/test_distributed_cpu.py; not measured on multi-GPU hardware)")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
-                    help="fnx_set_deep_kernel: 0 never, 1 launches of <= 2 views (library default), 2 always")
+                    help="deep-tile forward kernel (fnx_raster_opts_t.deep_kernel): 0 never (library default), 1 launches of <= 2 views, 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="also time the SH pipe's rasteriser (colours as spherical-harmonics coefficients of this degree) "
                          "on the configuration's Gaussians: record key `sh` (not part of the timed training step)")

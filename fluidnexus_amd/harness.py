@@ -152,6 +152,9 @@ class HotLoop:
         # sum to everybody.  bench.py --shared-terms last-rank picks the LAST rank: round-robin sharding gives
         # it the fewest views, so the extra work lands on the rank that would otherwise wait (view-batched loop only).
         self.shared_terms_rank = shared_terms_rank
+        if shared_terms_rank is not None and not batched_views:
+            raise ValueError("shared_terms_rank is implemented by the view-batched loop only (batched_views=True): the serial / "
+                             "parallel loops evaluate the view-independent terms per view or on rank 0")
         self.emulated = None  # (rank, world) of the run whose share `view_subset` is (bench.py --emulate-world)
         self.image_loss = image_loss
         self.fused_physics = fused_physics
@@ -436,10 +439,13 @@ class HotLoop:
         dist_here = (shared == erank) if dist_shared else True
         n_dist_weight = batch if dist_shared else len(mine)
         use_dist = bool(mine) and dist_here and c.get("lambda_current_distance", 0.0) > 0
+        physics_launched = []
+
         def launch_physics():
             nonlocal gp, n_phys
-            if not phys_here:
+            if not phys_here or physics_launched:  # once per iteration, however often the hook fires
                 return
+            physics_launched.append(1)
             self.side_stream.wait_event(fork)
             with torch.cuda.stream(self.side_stream):
                 # work items of the hidden-particle grid for the cell-by-cell hidden<-visual backward at the end
