@@ -15,7 +15,7 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
            "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials",
            "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum", "fnx_adam_step_grid",
-           "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists")
+           "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists", "fnx_stream_delay")
 
 
 def physics():
@@ -45,6 +45,8 @@ def physics():
     lib.fnx_distance_loss_partials.argtypes = [i]
     lib.fnx_distance_loss.restype = i
     lib.fnx_distance_loss.argtypes = [p, i, f, p, p, p, p]
+    lib.fnx_stream_delay.restype = i
+    lib.fnx_stream_delay.argtypes = [f, p]
     lib.fnx_distance_table_bytes.restype = C.c_size_t
     lib.fnx_distance_table_bytes.argtypes = [i]
     lib.fnx_distance_loss_lists.restype = i

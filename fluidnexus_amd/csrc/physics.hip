@@ -1598,6 +1598,20 @@ int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, floa
     return hip_check("distance_loss");
 }
 
+// One wave that sleeps: delays whatever is enqueued behind it on its stream without taking more than a wave slot.
+__global__ void __launch_bounds__(64)
+delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int fnx_stream_delay(float microseconds, fnx_stream_t stream) {
+    if (!(microseconds > 0.f)) return FNX_OK;
+    // wall_clock64 ticks at 100 MHz on this family
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0f));
+    return hip_check("stream_delay");
+}
+
 size_t fnx_distance_table_bytes(int N) { return dist_table_bytes(N); }
 
 int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,

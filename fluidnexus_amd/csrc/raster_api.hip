@@ -29,7 +29,8 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
                        uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow,
-                       char *coh_state, int coherent, const uint4 *krec);
+                       char *coh_state, int coherent, const uint4 *krec, int W, int H, uint16_t *blk_hist,
+                       uint32_t *blk_total, int *hist_done);
 void launch_rank_hist(hipStream_t s, int P, int W, int H, const uint2 *rect_sorted, uint16_t *blk_hist,
                       uint32_t *blk_total, int V, const ViewBatch &vb);
 void launch_emit(hipStream_t s, int P, int W, int H, const uint2 *sorted3, const uint2 *sorted4,
@@ -407,11 +408,13 @@ int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffer, 
     {
     ProfScope ps(2, s);
     // (key, id) pair buffers: sort_key0|sort_key1 and sort_val0|sort_val1 are adjacent P-word arrays
+    int hist_done = 0;  // the coherent sort counts the instances per (rank block, tile) on its way when the tiles fit its LDS
     fnx::launch_depth_sort(s, P, g.sort_key0, (uint2 *)g.sort_key0, (uint2 *)g.sort_val0, g.sort_hist, g.rect,
                            g.rect_sorted, V, vb, op.sort_mode == FNX_SORT_NARROW ? 1 : 0, sort_state, coherent ? 1 : 0,
-                           g.krec);
-    fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, V,
-                          vb);
+                           g.krec, width, height, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total, &hist_done);
+    if (!hist_done)
+        fnx::launch_rank_hist(s, P, width, height, g.rect_sorted, g.blk_hist, g.sort_hist + fnx::sort_scratch(P).blk_total,
+                              V, vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
                           op.deep_min, img.tile_order, img.tile_deep, V, vb, st);

@@ -439,12 +439,27 @@ __device__ void coh_fallback_sort(int P, const uint32_t *raw, uint2 *pa, uint2 *
     }
 }
 
+// (defined with rank_hist_kernel below) per-(rank block, tile) instance counts of one block of kSplatBlock ranks
+template <class RectAt>
+__device__ __forceinline__ void rank_hist_block(int blk, int tid, int P, int T, int gx, int gy, RectAt rect_at,
+                                                uint32_t *s_hist, uint32_t *s_total, uint16_t *__restrict__ blk_hist,
+                                                uint32_t *__restrict__ blk_total, bool write);
+// What the coherent sort needs to do rank_hist_kernel's work on its way (T == 0: not fused, the kernel is launched)
+struct FusedHist {
+    int T, gx, gy;
+    uint16_t *blk_hist;   // view 0's arrays (stride: the geometry blob's)
+    uint32_t *blk_total;
+};
+static_assert(kCohOut / kSplatBlock == kCohThreads / 256, "one 256-thread group per rank block of the chunk");
+constexpr int kFusedHistMaxTiles = (int)(kCohLdsA / 4) / (kCohOut / kSplatBlock);  // the groups' histograms share the output chunk's LDS
+
 __global__ void __launch_bounds__(kCohThreads)  // two workgroups per unit (60 KiB of LDS each)
 sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__restrict__ krec,
                    uint2 *__restrict__ pairs_tmp, uint2 *__restrict__ pairs_out, uint32_t *__restrict__ scratch,
                    SortScratch L, const uint2 *__restrict__ rect, uint2 *__restrict__ rect_sorted,
-                   char *__restrict__ state, size_t state_stride, SortStateLayout SL, size_t geom_stride) {
+                   char *__restrict__ state, size_t state_stride, SortStateLayout SL, size_t geom_stride, FusedHist fh) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kCohLdsBytes];
+    __shared__ uint32_t s_htot[kCohThreads / 256];
     u64 *s_out = reinterpret_cast<u64 *>(s_raw);                           // the output chunk is staged here
     u64 *s_t = reinterpret_cast<u64 *>(s_raw + kCohLdsA);                  // bucketed copy of the window
     u64 *s_split = reinterpret_cast<u64 *>(s_raw + kCohLdsA + kCohLdsT);   // [256] sorted sample of the window
@@ -463,6 +478,8 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     rect = view_at(rect, geom_stride, vw);
     rect_sorted = view_at(rect_sorted, geom_stride, vw);
     state += state_stride * (size_t)vw;
+    fh.blk_hist = view_at(fh.blk_hist, geom_stride, vw);
+    fh.blk_total = view_at(fh.blk_total, geom_stride, vw);
     uint32_t *ctl = scratch + L.ctl;
     uint32_t *hdr = reinterpret_cast<uint32_t *>(state + SL.hdr);
     u64 *bounds = reinterpret_cast<u64 *>(state + SL.bounds);
@@ -645,6 +662,17 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             bounds[2 * c] = s_out[0];
             bounds[2 * c + 1] = s_out[n_out - 1];
         }
+        if (fh.T && !(FNX_EXP_COH & 2)) {
+            // rank_hist_kernel's work for the chunk's rank blocks, from the rectangles in LDS: one 256-thread group per
+            // block, their histograms where the output chunk was staged (it is out by now)
+            __syncthreads();
+            const int grp = tid >> 8, blk = c * (kCohOut / kSplatBlock) + grp;
+            const uint32_t *s_orect = reinterpret_cast<const uint32_t *>(s_t);
+            rank_hist_block(blk, tid & 255, P, fh.T, fh.gx, fh.gy,
+                            [&](int rank) { return unpack_rect8(s_orect[rank - c * kCohOut]); },
+                            reinterpret_cast<uint32_t *>(s_raw) + (size_t)grp * fh.T, &s_htot[grp], fh.blk_hist, fh.blk_total,
+                            blk * kSplatBlock < P);
+        }
     }
     if (FNX_EXP_COH) bad = 0;
     if (bad) atomicOr(&s_flag, bad);
@@ -673,6 +701,13 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     if (fail) {
         coh_fallback_sort(P, raw_keys, pairs_tmp, pairs_out, inv, rect, rect_sorted, reinterpret_cast<uint32_t *>(s_raw));
         __threadfence();
+        if (fh.T) {  // ... and the counts of every rank block again, from the order just written
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int blk = 0; blk < (P + kSplatBlock - 1) / kSplatBlock; blk++)
+                rank_hist_block(blk, tid, P, fh.T, fh.gx, fh.gy, [&](int rank) { return rect_sorted[rank]; },
+                                reinterpret_cast<uint32_t *>(s_raw), &s_htot[0], fh.blk_hist, fh.blk_total, true);
+        }
     }
     if (tid == 0) {
         ctl[SORT_CTL_KMIN] = 0u;      // this mode's pairs hold the depth bits themselves
@@ -697,25 +732,21 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
 // does not add 1 to every tile of its rectangle: per tile row it adds +1 at the first column and -1
 // just past the last one (2 atomics per row instead of one per tile), and the counts are the running
 // sums along each tile row, formed once per block.
-__global__ void __launch_bounds__(256)
-rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, int gy, uint16_t *__restrict__ blk_hist,
-                 uint32_t *__restrict__ blk_total, const ViewBatch vb) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // T row-delta counters (mod 2^32)
-    __shared__ uint32_t s_total;
-    {
-        const int vw = blockIdx.y;
-        rect_sorted = view_at(rect_sorted, vb.geom, vw);
-        blk_hist = view_at(blk_hist, vb.geom, vw);
-        blk_total = view_at(blk_total, vb.geom, vw);
-    }
-    if (threadIdx.x == 0) s_total = 0;
-    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0;
+// The block's work as a device function: `tid` in [0, 256) of a 256-thread group whose threads all reach the same
+// __syncthreads() (a whole workgroup, or one half of the coherent sort's 512-thread workgroup beside the other half);
+// `rect_at(rank)` = tile rectangle of a rank of the block, s_hist: T words of LDS of the group's own, s_total: one word.
+template <class RectAt>
+__device__ __forceinline__ void rank_hist_block(int blk, int tid, int P, int T, int gx, int gy, RectAt rect_at,
+                                                uint32_t *s_hist, uint32_t *s_total, uint16_t *__restrict__ blk_hist,
+                                                uint32_t *__restrict__ blk_total, bool write) {
+    if (tid == 0) *s_total = 0;
+    for (int i = tid; i < T; i += 256) s_hist[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSplatBlock / 256; k++) {
-        const int rank = blockIdx.x * kSplatBlock + k * 256 + threadIdx.x;
+        const int rank = blk * kSplatBlock + k * 256 + tid;
         if (rank >= P) break;
-        const uint2 r = rect_sorted[rank];
+        const uint2 r = rect_at(rank);
         const int x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
         if (x1 > x0)
             for (int y = y0; y < y1; y++) {
@@ -726,7 +757,7 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
     __syncthreads();
     {  // running sum along every tile row: a half-wave (rows of <= 32 tiles: two rows per wave at a time) or a wave per
        // row, 32 / 64 tiles per step with a shuffle scan (one thread per row walked the row through LDS serially)
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int lane = tid & 63, w = tid >> 6;
         const int seg = gx <= 32 ? 32 : 64, rows_at_once = 64 / seg;
         const int sl = lane & (seg - 1), sub = lane / seg;
         for (int y0 = w * rows_at_once; y0 < gy; y0 += 4 * rows_at_once) {
@@ -746,18 +777,33 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
         }
     }
     __syncthreads();
-    uint16_t *row = blk_hist + (size_t)blockIdx.x * T;
+    uint16_t *row = blk_hist + (size_t)blk * T;
     uint32_t sum = 0;
-    for (int i = threadIdx.x; i < T; i += 256) {
-        row[i] = (uint16_t)s_hist[i];
+    for (int i = tid; i < T; i += 256) {
+        if (write) row[i] = (uint16_t)s_hist[i];
         sum += s_hist[i];
     }
     // instances of the whole block: emit splits heavy blocks over several workgroups
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_total, sum);
+    if ((tid & 63) == 0) atomicAdd(s_total, sum);
     __syncthreads();
-    if (threadIdx.x == 0) blk_total[blockIdx.x] = s_total;
+    if (tid == 0 && write) blk_total[blk] = *s_total;
+}
+
+__global__ void __launch_bounds__(256)
+rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, int gy, uint16_t *__restrict__ blk_hist,
+                 uint32_t *__restrict__ blk_total, const ViewBatch vb) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // T row-delta counters (mod 2^32)
+    __shared__ uint32_t s_total;
+    {
+        const int vw = blockIdx.y;
+        rect_sorted = view_at(rect_sorted, vb.geom, vw);
+        blk_hist = view_at(blk_hist, vb.geom, vw);
+        blk_total = view_at(blk_total, vb.geom, vw);
+    }
+    rank_hist_block((int)blockIdx.x, (int)threadIdx.x, P, T, gx, gy, [&](int rank) { return rect_sorted[rank]; }, s_hist,
+                    &s_total, blk_hist, blk_total, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1137,13 +1183,20 @@ void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, 
 // otherwise the radix passes, which leave the state seeded when it is given.  (coh_state: already aligned.)
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
                        uint32_t *scratch, const uint2 *rect, uint2 *rect_sorted, int V, const ViewBatch &vb, int narrow,
-                       char *coh_state, int coherent, const uint4 *krec) {
+                       char *coh_state, int coherent, const uint4 *krec, int W, int H, uint16_t *blk_hist,
+                       uint32_t *blk_total, int *hist_done) {
+    *hist_done = 0;
     const int NSB = sort_blocks(P);
     const SortScratch L = sort_scratch(P);
     const SortStateLayout SL = sort_state_layout(P);
     if (coherent && coh_state) {
+        FusedHist fh{0, tiles_x(W), tiles_y(H), blk_hist, blk_total};
+        if (fh.gx * fh.gy <= kFusedHistMaxTiles && blk_hist && blk_total) {
+            fh.T = fh.gx * fh.gy;
+            *hist_done = 1;  // the caller does not launch rank_hist_kernel
+        }
         hipLaunchKernelGGL(sort_repair_kernel, dim3((P + kCohOut - 1) / kCohOut, V), dim3(kCohThreads), 0, s, P, raw_keys,
-                           krec, pairs_a, pairs_b, scratch, L, rect, rect_sorted, coh_state, SL.total, SL, vb.geom);
+                           krec, pairs_a, pairs_b, scratch, L, rect, rect_sorted, coh_state, SL.total, SL, vb.geom, fh);
         return;
     }
     uint32_t *hist = scratch + L.hist, *hist_rel = scratch + L.hist_rel, *totals = scratch + L.totals,

@@ -126,6 +126,9 @@ _PHYSICS_AT_HOOK = os.environ.get("FNX_PHYSICS_EARLY", "0") == "hook"
 # "early" = as soon as the rendered positions exist (under preprocess / sort), "loss" = behind the image loss (under the
 # blend backward)
 _DIST_AT = os.environ.get("FNX_DIST_AT", "hook")
+# ... and how long behind that point its first kernel starts (a sleeping wave in front of it, fnx_stream_delay): the fork
+# point is a kernel boundary of the main chain, the delay moves the branch under the kernel BEHIND that boundary
+_DIST_DELAY_US = float(os.environ.get("FNX_DIST_DELAY_US", "0"))
 
 
 class HotLoop:
@@ -501,6 +504,9 @@ class HotLoop:
                 else:  # the forward did not pass the hook: order the branch behind everything enqueued so far
                     self.dist_stream.wait_stream(main)
                 with torch.cuda.stream(self.dist_stream):
+                    if _DIST_DELAY_US > 0:
+                        from . import _physics_lib as _PL
+                        _PL.check(_PL.physics().fnx_stream_delay(_DIST_DELAY_US, torch.cuda.current_stream().cuda_stream))
                     n_vis = gm._visual_xyz.shape[0]
                     self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
                                                                           c["distance_threshold_visual"])

@@ -165,6 +165,9 @@ int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, floa
  * with the same N and ZERO-FILLED ONCE (entries carry the number of the call that wrote them, so the table is never
  * cleared); one call at a time per table.  loss_out[0] = the loss (partial sums added in workgroup order by the
  * workgroup that arrives last); grad as above (may be NULL). */
+/* Scheduling aid: one sleeping wave on `stream` for about `microseconds` (a side branch of a captured graph can only fork
+ * at a kernel boundary of the main chain; this moves its start INTO the kernel that follows the fork point). */
+int fnx_stream_delay(float microseconds, fnx_stream_t stream);
 size_t fnx_distance_table_bytes(int N);
 int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,
                             fnx_stream_t stream);
