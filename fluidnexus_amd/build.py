@@ -37,6 +37,7 @@ def _stale(out: str, srcs: list[str]) -> bool:
         return True
     t = os.path.getmtime(out)
     deps = list(srcs) + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    deps += [os.path.join(_CSRC, "lab", f) for f in os.listdir(os.path.join(_CSRC, "lab")) if f.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "fnx_raster.h"))
     deps.append(os.path.join(_HERE, "..", "include", "fnx_physics.h"))
     deps.append(os.path.join(_HERE, "..", "include", "fnx_losses.h"))

@@ -27,9 +27,7 @@
 #else
 #define FNX_FLUSH_ADD(p, v) unsafeAtomicAdd((p), (v))
 #endif
-#ifndef FNX_ABLATE
-#define FNX_ABLATE 0  // 1: no global flush, 2: no cross-lane fold, 3: staging only (timing experiments)
-#endif
+#include "lab/fnx_lab.h"  // experiment switches (all off in the production build)
 
 #ifdef FNX_EXP_BCLK  // developer timing: per-phase cycles of wave 0 / lane 0 of every workgroup, summed over the launch
 __device__ unsigned long long g_bwd_clock[16];

@@ -25,6 +25,7 @@
 // id order, so the resulting lists are bit-identical to the reference's point_list.
 #include "fnx_device.h"
 #include "fnx_state.h"
+#include "lab/fnx_lab.h"  // experiment switches (all off in the production build)
 
 namespace fnx {
 
@@ -330,9 +331,6 @@ constexpr int kCohSampleThreads = 16 / kCohPer;  // threads per splitter: one sp
 constexpr int kCohParts = kCohThreads / 256;     // the 256 samples are ranked by kCohParts threads each
 static_assert(kCohPer * kCohSampleThreads == 16 && kCohParts * 256 == kCohThreads && kCohOut % kCohThreads == 0, "thread counts");
 typedef unsigned long long u64;
-#ifndef FNX_EXP_COH
-#define FNX_EXP_COH 0  // timing experiments (tools/build_variant.py; results wrong, verification off): 2 no rectangle / inv stores, 4 no window sort
-#endif
 // LDS layout of sort_repair_kernel: the output chunk | the bucketed window | splitters | bucket counts | starts | per
 // bucketed position: its bucket, then its final window position (the window itself lives in registers)
 constexpr size_t kCohLdsA = (size_t)kCohOut * 8;
@@ -815,9 +813,6 @@ rank_hist_kernel(int P, int T, const uint2 *__restrict__ rect_sorted, int gx, in
 // most kEmitTileWindow (the LDS arrays are per window).
 #ifndef FNX_EMIT_THREADS
 #define FNX_EMIT_THREADS 512
-#endif
-#ifndef FNX_EXP_EMIT
-#define FNX_EXP_EMIT 0  // timing experiments (tools/build_variant.py): 10 loads only, 11 no bitmask / output, 12 no store, 13 lane-contiguous store
 #endif
 #ifdef FNX_EXP_CLOCK  // developer timing: per-workgroup [start, end, sub-batches, instances] of the last emit launch
 __device__ unsigned long long g_emit_clock[4 * 16384];
