@@ -118,7 +118,10 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
     shared_rank = None
     # (an emulated share keeps the per-view form unless asked: without the all-reduce a rank that drops the terms would
     # optimise a different objective, its particles drift and the timed workload is no longer the configuration's)
-    if a.shared_terms == "last-rank":
+    # auto: last-rank as soon as there is more than one rank (the sum after the all-reduce is the same, gloo-tested in
+    # tests/test_distributed_cpu.py, and the work lands on the rank with the fewest views); a single rank has nobody to share with
+    if a.shared_terms == "last-rank" or (a.shared_terms == "auto" and shard_n > 1 and view_mode == "batched"
+                                         and not (a.emulate_world > 1)):
         shared_rank = shard_n - 1
     loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once,
                       shared_terms_rank=shared_rank,
@@ -565,11 +568,12 @@ def main():
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's share to time")
-    ap.add_argument("--shared-terms", default="per-view", choices=["per-view", "last-rank"],
+    ap.add_argument("--shared-terms", default="auto", choices=["auto", "per-view", "last-rank"],
                     help="who evaluates the view-independent terms (physics, distance loss) in a multi-rank run: every rank, "
                          "once per local view (per-view, default: the reference's evaluation count, rank by rank), or only the "
                          "last rank -- the one with the fewest views -- `batch` times (last-rank: same sum after the "
-                         "all-reduce, tests/test_distributed_cpu.py; not measured on multi-GPU hardware)")
+                         "all-reduce, tests/test_distributed_cpu.py; not measured on multi-GPU hardware); auto = last-rank "
+                         "whenever there is more than one rank")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="deep-tile forward kernel (fnx_raster_opts_t.deep_kernel): 0 never (library default), 1 launches of <= 2 views, 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
@@ -1001,6 +1005,16 @@ def main():
             import traceback
             traceback.print_exc()
             print(f"[bench] drop-in leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if a.emulate_world > 1:
+        # what the emulation leaves out, priced with a stated model: one ring all-reduce of the leaf gradient per iteration
+        # over xGMI (point-to-point links, ~153 GB/s each: MI355X_MICROARCH.md / the task's hardware notes), 2 (n - 1) steps of
+        # bytes / n each at 80 % of a link, 3 us per step, 10 us of launch + stream synchronisation around the collective
+        n_r, nbytes = a.emulate_world, 4 * 3 * int(getattr(gm, "_estimate_xyz_nn", gm._visual_xyz).shape[0])
+        t_comm = 10e-6 + 2 * (n_r - 1) * (3e-6 + nbytes / n_r / (0.8 * 153e9))
+        out["emulated_collectives"] = {"all_reduce_bytes": nbytes, "ranks": n_r, "model_us": t_comm * 1e6,
+                                       "iters_per_s_with_model": 1.0 / (dt / a.steps + t_comm),
+                                       "model": "10 us + 2 (n - 1) x (3 us + bytes / n / (0.8 x 153 GB/s)): ring over point-to-point "
+                                                "xGMI links; a bound, not a measurement"}
     if a.frames > 0 and cfg_id != 2 and a.stage == "physical" and a.emulate_world <= 1:
         try:
             out["sequence"] = sequence_timing(a, dev, cfg_id, rank, world, use_dist, dt / a.steps * 1e3)

@@ -129,6 +129,11 @@ _DIST_AT = os.environ.get("FNX_DIST_AT", "hook")
 # ... and how long behind that point its first kernel starts (a sleeping wave in front of it, fnx_stream_delay): the fork
 # point is a kernel boundary of the main chain, the delay moves the branch under the kernel BEHIND that boundary
 _DIST_DELAY_US = float(os.environ.get("FNX_DIST_DELAY_US", "0"))
+# Multi-rank runs: record the RCCL all-reduce INSIDE the hipGraph (local phase | all-reduce | fused step, k iterations per
+# graph) instead of replaying the local phase and issuing the collective and the step eagerly.  Opt-in: it could only be
+# tried with one rank on the builder's single-GPU box (bench.py FNX_FORCE_DIST=1), and a collective that hangs inside a
+# graph on a multi-GPU node cannot be caught from here; if the capture raises, the eager path is used.
+_GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
 
 
 class HotLoop:
@@ -281,6 +286,22 @@ class HotLoop:
             # "write access to a read-only page".  A 0.3 MB all-reduce costs one launch either way.
             self._reduce_buf = torch.zeros_like(self.gm._estimate_xyz_nn.detach())
             torch.cuda.synchronize()
+            if _GRAPH_ALLREDUCE and self.fused_step:
+                try:
+                    itr0, tot0 = self.itr, self.gm.total_iterations
+                    with torch.cuda.graph(g, stream=self.stream):
+                        for _ in range(int(iterations)):
+                            self._iteration_body_batched(phase="local")
+                            dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
+                            self._finish_step(len(self.cams), grad=self._reduce_buf)
+                    self.itr, self.gm.total_iterations = itr0, tot0
+                    self.graph, self.graph_iterations, self._replay, self.graph_finish = g, int(iterations), True, None
+                    return g
+                except Exception as e:  # the collective refused to be captured: the eager path below
+                    print(f"[harness] all-reduce inside the graph failed ({type(e).__name__}: {e}); eager collective", flush=True)
+                    self.itr, self.gm.total_iterations = itr0, tot0
+                    g = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=self.stream):
                 self._iteration_body_batched(phase="local")
             if self.fused_step:
@@ -442,6 +463,9 @@ class HotLoop:
         dist_here = (shared == erank) if dist_shared else True
         n_dist_weight = batch if dist_shared else len(mine)
         use_dist = bool(mine) and dist_here and c.get("lambda_current_distance", 0.0) > 0
+        if use_dist:
+            from .physics import prefer_distance_lists
+            prefer_distance_lists(len(mine) >= 3)  # see there: lists beside a long blend forward, the grid beside a short one
         physics_launched = []
 
         def launch_physics():

@@ -273,6 +273,18 @@ class _DistanceLoss(torch.autograd.Function):
 
 _DIST_TABLES: dict = {}  # (device, stream, N) -> persistent bucket table of fnx_distance_loss_lists
 _DIST_LISTS = os.environ.get("FNX_DIST_GRID", "0") != "1"  # FNX_DIST_GRID=1: the counted / scanned / filled grid version
+_DIST_FORCED = "FNX_DIST_GRID" in os.environ
+
+
+def prefer_distance_lists(enabled: bool):
+    """Which implementation distance_loss_value_and_grad uses (both exact, tests/test_physics_gpu.py): the linked-list one
+    (two launches, one thread per point: few waves next to a long blend forward -- config 3, five views: +14 it/s) or the
+    counted grid (five launches, eight lanes per point: shorter end to end, which wins when the branch itself is the
+    critical path -- one or two views per rank: 917 against 882 it/s on a rank's share of config 5).  The loops choose by
+    their view count; FNX_DIST_GRID in the environment pins it."""
+    global _DIST_LISTS
+    if not _DIST_FORCED:
+        _DIST_LISTS = bool(enabled)
 
 
 def _distance_table(dev, N):
