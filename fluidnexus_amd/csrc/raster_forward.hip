@@ -267,11 +267,12 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             // stamped with this call's number -- a record the repair kernel finds without that stamp was not written now
             const char *stv = coh.state + coh.stride * (size_t)vw;
             const uint32_t slot = reinterpret_cast<const uint32_t *>(stv + coh.inv)[idx];
-            if (slot < (uint32_t)P)
-                view_at(coh.krec, vb.geom, vw)[slot] =
-                    make_uint4(key & 0x7FFFFFFFu, (uint32_t)idx,
-                               visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
-                               reinterpret_cast<const uint32_t *>(stv + coh.hdr)[COH_EPOCH]);
+            if (slot < (uint32_t)P) {
+                const uint4 rec = make_uint4(key & 0x7FFFFFFFu, (uint32_t)idx,
+                                             visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
+                                             reinterpret_cast<const uint32_t *>(stv + coh.hdr)[COH_EPOCH]);
+                view_at(coh.krec, vb.geom, vw)[slot] = rec;
+            }
         }
         // tile rectangle for the binning kernels ((0, 0) = no instances)
         rect[idx] = visible ? make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16))

@@ -4,7 +4,7 @@
 # rocprofv3 counter passes are separate runs with --kernel-trace only (no sys/hip/hsa tracing).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 ARGS="$*"
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -100,9 +100,18 @@ with open(os.path.join(DST, f"{TAG}_sq_counters.md"), "w") as f:
                 f"{100 * c.get('SQ_INSTS_VALU', 0) / (us * 1e-6 * 933e9):.0f} | {100 * c.get('SQ_ACTIVE_INST_VALU', 0) / cap:.0f} | "
                 f"{100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} | {100 * c.get('SQ_WAIT_ANY', 0) / wc:.0f} |\n")
 # the same counters for bench.py (roofline.valu): per kernel the per-launch averages and the counter run's duration
-json.dump({"_note": "per-launch averages of the SQ counter pass (see the .md of the same name)",
-           **{k: dict(c, us=sum(dur[k]) / len(dur[k])) for k, c in sq.items() if "fnx::" in k or ("kernel" in k and "at::" not in k)}},
-          open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
+def _derived(k, c):
+    us = sum(dur[k]) / len(dur[k])
+    wc = max(c.get("SQ_WAVE_CYCLES", 1), 1)
+    return dict(c, us=us, valu_busy=c.get("SQ_ACTIVE_INST_VALU", 0) / (us * 2400 / 4 * 1024),
+                wait_frac=c.get("SQ_WAIT_ANY", 0) / wc, stall_frac=c.get("SQ_WAIT_INST_ANY", 0) / wc)
+
+
+sq_json = {"_note": "per-launch averages of the SQ counter pass (see the .md of the same name); valu_busy = SQ_ACTIVE_INST_VALU x 4 / "
+                    "(us x 2.4 GHz x 1024 SIMDs), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; lds_busy (from the LDS pass) = "
+                    "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES",
+           **{k: _derived(k, c) for k, c in sq.items() if "fnx::" in k or ("kernel" in k and "at::" not in k)}}
+json.dump(sq_json, open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 # 6. LDS pipeline
 if os.path.exists(os.path.join(SRC, "pmc_lds", "r_counter_collection.csv")):
     lds, dur = pmc("pmc_lds"), durations("pmc_lds")
@@ -120,4 +129,8 @@ if os.path.exists(os.path.join(SRC, "pmc_lds", "r_counter_collection.csv")):
             act = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
             f.write(f"| `{k[:60]}` | {us:.1f} | {c['SQ_INSTS_LDS'] / 1e6:.2f} | {100 * act / max(c.get('SQ_BUSY_CU_CYCLES', 1), 1):.0f} | "
                     f"{100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(act, 1):.0f} | {act / c['SQ_INSTS_LDS']:.1f} |\n")
+    for k, c in lds.items():
+        if k in sq_json and c.get("SQ_BUSY_CU_CYCLES"):
+            sq_json[k]["lds_busy"] = c.get("SQ_LDS_IDX_ACTIVE", 0.0) / c["SQ_BUSY_CU_CYCLES"]
+    json.dump(sq_json, open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(DST)))
