@@ -283,7 +283,9 @@ def rasterise_timing(gm, cams, views, cfg_id, channels, bg, stage="physical"):
     xyz, opac, scales, rots, cols = scene_arrays(gm, cfg_id, stage)
     dev = bg.device
     _, GRsetting, _ = get_render_pipe("render_fluid" if channels == 1 else "render_dynamics")
-    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, 0) for v in views], channels=channels)
+    # (a stand-alone render: the depth sort from scratch, not the loop's repair of the previous iteration's order)
+    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, 0) for v in views], channels=channels,
+                                 options=dict(coherent_sort=0))
     L = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in
          dict(means3D=xyz, opacities=opac, scales=scales, rotations=rots, colors=cols).items()}
     P, V = xyz.shape[0], len(views)
@@ -323,7 +325,7 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
     xyz, opac, scales, rots, _ = scene_arrays(gm, cfg_id, stage)
     dev = bg.device
     _, GRsetting, _ = get_render_pipe("render_gs")
-    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, degree) for v in views], channels=3)
+    rv = GaussianRasterizerViews([_settings(GRsetting, cams[v], bg, 1.0, degree) for v in views], channels=3, options=dict(coherent_sort=0))
     P, V = xyz.shape[0], len(views)
     rng = np.random.RandomState(5)
     shs = np.zeros((P, 16, 3), np.float32)
@@ -998,7 +1000,7 @@ def main():
             print(f"[bench] exact-mode leg failed: {type(e).__name__}: {e}", file=sys.stderr)
         finally:
             rasterizer.set_blend_math(a.blend_math)
-    if not a.no_drop_in and cfg_id != 2 and a.stage == "physical" and world == 1 and a.emulate_world <= 1:
+    if not a.no_drop_in and cfg_id in (3, 4) and a.stage == "physical" and world == 1 and a.emulate_world <= 1:
         try:
             out["drop_in"] = drop_in_timing(a, dev, cfg_id)
         except Exception as e:

@@ -11,8 +11,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "$ARGS" > $O/args.txt
 python $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py $ARGS --no-cpu-baseline > $O/stats.log 2>&1
-EAGER="python $R/bench.py $ARGS --no-cpu-baseline --no-graph --steps 5 --warmup 2"
+# (the profiled runs leave out the record's side legs -- exact-mode re-capture, drop-in loop -- so that the traces hold
+# the timed configuration's kernels only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py $ARGS --no-cpu-baseline --no-exact-leg --no-drop-in > $O/stats.log 2>&1
+EAGER="python $R/bench.py $ARGS --no-cpu-baseline --no-exact-leg --no-drop-in --no-graph --steps 5 --warmup 2"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o r -- $EAGER > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o r -- $EAGER > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
