@@ -375,7 +375,7 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
                    "Gaussian's own coefficients: no operand is shared between Gaussians, 192 B of coefficients feed 96 "
                    "multiply-adds (0.5 flop/B against a machine balance of ~20), so the kernel is bound by reading the "
                    "coefficients and the f32 matrix pipe has nothing to reuse; scalar FMAs in the preprocess kernel, "
-                   "no MFMA instruction in the library (DESIGN.md 4.7)"}
+                   "no MFMA instruction in the library (DESIGN.md 4.8)"}
 
 
 def drop_in_timing(a, dev, cfg_id, steps=8):

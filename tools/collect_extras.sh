@@ -27,6 +27,11 @@ run c3_nosplit "" --no-static-split
 run c3_r01scene "" --scene r01
 run c3_screen_grad "FNX_SCREEN_GRAD=1"
 run c3_dist1 "FNX_FORCE_DIST=1"
+run c3_dist1_graph "FNX_FORCE_DIST=1,FNX_GRAPH_ALLREDUCE=1"
+run c3_radix "" --sort radix
+run c3_dist_grid "FNX_DIST_GRID=1"
+run c3_seq250 "" --frames 3 --iters-per-frame 250
+run c3_seq1000 "" --frames 3 --iters-per-frame 1000
 run c3_full_geometry "" --full-geometry --sort-four-passes
 run c4_emu4 "" --config 4 --emulate-world 4
 run c4_emu4_deep "" --config 4 --emulate-world 4 --deep-kernel 1
