@@ -364,11 +364,17 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
     # per splat and view: reads xyz 12 + scale 12 + rotation 16 + opacity 4 + SH 16 x 12 = 236 B; a visible splat writes
     # the per-splat state of SURVEY 8(d) (60 B) + sort key 4 + rect 8 + blend record 64 + rgb 12 + clamped 3 = 151 B
     bytes_launch = V * (P * 236 + p_vis * 151)
+    # round 4: a view batch evaluates the colours once per GAUSSIAN for all views (sh_colors_views_kernel: 192 + 12 B in,
+    # 15 B out per view), the preprocess then reads 44 + 12 B per (splat, view): what the two kernels have to move
+    moved = P * (204 + 15 * V) + V * (P * 56 + p_vis * 151)
     us = pre_ms / max(pre_n, 1) * 1e3
     return {"degree": degree, "gaussians": P, "views_per_launch": V, "rasterise_ms_per_view": out,
             "preprocess": {"avg_launch_us": us, "algorithmic_bytes_per_launch": int(bytes_launch),
                            "GBps": bytes_launch / (us * 1e-6) / 1e9 if us > 0 else None,
                            "frac_of_hbm_peak": bytes_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
+                           "kernels": "sh_colors_views_kernel (coefficients read once per Gaussian for all views) + preprocess_kernel",
+                           "moved_bytes_per_launch": int(moved),
+                           "moved_frac_of_hbm_peak": moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
                            "bound": "hbm"},
             "mfma_util": 0,
             "why": "the SH contraction is a 1 x 16 . 16 x 3 product per (Gaussian, view) whose 16 x 3 operand is the "

@@ -46,12 +46,9 @@ namespace fnx {
 
 // ---------------------------------------------------------------------------------------------
 // SH -> RGB (ch3 forward.cu:20-67).  Only reachable with channels == 3.
-__device__ inline void sh_to_rgb(int idx, int deg, int M, const float *means, const float *campos, const float *shs,
-                                 uint8_t *clamped, float *out) {
-    float dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
+__device__ __forceinline__ void sh_eval(int deg, float dx, float dy, float dz, const float *sh, uint8_t *clamped3, float *out) {
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
-    const float *sh = shs + (size_t)idx * M * 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #define SH(k) sh[(k) * 3 + c]
@@ -74,8 +71,42 @@ __device__ inline void sh_to_rgb(int idx, int deg, int M, const float *means, co
         }
 #undef SH
         result += 0.5f;
-        clamped[3 * idx + c] = (result < 0);
+        clamped3[c] = (result < 0);
         out[c] = result > 0.0f ? result : 0.0f;
+    }
+}
+__device__ inline void sh_to_rgb(int idx, int deg, int M, const float *means, const float *campos, const float *shs,
+                                 uint8_t *clamped, float *out) {
+    sh_eval(deg, means[3 * idx] - campos[0], means[3 * idx + 1] - campos[1], means[3 * idx + 2] - campos[2],
+            shs + (size_t)idx * M * 3, clamped + 3 * (size_t)idx, out);
+}
+
+// View batches with SH colours: the colour of every (Gaussian, view) in one pass over the GAUSSIANS -- the 4 M 3 bytes of
+// coefficients (192 for degree 3) are read once and evaluated for all V view directions, instead of once per view by
+// the preprocess (V x 192 of the ~1 100 bytes per Gaussian a 5-view launch moved: profiles/r03_sh_*).  Same expression,
+// same order: bit-identical colours and clamp flags; they are written for every Gaussian, visible in a view or not.
+__global__ void __launch_bounds__(256)
+sh_colors_views_kernel(int P, int D, int M, int V, const float *__restrict__ means3D, const float *__restrict__ campos,
+                       const float *__restrict__ shs, uint8_t *__restrict__ clamped, float *__restrict__ rgb,
+                       size_t geom_stride) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    float sh[48];
+    const float *src = shs + (size_t)idx * M * 3;
+#pragma unroll
+    for (int k = 0; k < 48; k++) sh[k] = k < 3 * M ? src[k] : 0.f;
+    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+    for (int v = 0; v < V; v++) {
+        float col[3];
+        uint8_t cl[3];
+        sh_eval(D, mx - campos[3 * v], my - campos[3 * v + 1], mz - campos[3 * v + 2], sh, cl, col);
+        float *o = view_at(rgb, geom_stride, v) + 3 * (size_t)idx;
+        uint8_t *c = view_at(clamped, geom_stride, v) + 3 * (size_t)idx;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            o[k] = col[k];
+            c[k] = cl[k];
+        }
     }
 }
 
@@ -138,7 +169,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                   float4 *__restrict__ conic_opacity, int gx, int gy, uint32_t *__restrict__ tiles_touched,
                   uint32_t *__restrict__ sort_key, uint32_t *__restrict__ key_min_blk, uint2 *__restrict__ rect,
                   float4 *__restrict__ blend_rec, int prefiltered, const StaticRef st, const ViewBatch vb, int lean,
-                  float *__restrict__ zero3, const CohRef coh) {
+                  float *__restrict__ zero3, const CohRef coh, int sh_pre) {
     // lean (fnx_set_lean_geometry): the copies of the reference's GeometryState that nothing in this library reads back
     // (means2D, depths, conic_opacity, tiles_touched: the blend records carry the same numbers) are not written, and the
     // world covariance -- the same for every view -- is written by view 0 only (the backward reads it at stride 0)
@@ -228,7 +259,10 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                 tile_rect(px, py, (int)my_radius, gx, gy, x0, y0, x1, y1);
                 if ((uint32_t)(x1 - x0) * (uint32_t)(y1 - y0) != 0) {
                     float col[3] = {0.f, 0.f, 0.f};
-                    if (colors_precomp == nullptr) {
+                    if (colors_precomp == nullptr && sh_pre) {  // sh_colors_views_kernel evaluated it (and the clamp flags)
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) col[ch] = rgb[(size_t)idx * C + ch];
+                    } else if (colors_precomp == nullptr) {
                         sh_to_rgb(idx, D, M, means3D, campos, shs, clamped, col);
                         rgb[(size_t)idx * C + 0] = col[0];
                         if (C > 1) rgb[(size_t)idx * C + 1] = col[1];
@@ -1039,11 +1073,17 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
                                 float *zero3, const CohRef &coh) {
     const int gx = tiles_x(W), gy = tiles_y(H);
+    // view batches with SH colours: every Gaussian's coefficients read once for all views (the SH pipe is 3-channel, and
+    // its means3D / campos are the same arrays the preprocess reads)
+    const int sh_pre = (C == 3 && V > 1 && colors_precomp == nullptr && shs != nullptr && campos != nullptr && M <= 16) ? 1 : 0;
+    if (sh_pre)
+        hipLaunchKernelGGL(sh_colors_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, campos, shs,
+                           clamped, rgb, vb.geom);
     const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy, tiles_touched,
-                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean, zero3, coh);
+                       sort_key, key_min_blk, rect, blend_rec, prefiltered, st, vb, lean, zero3, coh, sh_pre);
 }
 
 void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *means3D, const float *scales,
