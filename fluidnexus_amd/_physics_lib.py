@@ -15,7 +15,9 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_pbf_confirm", "fnx_visual_advect", "fnx_knn_mean_dist2", "fnx_visual_interp_forward_cells", "fnx_grid_cell_items_bytes",
            "fnx_grid_cell_items", "fnx_visual_interp_backward_cells", "fnx_distance_loss", "fnx_distance_loss_partials",
            "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum", "fnx_adam_step_grid",
-           "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists", "fnx_stream_delay")
+           "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists", "fnx_stream_delay",
+           "fnx_knn_cut", "fnx_density_forward_kcap", "fnx_density_backward_kcap", "fnx_visual_interp_forward_kcap",
+           "fnx_visual_interp_backward_kcap")
 
 
 def physics():
@@ -70,6 +72,16 @@ def physics():
     lib.fnx_grid_cell_items_bytes.argtypes = [i]
     lib.fnx_grid_cell_items.restype = i
     lib.fnx_grid_cell_items.argtypes = [p, i, p, p]
+    lib.fnx_knn_cut.restype = i
+    lib.fnx_knn_cut.argtypes = [p, i, i, f, i, p, p, p]
+    lib.fnx_density_forward_kcap.restype = i
+    lib.fnx_density_forward_kcap.argtypes = [p, i, p, f, f, p, p, p, p]
+    lib.fnx_density_backward_kcap.restype = i
+    lib.fnx_density_backward_kcap.argtypes = [p, i, p, f, f, p, p, p, p, p]
+    lib.fnx_visual_interp_forward_kcap.restype = i
+    lib.fnx_visual_interp_forward_kcap.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
+    lib.fnx_visual_interp_backward_kcap.restype = i
+    lib.fnx_visual_interp_backward_kcap.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p, p]
     lib.fnx_visual_interp_backward.restype = i
     lib.fnx_visual_interp_backward.argtypes = [p, i, p, p, i, f, f, f, p, p, p, p, p, p]
     lib.fnx_visual_interp_backward_cells.restype = i

@@ -286,6 +286,96 @@ density_backward_kernel(const float *__restrict__ xyz, int N, const float *__res
     }
 }
 
+// ---- max_num_neighbors (K-cap) mode ---------------------------------------------------------------
+// torch_cluster's CUDA radius kernel (the one the reference's searches run on, gm_dynamics.py:1276,1302,1463 with
+// max_num_neighbors = KNN_K) walks the points of x in INDEX order for every query and stops after K hits: a query
+// keeps the K SMALLEST INDICES among its neighbours within r.  cut[q] = that K-th smallest index (0xFFFFFFFF when
+// the query has at most K neighbours), so "q keeps neighbour j" is the one comparison j <= cut[q].  L lanes per query:
+// a counting pass, and only for a query over the cap a bisection on the index (31 counting passes at most).
+template <int L>
+__device__ __forceinline__ uint32_t group_sum_all(uint32_t v) {  // sum over the L consecutive lanes of a group, in all of them
+    for (int off = 1; off < L; off <<= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+
+constexpr int kCutLanes = 8;
+__global__ void __launch_bounds__(256)
+knn_cut_kernel(const float *__restrict__ queries, int Nq, float inv_cell, float H2, uint32_t mask,
+               const uint32_t *__restrict__ start, const float4 *__restrict__ rec, uint32_t K,
+               uint32_t *__restrict__ cut) {
+    const int q = blockIdx.x * (256 / kCutLanes) + (threadIdx.x / kCutLanes), sub = threadIdx.x & (kCutLanes - 1);
+    const int qq = min(q, Nq - 1);
+    const float px = queries[3 * qq], py = queries[3 * qq + 1], pz = queries[3 * qq + 2];
+    auto count_upto = [&](uint32_t bound) {
+        uint32_t c = 0;
+        for_neighbours<kCutLanes>(sub, px, py, pz, inv_cell, H2, mask, start, rec,
+                                  [&](uint32_t, uint32_t j, float, float, float, float) { c += j <= bound ? 1u : 0u; });
+        return group_sum_all<kCutLanes>(c);
+    };
+    uint32_t result = 0xFFFFFFFFu;
+    if (count_upto(0xFFFFFFFFu) > K) {  // uniform over the group's lanes
+        uint32_t lo = 0, hi = 0x7FFFFFFFu;  // the smallest index with count(<= index) >= K
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (count_upto(mid) >= K) hi = mid; else lo = mid + 1;
+        }
+        result = lo;
+    }
+    if (sub == 0 && q < Nq) cut[q] = result;
+}
+
+// gm_dynamics.py:1276-1290 with the cap: the edge (query q -> kept neighbour i) adds poly6 at the NEIGHBOUR's index
+// (radius_graph, flow = source_to_target, swaps the two rows), so p_i = sum over q with i <= cut[q] of poly6(r2_iq).
+__global__ void __launch_bounds__(256)
+density_forward_kcap_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell,
+                            float H2, float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
+                            const float4 *__restrict__ rec, const uint32_t *__restrict__ cut,
+                            float *__restrict__ p_ratio) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int ii = min(i, N - 1);
+    float acc = 0.f;
+    for_neighbours<16>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                       [&](uint32_t, uint32_t q, float, float, float, float r2) {
+                           if ((uint32_t)ii > cut[q]) return;
+                           const float t = H2 - r2;
+                           acc += term1 * (t * t * t);
+                       });
+    acc = row_sum15(acc);
+    if (sub == 15 && i < N) p_ratio[i] = acc / imass[i] / p0;
+}
+
+// d/dx_i of sum_i g_i p_ratio_i with the edge set frozen: pairs (i, j) enter once for "j keeps i" (weight G_i) and
+// once for "i keeps j" (weight G_j).
+__global__ void __launch_bounds__(256)
+density_backward_kcap_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell,
+                             float H2, float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
+                             const float4 *__restrict__ rec, const uint32_t *__restrict__ cut,
+                             const float *__restrict__ g, float *__restrict__ dL_dxyz) {
+    const int i = blockIdx.x * kDPerWg + (threadIdx.x / kDL), sub = threadIdx.x & (kDL - 1);
+    const int ii = min(i, N - 1);
+    const float Gi = g[ii] / imass[ii] / p0;
+    const uint32_t cut_i = cut[ii];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for_neighbours<kDL>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
+                        [&](uint32_t, uint32_t j, float ex, float ey, float ez, float r2) {
+                            const float Gj = g[j] / imass[j] / p0;
+                            const float t = H2 - r2;
+                            const float dW = -3.0f * term1 * (t * t);
+                            const float k = (((uint32_t)ii <= cut[j] ? Gi : 0.f) + (j <= cut_i ? Gj : 0.f)) * dW * 2.0f;
+                            ax += k * ex;
+                            ay += k * ey;
+                            az += k * ez;
+                        });
+    ax = density_lane_sum(ax);
+    ay = density_lane_sum(ay);
+    az = density_lane_sum(az);
+    if (sub == kDL - 1 && i < N) {
+        dL_dxyz[3 * i + 0] = ax;
+        dL_dxyz[3 * i + 1] = ay;
+        dL_dxyz[3 * i + 2] = az;
+    }
+}
+
 // ---- physical-particle stage, fused (fnx_physical_stage) -------------------------------------------
 // x = x_nn * sf and the one-tick advected guess x' (gm_dynamics.py:1014-1030, same operation order as
 // the reference's tensor expression); also sum (x - x_est)^2 -> terms[0].
@@ -849,6 +939,45 @@ visual_forward_kernel(const float *__restrict__ visual, int V, float inv_cell, f
     }
 }
 
+// The same with the cap (gm_dynamics.py:1463-1468, radius(x = hidden, y = visual, max_num_neighbors = KNN_K)): the visual
+// particle keeps the hidden particles with index <= cutv[v] (knn_cut_kernel).
+__global__ void __launch_bounds__(256)
+visual_forward_kcap_kernel(const float *__restrict__ visual, int V, float inv_cell, float H2, float term1, float secs,
+                           float eps, uint32_t mask, const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                           const float4 *__restrict__ u, const uint32_t *__restrict__ cutv, float *__restrict__ out,
+                           float *__restrict__ sum_w, float *__restrict__ wvel) {
+    const int v = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const int vv = min(v, V - 1);
+    const float px = visual[3 * vv], py = visual[3 * vv + 1], pz = visual[3 * vv + 2];
+    const uint32_t cv = cutv[vv];
+    float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for_neighbours<8>(sub, px, py, pz, inv_cell, H2, mask, start, rec,
+                      [&](uint32_t s, uint32_t j, float, float, float, float r2) {
+                          if (j > cv) return;
+                          const float t = H2 - r2;
+                          const float w = term1 * (t * t * t);
+                          const float4 uj = u[s];
+                          S += w;
+                          ax += uj.x * w;
+                          ay += uj.y * w;
+                          az += uj.z * w;
+                      });
+    S = oct_sum7(S);
+    ax = oct_sum7(ax);
+    ay = oct_sum7(ay);
+    az = oct_sum7(az);
+    if (sub == 7 && v < V) {
+        sum_w[v] = S;
+        wvel[3 * v + 0] = ax;
+        wvel[3 * v + 1] = ay;
+        wvel[3 * v + 2] = az;
+        const float Sc = fmaxf(S, eps);
+        out[3 * v + 0] = px + ax * secs / Sc;
+        out[3 * v + 1] = py + ay * secs / Sc;
+        out[3 * v + 2] = pz + az * secs / Sc;
+    }
+}
+
 // Cell-centric form of the same interpolation.  The visual particles are static within a frame, so their own
 // hash grid (built once) lists them cell by cell; one wave takes 64 consecutive slots of that list -- particles
 // of one or two cells -- stages the hidden particles of the cell's 27-neighbourhood (position + velocity, ~200
@@ -1094,6 +1223,43 @@ visual_backward_kernel(const float *__restrict__ hidden, const float *__restrict
     }
 }
 
+// The capped backward: one wave per hidden particle j over the VISUAL grid; the pair (v, j) exists iff j <= cutv[v].
+// Plain lanes-over-candidates walk (the mode is for parity with capped reference runs, not a tuned path).
+__global__ void __launch_bounds__(256)
+visual_backward_kcap_kernel(const float *__restrict__ hidden, const float *__restrict__ hidden_prev, int N,
+                            float inv_cell, float H2, float term1, float secs, uint32_t mask,
+                            const uint32_t *__restrict__ start, const float4 *__restrict__ rec,
+                            const float4 *__restrict__ a0, const uint32_t *__restrict__ cutv,
+                            float *__restrict__ dL_dhidden) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= N) return;  // whole wave
+    const float hx = hidden[3 * j], hy = hidden[3 * j + 1], hz = hidden[3 * j + 2];
+    const float ux = (hx - hidden_prev[3 * j]) / secs, uy = (hy - hidden_prev[3 * j + 1]) / secs,
+                uz = (hz - hidden_prev[3 * j + 2]) / secs;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for_neighbours<64>(lane, hx, hy, hz, inv_cell, H2, mask, start, rec,
+                       [&](uint32_t s, uint32_t v, float ex, float ey, float ez, float r2) {
+                           if ((uint32_t)j > cutv[v]) return;
+                           const float4 G = a0[s];
+                           const float t = H2 - r2;
+                           const float wgt = term1 * (t * t * t);
+                           const float dW = -3.0f * term1 * (t * t);
+                           const float k = (secs * (G.x * ux + G.y * uy + G.z * uz) - G.w) * dW * 2.0f;
+                           ax += wgt * G.x + k * ex;
+                           ay += wgt * G.y + k * ey;
+                           az += wgt * G.z + k * ez;
+                       });
+    ax = wave_sum63(ax);
+    ay = wave_sum63(ay);
+    az = wave_sum63(az);
+    if (lane == 63) {
+        dL_dhidden[3 * j + 0] = ax;
+        dL_dhidden[3 * j + 1] = ay;
+        dL_dhidden[3 * j + 2] = az;
+    }
+}
+
 // Cell-centric form of the same backward.  The hidden particles of one cell (a work item of the HIDDEN grid,
 // fnx_grid_cell_items) see the same 27 visual buckets, so a 4-wave workgroup takes an item: lanes = candidates
 // (~1 750 visual slots of the neighbourhood, flattened; position + payload loaded once per CELL instead of once per
@@ -1303,6 +1469,40 @@ int fnx_density_backward(const float *xyz, int N, const float *imass, float H, f
     hipLaunchKernelGGL(density_backward_kernel, dim3((N + kDPerWg - 1) / kDPerWg), dim3(256), 0, (hipStream_t)stream, xyz, N,
                        imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, dL_dp_ratio, 1.0f, dL_dxyz);
     return hip_check("density_backward");
+}
+
+int fnx_knn_cut(const float *queries, int Nq, int N_points, float H, int K, const char *points_grid, uint32_t *cut,
+                fnx_stream_t stream) {
+    if (Nq == 0) return FNX_OK;
+    if (Nq < 0 || N_points < 0 || K < 1 || !queries || !points_grid || !cut)
+        return fail(FNX_ERR_INVALID_ARG, "knn_cut: bad argument");
+    GridView g = carve(const_cast<char *>(points_grid), N_points);
+    hipLaunchKernelGGL(knn_cut_kernel, dim3((Nq + 256 / kCutLanes - 1) / (256 / kCutLanes)), dim3(256), 0,
+                       (hipStream_t)stream, queries, Nq, 1.0f / H, H * H, g.M - 1, g.start, g.rec, (uint32_t)K, cut);
+    return hip_check("knn_cut");
+}
+
+int fnx_density_forward_kcap(const float *xyz, int N, const float *imass, float H, float p0, const char *grid,
+                             const uint32_t *cut, float *p_ratio, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !imass || !grid || !cut || !p_ratio)
+        return fail(FNX_ERR_INVALID_ARG, "density_forward_kcap: bad argument");
+    GridView g = carve(const_cast<char *>(grid), N);
+    hipLaunchKernelGGL(density_forward_kcap_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, xyz, N, imass,
+                       1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, cut, p_ratio);
+    return hip_check("density_forward_kcap");
+}
+
+int fnx_density_backward_kcap(const float *xyz, int N, const float *imass, float H, float p0, const char *grid,
+                              const uint32_t *cut, const float *dL_dp_ratio, float *dL_dxyz, fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (N < 0 || !xyz || !imass || !grid || !cut || !dL_dp_ratio || !dL_dxyz)
+        return fail(FNX_ERR_INVALID_ARG, "density_backward_kcap: bad argument");
+    GridView g = carve(const_cast<char *>(grid), N);
+    hipLaunchKernelGGL(density_backward_kcap_kernel, dim3((N + kDPerWg - 1) / kDPerWg), dim3(256), 0, (hipStream_t)stream,
+                       xyz, N, imass, 1.0f / H, H * H, poly6_term1(H), p0, g.M - 1, g.start, g.rec, cut, dL_dp_ratio,
+                       dL_dxyz);
+    return hip_check("density_backward_kcap");
 }
 
 int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float *x_est, const float *x_prev,
@@ -1680,6 +1880,41 @@ int fnx_visual_interp_forward(const float *visual, int V, const float *hidden, c
     hipLaunchKernelGGL(visual_forward_kernel, dim3((V + 31) / 32), dim3(256), 0, (hipStream_t)stream, visual, V,
                        1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel);
     return hip_check("visual_interp_forward");
+}
+
+int fnx_visual_interp_forward_kcap(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                   float H, float secs, float eps, const char *hidden_grid, const uint32_t *cutv,
+                                   float *out, float *sum_w, float *wvel, fnx_stream_t stream) {
+    if (V == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !visual || !hidden_grid || !cutv || !out || !sum_w || !wvel ||
+        (N > 0 && (!hidden || !hidden_prev)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_forward_kcap: bad argument");
+    GridView g = carve(const_cast<char *>(hidden_grid), N);
+    if (N > 0)
+        hipLaunchKernelGGL(slot_velocity_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec, N,
+                           hidden_prev, secs, g.aux0);
+    hipLaunchKernelGGL(visual_forward_kcap_kernel, dim3((V + 31) / 32), dim3(256), 0, (hipStream_t)stream, visual, V,
+                       1.0f / H, H * H, poly6_term1(H), secs, eps, g.M - 1, g.start, g.rec, g.aux0, cutv, out, sum_w,
+                       wvel);
+    return hip_check("visual_interp_forward_kcap");
+}
+
+int fnx_visual_interp_backward_kcap(const float *visual, int V, const float *hidden, const float *hidden_prev, int N,
+                                    float H, float secs, float eps, const char *visual_grid, const uint32_t *cutv,
+                                    const float *sum_w, const float *wvel, const float *dL_dout, float *dL_dhidden,
+                                    fnx_stream_t stream) {
+    if (N == 0) return FNX_OK;
+    if (V < 0 || N < 0 || !hidden || !hidden_prev || !visual_grid || !dL_dhidden ||
+        (V > 0 && (!visual || !cutv || !sum_w || !wvel || !dL_dout)))
+        return fail(FNX_ERR_INVALID_ARG, "visual_interp_backward_kcap: bad argument");
+    GridView g = carve(const_cast<char *>(visual_grid), V);
+    if (V > 0)
+        hipLaunchKernelGGL(slot_visual_payload_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, g.rec,
+                           V, sum_w, wvel, dL_dout, (const float *)nullptr, 0.0f, secs, eps, g.aux0);
+    hipLaunchKernelGGL(visual_backward_kcap_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden,
+                       hidden_prev, N, 1.0f / H, H * H, poly6_term1(H), secs, g.M - 1, g.start, g.rec, g.aux0, cutv,
+                       dL_dhidden);
+    return hip_check("visual_interp_backward_kcap");
 }
 
 size_t fnx_grid_cell_items_bytes(int N) { return 64 + ((size_t)(N > 0 ? N : 0) + (size_t)(N > 0 ? N : 0) / 64 + 1) * 8; }

@@ -696,15 +696,28 @@ class GaussianModel:
             self._state_memos[slot] = hit
         return hit[1]
 
+    # max_num_neighbors mode (:1276, :1302, :1463 pass max_num_neighbors=self.KNN_K to torch_cluster): off by default --
+    # the kernels then take every pair within H, which is the same thing while no list reaches KNN_K (knn_k_report).
+    # On: the three searches keep the KNN_K smallest indices per query, as torch_cluster's CUDA kernel does; runs
+    # through the per-particle kernels (no fused stage, no memo / deferral).
+    knn_cap = False
+
+    def set_knn_cap(self, enabled: bool):
+        self.knn_cap = bool(enabled)
+        self.invalidate_caches()
+
+    def _knn_k(self):
+        return int(self.KNN_K) if self.knn_cap else None
+
     def get_gas_constraints_from_exyz_nn(self):
         """p_ratio [N,1] at the optimised positions (fused neighbour search + poly6 density)."""
         x = self._estimate_xyz_nn * self.scale_factor
-        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("est", x))
+        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("est", x), knn_k=self._knn_k())
 
     def get_gas_constraints_from_vel_nn_guess(self):
         """p_ratio [N,1] after advecting one tick with the implied velocity."""
         x = self.get_guess_hidden_particles_from_nn()
-        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("guess", x))
+        return physics.density_ratio(x, self._imass, self.H, self.p0, self._cached_grid("guess", x), knn_k=self._knn_k())
 
     def _scaled_estimate(self):
         """_estimate_xyz_nn * scale_factor; after a fused step (fused_step_current) the product is already resident."""
@@ -719,6 +732,10 @@ class GaussianModel:
         visual = self._visual_xyz.detach()
         if self._visual_grid is None or self._visual_grid[0] is not self._visual_xyz:
             self._visual_grid = (self._visual_xyz, physics.HashGrid(visual, self.H))
+        if self.knn_cap:
+            x = self._estimate_xyz_nn * self.scale_factor
+            return physics.visual_from_hidden(visual, x, self._xyz, self.H, self._secs, self.EPSILON, self._visual_grid[1],
+                                              self._cached_grid("est", x), knn_k=self._knn_k())
         key = (id(self._estimate_xyz_nn), self._estimate_xyz_nn._version, id(self._visual_xyz))
         if (self._visual_memo[0] == key and "out" in self._visual_memo[1] and not torch.is_grad_enabled()
                 and getattr(self, "share_visual_output", False)):

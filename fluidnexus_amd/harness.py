@@ -134,6 +134,9 @@ _DIST_DELAY_US = float(os.environ.get("FNX_DIST_DELAY_US", "0"))
 # tried with one rank on the builder's single-GPU box (bench.py FNX_FORCE_DIST=1), and a collective that hangs inside a
 # graph on a multi-GPU node cannot be caught from here; if the capture raises, the eager path is used.
 _GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
+# One fork point for both side branches (the rasteriser's between-stages hook) instead of two: every fork / join of the
+# captured graph costs the main chain ~5 us in front of the kernel behind it
+_SINGLE_FORK = os.environ.get("FNX_SINGLE_FORK", "0") == "1"
 
 
 class HotLoop:
@@ -166,6 +169,9 @@ class HotLoop:
         self.emulated = None  # (rank, world) of the run whose share `view_subset` is (bench.py --emulate-world)
         self.image_loss = image_loss
         self.fused_physics = fused_physics
+        if getattr(gm, "knn_cap", False) and (fused_physics or defer_visual_backward):
+            raise ValueError("gm.knn_cap (max_num_neighbors mode) runs through the per-term physics methods: "
+                             "HotLoop(fused_physics=False, defer_visual_backward=False)")
         self.force_all_reduce = force_all_reduce
         gm.defer_visual_backward = bool(defer_visual_backward)
         dev = gm._xyz.device
@@ -452,7 +458,9 @@ class HotLoop:
             self.dist_stream = torch.cuda.Stream(device=gm._xyz.device)
         gp, n_phys, gd = None, 0, None
         fork = torch.cuda.Event()
-        fork.record(main)
+        single_fork = _SINGLE_FORK and bool(mine) and not self.dual_channel and not _PHYSICS_EARLY
+        if not single_fork:
+            fork.record(main)
         # who evaluates the view-independent terms, and how many times their gradient counts (see __init__)
         shared = self.shared_terms_rank if self.shared_terms_rank is not None else (None if self.physics_per_view else 0)
         erank, eworld = self.emulated or (self.rank, self.world)
@@ -473,7 +481,10 @@ class HotLoop:
             if not phys_here or physics_launched:  # once per iteration, however often the hook fires
                 return
             physics_launched.append(1)
-            self.side_stream.wait_event(fork)
+            if single_fork and not forked_d:  # the forward did not pass the hook: behind everything enqueued so far
+                self.side_stream.wait_stream(main)
+            else:
+                self.side_stream.wait_event(fork_d if single_fork else fork)
             with torch.cuda.stream(self.side_stream):
                 # work items of the hidden-particle grid for the cell-by-cell hidden<-visual backward at the end
                 # of the iteration: two tiny kernels, off the critical path on this branch
@@ -497,11 +508,11 @@ class HotLoop:
             if use_dist and _DIST_AT == "early":
                 fork_d.record(main)
                 forked_d.append(1)
-            if (use_dist and _DIST_AT == "hook") or _PHYSICS_AT_HOOK:
+            if (use_dist and _DIST_AT == "hook") or _PHYSICS_AT_HOOK or single_fork:
                 def _hook():
                     if _PHYSICS_AT_HOOK:
                         launch_physics()
-                    if use_dist and _DIST_AT == "hook":
+                    if (use_dist and _DIST_AT == "hook") or single_fork:
                         fork_d.record(torch.cuda.current_stream())
                         forked_d.append(1)
                 rasterizer.set_between_stages_hook(_hook)

@@ -3,7 +3,7 @@
 `density_ratio`  == the arithmetic of GaussianModel.get_gas_constraints_from_exyz_nn after the
                     scaling (gm_dynamics.py:1276-1292): radius_graph + poly6 + index_add_ + 2 divisions;
 `visual_from_hidden` == GaussianModel.get_visual_xyz_from_nn after the scaling (gm_dynamics.py:1463-1496).
-Both fuse the neighbour search; see the header for the neighbour rule and the KNN_K caveat.
+Both fuse the neighbour search; see the header for the neighbour rule; `knn_k=` selects the max_num_neighbors mode.
 """
 from __future__ import annotations
 
@@ -80,9 +80,54 @@ class _DensityRatio(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def density_ratio(xyz, imass, H, p0, grid=None):
+def knn_cut(queries, points_grid, H, K):
+    """int32 [Nq] holding uint32 bit patterns: the K-th smallest index among the points of `points_grid` within H of each
+    query, 0xFFFFFFFF (-1) where a query has at most K of them -- torch_cluster's max_num_neighbors rule on CUDA (the
+    first K hits in index order; include/fnx_physics.h, fnx_knn_cut)."""
+    lib = PL.physics()
+    queries = _req(queries.detach())
+    cut = torch.empty(queries.shape[0], dtype=torch.int32, device=queries.device)
+    PL.check(lib.fnx_knn_cut(queries.data_ptr() if queries.shape[0] else None, queries.shape[0], points_grid.N, float(H),
+                             int(K), points_grid.blob.data_ptr(), cut.data_ptr(), _stream()))
+    return cut
+
+
+class _DensityRatioCapped(torch.autograd.Function):
+    """_DensityRatio on the edge set radius_graph(loop=True, max_num_neighbors=K) keeps (gm_dynamics.py:1276-1290)."""
+
+    @staticmethod
+    def forward(ctx, xyz, imass, H, p0, grid, K):
+        lib = PL.physics()
+        xyz, imass = _req(xyz), _req(imass)
+        N = xyz.shape[0]
+        if grid is None:
+            grid = HashGrid(xyz, H)
+        cut = knn_cut(xyz, grid, H, K)
+        out = torch.empty(N, 1, dtype=torch.float32, device=xyz.device)
+        PL.check(lib.fnx_density_forward_kcap(xyz.data_ptr(), N, imass.data_ptr(), H, p0, grid.blob.data_ptr(),
+                                              cut.data_ptr(), out.data_ptr(), _stream()))
+        ctx.save_for_backward(xyz, imass, grid.blob, cut)
+        ctx.consts = (H, p0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = PL.physics()
+        xyz, imass, blob, cut = ctx.saved_tensors
+        H, p0 = ctx.consts
+        g = _req(g)
+        dx = torch.empty_like(xyz)
+        PL.check(lib.fnx_density_backward_kcap(xyz.data_ptr(), xyz.shape[0], imass.data_ptr(), H, p0, blob.data_ptr(),
+                                               cut.data_ptr(), g.data_ptr(), dx.data_ptr(), _stream()))
+        return dx, None, None, None, None, None
+
+
+def density_ratio(xyz, imass, H, p0, grid=None, knn_k=None):
     """p_ratio [N,1] of positions xyz [N,3] (scaled units), inverse masses imass [N,1].
-    `grid`: an up-to-date HashGrid over xyz (cell = H) to reuse; built here when None."""
+    `grid`: an up-to-date HashGrid over xyz (cell = H) to reuse; built here when None.
+    `knn_k`: reproduce max_num_neighbors = knn_k (per-particle kernels, not the fused stage); None = all pairs."""
+    if knn_k is not None:
+        return _DensityRatioCapped.apply(xyz, imass, float(H), float(p0), grid, int(knn_k))
     return _DensityRatio.apply(xyz, imass, float(H), float(p0), grid)
 
 
@@ -183,13 +228,55 @@ def flush_deferred_visual_backward(memo):
                             sum_w, wvel, g, memo.pop("g_extra", None))
 
 
+class _VisualFromHiddenCapped(torch.autograd.Function):
+    """_VisualFromHidden where a visual particle keeps max_num_neighbors = K hidden particles (gm_dynamics.py:1463-1468);
+    no memo, no deferral: the mode exists for parity with capped reference runs."""
+
+    @staticmethod
+    def forward(ctx, visual, hidden, hidden_prev, H, secs, eps, visual_grid, hgrid, K):
+        lib = PL.physics()
+        visual, hidden, hidden_prev = _req(visual), _req(hidden), _req(hidden_prev)
+        V, N = visual.shape[0], hidden.shape[0]
+        if hgrid is None:
+            hgrid = HashGrid(hidden, H)
+        if visual_grid is None:
+            visual_grid = HashGrid(visual, H)
+        cutv = knn_cut(visual, hgrid, H, K)
+        out = torch.empty_like(visual)
+        sum_w = torch.empty(V, dtype=torch.float32, device=visual.device)
+        wvel = torch.empty(V, 3, dtype=torch.float32, device=visual.device)
+        PL.check(lib.fnx_visual_interp_forward_kcap(visual.data_ptr(), V, hidden.data_ptr(), hidden_prev.data_ptr(), N, H,
+                                                    secs, eps, hgrid.blob.data_ptr(), cutv.data_ptr(), out.data_ptr(),
+                                                    sum_w.data_ptr(), wvel.data_ptr(), _stream()))
+        hgrid.velocity_of = (hidden_prev.data_ptr(), float(secs))
+        ctx.save_for_backward(visual, hidden, hidden_prev, sum_w, wvel, visual_grid.blob, cutv)
+        ctx.consts = (H, secs, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = PL.physics()
+        visual, hidden, hidden_prev, sum_w, wvel, vblob, cutv = ctx.saved_tensors
+        H, secs, eps = ctx.consts
+        g = _req(g)
+        dh = torch.empty_like(hidden)
+        PL.check(lib.fnx_visual_interp_backward_kcap(visual.data_ptr(), visual.shape[0], hidden.data_ptr(),
+                                                     hidden_prev.data_ptr(), hidden.shape[0], H, secs, eps, vblob.data_ptr(),
+                                                     cutv.data_ptr(), sum_w.data_ptr(), wvel.data_ptr(), g.data_ptr(),
+                                                     dh.data_ptr(), _stream()))
+        return None, dh, None, None, None, None, None, None, None
+
+
 def visual_from_hidden(visual, hidden, hidden_prev, H, secs, eps=1e-8, visual_grid=None, hidden_grid=None,
-                       memo=None, share_output=False):
+                       memo=None, share_output=False, knn_k=None):
     """visual [V,3] (constant), hidden [N,3] (differentiable), hidden_prev [N,3] -> advected visual [V,3].
     `visual_grid`: a HashGrid over `visual` to reuse across iterations (visual is fixed within a frame);
     `hidden_grid`: an up-to-date HashGrid over `hidden`; `memo`: a dict the caller keeps for as long as
     the inputs are unchanged -- the forward kernel then runs once and later calls only add an autograd
     node (the views of one iteration all see the same particle state)."""
+    if knn_k is not None:  # max_num_neighbors = knn_k: per-particle kernels, evaluated on every call
+        return _VisualFromHiddenCapped.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
+                                             hidden_grid, int(knn_k))
     out = _VisualFromHidden.apply(visual, hidden, hidden_prev, float(H), float(secs), float(eps), visual_grid,
                                   hidden_grid, memo)
     # memoised results are handed out as copies unless the caller promises not to modify them in place
@@ -207,6 +294,9 @@ class _PhysicalStageLoss(torch.autograd.Function):
     def run(x_nn, gm, lam_e, lam_g, lam_n):
         """The launch sequence: returns (terms [3], loss [], grad [N,3]) -- views of one device buffer."""
         lib = PL.physics()
+        if getattr(gm, "knn_cap", False):
+            raise RuntimeError("the fused physical stage takes all pairs within H; with gm.knn_cap (max_num_neighbors mode) "
+                               "use the per-term methods (HotLoop(fused_physics=False))")
         x = _req(x_nn.detach())
         N = x.shape[0]
         dev = x.device

@@ -11,6 +11,10 @@ spiky_grad :193-199, confirm_guess_hidden_particles :1323-1337, update_visual_pa
 by tests/golden/pbf.npz in the same way.  The edge list comes from torch_cluster.radius{,_graph}
 (1.6.3, not vendored): parity is unpinned at that boundary; here an edge is every ordered pair
 with distance < r (self-loop included), and clouds are kept below KNN_K neighbours per particle.
+`knn_k=K` restates max_num_neighbors as torch_cluster's CUDA kernel applies it (csrc/cuda/radius_cuda.cu of
+1.6.x: one thread per query walks the points of its batch in index order, records every hit and stops at K):
+a query keeps its K smallest-index neighbours.  (The library's CPU path differs -- a k-d tree's result order --
+but the reference runs on CUDA.)  That mode is pinned against nothing but this restatement: parity unpinned.
 """
 from __future__ import annotations
 
@@ -19,8 +23,9 @@ import torch
 
 
 class PhysicsOracle:
-    def __init__(self, H=2.0, p0=1.5, secs=0.033, scale_factor=100.0, eps=1e-8, buoyancy_max_y=0.0):
+    def __init__(self, H=2.0, p0=1.5, secs=0.033, scale_factor=100.0, eps=1e-8, buoyancy_max_y=0.0, knn_k=None):
         self.H, self.p0, self.secs, self.scale_factor, self.EPSILON = H, p0, secs, scale_factor, eps
+        self.knn_k = knn_k  # None: every pair within H; K: the searches of the three loss terms keep K per query
         self.H2 = H ** 2
         self.poly6_term1 = 315.0 / (64.0 * np.pi * H ** 9)  # gm_dynamics.py:130
         self.buoyancy_max_y = buoyancy_max_y
@@ -34,8 +39,23 @@ class PhysicsOracle:
         d = torch.cdist(y.detach().double(), x.detach().double())
         return torch.nonzero(d < r, as_tuple=True)
 
+    @staticmethod
+    def _edges_capped(y, x, r, K):
+        """_edges with max_num_neighbors = K: per query (row) the first K hits in index order of x."""
+        row, col = PhysicsOracle._edges(y, x, r)  # row-major: rows ascending, cols ascending within a row
+        first = torch.searchsorted(row, torch.arange(y.shape[0]))  # position of every row's first edge
+        keep = (torch.arange(row.shape[0]) - first[row]) < K
+        return row[keep], col[keep]
+
     def p_ratio(self, xyz_scaled, imass):
         N = xyz_scaled.shape[0]
+        if self.knn_k is not None:
+            # radius_graph(flow="source_to_target") returns (neighbour, query) and :1288 accumulates on its first row:
+            # the kept edge (query q, neighbour i) adds to p_i
+            q, i = self._edges_capped(xyz_scaled, xyz_scaled, self.H, self.knn_k)
+            vals = self.poly6(torch.sum((xyz_scaled[i] - xyz_scaled[q]) ** 2, dim=1))
+            pi = torch.zeros(N, dtype=xyz_scaled.dtype).index_add_(0, i, vals)
+            return pi.unsqueeze(1) / imass / self.p0
         row, col = self._edges(xyz_scaled, xyz_scaled, self.H)
         diff = xyz_scaled[row] - xyz_scaled[col]
         vals = self.poly6(torch.sum(diff ** 2, dim=1))
@@ -62,7 +82,8 @@ class PhysicsOracle:
         est = x_nn * self.scale_factor
         vel = (est - x_prev) / self.secs
         V = visual_xyz.shape[0]
-        row, col = self._edges(visual_xyz, est, self.H)
+        row, col = (self._edges(visual_xyz, est, self.H) if self.knn_k is None
+                    else self._edges_capped(visual_xyz, est, self.H, self.knn_k))
         diff = visual_xyz[row] - est[col]
         p6 = self.poly6(torch.sum(diff ** 2, dim=1))
         vv = torch.zeros(V, 3, dtype=est.dtype).index_add_(0, row, vel[col] * p6.unsqueeze(-1))

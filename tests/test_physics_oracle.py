@@ -58,3 +58,28 @@ def test_distance_loss_oracle_matches_reference(tag):
         assert loss > 0
         assert abs(float(D[f"loss32_{tag}"]) - loss) <= 1e-3 * loss          # the reference's fp32 noise
         assert np.abs(D[f"grad32_{tag}"] - g64).max() <= 2e-2 * scale
+
+
+def test_capped_edges_keep_the_first_k_by_index():
+    """max_num_neighbors as torch_cluster's CUDA kernel applies it (oracle header): hand case on a line."""
+    from oracle.physics_oracle import PhysicsOracle
+    x = torch.tensor([[0.0, 0, 0], [0.5, 0, 0], [1.0, 0, 0], [1.5, 0, 0], [5.0, 0, 0]])
+    row, col = PhysicsOracle._edges_capped(x, x, 1.2, 2)
+    kept = {q: [int(c) for r, c in zip(row, col) if int(r) == q] for q in range(5)}
+    # within 1.2: 0 -> {0,1,2}; 1 -> {0,1,2,3}; 2 -> {0,1,2,3}; 3 -> {1,2,3}; 4 -> {4}; first two by index each
+    assert kept == {0: [0, 1], 1: [0, 1], 2: [0, 1], 3: [1, 2], 4: [4]}
+    o = PhysicsOracle(H=1.2, p0=1.0, knn_k=2)
+    im = torch.ones(5, 1)
+    w = lambda a, b: float(o.poly6(torch.tensor(float(a - b) ** 2)))  # noqa: E731
+    # the kept edge (query q, neighbour i) adds at i (radius_graph's source_to_target swap + index_add_ on row)
+    want = [w(0, 0) + w(0.5, 0) + w(1.0, 0), w(0, 0.5) + w(0.5, 0.5) + w(1.0, 0.5) + w(1.5, 0.5), w(1.5, 1.0), 0.0, w(0, 0)]
+    got = o.p_ratio(x, im).squeeze(1)
+    assert torch.allclose(got, torch.tensor(want), rtol=1e-6)
+    # a cap no list reaches changes nothing
+    big, none = PhysicsOracle(H=1.2, p0=1.0, knn_k=50), PhysicsOracle(H=1.2, p0=1.0)
+    assert torch.allclose(big.p_ratio(x, im), none.p_ratio(x, im), rtol=1e-6)
+    v = torch.tensor([[0.6, 0.1, 0.0], [4.8, 0, 0]])
+    xp = x - 0.05
+    assert torch.allclose(big.visual_xyz_from_nn(x / 100, xp, v), none.visual_xyz_from_nn(x / 100, xp, v))
+    xq = x * 0.9 - 0.05  # velocities that differ from particle to particle: the kept subset shows in the average
+    assert not torch.allclose(o.visual_xyz_from_nn(x / 100, xq, v)[0], none.visual_xyz_from_nn(x / 100, xq, v)[0])
