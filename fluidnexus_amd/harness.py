@@ -543,8 +543,15 @@ class HotLoop:
                         from . import _physics_lib as _PL
                         _PL.check(_PL.physics().fnx_stream_delay(_DIST_DELAY_US, torch.cuda.current_stream().cuda_stream))
                     n_vis = gm._visual_xyz.shape[0]
-                    self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
-                                                                          c["distance_threshold_visual"])
+                    if os.environ.get("FNX_DIST_NOOP") == "1":  # developer probe: the branch's fork / join without its work
+                        from . import _physics_lib as _PL
+                        if getattr(self, "_gd_zero", None) is None:
+                            self._gd_zero = torch.zeros(n_vis, 3, device=means3D.device)
+                        _PL.check(_PL.physics().fnx_stream_delay(1.0, torch.cuda.current_stream().cuda_stream))
+                        self.last_distance, gd = None, self._gd_zero
+                    else:
+                        self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
+                                                                              c["distance_threshold_visual"])
             # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
             # that saves the ones seed and its copies), then back through the rasteriser
             if dimg_ready is not None:
