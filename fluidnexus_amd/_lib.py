@@ -76,7 +76,7 @@ SYMBOLS = (
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
     "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
     "fnx_forward_stage1_views_split_opts", "fnx_forward_stage2_views_split_opts", "fnx_rasterize_backward_views_split_opts",
-    "fnx_sort_state_bytes", "fnx_sort_state_read",
+    "fnx_sort_state_bytes", "fnx_sort_state_read", "fnx_sort_state_outliers",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
@@ -179,6 +179,8 @@ def raster():
     lib.fnx_rasterize_backward_views_split_opts.argtypes = lib.fnx_rasterize_backward_views_split.argtypes[:-1] + [p, op, p]
     lib.fnx_sort_state_bytes.restype = c_size_t
     lib.fnx_sort_state_bytes.argtypes = [i]
+    lib.fnx_sort_state_outliers.restype = i
+    lib.fnx_sort_state_outliers.argtypes = [p, i, i, p, C.POINTER(C.c_uint32)]
     lib.fnx_sort_state_read.restype = i
     lib.fnx_sort_state_read.argtypes = [p, i, i, p, C.POINTER(C.c_uint32)]
     lib.fnx_binning_layout_split.argtypes = [c_int64, c_int64, C.POINTER(BinningLayout)]

@@ -105,20 +105,34 @@ inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
 
 // Temporal-coherence depth sort (fnx_raster_opts_t.sort_mode = FNX_SORT_COHERENT, raster_binning.hip): the caller's
 // persistent per-view state.  Header words, the (key, id) bounds every repair workgroup publishes for its chunk of ranks
-// (first | last, u64 each), and inv[id] = depth rank of splat id in the previous call's order.
+// (first | last, u64 each), inv[id] = depth rank of splat id in the previous call's order, and what the OUTLIERS need
+// (splats that travel further than a repair window reaches, a handful per call: fringe particles whose interpolated
+// velocity is noise): samples[j] = the previous order's depth bits at rank kCohSampleStep * j, by which the preprocess
+// tells that a splat has left its neighbourhood; such a splat's record goes to olist[] instead of the slot of its
+// previous rank (which gets a hole record), and holes[b] counts the holes in ranks [1024 b, 1024 (b + 1)).
 enum { COH_MAGIC = 0, COH_EPOCH = 1, COH_ARRIVED = 2, COH_FAIL = 3, COH_FALLBACKS = 4, COH_REPAIRS = 5,
-       COH_WHY = 6,  // sticky: why calls fell back (1 record not of this call, 2 bucket overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded)
+       COH_WHY = 6,  // sticky: why calls fell back (1 record not of this call, 2 bucket overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded, 32 more outliers than kCohOutlierCap)
+       COH_NOUT = 7,        // outliers appended by this call's preprocess (reset by the repair kernel)
+       COH_SAMPLES_OK = 8,  // 1: samples[] describe the order inv[] refers to (a repair call wrote both)
+       COH_OUTLIERS = 9,    // running total of outliers taken (statistics)
        COH_HDR_WORDS = 64 };
+constexpr int kCohOutlierCap = 256;          // per view and call; more -> the call falls back to the full sort
+constexpr int kCohSampleStep = 128;          // ranks between two samples
+constexpr int kCohSampleReach = 3;           // a splat stays where it is while its key lies within [sample(jb - 3), sample(jb + 4)], jb = rank / 128: at most 511 ranks
+constexpr uint32_t kCohHoleId = 0xFFFFFFFEu;  // id of a hole record
 struct SortStateLayout {
-    size_t hdr, bounds, inv, total;
+    size_t hdr, bounds, inv, samples, holes, olist, total;
 };
 inline SortStateLayout sort_state_layout(int P) {
     const size_t p = (size_t)(P > 0 ? P : 0), nc = (p + kSplatBlock - 1) / kSplatBlock;
     SortStateLayout o;
     size_t off = 0;
-    o.hdr = off;    off = align_up(off + COH_HDR_WORDS * 4);
-    o.bounds = off; off = align_up(off + nc * 16);
-    o.inv = off;    off = align_up(off + p * 4);
+    o.hdr = off;     off = align_up(off + COH_HDR_WORDS * 4);
+    o.bounds = off;  off = align_up(off + nc * 16);
+    o.inv = off;     off = align_up(off + p * 4);
+    o.samples = off; off = align_up(off + (p / kCohSampleStep + 2) * 4);
+    o.holes = off;   off = align_up(off + (p / 1024 + 2) * 4);
+    o.olist = off;   off = align_up(off + (size_t)kCohOutlierCap * 16);
     o.total = off + kAlign;
     return o;
 }
@@ -127,7 +141,7 @@ struct CohRef {
     uint4 *krec;    // view 0's record array inside the geometry blob (stride: ViewBatch::geom)
     char *state;    // aligned start of view 0's sort state
     size_t stride;  // bytes between consecutive views' states
-    size_t hdr, inv;
+    size_t hdr, inv, samples, holes, olist;
 };
 // The blend forward refreshes inv[id] = rank from the sorted pairs on its way (pairs == nullptr: nothing to do): one
 // million scattered 4-byte stores disappear under a throughput-bound kernel instead of extending the sort's launch.

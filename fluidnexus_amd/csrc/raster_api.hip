@@ -396,6 +396,9 @@ int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffer, 
         coh.stride = SL.total;
         coh.hdr = SL.hdr;
         coh.inv = SL.inv;
+        coh.samples = SL.samples;
+        coh.holes = SL.holes;
+        coh.olist = SL.olist;
     }
     {
     ProfScope ps(3, s);
@@ -810,6 +813,15 @@ int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t st
     out[0] = h[fnx::COH_REPAIRS];
     out[1] = h[fnx::COH_FALLBACKS];
     out[2] = h[fnx::COH_WHY];
+    return FNX_OK;
+}
+int fnx_sort_state_outliers(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t *out) {
+    if (!sort_state || !out || P < 0 || view < 0) return fail(FNX_ERR_INVALID_ARG, "bad argument");
+    const fnx::SortStateLayout SL = fnx::sort_state_layout(P);
+    const char *src = aligned(sort_state) + SL.total * (size_t)view + SL.hdr + 4 * fnx::COH_OUTLIERS;
+    hipError_t e = hipMemcpyAsync(out, src, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "sort_state_outliers: %s", hipGetErrorString(e));
     return FNX_OK;
 }
 int fnx_set_sort_narrow(int on) {

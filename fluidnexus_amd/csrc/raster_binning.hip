@@ -192,7 +192,7 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
     __shared__ uint32_t s_cnt[4][kSortRadix];   // per-wave digit counts, then per-wave running offsets
     __shared__ uint32_t s_wtot[4];
     bool with_rect = false;
-    uint32_t kmin = 0;
+    uint32_t kmin = 0, kmin_all = 0;  // kmin_all: for the samples of the final order (the pairs' keys are relative to it)
     {
         const int vw = blockIdx.y;
         ctl = view_at(ctl, geom_stride, vw);
@@ -200,6 +200,7 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
         if (pass == SORT_FOURTH && !wide) return;
         if (pass == SORT_FIRST) kmin = ctl[SORT_CTL_KMIN];
         with_rect = (pass == SORT_THIRD && !wide) || pass == SORT_FOURTH;
+        if (with_rect && coh_state) kmin_all = ctl[SORT_CTL_KMIN];
         raw_keys = view_at(raw_keys, geom_stride, vw);
         pairs_in = view_at(pairs_in, geom_stride, vw);
         pairs_out = view_at(pairs_out, geom_stride, vw);
@@ -216,6 +217,8 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
         hdr[COH_MAGIC] = coh_magic(P);
         hdr[COH_ARRIVED] = 0u;
         hdr[COH_FAIL] = 0u;
+        hdr[COH_SAMPLES_OK] = 1u;  // written below, rank by rank
+        hdr[COH_NOUT] = 0u;
     }
     const int shift = pass * kSortBits;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -280,7 +283,15 @@ sort_scatter_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint2 *_
             const uint32_t pos = run_off[d] + r;
             pairs_out[pos] = kv[k];
             if (with_rect) rect_sorted[pos] = rect[kv[k].y];
-            if (coh_inv) coh_inv[kv[k].y] = pos;
+            if (coh_inv) {
+                coh_inv[kv[k].y] = pos;
+                // the samples the next (first repair) call's preprocess tells its outliers by: the depth bits at every
+                // kCohSampleStep-th rank.  (With culled splats in the view this order -- culled last -- is not the repair
+                // calls' order and the samples of the tail mean little: the first repair call then takes its full sort,
+                // as it would without them.)
+                if (pos % (uint32_t)kCohSampleStep == 0u)
+                    reinterpret_cast<uint32_t *>(coh_state + SL.samples)[pos / (uint32_t)kCohSampleStep] = (kv[k].x + kmin_all) & 0x7FFFFFFFu;
+            }
         }
         // the wave's LDS reads above are issued before this write (in-order per wave)
         if (valid[k] && (same & lt_mask) == 0ull) run_off[d] = run_off[d] + (uint32_t)__popcll(same);
@@ -333,10 +344,14 @@ static_assert(kCohPer * kCohSampleThreads == 16 && kCohParts * 256 == kCohThread
 typedef unsigned long long u64;
 // LDS layout of sort_repair_kernel: the output chunk | the bucketed window | splitters | bucket counts | starts | per
 // bucketed position: its bucket, then its final window position (the window itself lives in registers)
+constexpr int kCohE = kCohPer + 1;                   // elements per thread: its window positions + one outlier
+constexpr int kCohCap = kCohWin + kCohOutlierCap;    // elements a workgroup sorts at most
+static_assert(kCohOutlierCap <= kCohThreads && kCohE * kCohThreads >= kCohCap, "one outlier per thread");
 constexpr size_t kCohLdsA = (size_t)kCohOut * 8;
-constexpr size_t kCohLdsT = (size_t)kCohWin * 8;
-constexpr size_t kCohLdsBytes = kCohLdsA + kCohLdsT + 256 * 8 + 2 * 272 * 4 + (size_t)kCohWin * 2;
-static_assert(kCohLdsBytes <= 64 * 1024, "static LDS");
+constexpr size_t kCohLdsT = (size_t)kCohCap * 8;
+constexpr size_t kCohLdsBytes = kCohLdsA + kCohLdsT + 256 * 8 + 2 * 272 * 4 + (size_t)kCohCap * 2;
+static_assert(kCohLdsBytes + 256 <= 64 * 1024, "static LDS");
+constexpr int kCohPosBias = 1024;  // final window positions are stored biased (holes in front of the window shift them below 0)
 
 __device__ __forceinline__ uint32_t sort_key_bits(uint32_t raw) { return raw & 0x7FFFFFFFu; }  // depth bits, culled or not
 __device__ __forceinline__ uint2 unpack_rect8(uint32_t r) {
@@ -466,6 +481,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     uint16_t *s_bid = reinterpret_cast<uint16_t *>(s_start + 272);          // [kCohWin] bucket, then final position
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_flag, s_last;
+    __shared__ uint32_t s_holes_before, s_out_below;  // holes in front of the window; outliers below everything the window sorts
     const int vw = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = blockIdx.x, nc = gridDim.x;
     raw_keys = view_at(raw_keys, geom_stride, vw);
@@ -482,7 +498,14 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     uint32_t *hdr = reinterpret_cast<uint32_t *>(state + SL.hdr);
     u64 *bounds = reinterpret_cast<u64 *>(state + SL.bounds);
     uint32_t *__restrict__ inv = reinterpret_cast<uint32_t *>(state + SL.inv);
-    if (tid == 0) s_flag = 0u;
+    uint32_t *__restrict__ samples = reinterpret_cast<uint32_t *>(state + SL.samples);
+    uint32_t *__restrict__ holes = reinterpret_cast<uint32_t *>(state + SL.holes);
+    const uint4 *__restrict__ olist = reinterpret_cast<const uint4 *>(state + SL.olist);
+    if (tid == 0) {
+        s_flag = 0u;
+        s_holes_before = 0u;
+        s_out_below = 0u;
+    }
     if (tid < 272) {
         s_cnt[tid] = 0u;
         s_start[tid] = 0u;
@@ -501,8 +524,8 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         // element's position, the ones behind rank P - 1 lie behind every output.
         const long long gt = (long long)c * kCohOut - kCohMargin + (long long)kCohPer * tid;
         const int n_left = (int)max(0ll, (long long)kCohMargin - (long long)c * kCohOut);
-        uint4 rec[kCohPer];
-        bool real[kCohPer];
+        uint4 rec[kCohE];  // [kCohPer]: the thread's outlier, if any
+        bool real[kCohE];
 #pragma unroll
         for (int k = 0; k < kCohPer; k++) {
             const long long g = gt + k;
@@ -510,16 +533,27 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             rec[k] = make_uint4(0u, 0u, 0u, 0u);
             if (real[k]) rec[k] = krec[g];
         }
-        u64 v[kCohPer];
+        // the call's outliers (records the preprocess kept out of the slots of their previous ranks): every workgroup
+        // takes all of them, one per thread; those its window has no place for only count (below) or drop out (above)
+        const uint32_t n_outl = hdr[COH_NOUT];
+        if (n_outl > (uint32_t)kCohOutlierCap) bad |= 32u;
+        real[kCohPer] = (uint32_t)tid < min(n_outl, (uint32_t)kCohOutlierCap);
+        rec[kCohPer] = make_uint4(0u, 0u, 0u, 0u);
+        if (real[kCohPer]) rec[kCohPer] = olist[tid];
+        uint32_t holes_part = 0;  // holes in front of the window's first rank (a multiple of 1024): that many fewer elements there
+        for (int b = tid, nb = (int)(max(0ll, (long long)c * kCohOut - kCohMargin) >> 10); b < nb; b += kCohThreads)
+            holes_part += holes[b];
+        u64 v[kCohE];
 #pragma unroll
-        for (int k = 0; k < kCohPer; k++) {
+        for (int k = 0; k < kCohE; k++) {
+            if (real[k] && rec[k].w == epoch && rec[k].y == kCohHoleId && k < kCohPer) real[k] = false;  // its splat is in the outlier list
             if (real[k] && (rec[k].w != epoch || rec[k].y >= (uint32_t)P)) {  // not written by this call's preprocess
                 bad |= 1u;
                 real[k] = false;
             }
             v[k] = real[k] ? (((u64)rec[k].x << 32) | rec[k].y) : 0ull;
         }
-        uint32_t at[kCohPer];  // where the element lies in the bucketed copy
+        uint32_t at[kCohE];  // where the element lies in the bucketed copy
         if (FNX_EXP_COH & 4) {
 #pragma unroll
             for (int k = 0; k < kCohPer; k++) {
@@ -536,6 +570,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         // value (empty buckets).
         if (tid % kCohSampleThreads == 0) s_t[tid / kCohSampleThreads] = real[0] ? v[0] : ~0ull;  // s_t is free until the bucketed copy is written
         __syncthreads();
+        if (holes_part) atomicAdd(&s_holes_before, holes_part);  // (zeroed before the barrier above, read after later ones)
         {
             constexpr int kSpan = 256 / kCohParts;
             const int j = tid & 255, first = (tid >> 8) * kSpan;  // sample j against samples [first, first + kSpan)
@@ -555,9 +590,36 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         if (tid < 256) s_split[s_start[tid]] = s_t[tid];
         __syncthreads();
         // bucket = number of splitters below the element: 0 .. 256
-        uint32_t bk[kCohPer];
+        // an outlier takes part in this window's sort if it lies between the window's smallest and largest sample (the
+        // first / last window of the view: from the bottom / to the top); below that it counts into the positions
+        // (every element of buckets >= 1 lies above it; bucket 0 sits in the lower margin), above that it is somebody else's
+        if (real[kCohPer]) {
+            u64 top = 0ull;  // largest sample that is a real element
+            {
+                int lo = 0, hi = 256;  // first of the "no element" samples (they sort last)
 #pragma unroll
-        for (int k = 0; k < kCohPer; k++) {
+                for (int step = 0; step < 9; step++) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lo < hi) {
+                        if (s_split[mid] != ~0ull) lo = mid + 1;
+                        else hi = mid;
+                    }
+                }
+                top = lo > 0 ? s_split[lo - 1] : 0ull;
+            }
+            // (the last TWO windows reach the end of the order: an outlier that belongs there must not drop out of the one
+            // whose chunk it may still touch)
+            const bool first = c == 0, last = c >= nc - 2;
+            if (!first && v[kCohPer] < s_split[0]) {
+                atomicAdd(&s_out_below, 1u);
+                real[kCohPer] = false;
+            } else if (!last && v[kCohPer] > top) {
+                real[kCohPer] = false;
+            }
+        }
+        uint32_t bk[kCohE];
+#pragma unroll
+        for (int k = 0; k < kCohE; k++) {
             int lo = 0, hi = 256;
 #pragma unroll
             for (int step = 0; step < 9; step++) {
@@ -570,7 +632,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             bk[k] = (uint32_t)lo;
         }
 #pragma unroll
-        for (int k = 0; k < kCohPer; k++) at[k] = real[k] ? atomicAdd(&s_cnt[bk[k]], 1u) : 0u;  // slot inside the bucket
+        for (int k = 0; k < kCohE; k++) at[k] = real[k] ? atomicAdd(&s_cnt[bk[k]], 1u) : 0u;  // slot inside the bucket
         __syncthreads();
         uint32_t n_mine = 0, inc = 0;
         if (tid < 256) {  // bucket starts: exclusive prefix of the sizes (thread = bucket)
@@ -592,7 +654,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kCohPer; k++)
+        for (int k = 0; k < kCohE; k++)
             if (real[k]) {
                 at[k] += s_start[bk[k]];
                 s_t[at[k]] = v[k];
@@ -603,8 +665,11 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         // kCohOut positions are the chunk.  Threads take the BUCKETED positions (lanes = consecutive positions: a wave
         // spans four or five buckets, so its lanes loop about equally long and read the same LDS words: broadcasts).
         const uint32_t n_real = s_start[256] + s_cnt[256];
+        // rank of the window's first sorted element in the whole order = ranks in front of the window - their holes +
+        // the outliers below the window
+        const int shift = (int)s_out_below - (int)s_holes_before;
 #pragma unroll
-        for (int k = 0; k < kCohPer; k++) {
+        for (int k = 0; k < kCohE; k++) {
             const uint32_t p = (uint32_t)(k * kCohThreads + tid);
             const bool on = p < n_real;
             const uint32_t b = on ? s_bid[p] : 0u;
@@ -618,10 +683,10 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
                 below += (j + 2 < n && q2 < x) ? 1u : 0u;
                 below += (j + 3 < n && q3 < x) ? 1u : 0u;
             }
-            const int fw = n_left + (int)(base + below);  // final window position, < kCohWin
+            const int fw = n_left + (int)(base + below) + shift;  // final window position
             const int o = fw - kCohMargin;
             if (on) {
-                s_bid[p] = (uint16_t)fw;  // for the element's owner (only this thread read the bucket stored here)
+                s_bid[p] = (uint16_t)(fw + kCohPosBias);  // for the element's owner (only this thread read the bucket stored here)
                 if (o >= 0 && o < kCohOut) s_out[o] = x;
             }
         }
@@ -633,8 +698,12 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
             const int o = k * kCohThreads + tid;
             if (o < n_out) {
                 const u64 x = s_out[o];
-                if ((uint32_t)x < (uint32_t)P) pairs_out[(size_t)c * kCohOut + o] = make_uint2((uint32_t)(x >> 32), (uint32_t)x);
-                else bad |= 4u;
+                if ((uint32_t)x < (uint32_t)P) {
+                    pairs_out[(size_t)c * kCohOut + o] = make_uint2((uint32_t)(x >> 32), (uint32_t)x);
+                    if (o % kCohSampleStep == 0) samples[(c * kCohOut + o) / kCohSampleStep] = (uint32_t)(x >> 32);
+                } else {
+                    bad |= 4u;
+                }
                 if (o + 1 < n_out && !(x < s_out[o + 1])) bad |= 4u;
             }
         }
@@ -644,9 +713,9 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         if (!(FNX_EXP_COH & 2)) {
             uint32_t *s_orect = reinterpret_cast<uint32_t *>(s_t);
 #pragma unroll
-            for (int k = 0; k < kCohPer; k++) {
+            for (int k = 0; k < kCohE; k++) {
                 if (!real[k]) continue;
-                const int o = (int)s_bid[at[k]] - kCohMargin;
+                const int o = (int)s_bid[at[k]] - kCohPosBias - kCohMargin;
                 if (o >= 0 && o < n_out) s_orect[o] = rec[k].z;
             }
             __syncthreads();
@@ -698,6 +767,8 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     const bool fail = s_flag != 0u;
     if (fail) {
         coh_fallback_sort(P, raw_keys, pairs_tmp, pairs_out, inv, rect, rect_sorted, reinterpret_cast<uint32_t *>(s_raw));
+        __syncthreads();
+        for (int j = tid; j * kCohSampleStep < P; j += 256) samples[j] = pairs_out[(size_t)j * kCohSampleStep].x;
         __threadfence();
         if (fh.T) {  // ... and the counts of every rank block again, from the order just written
             __syncthreads();
@@ -707,7 +778,11 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
                                 reinterpret_cast<uint32_t *>(s_raw), &s_htot[0], fh.blk_hist, fh.blk_total, true);
         }
     }
+    for (int b = tid; b < P / 1024 + 2; b += 256) holes[b] = 0u;  // every workgroup has read them: clean for the next call
     if (tid == 0) {
+        hdr[COH_OUTLIERS] = hdr[COH_OUTLIERS] + min(hdr[COH_NOUT], (uint32_t)kCohOutlierCap);
+        hdr[COH_NOUT] = 0u;
+        hdr[COH_SAMPLES_OK] = 1u;     // samples[] and inv[] (the blend forward's job, from these pairs) describe this call's order
         ctl[SORT_CTL_KMIN] = 0u;      // this mode's pairs hold the depth bits themselves
         ctl[SORT_CTL_WIDE] = 0u;      // emit reads the order from the three-pass buffer
         ctl[SORT_CTL_OVERFLOW] = 0u;  // keys are compared whole: no span limit in this mode

@@ -299,12 +299,28 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
         if (coh.state) {
             // temporal-coherence sort (raster_binning.hip): the splat's record goes to the slot of its PREVIOUS depth rank,
             // stamped with this call's number -- a record the repair kernel finds without that stamp was not written now
-            const char *stv = coh.state + coh.stride * (size_t)vw;
+            char *stv = coh.state + coh.stride * (size_t)vw;
             const uint32_t slot = reinterpret_cast<const uint32_t *>(stv + coh.inv)[idx];
             if (slot < (uint32_t)P) {
-                const uint4 rec = make_uint4(key & 0x7FFFFFFFu, (uint32_t)idx,
-                                             visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
-                                             reinterpret_cast<const uint32_t *>(stv + coh.hdr)[COH_EPOCH]);
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(stv + coh.hdr);
+                const uint32_t kbits = key & 0x7FFFFFFFu, epoch = hdr[COH_EPOCH];
+                uint4 rec = make_uint4(kbits, (uint32_t)idx,
+                                       visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
+                                       epoch);
+                // has the splat left the neighbourhood of its previous rank (by the previous order's sampled keys)?  Then
+                // its record travels in the outlier list and the slot gets a hole; the repair kernel merges the list in.
+                if (hdr[COH_SAMPLES_OK] == 1u) {
+                    const uint32_t *smp = reinterpret_cast<const uint32_t *>(stv + coh.samples);
+                    const uint32_t jb = slot / (uint32_t)kCohSampleStep, ns = ((uint32_t)P + kCohSampleStep - 1) / kCohSampleStep;
+                    const uint32_t lo = jb >= (uint32_t)kCohSampleReach ? smp[jb - kCohSampleReach] : 0u;
+                    const uint32_t hi = jb + kCohSampleReach + 1 < ns ? smp[jb + kCohSampleReach + 1] : 0x7FFFFFFFu;
+                    if (kbits < lo || kbits > hi) {
+                        const uint32_t n = atomicAdd(&hdr[COH_NOUT], 1u);
+                        if (n < (uint32_t)kCohOutlierCap) reinterpret_cast<uint4 *>(stv + coh.olist)[n] = rec;
+                        atomicAdd(&reinterpret_cast<uint32_t *>(stv + coh.holes)[slot >> 10], 1u);
+                        rec = make_uint4(0u, kCohHoleId, 0u, epoch);
+                    }
+                }
                 view_at(coh.krec, vb.geom, vw)[slot] = rec;
             }
         }

@@ -22,7 +22,7 @@ SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libfnx_losses.so")
+        path = os.environ.get("FNX_LOSSES_LIB") or os.path.join(_HERE, "libfnx_losses.so")  # env: developer variants
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build the HIP extension first (python -m fluidnexus_amd.build). "
                                "fluidnexus_amd has no CPU fallback.")

@@ -451,9 +451,9 @@ class ViewBatch:
             return ent, False  # this call's radix passes seed it
         return ent, True
 
-    def sort_counters(self, channels, P, why=False):
-        """Per view (calls in coherent mode, of those: in-launch full sorts[, why: fnx_sort_state_read's bit mask]) --
-        blocking read-back."""
+    def sort_counters(self, channels, P, why=False, outliers=False):
+        """Per view (calls in coherent mode, of those: in-launch full sorts[, why: fnx_sort_state_read's bit mask][, splats
+        taken as outliers so far: fnx_sort_state_outliers]) -- blocking read-back."""
         ent = self._sort_state.get((int(channels), int(P)))
         if ent is None:
             return []
@@ -462,7 +462,12 @@ class ViewBatch:
         for v in range(self.V):
             pair = (C.c_uint32 * 3)()
             _lib.check(lib.fnx_sort_state_read(ent.data_ptr(), int(P), v, stream, pair))
-            out.append((int(pair[0]), int(pair[1])) + ((int(pair[2]),) if why else ()))
+            row = (int(pair[0]), int(pair[1])) + ((int(pair[2]),) if why else ())
+            if outliers:
+                n = C.c_uint32(0)
+                _lib.check(lib.fnx_sort_state_outliers(ent.data_ptr(), int(P), v, stream, C.byref(n)))
+                row += (int(n.value),)
+            out.append(row)
         return out
 
     def depth_hint(self, channels):

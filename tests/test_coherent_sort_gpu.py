@@ -49,6 +49,15 @@ class _Views:
             out.append((int(pair[0]), int(pair[1])))
         return out
 
+    def outliers(self, P):
+        out = []
+        for v in range(self.V):
+            n = C.c_uint32(0)
+            self._lib.check(self.lib.fnx_sort_state_outliers(self.state[P].data_ptr(), P, v,
+                                                             torch.cuda.current_stream().cuda_stream, C.byref(n)))
+            out.append(int(n.value))
+        return out
+
     def render(self, g, sort_mode, with_state=True, blend_math=0):
         from tests.hip_harness import _t, _p, _view
         lib, _lib, dev, V, W, H, Cn = self.lib, self._lib, self.dev, self.V, self.W, self.H, self.Cn
@@ -121,6 +130,58 @@ def test_coherent_equals_radix_while_the_splats_drift(P):
         _same(ref, got, f"step {it}")
     # an optimiser-sized drift never needed the in-launch full sort
     assert rv.counters(P) == [(steps, 0)] * 3
+
+
+@pytest.mark.parametrize("P,K", [(5000, 3), (20_000, 1), (20_000, 40), (20_000, 200), (60_000, 120)])
+def test_far_travellers_are_merged_in_as_outliers_without_a_full_sort(P, K):
+    """While the cloud drifts, K splats per call jump anywhere in it (fringe particles of a later frame do: their
+    interpolated velocity is noise) -- among them one to the very front and one to the very back of every view's order.
+    They travel in the outlier list (include/fnx_raster.h fnx_sort_state_outliers); the order stays the radix sort's, bit
+    for bit, and no call needs the in-launch full sort."""
+    from fluidnexus_amd import _lib
+    W, H = 112, 96
+    cams = S.arc_cameras(3, W, H, device="cpu")
+    rv = _Views(cams, W, H)
+    g = _scene(P, seed=P + K)
+    rng = np.random.RandomState(K)
+    rv.render(g, _lib.FNX_SORT_FULL)       # seeds the state (radix order: no samples yet)
+    rv.render(g, _lib.FNX_SORT_COHERENT)   # first repair call: writes the samples the outlier test needs
+    lo, hi = g["means3D"].min(0), g["means3D"].max(0)
+    steps = 6
+    for it in range(steps):
+        g["means3D"] = (g["means3D"] + rng.normal(size=g["means3D"].shape).astype(np.float32) * 2e-4).astype(np.float32)
+        sel = rng.choice(P, size=K, replace=False)
+        g["means3D"][sel] = rng.uniform(lo, hi, size=(K, 3)).astype(np.float32)
+        c0 = cams[0].camera_center.numpy()
+        towards = (g["means3D"].mean(0) - c0) / np.linalg.norm(g["means3D"].mean(0) - c0)
+        g["means3D"][sel[0]] = (c0 + towards * 0.3).astype(np.float32)                   # nearest of view 0
+        if K > 1:
+            g["means3D"][sel[1]] = (c0 + towards * (10.0 + it)).astype(np.float32)       # farthest of every view
+        ref = rv.render(g, _lib.FNX_SORT_FULL, with_state=False)
+        got = rv.render(g, _lib.FNX_SORT_COHERENT)
+        _same(ref, got, f"step {it}")
+    assert rv.counters(P) == [(steps + 1, 0)] * 3, rv.counters(P)
+    # (a jump can land within reach of the old rank in one of the views: the count is a lower bound, not K per call)
+    assert all(n >= steps * max(1, K // 2) - 2 for n in rv.outliers(P)), rv.outliers(P)
+
+
+def test_more_far_travellers_than_the_outlier_list_holds_cost_a_full_sort_and_nothing_else():
+    from fluidnexus_amd import _lib
+    W, H, P, K = 112, 96, 20_000, 1500
+    cams = S.arc_cameras(2, W, H, device="cpu")
+    rv = _Views(cams, W, H)
+    g = _scene(P, seed=77)
+    rng = np.random.RandomState(5)
+    rv.render(g, _lib.FNX_SORT_FULL)
+    rv.render(g, _lib.FNX_SORT_COHERENT)
+    lo, hi = g["means3D"].min(0), g["means3D"].max(0)
+    for it in range(3):
+        sel = rng.choice(P, size=K if it < 2 else 5, replace=False)
+        g["means3D"][sel] = rng.uniform(lo, hi, size=(sel.size, 3)).astype(np.float32)
+        ref = rv.render(g, _lib.FNX_SORT_FULL, with_state=False)
+        got = rv.render(g, _lib.FNX_SORT_COHERENT)
+        _same(ref, got, f"step {it}")
+    assert rv.counters(P) == [(4, 2)] * 2, rv.counters(P)   # the two crowded calls fell back, the third did not
 
 
 def test_coherent_survives_visibility_changes_without_a_full_sort():

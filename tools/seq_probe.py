@@ -9,7 +9,7 @@ from fluidnexus_amd.renderer import pipes
 
 a = types.SimpleNamespace(no_graph=False, host_sync=False, scene="backdrop", stage="physical", no_distance=False, views="batched",
                           unfused_physics=False, image_loss="fused", emulate_world=0, shared_terms="per-view", physics_once=False,
-                          torch_adam=False, frames=2, iters_per_frame=60, graph_iters=5)
+                          torch_adam=False, frames=2, iters_per_frame=60, graph_iters=5, sort="radix" if "--radix" in sys.argv else "coherent")
 dev = torch.device("cuda", 0)
 rasterizer.set_blend_math("fast"); rasterizer.set_lean_geometry(True); rasterizer.set_coherent_sort("--radix" not in sys.argv)
 rasterizer.set_host_sync(False)
