@@ -501,7 +501,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         rasterizer.check_status()
         if a.sort == "coherent":
             c1 = rasterizer.coherent_sort_counters()
-            if c1[1] - c0[1] > 0:
+            if c1[1] - c0[1] > rasterizer.coherent_sort_states():
                 rasterizer.set_coherent_sort(False)
                 sort_switched.append(len(counts))
         if graph and n - done - 1 >= gi:
@@ -701,7 +701,11 @@ def main():
         # the coherent sort is exact whatever the scene does, but a scene whose splats jump further than its repair window
         # pays a full in-launch sort per call: look at the warm-up's counters before committing to it
         calls, falls = rasterizer.coherent_sort_counters()
-        if calls and falls > 0.02 * calls:
+        falls = max(0, falls - rasterizer.coherent_sort_states())  # a state's first repair call may pay it once (see there)
+        if rasterizer.coherent_sort_states() == 0:
+            sort_note = ("coherent sort not used: more repair workgroups per launch than pay "
+                         f"(rasterizer.coherent_sort_pays, limit {rasterizer.COHERENT_MAX_WORKGROUPS})")
+        elif calls and falls > 0.02 * calls:
             rasterizer.set_coherent_sort(False)
             sort_note = f"coherent sort switched off after the warm-up: {falls} in-launch full sorts in {calls} view calls"
     graph_mode = False

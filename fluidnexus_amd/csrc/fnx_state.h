@@ -111,12 +111,12 @@ inline int splat_blocks(int P) { return (P + kSplatBlock - 1) / kSplatBlock; }
 // tells that a splat has left its neighbourhood; such a splat's record goes to olist[] instead of the slot of its
 // previous rank (which gets a hole record), and holes[b] counts the holes in ranks [1024 b, 1024 (b + 1)).
 enum { COH_MAGIC = 0, COH_EPOCH = 1, COH_ARRIVED = 2, COH_FAIL = 3, COH_FALLBACKS = 4, COH_REPAIRS = 5,
-       COH_WHY = 6,  // sticky: why calls fell back (1 record not of this call, 2 bucket overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded, 32 more outliers than kCohOutlierCap)
+       COH_WHY = 6,  // sticky: why calls fell back (1 record not of this call, 2 bucket overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded)
        COH_NOUT = 7,        // outliers appended by this call's preprocess (reset by the repair kernel)
        COH_SAMPLES_OK = 8,  // 1: samples[] describe the order inv[] refers to (a repair call wrote both)
        COH_OUTLIERS = 9,    // running total of outliers taken (statistics)
        COH_HDR_WORDS = 64 };
-constexpr int kCohOutlierCap = 256;          // per view and call; more -> the call falls back to the full sort
+constexpr int kCohOutlierCap = 256;          // per view and call; further candidates stay in the slots of their previous ranks
 constexpr int kCohSampleStep = 128;          // ranks between two samples
 constexpr int kCohSampleReach = 3;           // a splat stays where it is while its key lies within [sample(jb - 3), sample(jb + 4)], jb = rank / 128: at most 511 ranks
 constexpr uint32_t kCohHoleId = 0xFFFFFFFEu;  // id of a hole record

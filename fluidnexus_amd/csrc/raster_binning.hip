@@ -535,9 +535,8 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         }
         // the call's outliers (records the preprocess kept out of the slots of their previous ranks): every workgroup
         // takes all of them, one per thread; those its window has no place for only count (below) or drop out (above)
-        const uint32_t n_outl = hdr[COH_NOUT];
-        if (n_outl > (uint32_t)kCohOutlierCap) bad |= 32u;
-        real[kCohPer] = (uint32_t)tid < min(n_outl, (uint32_t)kCohOutlierCap);
+        const uint32_t n_outl = min(hdr[COH_NOUT], (uint32_t)kCohOutlierCap);  // (candidates beyond the list's size stayed in their slots)
+        real[kCohPer] = (uint32_t)tid < n_outl;
         rec[kCohPer] = make_uint4(0u, 0u, 0u, 0u);
         if (real[kCohPer]) rec[kCohPer] = olist[tid];
         uint32_t holes_part = 0;  // holes in front of the window's first rank (a multiple of 1024): that many fewer elements there

@@ -315,10 +315,14 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     const uint32_t lo = jb >= (uint32_t)kCohSampleReach ? smp[jb - kCohSampleReach] : 0u;
                     const uint32_t hi = jb + kCohSampleReach + 1 < ns ? smp[jb + kCohSampleReach + 1] : 0x7FFFFFFFu;
                     if (kbits < lo || kbits > hi) {
+                        // (a full list is no failure: the splat stays in its slot like any other, and the repair window
+                        // either reaches its new place or the call takes the full sort, as it would without the list)
                         const uint32_t n = atomicAdd(&hdr[COH_NOUT], 1u);
-                        if (n < (uint32_t)kCohOutlierCap) reinterpret_cast<uint4 *>(stv + coh.olist)[n] = rec;
-                        atomicAdd(&reinterpret_cast<uint32_t *>(stv + coh.holes)[slot >> 10], 1u);
-                        rec = make_uint4(0u, kCohHoleId, 0u, epoch);
+                        if (n < (uint32_t)kCohOutlierCap) {
+                            reinterpret_cast<uint4 *>(stv + coh.olist)[n] = rec;
+                            atomicAdd(&reinterpret_cast<uint32_t *>(stv + coh.holes)[slot >> 10], 1u);
+                            rec = make_uint4(0u, kCohHoleId, 0u, epoch);
+                        }
                     }
                 }
                 view_at(coh.krec, vb.geom, vw)[slot] = rec;

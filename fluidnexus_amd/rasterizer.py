@@ -78,8 +78,9 @@ def set_coherent_sort(enabled: bool):
     """View batches: after the first call of a (camera batch, channel count, splat count) the depth order of the
     PREVIOUS call is repaired in one launch instead of running the radix passes (FNX_SORT_COHERENT; the state lives on
     the ViewBatch).  Exact by construction: the repaired order is verified on the device and a view that fails is
-    sorted from scratch inside the same launch (`ViewBatch.sort_counters()` reports how often)."""
-    _OPTS["coherent_sort"] = 1 if enabled else 0
+    sorted from scratch inside the same launch (`ViewBatch.sort_counters()` reports how often).  True / 1: where it pays
+    (coherent_sort_pays); 2: always."""
+    _OPTS["coherent_sort"] = int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0)
 
 
 _KEEP_LAST = False   # keep_last_blobs(): remember the image blobs of the most recent view-batched forward
@@ -125,6 +126,24 @@ def coherent_sort_counters():
     return calls, falls
 
 
+COHERENT_MAX_WORKGROUPS = 640
+
+
+def coherent_sort_pays(P, V):
+    """The repair launch is one 512-thread workgroup per 2 048 ranks and view, two resident per compute unit (LDS): up to
+    ~2.5 per compute unit it is one round of work and beats the nine radix launches (config 3: 490 workgroups, 58 against
+    88 us); BASELINE config 5 (350 k splats x 8 views = 1 368 workgroups, twice per iteration) runs it in rounds and
+    measured 320 against 341 it/s.  set_coherent_sort(2) / options=dict(coherent_sort=2) force the mode."""
+    return ((int(P) + 2047) // 2048) * int(V) <= COHERENT_MAX_WORKGROUPS
+
+
+def coherent_sort_states():
+    """How many (view, channel count, splat count) sort states are alive: a state's FIRST repair call may need the full
+    sort without that saying anything about the scene (the radix passes that seeded it order culled splats last, the
+    repair calls by depth), so a caller that judges the mode by coherent_sort_counters allows that many."""
+    return sum(vb.V * len(vb._sort_state) for vb in list(_VIEW_BATCHES or ()))
+
+
 def set_lean_geometry(enabled: bool):
     """View batches only: do not write the per-view GeometryState copies nothing reads back, one world covariance for
     all views (include/fnx_raster.h fnx_set_lean_geometry)."""
@@ -150,7 +169,7 @@ def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=N
             raise ValueError(f"unknown rasteriser options: {sorted(unknown)}")
         o.update(overrides)
     sort_mode, state_ptr = (_lib.FNX_SORT_NARROW if o["sort_narrow"] else _lib.FNX_SORT_FULL), None
-    if o["coherent_sort"] and P > 0:
+    if o["coherent_sort"] and P > 0 and (o["coherent_sort"] == 2 or coherent_sort_pays(P, vbatch.V)):
         state, seeded = vbatch.sort_state(channels, P)
         if state is not None:
             state_ptr = state.data_ptr()

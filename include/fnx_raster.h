@@ -93,13 +93,13 @@ size_t fnx_sort_state_bytes(int P);
 /* Host read-back (blocking) of a view's counters in a sort state: out[0] = calls in coherent mode, out[1] = of those,
  * calls that fell back to the in-launch full sort, out[2] = why they did, OR-ed over the calls (1: a record not written
  * by the call's preprocess, 2: a sample-sort bucket overflowed, 4: a chunk not strictly increasing, 8: a chunk boundary out
- * of order = an element moved further than the window margin, 16: unseeded state, 32: more than 256 splats of the view
- * left the neighbourhood of their previous rank in one call). */
+ * of order = an element moved further than the window margin, 16: unseeded state). */
 int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[3]);
 /* Running total of the splats a view's repair calls took as OUTLIERS: splats whose depth left the neighbourhood of their
  * previous rank (about 400 ranks either way, judged by the previous order's sampled keys) travel in a side list of at most
  * 256 per call and are merged in by every repair workgroup, so that a handful of far travellers per call -- fringe
- * particles whose interpolated velocity is noise -- does not cost the in-launch full sort. */
+ * particles whose interpolated velocity is noise -- does not cost the in-launch full sort.  (Candidates beyond the 256 stay
+ * in place: the repair window reaches 1 024 ranks, and a call it does not suffice for takes the full sort as before.) */
 int fnx_sort_state_outliers(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t *out);
 
 /* Scratch sizes [required<GeometryState>(P), required<ImageState>(W*H), required<BinningState>(R),
