@@ -620,12 +620,14 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
 #pragma unroll
         for (int k = 0; k < kCohE; k++) {
             int lo = 0, hi = 256;
+            if (k < kCohPer || real[k]) {  // (most waves hold no outlier)
 #pragma unroll
-            for (int step = 0; step < 9; step++) {
-                const int mid = (lo + hi) >> 1;
-                if (lo < hi) {
-                    if (s_split[mid] < v[k]) lo = mid + 1;
-                    else hi = mid;
+                for (int step = 0; step < 9; step++) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lo < hi) {
+                        if (s_split[mid] < v[k]) lo = mid + 1;
+                        else hi = mid;
+                    }
                 }
             }
             bk[k] = (uint32_t)lo;
@@ -669,6 +671,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         const int shift = (int)s_out_below - (int)s_holes_before;
 #pragma unroll
         for (int k = 0; k < kCohE; k++) {
+            if ((uint32_t)(k * kCohThreads) >= n_real) break;  // (uniform: the last round exists for the outliers)
             const uint32_t p = (uint32_t)(k * kCohThreads + tid);
             const bool on = p < n_real;
             const uint32_t b = on ? s_bid[p] : 0u;
