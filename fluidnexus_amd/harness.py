@@ -491,7 +491,13 @@ class HotLoop:
                 vmemo = gm._visual_memo[1]
                 if "hgrid" in vmemo:
                     vmemo["hitems"] = vmemo["hgrid"].cell_items(refresh=True)
-                if self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
+                if self.fused_physics and os.environ.get("FNX_PHYS_NOOP") == "1":  # developer probe: fork / join without the work
+                    from . import _physics_lib as _PL
+                    if getattr(self, "_gp_zero", None) is None:
+                        self._gp_zero = torch.zeros_like(gm._estimate_xyz_nn)
+                    _PL.check(_PL.physics().fnx_stream_delay(1.0, torch.cuda.current_stream().cuda_stream))
+                    gp = self._gp_zero
+                elif self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
                     from .physics import physical_stage_value_and_grad
                     _, gp = physical_stage_value_and_grad(gm, c["lambda_exyz"], c["lambda_gas_constraints"],
                                                           c["lambda_next_gas_constraints"],
