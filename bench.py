@@ -539,8 +539,9 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             "particles_last_frame": {"hidden": counts[-1][0], "visual": counts[-1][1]},
             "emitted_per_frame": {"hidden": int(hid.shape[0]), "visual": int(vis.shape[0])},
             "frames_on_radix_sort": len(sort_switched),
-            "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, two eager "
-                    "iterations, static background re-binned, hipGraph re-captured (setup: its iterations count towards n) | "
+            "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, four eager "
+                    "iterations (two with --sort radix; the first seeds the depth sort's state, the others show whether the frame "
+                    "stays inside the coherent sort's reach), static background re-binned, hipGraph re-captured (setup: its iterations count towards n) | "
                     "replayed iterations | confirm + advect + confirm; frame_boundary_ms = ms_per_frame - n x the steady-state "
                     "ms_per_step of this record; a host sync at each segment boundary (4 per frame)"}
 
