@@ -40,12 +40,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Pixel (y, x) of channel c (or the 3-channel mean): the address is clamped into the image and the value selected
 // afterwards, so that the loads of an unrolled staging loop are unconditional and can all be in flight together.
-template <bool GREY>
+// GREY: 0 = per channel, 1 = both images are 3-channel and their grey means are compared, 2 = as 1 but the TARGET is
+// already its grey mean, one plane per image (it is constant across a frame's iterations: a third of the loads less).
+// MEAN: form the mean of three planes here; else one plane (plane c of a per-channel image, or a pre-averaged target).
+template <bool MEAN>
 __device__ __forceinline__ float load_px(const float *__restrict__ im, int H, int W, int c, int y, int x) {
     const bool in = x >= 0 && y >= 0 && x < W && y < H;  // zero padding outside
     const size_t o = (size_t)(in ? y : 0) * W + (in ? x : 0), hw = (size_t)H * W;
     float v;
-    if (GREY) v = ((im[o] + im[hw + o]) + im[2 * hw + o]) * (1.0f / 3.0f);  // torch.mean over the 3 channels
+    if (MEAN) v = ((im[o] + im[hw + o]) + im[2 * hw + o]) * (1.0f / 3.0f);  // torch.mean over the 3 channels
     else v = im[(size_t)c * hw + o];
     return in ? v : 0.f;
 }
@@ -53,7 +56,7 @@ __device__ __forceinline__ float load_px(const float *__restrict__ im, int H, in
 // The two Gaussian passes run on packed pairs (v_pk_fma_f32: two lanes of work per instruction) with the
 // multiply-adds fused; the image-loss values are compared with the reference's conv2d at a tolerance (its own
 // accumulation order is the library's), not bit for bit.
-template <bool GREY>
+template <int GREY>
 __global__ void __launch_bounds__(256)
 l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, Win win,
                        float *__restrict__ partials, float *__restrict__ dmaps) {
@@ -66,15 +69,15 @@ l1_ssim_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
     const int Ce = GREY ? 1 : C;
     const int n = blockIdx.z / Ce, c = blockIdx.z - n * Ce, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     img += (size_t)n * C * H * W;  // image n of the batch
-    gt += (size_t)n * C * H * W;
+    gt += (size_t)n * (GREY == 2 ? 1 : C) * H * W;
     dmaps += (size_t)n * 3 * Ce * H * W;
     constexpr int NLOAD = (HS * HS + 255) / 256;
     f2 rp[NLOAD];
 #pragma unroll
     for (int u = 0; u < NLOAD; u++) {  // all global loads first, then the LDS stores
         const int i = min(tid + u * 256, HS * HS - 1), ly = i / HS, lx = i - ly * HS;
-        rp[u].x = load_px<GREY>(img, H, W, c, y0 + ly - R, x0 + lx - R);
-        rp[u].y = load_px<GREY>(gt, H, W, c, y0 + ly - R, x0 + lx - R);
+        rp[u].x = load_px<GREY != 0>(img, H, W, c, y0 + ly - R, x0 + lx - R);
+        rp[u].y = load_px<GREY == 1>(gt, H, W, GREY == 2 ? 0 : c, y0 + ly - R, x0 + lx - R);
     }
 #pragma unroll
     for (int u = 0; u < NLOAD; u++) {
@@ -221,7 +224,7 @@ __device__ void combine_in_workgroup(const CombineArgs &a, float *s_term /* [kCo
     }
 }
 
-template <bool GREY>
+template <int GREY>
 __global__ void __launch_bounds__(256)
 l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, int C, int H, int W, Win win,
                         const float *__restrict__ dmaps, const float *__restrict__ g_l1,
@@ -239,7 +242,7 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     const int n = blockIdx.z / Ce, c = blockIdx.z - n * Ce, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const size_t hw = (size_t)H * W;
     img += (size_t)n * C * hw;
-    gt += (size_t)n * C * hw;
+    gt += (size_t)n * (GREY == 2 ? 1 : C) * hw;
     dmaps += (size_t)n * 3 * Ce * hw;
     dL_dimg += (size_t)n * C * hw;
     g_l1 += (size_t)n * g_stride;
@@ -326,7 +329,7 @@ l1_ssim_backward_kernel(const float *__restrict__ img, const float *__restrict__
     for (int j = 0; j < CSEG; j++) {
         const int py = y0 + ty + j;
         if (px >= W || py >= H) continue;
-        const float x = load_px<GREY>(img, H, W, c, py, px), y = load_px<GREY>(gt, H, W, c, py, px);
+        const float x = load_px<GREY != 0>(img, H, W, c, py, px), y = load_px<GREY == 1>(gt, H, W, GREY == 2 ? 0 : c, py, px);
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         float grad = gl1 * sgn + gss * (v01[j].x + 2.f * x * v01[j].y + y * v2[j]);
@@ -380,8 +383,9 @@ image_loss_combine_kernel(const float *__restrict__ partials, int N, int nt, flo
 
 template <typename... A>
 void launch_l1_ssim_backward(int grey, dim3 grid, hipStream_t stream, A... args) {
-    if (grey) hipLaunchKernelGGL(l1_ssim_backward_kernel<true>, grid, dim3(256), 0, stream, args...);
-    else hipLaunchKernelGGL(l1_ssim_backward_kernel<false>, grid, dim3(256), 0, stream, args...);
+    if (grey == 2) hipLaunchKernelGGL(l1_ssim_backward_kernel<2>, grid, dim3(256), 0, stream, args...);
+    else if (grey) hipLaunchKernelGGL(l1_ssim_backward_kernel<1>, grid, dim3(256), 0, stream, args...);
+    else hipLaunchKernelGGL(l1_ssim_backward_kernel<0>, grid, dim3(256), 0, stream, args...);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,7 +495,7 @@ int hip_check(const char *what) {
     if (e != hipSuccess) return fail(FNX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return FNX_OK;
 }
-bool args_ok(int C, int H, int W, int grey) { return C > 0 && H > 0 && W > 0 && (!grey || C == 3); }
+bool args_ok(int C, int H, int W, int grey) { return C > 0 && H > 0 && W > 0 && grey >= 0 && grey <= 2 && (!grey || C == 3); }
 
 }  // namespace
 
@@ -507,11 +511,14 @@ int fnx_l1_ssim_forward_batch(const float *img, const float *gt, int N, int C, i
         return fail(FNX_ERR_INVALID_ARG, "l1_ssim_forward: bad argument (grey needs C == 3)");
     static const Win win = make_window();
     dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N * (grey ? 1 : C));
-    if (grey)
-        hipLaunchKernelGGL(l1_ssim_forward_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, win,
+    if (grey == 2)
+        hipLaunchKernelGGL(l1_ssim_forward_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, win,
+                           partials, dmaps);
+    else if (grey)
+        hipLaunchKernelGGL(l1_ssim_forward_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, win,
                            partials, dmaps);
     else
-        hipLaunchKernelGGL(l1_ssim_forward_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, win,
+        hipLaunchKernelGGL(l1_ssim_forward_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, img, gt, C, H, W, win,
                            partials, dmaps);
     return hip_check("l1_ssim_forward");
 }

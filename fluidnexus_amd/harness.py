@@ -137,6 +137,8 @@ _GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
 # One fork point for both side branches (the rasteriser's between-stages hook) instead of two: every fork / join of the
 # captured graph costs the main chain ~5 us in front of the kernel behind it
 _SINGLE_FORK = os.environ.get("FNX_SINGLE_FORK", "0") == "1"
+# The physical stage's targets as their grey means, formed once (FNX_GT_GREY=0: three planes, averaged per pixel and iteration)
+_GT_GREY = os.environ.get("FNX_GT_GREY", "1") == "1"
 
 
 class HotLoop:
@@ -409,15 +411,21 @@ class HotLoop:
         gm.optimizer.step()
         gm.optimizer.zero_grad()
 
-    def _gt_stack(self, mine, attr="original_image"):
+    def _gt_stack(self, mine, attr="original_image", grey_mean=False):
         """Ground-truth images of this rank's views as one [V,C,H,W] tensor (stacked once; the entry keeps the
-        images it was built from)."""
+        images it was built from).  grey_mean: their grey means [V,1,H,W] instead (losses.grey_mean_target: what the
+        physical stage compares, tpp:356-360; formed once per frame instead of per pixel and iteration)."""
         if self._gt_cache is None:
             self._gt_cache = {}
         imgs = [getattr(self.cams[v], attr) for v in mine]
-        hit = self._gt_cache.get(attr)
+        key = (attr, bool(grey_mean))
+        hit = self._gt_cache.get(key)
         if hit is None or len(hit[0]) != len(imgs) or any(a is not b for a, b in zip(hit[0], imgs)):
-            hit = self._gt_cache[attr] = (imgs, torch.stack(imgs).contiguous())
+            stack = torch.stack(imgs).contiguous()
+            if grey_mean:
+                from .losses import grey_mean_target
+                stack = grey_mean_target(stack)
+            hit = self._gt_cache[key] = (imgs, stack)
         return hit[1]
 
     def _iteration_body_batched(self, phase="all"):
@@ -533,7 +541,7 @@ class HotLoop:
         if mine:
             dimg_ready = None
             if use_dist and _DIST_AT == "loss":  # the image term first: the distance branch forks behind it
-                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine, grey_mean=_GT_GREY), c["lambda_dssim"],
                                                                  c["lambda_image"])
                 dimg_ready = (loss, per_view, dimg)
                 fork_d.record(main)
@@ -563,7 +571,7 @@ class HotLoop:
             if dimg_ready is not None:
                 loss, per_view, dimg = dimg_ready
             else:
-                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine), c["lambda_dssim"],
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine, grey_mean=_GT_GREY), c["lambda_dssim"],
                                                                  c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())

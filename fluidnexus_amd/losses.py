@@ -155,10 +155,14 @@ def image_loss_value_and_grad(img, gt, lambda_dssim, lambda_image=1.0, grey=True
         raise RuntimeError("fluidnexus_amd losses: tensors must be on a HIP device (no CPU path)")
     img = img.float().contiguous()
     gt = gt.float().contiguous()
-    if img.shape != gt.shape or img.dim() != 4:
+    # grey=True with a one-plane target [N,1,H,W]: the caller formed the target's grey mean once (grey_mean_target)
+    pre = bool(grey) and img.dim() == 4 and gt.dim() == 4 and gt.shape[1] == 1 and img.shape[1] == 3 \
+        and gt.shape[0] == img.shape[0] and gt.shape[2:] == img.shape[2:]
+    if not pre and (img.shape != gt.shape or img.dim() != 4):
         raise RuntimeError(f"image {tuple(img.shape)} / target {tuple(gt.shape)}: expected equal [N,C,H,W] shapes")
     N, Cn, H, W = img.shape
     Ce = 1 if grey else Cn
+    grey = 2 if pre else grey
     nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
     scratch = torch.empty(N * nt * 2 + N * 2 + 1, dtype=torch.float32, device=img.device)
     partials, per_image, loss = scratch[:N * nt * 2], scratch[N * nt * 2:N * nt * 2 + 2 * N], scratch[-1:]
@@ -172,6 +176,13 @@ def image_loss_value_and_grad(img, gt, lambda_dssim, lambda_image=1.0, grey=True
                                            partials.data_ptr(), dmaps.data_ptr(), per_image.data_ptr(), loss.data_ptr(),
                                            one.data_ptr(), dimg.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return loss.view(()), per_image.view(N, 2), dimg
+
+
+def grey_mean_target(gt):
+    """[N,3,H,W] -> [N,1,H,W]: the grey mean of a target batch exactly as the loss kernels form it per pixel
+    (((r + g) + b) * fp32(1/3)), to be computed ONCE per frame and handed to image_loss_value_and_grad(grey=True)."""
+    gt = gt.float()
+    return (((gt[:, 0] + gt[:, 1]) + gt[:, 2]) * torch.tensor(1.0 / 3.0, dtype=torch.float32, device=gt.device)).unsqueeze(1).contiguous()
 
 
 def fused_image_loss(img, gt, lambda_dssim, lambda_image=1.0, grey=True):

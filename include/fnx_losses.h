@@ -24,6 +24,10 @@ extern "C" {
 typedef void *fnx_stream_t;
 int fnx_losses_abi_version(void);
 const char *fnx_losses_last_error(void);
+/* `grey`: 0 = the loss per channel; 1 = on the grey means of the two 3-channel images (train_physical_particle.py:356-360:
+ * torch.mean over the channels, repeated three times -- the three copies give the same value, so one is evaluated);
+ * 2 = as 1, but `gt` already holds the target's grey mean, ONE plane per image ([N,1,H,W], formed as ((r + g) + b) * (1/3)
+ * in fp32 like the kernel does): the target is constant across a frame's iterations, a third of the loads goes. */
 /* number of workgroup tiles (32x32 pixels per channel plane) = length of `partials` / 2 per image */
 int fnx_l1_ssim_tiles(int C, int H, int W, int grey);
 int fnx_l1_ssim_forward(const float *img, const float *gt, int C, int H, int W, int grey, float *partials,

@@ -35,3 +35,22 @@ def test_fused_grey_image_loss_vs_reference(tag):
     assert abs(v.item() - G[f"grey_{tag}"]) < 3e-6
     ref = G[f"dgrey_{tag}"]
     assert np.abs(x.grad.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-4
+
+
+def test_pre_averaged_target_equals_the_per_pixel_mean():
+    """grey = 2 (include/fnx_losses.h): the target's grey mean formed once (losses.grey_mean_target) instead of per pixel
+    and iteration.  The forward sees the same bits (loss and per-image terms are equal); in the backward the compiler
+    contracts `x - sum * (1/3)` into one FMA when it forms the mean itself (the kernels allow contraction, csrc/losses.hip),
+    so the gradient agrees to rounding, not bit for bit."""
+    from fluidnexus_amd.losses import image_loss_value_and_grad, grey_mean_target
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.rand(3, 3, 150, 201, device="cuda", generator=g)
+    gt = torch.rand(3, 3, 150, 201, device="cuda", generator=g)
+    a = image_loss_value_and_grad(img, gt, 0.2, 1.0)
+    b = image_loss_value_and_grad(img, grey_mean_target(gt), 0.2, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    scale = float(a[2].abs().max())
+    assert float((a[2] - b[2]).abs().max()) <= 1e-6 * scale
+    with pytest.raises(RuntimeError):
+        image_loss_value_and_grad(img, grey_mean_target(gt), 0.2, 1.0, grey=False)
