@@ -107,6 +107,7 @@ __device__ __forceinline__ void row_fold_accumulate(const float (&val)[NV], floa
 #ifndef FNX_BWD_WAVES
 #define FNX_BWD_WAVES 4  // waves per SIMD the register allocation of the blend backward aims at
 #endif
+template <bool WANT_COV = true>
 __device__ inline void geom_backward_view(const float3 mean, const float *cov3D, const float *view, const float *proj,
                                           float h_x, float h_y, float tan_fovx, float tan_fovy, float gc0, float gc1,
                                           float gc2, float g0, float g1, float *gm, float *dcv);
@@ -768,10 +769,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                         for (int k = 0; k < 6; k++) gcov[k] = cv[k];
                     }
                     const float3 mean = make_float3(gmean[0], gmean[1], gmean[2]);
-                    float gv[3], dv[6];
-                    geom_backward_view(mean, gcov, viewmatrix + 16 * vw,
+                    float gv[3];
+                    geom_backward_view<false>(mean, gcov, viewmatrix + 16 * vw,
                                        projmatrix + 16 * vw, vb.focal_x[vw], vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw],
-                                       -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, dv);
+                                       -0.5f * a[kConic], -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, nullptr);
 #pragma unroll
                     for (int k = 0; k < 3; k++) fl[k < kFl ? k : 0] = gv[k];
                 } else {
@@ -981,6 +982,7 @@ __device__ inline void cov3d_backward(int idx, const float *scale, float mod, co
 
 // Screen-space gradients of one splat in one view -> contribution to the mean (gm) and the world
 // covariance (dcv): EWA Jacobian with clamp masks, then the projection Jacobian of the 2D mean.
+template <bool WANT_COV>
 __device__ inline void geom_backward_view(const float3 mean, const float *cov3D, const float *view, const float *proj,
                                           float h_x, float h_y, float tan_fovx, float tan_fovy, float gc0, float gc1,
                                           float gc2, float g0, float g1, float *gm, float *dcv) {
@@ -1011,16 +1013,18 @@ __device__ inline void geom_backward_view(const float3 mean, const float *cov3D,
         dL_da = denom2inv * (-c * c * gc0 + 2 * b * c * gc1 + (denom - a * c) * gc2);
         dL_dc = denom2inv * (-a * a * gc2 + 2 * a * b * gc1 + (denom - a * c) * gc0);
         dL_db = denom2inv * 2 * (b * c * gc0 - (denom + 2 * b * b) * gc1 + a * b * gc2);
-        dcv[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
-        dcv[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
-        dcv[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
-        dcv[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db +
-                 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
-        dcv[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db +
-                 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
-        dcv[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db +
-                 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
-    } else {
+        if (WANT_COV) {  // (the positions-only backward has no use for the covariance's gradient)
+            dcv[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
+            dcv[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
+            dcv[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
+            dcv[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db +
+                     2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
+            dcv[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db +
+                     2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
+            dcv[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db +
+                     2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
+        }
+    } else if (WANT_COV) {
 #pragma unroll
         for (int i = 0; i < 6; i++) dcv[i] = 0;
     }

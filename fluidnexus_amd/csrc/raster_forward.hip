@@ -234,19 +234,20 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             const float4 p_hom = xform4x4(p_orig, proj);
             const float p_w = 1.0f / (p_hom.w + 0.0000001f);
             const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
-            const float *cov3D;
+            // (the six values in registers either way: a pointer that may refer to a local array puts the array into
+            // scratch memory, and a kernel with a scratch segment costs the queue ~5 us in front of its launch)
             float c3[6];
             if (cov3D_precomp != nullptr) {
-                cov3D = cov3D_precomp + (size_t)idx * 6;
+#pragma unroll
+                for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[(size_t)idx * 6 + k];
             } else {
                 cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, c3);
                 if (!lean) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) cov3Ds[(size_t)idx * 6 + k] = c3[k];
                 }
-                cov3D = c3;
             }
-            const float3 cov = cov2d_ewa(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view);
+            const float3 cov = cov2d_ewa(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, c3, view);
             const float det = (cov.x * cov.z - cov.y * cov.y);
             if (det != 0.0f) {
                 const float det_inv = 1.f / det;

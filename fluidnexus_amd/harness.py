@@ -536,7 +536,7 @@ class HotLoop:
                                             scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
             finally:
                 rasterizer.set_between_stages_hook(None)
-        if not _PHYSICS_EARLY and not (_PHYSICS_AT_HOOK and mine):
+        if not _PHYSICS_EARLY and not (_PHYSICS_AT_HOOK and mine) and not (single_fork and use_dist):
             launch_physics()
         if mine:
             dimg_ready = None
@@ -566,6 +566,8 @@ class HotLoop:
                     else:
                         self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],
                                                                               c["distance_threshold_visual"])
+            if single_fork and use_dist:  # behind the distance kernels, the order the two branches run in anyway
+                launch_physics()
             # image term and its gradient with respect to the rendered batch (no autograd node for the loss:
             # that saves the ones seed and its copies), then back through the rasteriser
             if dimg_ready is not None:
