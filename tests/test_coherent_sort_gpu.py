@@ -324,3 +324,30 @@ def test_two_rasteriser_instances_with_different_options_interleaved_on_two_stre
         for a, b in zip(got, ref):  # equal up to the order of the backward's atomics
             scale = b.abs().max().item() + 1e-20
             assert (a - b).abs().max().item() / scale < 2e-4
+
+
+def test_full_size_plume_with_far_travellers_stays_bit_equal_to_the_radix_order():
+    """BASELINE config 3's per-call splats at full size (200 k plume Gaussians, 5 views at 512 x 512): optimiser-sized
+    drift plus 40 splats per call that jump anywhere in the plume; point_list, ranges and pixels equal the radix path's
+    on every call and no call takes the in-launch full sort."""
+    from fluidnexus_amd import _lib
+    W = H = 512
+    P = 200_000
+    cams = S.arc_cameras(5, W, H, device="cpu")
+    rv = _Views(cams, W, H)
+    g = S.plume_gaussians(P, seed=0, channels=3)
+    rng = np.random.RandomState(2)
+    rv.render(g, _lib.FNX_SORT_FULL)
+    rv.render(g, _lib.FNX_SORT_COHERENT)
+    lo, hi = np.percentile(g["means3D"], 2, axis=0), np.percentile(g["means3D"], 98, axis=0)
+    steps = 3
+    for it in range(steps):
+        g["means3D"] = (g["means3D"] + rng.normal(size=g["means3D"].shape).astype(np.float32) * 1e-5).astype(np.float32)
+        sel = rng.choice(P, size=40, replace=False)
+        g["means3D"][sel] = rng.uniform(lo, hi, size=(40, 3)).astype(np.float32)
+        ref = rv.render(g, _lib.FNX_SORT_FULL, with_state=False)
+        got = rv.render(g, _lib.FNX_SORT_COHERENT)
+        _same(ref, got, f"step {it}")
+        assert min(ref["counts"]) > 400_000
+    assert rv.counters(P) == [(steps + 1, 0)] * 5, rv.counters(P)
+    assert all(n >= 20 * steps for n in rv.outliers(P)), rv.outliers(P)
