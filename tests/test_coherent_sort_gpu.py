@@ -132,7 +132,7 @@ def test_coherent_equals_radix_while_the_splats_drift(P):
     assert rv.counters(P) == [(steps, 0)] * 3
 
 
-@pytest.mark.parametrize("P,K", [(5000, 3), (20_000, 1), (20_000, 40), (20_000, 200), (60_000, 120)])
+@pytest.mark.parametrize("P,K", [(300, 2), (700, 2), (2049, 5), (4097, 30), (5000, 3), (20_000, 1), (20_000, 40), (20_000, 200), (60_000, 120)])
 def test_far_travellers_are_merged_in_as_outliers_without_a_full_sort(P, K):
     """While the cloud drifts, K splats per call jump anywhere in it (fringe particles of a later frame do: their
     interpolated velocity is noise) -- among them one to the very front and one to the very back of every view's order.
@@ -162,7 +162,9 @@ def test_far_travellers_are_merged_in_as_outliers_without_a_full_sort(P, K):
         _same(ref, got, f"step {it}")
     assert rv.counters(P) == [(steps + 1, 0)] * 3, rv.counters(P)
     # (a jump can land within reach of the old rank in one of the views: the count is a lower bound, not K per call)
-    assert all(n >= steps * max(1, K // 2) - 2 for n in rv.outliers(P)), rv.outliers(P)
+    # (... and a view of fewer than ~1 000 splats is one repair window: nothing there ever counts as out of reach)
+    if P >= 4000:
+        assert all(n >= steps * max(1, K // 2) - 2 for n in rv.outliers(P)), rv.outliers(P)
 
 
 def test_more_far_travellers_than_the_outlier_list_holds_cost_a_full_sort_and_nothing_else():
