@@ -113,6 +113,9 @@ def build_smoke_frame(P_fluid=200_000, P_background=100_000, hidden_dims=(20, 62
     return gm, cams
 
 
+# ---- developer switches (environment; all off / default in every measured configuration; DESIGN 4.7 has what each one
+# measured).  None of them changes results except the two *_NOOP probes, which REPLACE a side branch's work by a sleeping
+# wave and a zero gradient to show what its fork and join cost alone.
 # The position stages read no screen-space gradient ("viewspace_points" feeds the background stage's densification
 # only): without it the rasteriser's backward adds straight into dL/dmeans3D (geometry_only = 3).  FNX_SCREEN_GRAD=1
 # keeps the reference's behaviour (the 2D-mean gradient is produced as well).
@@ -139,6 +142,8 @@ _GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
 _SINGLE_FORK = os.environ.get("FNX_SINGLE_FORK", "0") == "1"
 # The physical stage's targets as their grey means, formed once (FNX_GT_GREY=0: three planes, averaged per pixel and iteration)
 _GT_GREY = os.environ.get("FNX_GT_GREY", "1") == "1"
+_DIST_NOOP = os.environ.get("FNX_DIST_NOOP") == "1"  # probe: the distance branch without its kernels (WRONG gradients)
+_PHYS_NOOP = os.environ.get("FNX_PHYS_NOOP") == "1"  # probe: the physics branch without its kernels (WRONG gradients)
 
 
 class HotLoop:
@@ -499,7 +504,7 @@ class HotLoop:
                 vmemo = gm._visual_memo[1]
                 if "hgrid" in vmemo:
                     vmemo["hitems"] = vmemo["hgrid"].cell_items(refresh=True)
-                if self.fused_physics and os.environ.get("FNX_PHYS_NOOP") == "1":  # developer probe: fork / join without the work
+                if self.fused_physics and _PHYS_NOOP:  # developer probe: fork / join without the work
                     from . import _physics_lib as _PL
                     if getattr(self, "_gp_zero", None) is None:
                         self._gp_zero = torch.zeros_like(gm._estimate_xyz_nn)
@@ -557,7 +562,7 @@ class HotLoop:
                         from . import _physics_lib as _PL
                         _PL.check(_PL.physics().fnx_stream_delay(_DIST_DELAY_US, torch.cuda.current_stream().cuda_stream))
                     n_vis = gm._visual_xyz.shape[0]
-                    if os.environ.get("FNX_DIST_NOOP") == "1":  # developer probe: the branch's fork / join without its work
+                    if _DIST_NOOP:  # developer probe: the branch's fork / join without its work
                         from . import _physics_lib as _PL
                         if getattr(self, "_gd_zero", None) is None:
                             self._gd_zero = torch.zeros(n_vis, 3, device=means3D.device)
