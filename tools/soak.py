@@ -17,6 +17,7 @@ loop.make_targets()
 rasterizer.set_host_sync(False)
 rasterizer.set_blend_math("exact" if "exact" in sys.argv[2:] else "fast")  # the bench's settings
 rasterizer.set_lean_geometry(True)
+rasterizer.set_coherent_sort("radix" not in sys.argv[2:])  # the bench's depth sort
 for _ in range(3):
     loop.iteration()
 rasterizer.check_status()
@@ -46,3 +47,6 @@ x = gm._estimate_xyz_nn.detach()
 print(f"{done} iterations in {dt:.1f} s = {done / dt:.0f} it/s; finite {bool(torch.isfinite(x).all())}; "
       f"loss {first['total']:.6f} -> {loop.last['total']:.6f}; l1 {first['l1']:.6f} -> {loop.last['l1']:.6f}; "
       f"memory {mem0 / 2**20:.0f} -> {torch.cuda.memory_allocated() / 2**20:.0f} MiB; step {float(gm.optimizer.state[gm._estimate_xyz_nn]['step']):.0f}")
+for vb in list(rasterizer._VIEW_BATCHES or ()):
+    for key in list(vb._sort_state):
+        print("coherent sort, per view (calls, in-launch full sorts, why, outliers taken):", vb.sort_counters(*key, why=True, outliers=True))
