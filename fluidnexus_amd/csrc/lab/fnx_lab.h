@@ -19,6 +19,18 @@
 #ifndef FNX_ABLATE
 #define FNX_ABLATE 0
 #endif
+// raster_forward.hip -- barrier probe; results WRONG except 0: 1 = the staging and list barriers of the blend forward's batch
+//   loop become wave-local waits (an upper bound for what a barrier-free batch structure could buy; round 5, config 3:
+//   296.6 -> 295.5 us, i.e. nothing -- the forward does not wait at its barriers).
+//   The backward's counterpart lives in lab/bwd_async_flush.patch (tools/build_variant.py --patch): bits 2 / 4 / 8 = its
+//   barriers A / B / C.  Its numbers (8: 316 -> 254 us, 14: 229 us) are NOT a bound: without barrier C the waves of a
+//   workgroup read different tickets and stop working on the same item.  The legitimate forms the same patch holds --
+//   the flush behind the next item's barrier A, and the double-buffered flush that early waves take in chunks while the
+//   slowest quadrant still walks -- measured 318.8 and 319.9 us against 316.4 (parity-green): the backward does not wait
+//   at its barriers either.
+#ifndef FNX_EXP_NOBAR
+#define FNX_EXP_NOBAR 0
+#endif
 // Defined-or-not switches (all off in production):
 //   FNX_EXP_CLOCK      per-phase / per-workgroup clocks of emit_kernel and blend_forward_kernel (tools/kernel_lab.py,
 //                      tools/deep_probe.py read them through fnx_debug_* exports)
@@ -27,5 +39,5 @@
 //   FNX_EXP_WG_ATOMICS blend backward flush with workgroup-scope atomics -- WRONG sums across XCDs (timing only)
 //   FNX_EXP_COLDREC    one more cold 16-byte gather per entry in the blend backward (timing only)
 // Tuning constants with production defaults next to their use (not experiments): FNX_FWD_WAVES, FNX_FWD_GROUP,
-// FNX_BWD_WAVES, FNX_BWD_GROUP, FNX_BWD_CHUNK, FNX_BWD_DYNAMIC, FNX_EARLY_GATHER, FNX_EMIT_THREADS, FNX_EMIT_CHUNK,
+// FNX_BWD_WAVES, FNX_BWD_GROUP, FNX_EMIT_THREADS, FNX_EMIT_CHUNK,
 // FNX_EMIT_MASK_WORDS, FNX_EMIT_BANDS, FNX_EMIT_BAND_TARGET, FNX_DEEP_GROUPS, FNX_DEEP_PRIO, FNX_COH_THREADS.

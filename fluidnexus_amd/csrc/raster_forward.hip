@@ -38,6 +38,13 @@ extern "C" int fnx_debug_fwd_wg(unsigned long long *host, int n) {
 #else
 #define FNX_LOOP_BARRIER() __syncthreads()
 #endif
+// lab probe (results WRONG): the staging / list barriers of the blend forward's batch loop become wave-local waits --
+// an upper bound for what a barrier-free batch structure could buy (fnx_lab.h, FNX_EXP_NOBAR)
+#if FNX_EXP_NOBAR & 1
+#define FNX_LOOP_BARRIER_BC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define FNX_LOOP_BARRIER_BC() FNX_LOOP_BARRIER()
+#endif
 #ifndef FNX_DEEP_PRIO
 #define FNX_DEEP_PRIO 3  // wave priority (0..3) of the tiles that went deep in the previous forward
 #endif
@@ -887,7 +894,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
             for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
-        FNX_LOOP_BARRIER();
+        FNX_LOOP_BARRIER_BC();
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
         // a block whose 16 pixels have all stopped gets an empty list: the wave's step count is its longest list, and a
         // finished block must not be the one that keeps it walking
@@ -908,7 +915,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             next_cnt = base + 256u < r1 ? min(256u, r1 - base - 256u) : 0u;
             next_id = merge_batch(next_cnt);
         }
-        FNX_LOOP_BARRIER();
+        FNX_LOOP_BARRIER_BC();
         if (SPLIT) {
             if (next_cnt) {
                 const uint32_t a = s_adv;
