@@ -925,6 +925,18 @@ def main():
                           for key in list(vb._sort_state)]
     except Exception as e:
         print(f"[bench] sort counters unavailable: {type(e).__name__}: {e}", file=sys.stderr)
+    dist_lists = None
+    try:  # Verlet pair lists of the distance loss: how many of the run's calls had to rebuild them (device counters)
+        from fluidnexus_amd import physics as _ph
+        if _ph._DIST_LISTS and _ph._DIST_VERLET and not a.no_distance:
+            cs = _ph.distance_verlet_counters()
+            dist_lists = {"what": "fnx_distance_loss_verlet: pairs within threshold + skin kept between calls, validity checked "
+                                  "on the device every call, rebuilt inside the same launch sequence when a point has moved "
+                                  "further than skin / 2",
+                          "calls": sum(c[2] for c in cs), "rebuilds": sum(c[3] for c in cs),
+                          "points_over_capacity_at_last_rebuild": sum(c[4] for c in cs), "slots_per_point": _ph.DIST_VERLET_K}
+    except Exception as e:
+        print(f"[bench] distance pair-list counters unavailable: {type(e).__name__}: {e}", file=sys.stderr)
     knn = None
     if cfg_id != 2 and a.stage == "physical":
         knn = gm.knn_k_report()  # outside the timed region: are the reference's neighbour lists below their cap here?
@@ -961,7 +973,8 @@ def main():
                                           "(tests/test_fast_math_gpu.py)",
                                   "exact": "exact: bit-reproducible blend arithmetic (equal to the CPU oracle bit for bit)"}[a.blend_math],
                    "static_split": bool(pipes._STATIC_SPLIT and cfg_id != 2),
-                   "distance_loss": not a.no_distance, "scene": a.scene if cfg_id in (3, 4) else "backdrop",
+                   "distance_loss": not a.no_distance, "distance_pair_lists": dist_lists,
+                   "scene": a.scene if cfg_id in (3, 4) else "backdrop",
                    "scene_note": ("background Gaussians BEHIND the plume: the fluid is visible to every camera and its image "
                                   "gradient is non-zero" if (a.scene == "backdrop" or cfg_id not in (3, 4)) else
                                   "round-1 layout: background cloud around the plume (the fluid is occluded in every view, "

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 2  # include/fnx_physics.h FNX_PHYSICS_ABI_VERSION
+ABI_VERSION = 3  # include/fnx_physics.h FNX_PHYSICS_ABI_VERSION
 
 SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes", "fnx_grid_build",
            "fnx_density_forward", "fnx_density_backward", "fnx_visual_interp_forward", "fnx_visual_interp_backward",
@@ -17,7 +17,7 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum", "fnx_adam_step_grid",
            "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists", "fnx_stream_delay",
            "fnx_knn_cut", "fnx_density_forward_kcap", "fnx_density_backward_kcap", "fnx_visual_interp_forward_kcap",
-           "fnx_visual_interp_backward_kcap")
+           "fnx_visual_interp_backward_kcap", "fnx_distance_verlet_bytes", "fnx_distance_loss_verlet")
 
 
 def physics():
@@ -53,6 +53,10 @@ def physics():
     lib.fnx_distance_table_bytes.argtypes = [i]
     lib.fnx_distance_loss_lists.restype = i
     lib.fnx_distance_loss_lists.argtypes = [p, i, f, p, p, p, p]
+    lib.fnx_distance_verlet_bytes.restype = C.c_size_t
+    lib.fnx_distance_verlet_bytes.argtypes = [i, i]
+    lib.fnx_distance_loss_verlet.restype = i
+    lib.fnx_distance_loss_verlet.argtypes = [p, i, f, f, p, p, i, p, p, p]
     lib.fnx_density_forward.restype = i
     lib.fnx_density_forward.argtypes = [p, i, p, f, f, p, p, p]
     lib.fnx_density_backward.restype = i

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "../../include/fnx_physics.h"
 #include "../../include/fnx_raster.h"
@@ -1672,9 +1673,10 @@ constexpr uint32_t kDistNone = 0xFFFFFFFFu;
 
 __global__ void __launch_bounds__(256)
 distance_build_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask, const uint32_t *__restrict__ hdr,
-                      unsigned long long *__restrict__ head, float4 *__restrict__ node) {
+                      unsigned long long *__restrict__ head, float4 *__restrict__ node, const uint32_t *__restrict__ need) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    if (need && need[0] == 0u) return;  // Verlet form: the pair lists of an earlier call still hold
     const uint32_t stamp = hdr[0] + 1u;  // never 0: a zero-filled table entry belongs to no call
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const uint32_t h = cell_hash(cell_of(x, y, z, inv_cell), mask);
@@ -1826,10 +1828,243 @@ int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *tabl
     DistTable t = carve_dist(table, N);
     const float inv = 1.0f / (2.0f * threshold);
     const int nb = (N + 255) / 256;
-    hipLaunchKernelGGL(distance_build_kernel, dim3(nb), dim3(256), 0, s, xyz, N, inv, t.M - 1, t.hdr, t.head, t.node);
+    hipLaunchKernelGGL(distance_build_kernel, dim3(nb), dim3(256), 0, s, xyz, N, inv, t.M - 1, t.hdr, t.head, t.node,
+                       (const uint32_t *)nullptr);
     hipLaunchKernelGGL(distance_lists_kernel, dim3(nb), dim3(256), 0, s, N, inv, threshold, t.M - 1, t.hdr, t.head, t.node,
                        t.partial, grad, loss_out);
     return hip_check("distance_loss_lists");
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same loss with VERLET pair lists (round 5).  The rendered positions of consecutive optimiser steps differ by ~1e-4
+// (lr), the threshold is 2e-3: the set of pairs closer than `threshold` hardly changes from call to call, yet the search
+// above pays ~13 dependent random loads per point every call -- and what the branch costs the iteration is exactly that
+// memory traffic beside the rasteriser's emit / blend forward.  Here a call that finds its lists still valid
+// reads, per point, its <= K stored neighbour indices (coalesced) and their current positions -- no hash table at all.
+//   * lists: for every point the indices of the points within R = threshold + skin of it AT BUILD TIME (ref[] holds the
+//     build-time positions), K slots per point, slot-major (nbr[k N + i]).
+//   * validity: a pair that is not in the lists was >= R apart at build time; while no point has moved further than
+//     skin / 2 from its ref[] it is still >= threshold apart, i.e. contributes nothing.  distance_verlet_check_kernel
+//     tests exactly that every call (plus: state built for this N and threshold, no list overflowed) and raises `need`;
+//   * rebuild, inside the same launch sequence (no host decision, graph-capturable): distance_build_kernel fills the
+//     stamped bucket lists (it returns at once when `need` is 0), and distance_verlet_kernel runs its FULL form -- the 27
+//     cells around the point (cell = 2 threshold >= R), collecting the lists and evaluating the loss on its way.
+// Both forms add the same terms (the pairs closer than `threshold`), in an order that depends on the form: equal within
+// fp32 summation order, like the two grid forms above.  A list that overflows K leaves the state invalid: every call then
+// takes the full form (correct, slow; the counters say so).
+enum { VL_VALID = 0, VL_NEED = 1, VL_CALLS = 2, VL_REBUILDS = 3, VL_OVERFLOW = 4, VL_N = 5, VL_THR = 6, VL_K = 7,
+       VL_ARRIVED = 8, VL_OVERFLOW_NOW = 9, VL_SKIN = 10 };
+struct VerletState {
+    uint32_t *hdr;
+    float4 *ref;
+    uint32_t *cnt;
+    uint32_t *nbr;
+};
+inline size_t verlet_bytes(int N, int K) {
+    const size_t n = (size_t)(N > 0 ? N : 0);
+    size_t off = align_up(256);
+    off = align_up(off + n * 16);
+    off = align_up(off + n * 4);
+    off = align_up(off + n * 4 * (size_t)(K > 0 ? K : 0));
+    return off + kAlign;
+}
+inline VerletState carve_verlet(char *blob, int N, int K) {
+    char *b = (char *)(((uintptr_t)blob + kAlign - 1) / kAlign * kAlign);
+    const size_t n = (size_t)(N > 0 ? N : 0);
+    VerletState v;
+    size_t off = 0;
+    v.hdr = (uint32_t *)(b + off); off = align_up(off + 256);
+    v.ref = (float4 *)(b + off);   off = align_up(off + n * 16);
+    v.cnt = (uint32_t *)(b + off); off = align_up(off + n * 4);
+    v.nbr = (uint32_t *)(b + off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+distance_verlet_check_kernel(const float *__restrict__ xyz, int N, const float4 *__restrict__ ref, uint32_t *__restrict__ hdr,
+                             float lim2, uint32_t thr_bits, uint32_t skin_bits, uint32_t K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i == 0) {
+        hdr[VL_CALLS] += 1u;
+        bad = hdr[VL_VALID] == 0u || hdr[VL_N] != (uint32_t)N || hdr[VL_THR] != thr_bits || hdr[VL_SKIN] != skin_bits ||
+              hdr[VL_K] != K;
+    }
+    if (i < N) {
+        const float4 r = ref[i];
+        const float dx = xyz[3 * i] - r.x, dy = xyz[3 * i + 1] - r.y, dz = xyz[3 * i + 2] - r.z;
+        bad |= !(dx * dx + dy * dy + dz * dz <= lim2);  // (a NaN position asks for a rebuild too)
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) hdr[VL_NEED] = 1u;
+}
+
+__global__ void __launch_bounds__(256)
+distance_verlet_kernel(const float *__restrict__ xyz, int N, float inv_cell, float thr, float R, uint32_t mask,
+                       uint32_t *__restrict__ thdr, const unsigned long long *__restrict__ head,
+                       const float4 *__restrict__ node, float *__restrict__ partial, uint32_t *__restrict__ hdr,
+                       float4 *__restrict__ ref, uint32_t *__restrict__ cnt, uint32_t *__restrict__ nbr, int K,
+                       uint32_t thr_bits, uint32_t skin_bits, float *__restrict__ grad, float *__restrict__ loss_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool full = hdr[VL_NEED] != 0u;  // uniform over the launch: written by the check kernel in front of it
+    const float thr2 = thr * thr;
+    float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    auto pair_term = [&](float ex, float ey, float ez, float r2) {
+        if (!(r2 < thr2)) return;
+        const float d = sqrtf(r2);
+        const float t = thr - d;
+        if (!(t > 0.f)) return;
+        acc += t * t;
+        if (d > 0.f) {
+            const float kk = -4.0f * t / d;
+            ax += kk * ex;
+            ay += kk * ey;
+            az += kk * ez;
+        }
+    };
+    if (i < N) {
+        if (full) {
+            const uint32_t stamp = thdr[0] + 1u;
+            const float4 me = node[i];
+            const float px = me.x, py = me.y, pz = me.z;
+            const int3 c = cell_of(px, py, pz, inv_cell);
+            const float R2 = R * R;
+            uint32_t found = 0;
+            for (int dz = -1; dz <= 1; dz++) {  // nine bucket lists side by side per layer of cells
+                uint32_t cur[9];
+                {
+                    unsigned long long hd[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        hd[k] = head[cell_hash(make_int3(c.x + (k % 3) - 1, c.y + (k / 3) - 1, c.z + dz), mask)];
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        cur[k] = ((uint32_t)(hd[k] >> 32) == stamp && (uint32_t)hd[k] < (uint32_t)N) ? (uint32_t)hd[k] : kDistNone;
+                }
+                for (int guard = 0; guard < N; guard++) {
+                    bool any = false;
+                    float4 q[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (cur[k] != kDistNone) {
+                            q[k] = node[cur[k]];
+                            any = true;
+                        }
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        if (cur[k] == kDistNone) continue;
+                        const uint32_t j = cur[k];
+                        const uint32_t nx = __float_as_uint(q[k].w);
+                        cur[k] = nx < (uint32_t)N ? nx : kDistNone;
+                        if (j == (uint32_t)i) continue;
+                        const float ex = px - q[k].x, ey = py - q[k].y, ez = pz - q[k].z;
+                        const float r2 = ex * ex + ey * ey + ez * ez;
+                        if (!(r2 < R2)) continue;
+                        if (found < (uint32_t)K) nbr[(size_t)found * N + i] = j;
+                        found++;
+                        pair_term(ex, ey, ez, r2);
+                    }
+                }
+            }
+            cnt[i] = min(found, (uint32_t)K);
+            if (found > (uint32_t)K) atomicAdd(&hdr[VL_OVERFLOW_NOW], 1u);
+            ref[i] = make_float4(px, py, pz, 0.f);
+        } else {
+            const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            const uint32_t n = cnt[i];
+            for (uint32_t k0 = 0; k0 < n; k0 += 4) {  // four neighbours' gathers in flight at a time
+                uint32_t j[4];
+                float qx[4], qy[4], qz[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) j[k] = k0 + k < n ? nbr[(size_t)(k0 + k) * N + i] : (uint32_t)i;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    qx[k] = xyz[3 * (size_t)j[k]];
+                    qy[k] = xyz[3 * (size_t)j[k] + 1];
+                    qz[k] = xyz[3 * (size_t)j[k] + 2];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (j[k] == (uint32_t)i) continue;
+                    const float ex = px - qx[k], ey = py - qy[k], ez = pz - qz[k];
+                    pair_term(ex, ey, ez, ex * ex + ey * ey + ez * ez);
+                }
+            }
+        }
+        if (grad) {
+            grad[3 * i + 0] = ax;
+            grad[3 * i + 1] = ay;
+            grad[3 * i + 2] = az;
+        }
+    }
+    __shared__ float s_w[4];
+    __shared__ uint32_t s_last;
+    acc = wave_sum63(acc);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        __threadfence();
+        s_last = atomicAdd(&hdr[VL_ARRIVED], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the workgroup that arrives last: the loss (partial sums in workgroup order), the state's bookkeeping
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float tot = 0.f;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) tot += partial[b];
+    tot = wave_sum63(tot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        hdr[VL_ARRIVED] = 0u;
+        if (full) {
+            const uint32_t over = __hip_atomic_load(&hdr[VL_OVERFLOW_NOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hdr[VL_OVERFLOW] = over;
+            hdr[VL_OVERFLOW_NOW] = 0u;
+            hdr[VL_VALID] = over == 0u ? 1u : 0u;
+            hdr[VL_N] = (uint32_t)N;
+            hdr[VL_THR] = thr_bits;
+            hdr[VL_SKIN] = skin_bits;
+            hdr[VL_K] = (uint32_t)K;
+            hdr[VL_REBUILDS] += 1u;
+            thdr[0] = thdr[0] + 1u;  // the bucket table: the next build stamps its entries one higher
+        }
+        hdr[VL_NEED] = 0u;
+    }
+}
+
+size_t fnx_distance_verlet_bytes(int N, int K) { return verlet_bytes(N, K); }
+
+int fnx_distance_loss_verlet(const float *xyz, int N, float threshold, float skin, char *table, char *state, int K,
+                             float *grad, float *loss_out, fnx_stream_t stream) {
+    if (N < 0 || !loss_out || (N > 0 && (!xyz || !table || !state)) || !(threshold > 0.f) || !(skin > 0.f) ||
+        skin > threshold || K < 1 || K > 64)
+        return fail(FNX_ERR_INVALID_ARG, "distance_loss_verlet: bad argument (0 < skin <= threshold, 1 <= K <= 64)");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t *>(loss_out), (size_t)1);
+        return hip_check("distance_loss_verlet");
+    }
+    DistTable t = carve_dist(table, N);
+    VerletState v = carve_verlet(state, N, K);
+    const float inv = 1.0f / (2.0f * threshold);  // cell = 2 threshold >= R: the 27 cells around a point hold its R-ball
+    const int nb = (N + 255) / 256;
+    uint32_t thr_bits, skin_bits;
+    std::memcpy(&thr_bits, &threshold, 4);
+    std::memcpy(&skin_bits, &skin, 4);
+    const float lim = 0.5f * skin;
+    hipLaunchKernelGGL(distance_verlet_check_kernel, dim3(nb), dim3(256), 0, s, xyz, N, v.ref, v.hdr, lim * lim, thr_bits,
+                       skin_bits, (uint32_t)K);
+    hipLaunchKernelGGL(distance_build_kernel, dim3(nb), dim3(256), 0, s, xyz, N, inv, t.M - 1, t.hdr, t.head, t.node,
+                       (const uint32_t *)(v.hdr + VL_NEED));
+    hipLaunchKernelGGL(distance_verlet_kernel, dim3(nb), dim3(256), 0, s, xyz, N, inv, threshold, threshold + skin, t.M - 1,
+                       t.hdr, t.head, t.node, t.partial, v.hdr, v.ref, v.cnt, v.nbr, K, thr_bits, skin_bits, grad, loss_out);
+    return hip_check("distance_loss_verlet");
 }
 
 int fnx_adam_step(float *x, int n, const float *g0, float s0, const float *g1, float s1, const float *g2, float s2,

@@ -361,9 +361,17 @@ class _DistanceLoss(torch.autograd.Function):
         return grad * g, None
 
 
-_DIST_TABLES: dict = {}  # (device, stream, N) -> persistent bucket table of fnx_distance_loss_lists
 _DIST_LISTS = os.environ.get("FNX_DIST_GRID", "0") != "1"  # FNX_DIST_GRID=1: the counted / scanned / filled grid version
 _DIST_FORCED = "FNX_DIST_GRID" in os.environ
+# Verlet pair lists on top of the linked-list form (fnx_distance_loss_verlet): a call whose lists are still valid touches
+# no hash table.  OPT-IN (FNX_DIST_VERLET=1 / set_distance_verlet): exact and graph-capturable (tests/test_distance_verlet_gpu.py),
+# but measured SLOWER inside the config-3 loop (round 5, A/B in one gpurun call: 959 / 958 against 970 / 968 it/s): alone
+# a valid-lists call costs 36 us of kernels against 65, but a rebuild (27 cells) costs 115, the loop's first ~100
+# iterations rebuild every 4th call (the cloud drifts by lr per step) and 5 % of the later ones do (fringe particles that
+# jump), and what the branch costs the iteration is mostly being there beside emit, not its own traffic.
+# skin = threshold is the widest the 27-cell rebuild supports.
+_DIST_VERLET = os.environ.get("FNX_DIST_VERLET", "0") == "1"
+DIST_VERLET_K = 16  # list slots per point (config 3's plume: 2.7 neighbours on average within 2 thresholds)
 
 
 def prefer_distance_lists(enabled: bool):
@@ -377,25 +385,74 @@ def prefer_distance_lists(enabled: bool):
         _DIST_LISTS = bool(enabled)
 
 
-def _distance_table(dev, N):
-    """The zero-filled-once table of the linked-list distance loss for the CURRENT stream (one call at a time per table;
-    allocated outside graph capture: a captured iteration reuses the table its warm-up iterations created)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(N))
-    t = _DIST_TABLES.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        if len(_DIST_TABLES) > 16:
-            _DIST_TABLES.clear()
-        t = _DIST_TABLES[key] = torch.zeros(PL.physics().fnx_distance_table_bytes(int(N)), dtype=torch.uint8, device=dev)
-    return t
+def set_distance_verlet(enabled: bool):
+    """Verlet pair lists for the linked-list form (default off, see _DIST_VERLET)."""
+    global _DIST_VERLET
+    _DIST_VERLET = bool(enabled)
 
 
-def distance_loss_value_and_grad(positions, threshold, need_grad=True):
+class _DistanceBuffers:
+    """Persistent, zero-filled-once device state of the linked-list / Verlet distance loss, one entry per (device, stream,
+    N): the stamped bucket table and the pair-list state.  The kernels receive RAW pointers into these tensors, and a
+    captured hipGraph keeps such a pointer without a tensor reference: entries handed out while a stream is
+    capturing are pinned until release_captured(); otherwise the least recently used entries go once more than `keep`
+    exist (a sequence run changes N every frame)."""
+
+    def __init__(self, keep=4):
+        self.keep, self.entries, self.pinned, self.tick = keep, {}, set(), 0
+
+    def get(self, dev, N, K):
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(N), int(K))
+        capturing = torch.cuda.is_current_stream_capturing()
+        e = self.entries.get(key)
+        if e is None:
+            if capturing:
+                return None  # never allocate inside a capture: the warm-up iterations created the entry
+            lib = PL.physics()
+            e = self.entries[key] = dict(
+                table=torch.zeros(lib.fnx_distance_table_bytes(int(N)), dtype=torch.uint8, device=dev),
+                state=torch.zeros(lib.fnx_distance_verlet_bytes(int(N), int(K)), dtype=torch.uint8, device=dev), used=0)
+            for k in sorted((k for k in self.entries if k not in self.pinned and k != key),
+                            key=lambda k: self.entries[k]["used"])[:max(0, len(self.entries) - len(self.pinned) - self.keep)]:
+                del self.entries[k]
+        self.tick += 1
+        e["used"] = self.tick
+        if capturing:
+            self.pinned.add(key)
+        return e
+
+    def release_captured(self):
+        self.pinned.clear()
+
+    def counters(self):
+        """[(N, valid, calls, rebuilds, overflowed points)] of every live pair-list state (host read)."""
+        out = []
+        for (_, _, N, _), e in self.entries.items():
+            st = e["state"]
+            off = (-st.data_ptr()) % 256
+            h = st[off:off + 64].view(torch.int32).cpu().tolist()
+            out.append((N, h[0], h[2], h[3], h[4]))
+        return out
+
+
+_DIST_BUFFERS = _DistanceBuffers()
+
+
+def distance_verlet_counters():
+    return _DIST_BUFFERS.counters()
+
+
+def release_captured_distance_state():
+    """Un-pin the distance-loss buffers a destroyed hipGraph referred to."""
+    _DIST_BUFFERS.release_captured()
+
+
+def distance_loss_value_and_grad(positions, threshold, need_grad=True, skin=None):
     """(loss, d loss / d positions [N,3]) of utils/loss_utils.distance_loss(positions, threshold)
     (loss_utils.py:98-121: every pair closer than `threshold` pays (threshold - distance)^2, counted in both
     orders) on a hash grid with cell = threshold instead of the reference's dense N x N torch.cdist -- the same
-    sum, but O(N) memory, so it stays usable at 10^5 particles."""
+    sum, but O(N) memory, so it stays usable at 10^5 particles.  `skin`: margin of the Verlet pair lists (default:
+    `threshold`, the widest supported)."""
     lib = PL.physics()
     x = _req(positions.detach())
     if x.dim() != 2 or x.shape[1] != 3:
@@ -405,11 +462,16 @@ def distance_loss_value_and_grad(positions, threshold, need_grad=True):
         z = torch.zeros((), dtype=torch.float32, device=x.device)
         return z, torch.zeros_like(x)
     grad = torch.empty_like(x) if need_grad else None
-    table = _distance_table(x.device, N) if _DIST_LISTS else None
-    if table is not None:  # two launches, one thread per point (csrc/physics.hip fnx_distance_loss_lists)
+    buf = _DIST_BUFFERS.get(x.device, N, DIST_VERLET_K) if _DIST_LISTS else None
+    if buf is not None:  # one thread per point (csrc/physics.hip fnx_distance_loss_lists / _verlet)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        PL.check(lib.fnx_distance_loss_lists(x.data_ptr(), N, float(threshold), table.data_ptr(),
-                                             grad.data_ptr() if need_grad else None, loss.data_ptr(), _stream()))
+        if _DIST_VERLET:
+            PL.check(lib.fnx_distance_loss_verlet(x.data_ptr(), N, float(threshold), float(threshold if skin is None else skin),
+                                                  buf["table"].data_ptr(), buf["state"].data_ptr(), DIST_VERLET_K,
+                                                  grad.data_ptr() if need_grad else None, loss.data_ptr(), _stream()))
+        else:
+            PL.check(lib.fnx_distance_loss_lists(x.data_ptr(), N, float(threshold), buf["table"].data_ptr(),
+                                                 grad.data_ptr() if need_grad else None, loss.data_ptr(), _stream()))
         return loss[0], grad
     grid = torch.empty(lib.fnx_grid_bytes(N), dtype=torch.uint8, device=x.device)
     partials = torch.empty(lib.fnx_distance_loss_partials(N), dtype=torch.float32, device=x.device)

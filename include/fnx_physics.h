@@ -35,7 +35,7 @@ extern "C" {
 typedef void *fnx_stream_t;
 
 /* 2: fnx_adam_step gained `arrived` (before `stream`); compare with fnx_physics_abi_version() before anything else. */
-#define FNX_PHYSICS_ABI_VERSION 2
+#define FNX_PHYSICS_ABI_VERSION 3
 int fnx_physics_abi_version(void);
 const char *fnx_physics_last_error(void);
 
@@ -197,6 +197,19 @@ int fnx_stream_delay(float microseconds, fnx_stream_t stream);
 size_t fnx_distance_table_bytes(int N);
 int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,
                             fnx_stream_t stream);
+/* The same loss with VERLET pair lists (round 5): consecutive calls of the optimisation loop see positions that differ by
+ * ~lr, so the pairs closer than `threshold` are kept from call to call.  `state`: fnx_distance_verlet_bytes(N, K) bytes
+ * owned by the caller, PERSISTENT and ZERO-FILLED ONCE, one call at a time: per point the <= K indices of the points within
+ * threshold + skin of it when the lists were built, and its position then.  Every call checks on the device that no point
+ * has moved further than skin / 2 since (then no pair outside the lists can be closer than `threshold`); otherwise -- or
+ * when N, threshold, skin or K differ from the build's, or a list overflowed K -- the same launch sequence rebuilds the
+ * lists through the bucket table (`table`: as above, fnx_distance_table_bytes(N), cell = 2 threshold, 27 cells per point)
+ * and evaluates the loss on its way: no host decision, graph-capturable, always the exact pair set.
+ * 0 < skin <= threshold, 1 <= K <= 64.  The first 16 words of `state` (after 256-byte alignment) are counters a caller
+ * may read: valid, -, calls, rebuilds, points whose list overflowed at the last rebuild.  Same loss / grad contract. */
+size_t fnx_distance_verlet_bytes(int N, int K);
+int fnx_distance_loss_verlet(const float *xyz, int N, float threshold, float skin, char *table, char *state, int K,
+                             float *grad, float *loss_out, fnx_stream_t stream);
 
 /* Gradient mean + optimiser step of the particle positions in one launch (gm_dynamics.py:461-472 followed by
  * torch.optim.Adam.step with amsgrad = False, weight_decay = 0, maximize = False):
