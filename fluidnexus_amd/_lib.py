@@ -48,21 +48,37 @@ FNX_OPT_DEFAULT = -2147483648
 FNX_SORT_FULL, FNX_SORT_NARROW, FNX_SORT_COHERENT = 0, 1, 2
 
 
+class RasterDual(C.Structure):
+    """fnx_raster_dual_t (include/fnx_raster.h): the second, single-channel image of a dual-mode view batch."""
+    _fields_ = [("image_buffers1", c_void_p), ("background1", c_void_p), ("out_color1", c_void_p),
+                ("out_depth1", c_void_p), ("dL_dpix1", c_void_p)]
+
+
 class RasterOpts(C.Structure):
     """fnx_raster_opts_t (include/fnx_raster.h): the options of ONE call."""
     _fields_ = [("size", C.c_uint32), ("blend_math", C.c_int32), ("lean_geometry", C.c_int32), ("sort_mode", C.c_int32),
                 ("deep_kernel", C.c_int32), ("grad_splat_limit", C.c_int32), ("deep_threshold", C.c_uint32),
-                ("reserved0", C.c_uint32), ("zero3", c_void_p), ("sort_state", c_void_p)]
+                ("reserved0", C.c_uint32), ("zero3", c_void_p), ("sort_state", c_void_p),
+                ("dual", C.POINTER(RasterDual))]
 
 
 def make_opts(blend_math=0, lean_geometry=0, sort_mode=FNX_SORT_FULL, deep_kernel=0, grad_splat_limit=-1,
-              deep_threshold=0, zero3=None, sort_state=None) -> RasterOpts:
+              deep_threshold=0, zero3=None, sort_state=None, dual=None) -> RasterOpts:
     o = RasterOpts()
     o.size = C.sizeof(RasterOpts)
     o.blend_math, o.lean_geometry, o.sort_mode, o.deep_kernel = int(blend_math), int(lean_geometry), int(sort_mode), int(deep_kernel)
     o.grad_splat_limit, o.deep_threshold = int(grad_splat_limit), int(deep_threshold)
     o.zero3, o.sort_state = zero3, sort_state
+    if dual is not None:  # a RasterDual the caller keeps alive for the duration of the call
+        o.dual = C.pointer(dual)
     return o
+
+
+def make_dual(image_buffers1, background1, out_color1=None, out_depth1=None, dL_dpix1=None) -> RasterDual:
+    d = RasterDual()
+    d.image_buffers1, d.background1, d.out_color1, d.out_depth1, d.dL_dpix1 = (image_buffers1, background1, out_color1,
+                                                                               out_depth1, dL_dpix1)
+    return d
 
 # every symbol include/fnx_raster.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -76,12 +92,12 @@ SYMBOLS = (
     "fnx_forward_stage2_views_split", "fnx_rasterize_backward_views_split", "fnx_binning_layout_split", "fnx_static_layout",
     "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
     "fnx_forward_stage1_views_split_opts", "fnx_forward_stage2_views_split_opts", "fnx_rasterize_backward_views_split_opts",
-    "fnx_sort_state_bytes", "fnx_sort_state_read", "fnx_sort_state_outliers",
+    "fnx_sort_state_bytes", "fnx_sort_state_read", "fnx_sort_state_outliers", "fnx_binning_bytes_dual",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
 # scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def raster_path() -> str:
@@ -147,6 +163,8 @@ def raster():
     lib.fnx_static_bytes.argtypes = [i, i, i, c_int64]
     lib.fnx_binning_bytes_split.restype = c_size_t
     lib.fnx_binning_bytes_split.argtypes = [c_int64, c_int64]
+    lib.fnx_binning_bytes_dual.restype = c_size_t
+    lib.fnx_binning_bytes_dual.argtypes = [c_int64, c_int64]
     lib.fnx_static_finalize_views.restype = i
     lib.fnx_static_finalize_views.argtypes = [i, p, p, p, i, i, i, i, c_int64, p, p, p]
     lib.fnx_forward_stage1_views_split.restype = i

@@ -214,6 +214,18 @@ inline void binning_layout(int64_t R, int64_t R_static, bool split, fnx_binning_
     o->total = off + kAlign;
 }
 
+// Dual mode (fnx_raster_dual_t): the second image's per-batch hand-over (transmittance + accumulated value, 8 bytes per
+// pixel) sits behind everything else, so the plain layouts above do not move.
+inline size_t binning_dual_offset(int64_t R, int64_t R_static, bool split) {
+    fnx_binning_layout_t L;
+    binning_layout(R, R_static, split, &L);
+    return L.total - kAlign;
+}
+inline size_t binning_dual_total(int64_t R, int64_t R_static, bool split) {
+    size_t r = (size_t)(R > 0 ? R : 0), rs = (size_t)(split && R_static > 0 ? R_static : 0);
+    return align_up(binning_dual_offset(R, R_static, split) + blend_state_slots(r + rs) * (kBlendStateBytes / 2)) + kAlign;
+}
+
 // Static splat set binned once (fnx_static_finalize_views): everything the per-iteration kernels need from it.
 inline void static_layout(int P_static, int W, int H, int64_t R_static, fnx_static_layout_t *o) {
     size_t p = (size_t)(P_static > 0 ? P_static : 0), r = (size_t)(R_static > 0 ? R_static : 0);
@@ -250,6 +262,19 @@ struct StaticRef {
     size_t starts, radii, rec, pairs;  // byte offsets inside a blob
 };
 enum { SHDR_NUM_RENDERED = 0, SHDR_P = 1, SHDR_ID0 = 2 };
+
+// Dual mode of the blend kernels (fnx_raster_dual_t, round 5): a SECOND, single-channel image over the per-call splats
+// only (ids below the gradient limit), blended -- and differentiated -- in the same pass over the same lists as the first.
+// img1 == nullptr: off.  The second image's per-pixel arrays live in image blobs of their own (same layout and stride as
+// the first image's), its value per splat is channel 0 of the splat's colour.
+struct DualRef {
+    char *img1;                            // aligned start of view 0's second image blob (stride: ViewBatch::img)
+    size_t final_T, n_contrib, acc_final;  // byte offsets inside an image blob
+    const float *bg1;                      // [1] background of the second image
+    float *out_color1, *out_depth1;        // forward outputs [V,1,H,W]
+    const float *dL_dpix1;                 // backward input [V,1,H,W]
+    size_t bin_bstate1;                    // byte offset of the second image's per-batch state inside a binning blob
+};
 
 // header words inside the image blob
 // HDR_BIN_CAPACITY: the binning capacity stage 2 ran with (the binning blob's layout depends on it): the backward pass

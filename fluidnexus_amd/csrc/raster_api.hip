@@ -47,7 +47,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit, const InvUpdate &iu);
+                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -56,7 +56,7 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            const uint32_t *header, uint32_t capacity, uint32_t grad_limit, int V, const ViewBatch &vb,
                            const StaticRef &st, const float *means3D, const float *cov3Ds, size_t cov3D_stride,
                            const float *viewmatrix, const float *projmatrix, float *dL_dmean3D, int fast,
-                           uint32_t *status_out);
+                           uint32_t *status_out, const DualRef &du);
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,
                           const float *shs, const uint8_t *clamped, const float *scales, const float *rotations,
                           float scale_modifier, const float *cov3Ds, size_t cov3D_stride, const float *view,
@@ -173,7 +173,7 @@ bool channels_ok(int c) { return c == 1 || c == 3; }
 // Strides and intrinsics of a batch of V views (focal lengths as rasterizer_impl.cu:207-208).
 // P = splats this call preprocesses; with a static set (P_static > 0 and `split`) the binning blobs use the split layout
 int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *tan_fovx, const float *tan_fovy,
-                    fnx::ViewBatch *vb, bool split = false, int P_static = 0, int64_t R_static = 0) {
+                    fnx::ViewBatch *vb, bool split = false, int P_static = 0, int64_t R_static = 0, bool dual = false) {
     if (V < 1 || V > fnx::kMaxViews) return fail(FNX_ERR_INVALID_ARG, "V must be in [1, %d] (got %d)", fnx::kMaxViews, V);
     if (!tan_fovx || !tan_fovy) return fail(FNX_ERR_INVALID_ARG, "tan_fovx / tan_fovy is NULL");
     memset(vb, 0, sizeof(*vb));
@@ -181,7 +181,7 @@ int make_view_batch(int V, int P, int W, int H, int64_t capacity, const float *t
     vb->img = fnx_image_bytes(W, H);
     fnx_binning_layout_t BL;
     fnx::binning_layout(capacity, R_static, split, &BL);
-    vb->bin = BL.total;
+    vb->bin = dual ? fnx::binning_dual_total(capacity, R_static, split) : BL.total;
     vb->bin_pairs = BL.pairs;
     vb->bin_bstate = BL.bstate;
     vb->bin_items = BL.bwd_items;
@@ -215,6 +215,29 @@ int make_static_ref(const char *static_blobs, int P_dyn, int P_static, int W, in
     return FNX_OK;
 }
 
+// Dual mode (fnx_raster_dual_t): the kernels' view of it; `d` == NULL: off (every field zero)
+int make_dual_ref(const fnx_raster_dual_t *d, int channels, bool split, int width, int height, int64_t capacity,
+                  int64_t R_static, bool backward, fnx::DualRef *du) {
+    memset(du, 0, sizeof(*du));
+    if (!d) return FNX_OK;
+    if (channels != 3 || !split)
+        return fail(FNX_ERR_INVALID_ARG, "fnx_raster_dual_t needs channels = 3 and a static-split view batch");
+    if (!d->image_buffers1 || !d->background1 || (backward ? !d->dL_dpix1 : (!d->out_color1 || !d->out_depth1)))
+        return fail(FNX_ERR_INVALID_ARG, "fnx_raster_dual_t: a required pointer is NULL");
+    fnx_image_layout_t L;
+    fnx::image_layout(width, height, &L);
+    du->img1 = aligned(d->image_buffers1);
+    du->final_T = L.final_T;
+    du->n_contrib = L.n_contrib;
+    du->acc_final = L.acc_final;
+    du->bg1 = d->background1;
+    du->out_color1 = d->out_color1;
+    du->out_depth1 = d->out_depth1;
+    du->dL_dpix1 = d->dL_dpix1;
+    du->bin_bstate1 = fnx::binning_dual_offset(capacity, R_static, true);
+    return FNX_OK;
+}
+
 // Optional in-library kernel timing (bench.py roofline): HIP events recorded on the caller's
 // stream around one kernel class; elapsed times are summed when read.
 constexpr int kProfClasses = 7;  // 0 blend_forward, 1 blend_backward, 2 sort + counts + scans, 3 preprocess, 4 emit (5, 6: blend forward / backward of the 1-channel rasteriser)
@@ -242,6 +265,7 @@ struct Opts {
     uint32_t deep_min;
     float *zero3;
     char *sort_state;
+    const fnx_raster_dual_t *dual;
 };
 int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pending_limit, Opts *out) {
     out->blend_math = g_blend_math;
@@ -252,6 +276,7 @@ int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pend
     out->deep_min = g_deep_min;
     out->zero3 = pending_zero3;
     out->sort_state = nullptr;
+    out->dual = nullptr;
     if (!o) return FNX_OK;
     if (o->size != sizeof(fnx_raster_opts_t))
         return fail(FNX_ERR_INVALID_ARG, "fnx_raster_opts_t.size is %u, this library's is %u (ABI %d)", o->size,
@@ -266,6 +291,7 @@ int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pend
     if (o->deep_threshold) out->deep_min = o->deep_threshold;
     out->zero3 = o->zero3;
     out->sort_state = o->sort_state;
+    out->dual = o->dual;
     if (out->blend_math != 0 && out->blend_math != 1) return fail(FNX_ERR_INVALID_ARG, "blend_math must be 0 (exact) or 1 (fast)");
     if (out->sort_mode < FNX_SORT_FULL || out->sort_mode > FNX_SORT_COHERENT) return fail(FNX_ERR_INVALID_ARG, "bad sort_mode");
     if (out->sort_mode == FNX_SORT_COHERENT && !out->sort_state)
@@ -323,6 +349,9 @@ size_t fnx_binning_bytes_split(int64_t capacity, int64_t R_static_capacity) {
     fnx_binning_layout_t L;
     fnx::binning_layout(capacity, R_static_capacity, true, &L);
     return L.total;
+}
+size_t fnx_binning_bytes_dual(int64_t capacity, int64_t R_static_capacity) {
+    return fnx::binning_dual_total(capacity, R_static_capacity, true);
 }
 size_t fnx_static_bytes(int P_static, int W, int H, int64_t R_static_capacity) {
     fnx_static_layout_t L;
@@ -516,8 +545,14 @@ int fnx_forward_stage2_views_split_opts(int channels, int V, char *geom_buffer, 
     if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
     const float unused[fnx::kMaxViews] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (int rc = make_view_batch(V, P, width, height, binning_capacity, unused, unused, &vb, st.base != nullptr, P_static,
-                                 R_static_capacity))
+                                 R_static_capacity, op.dual != nullptr))
         return rc;
+    fnx::DualRef du;
+    if (int rc = make_dual_ref(op.dual, channels, st.base != nullptr, width, height, binning_capacity, R_static_capacity,
+                               false, &du))
+        return rc;
+    if (du.img1 && op.grad_limit != 0xFFFFFFFFu && op.grad_limit != (uint32_t)P)
+        return fail(FNX_ERR_INVALID_ARG, "fnx_raster_dual_t: grad_splat_limit must be P_dyn (the second image is the per-call splats')");
     hipStream_t s = (hipStream_t)stream;
     Geom g = carve_geom(geom_buffer, P, width, height);
     Img img = carve_img(image_buffer, width, height);
@@ -545,7 +580,7 @@ int fnx_forward_stage2_views_split_opts(int channels, int V, char *geom_buffer, 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb, op.blend_math, op.deep_kernel, op.grad_limit, iu);
+                                  st, materialize_all, V, vb, op.blend_math, op.deep_kernel, op.grad_limit, iu, du);
     }
     return hip_check("stage2");
 }
@@ -673,8 +708,14 @@ int fnx_rasterize_backward_views_split_opts(int channels, int V, int P, int D, i
     fnx::StaticRef st;
     if (int rc = make_static_ref(static_blobs, P, P_static, width, height, R_static_capacity, &st)) return rc;
     if (int rc = make_view_batch(V, P, width, height, binning_capacity, tan_fovx, tan_fovy, &vb, st.base != nullptr,
-                                 P_static, R_static_capacity))
+                                 P_static, R_static_capacity, op.dual != nullptr))
         return rc;
+    fnx::DualRef du;
+    if (int rc = make_dual_ref(op.dual, channels, st.base != nullptr, width, height, binning_capacity, R_static_capacity,
+                               true, &du))
+        return rc;
+    if (du.img1 && !positions_only)
+        return fail(FNX_ERR_INVALID_ARG, "fnx_raster_dual_t: the backward supports geometry_only = 3 (positions only)");
     if ((V > 1 || st.base) && !radii) return fail(FNX_ERR_INVALID_ARG, "radii [V,P] is required for V > 1");
     // static splats take no gradients: the limit stays within the per-call splats; the gradient arrays span all splats
     const int limit = (grad_splat_limit < 0 || grad_splat_limit > P) ? P : grad_splat_limit;
@@ -695,7 +736,7 @@ int fnx_rasterize_backward_views_split_opts(int channels, int V, int P, int D, i
                                    dL_dmean2D, dL_dconic, dL_dopacity_views, dL_dcolor_views, img.header,
                                    (uint32_t)binning_capacity,
                                    (uint32_t)limit, V, vb, st, means3D, cov3D_ptr, cov3D_stride, viewmatrix, projmatrix,
-                                   dL_dmean3D, op.blend_math, status_out);
+                                   dL_dmean3D, op.blend_math, status_out, du);
     }
     if (positions_only) return hip_check("backward");  // the blend backward's flush went through the geometry itself
     const int sum_appearance = (V > 1 && geometry_only != 1) ? 1 : 0;

@@ -115,7 +115,12 @@ __device__ inline void geom_backward_view(const float3 mean, const float *cov3D,
 // FAST: the arithmetic of the forward's fast mode (blend_forward_kernel: pre-scaled coefficients, log2(o) in the
 // exponent, one v_exp_f32), so that both passes see the same alphas; the per-entry sums of four consecutive entries are
 // folded together, one moment at a time (five 4-value folds per four entries instead of four 4 + 1 folds).
-template <int C, int MODE, bool FAST>
+// DUAL (fnx_raster_dual_t; C = 3, MODE 3): the forward blended a second, single-channel image over the dynamic entries in
+// the same pass (blend_forward_kernel); its loss gradient dL/dpixel1 enters every dynamic entry's dL/dalpha through the
+// second image's own transmittance / "what lies behind" recurrences, evaluated in the same walk on the same alphas:
+//     dL/dalpha_i = [first image's term] + [T1_i (c0_i dL1) - rest1_i / (1 - alpha_i)]   (dynamic entries in front of the
+//     second image's last contributor), and the moments / flush carry the sum.
+template <int C, int MODE, bool FAST, bool DUAL = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWD_WAVES, FNX_BWD_WAVES)))
 blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                       int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
@@ -126,7 +131,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                       uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb,
                       const float *__restrict__ means3D, const float *__restrict__ cov3Ds, size_t cov3D_stride,
                       const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
-                      float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out) {
+                      float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out, const DualRef du) {
+    static_assert(!DUAL || (C == 3 && MODE == 3), "dual mode: 3 channels, positions-only backward");
+    constexpr uint32_t kListStatic = 0x8000u, kListOffMask = 0x1FFFu;  // as in the forward's lists
     constexpr bool kMeans = MODE != 2, kAppearance = MODE == 0 || MODE == 2, kFusedGeom = MODE == 3;
     constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums
     constexpr int NV = kAppearance ? kCol + C : kOpac;
@@ -151,6 +158,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ uint16_t s_mask[256];
     __shared__ __attribute__((aligned(16))) uint32_t s_max[16];
     __shared__ uint32_t s_first[kMaxViews + 1];  // ticket of every view's first work item; [n_views] = all items
+    __shared__ unsigned long long s_dynmask[DUAL ? 4 : 1];  // DUAL: per staging wave, which slots hold dynamic entries
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
@@ -173,7 +181,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             // depends on it), contributes nothing; the mismatch is left in the view's status word (fnx_read_status)
             // ... or whose forward laid the work items and walking limits down for a SMALLER gradient limit than this call's
             // (fnx_request_gradient_limit; HDR_DYN_LIMIT): splats this call differentiates would be cut off
-            const bool cut = grad_limit > h[HDR_DYN_LIMIT];
+            // (dual mode: the second image was blended over ids < HDR_DYN_LIMIT; this call must differentiate exactly those)
+            const bool cut = grad_limit > h[HDR_DYN_LIMIT] || (DUAL && grad_limit != h[HDR_DYN_LIMIT]);
             const bool mismatch = h[HDR_BIN_CAPACITY] != capacity || cut;
             if (mismatch && blockIdx.x == 0) {
                 const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
@@ -294,6 +303,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         uint32_t last_contributor;
         float dL[C], total[C];
         float4 stt;
+        float T_final1, dL1, total1;  // DUAL: the second image's pixel
+        uint32_t last1;
+        float2 stt1;
     } ahead;
     ahead.valid = false;
 #ifdef FNX_EXP_BCLK
@@ -369,6 +381,29 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             }
             if (b) stt = bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];  // state in front of the batch, as the forward left it
         }
+        // DUAL: the second image's pixel (final T, last contributor, dL/dpixel, accumulated value, state in front of the batch)
+        float T_final1 = 0.f, dL1 = 0.f, total1 = 0.f;
+        uint32_t last1 = 0;
+        float2 stt1 = make_float2(1.f, 0.f);
+        if (DUAL) {
+            if (ahead.valid) {
+                T_final1 = ahead.T_final1;
+                dL1 = ahead.dL1;
+                total1 = ahead.total1;
+                last1 = ahead.last1;
+                stt1 = ahead.stt1;
+            } else {
+                const char *i1 = du.img1 + vb.img * (size_t)vw;
+                T_final1 = inside ? reinterpret_cast<const float *>(i1 + du.final_T)[pix_id] : 0.f;
+                last1 = inside ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[pix_id] : 0u;
+                dL1 = inside ? du.dL_dpix1[(size_t)vw * H * W + pix_id] : 0.f;
+                total1 = inside ? reinterpret_cast<const float *>(i1 + du.acc_final)[pix_id] : 0.f;
+                if (b) stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(point_list_v) + du.bin_bstate1)[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
+            }
+        }
+        float Tr1 = b ? stt1.x : 1.0f;
+        // what lies behind the entry, second image: (total1 - prefix1) dL1 + its background's share
+        float rest1 = DUAL ? (total1 * dL1 - (b ? stt1.y : 0.f) * dL1) + T_final1 * du.bg1[0] * dL1 : 0.f;
         float bg_dot_dpixel = 0.f, total_dot = 0.f;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) {
@@ -394,7 +429,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 
         // entry q (0-based from the front) is used by a pixel iff q < its n_contrib_v (backward.cu:467-469):
         // a block needs nothing behind its own max, the batch nothing behind the max of the tile's blocks
-        uint32_t m = last_contributor;
+        uint32_t m = DUAL ? max(last_contributor, last1) : last_contributor;
         for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
         if ((lane & 15) == 0) s_max[4 * w + row] = m;
         FNX_BCLK(1)  // item head: pixel inputs, block maxima
@@ -418,6 +453,10 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         const uint32_t cnt = min(256u, qmax - min(qmax, q0));
 
         // stage entries q = q0 + t (slot t), zero the slot accumulators
+        if (DUAL) {  // which staged entries are dynamic (= take gradients: the forward's limit equals this call's)
+            const unsigned long long dm = __ballot((uint32_t)tid < cnt && cur.id < grad_limit);
+            if (lane == 0) s_dynmask[DUAL ? w : 0] = dm;
+        }
         uint32_t qm = 0;
         if ((uint32_t)tid < cnt) {
             const uint32_t q = q0 + tid;  // cnt <= r1 - r0 - q0: the entry was fetched
@@ -458,11 +497,12 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
+            const uint32_t flag = (DUAL && !((s_dynmask[DUAL ? k : 0] >> lane) & 1ull)) ? kListStatic : 0u;
 #pragma unroll
             for (int bb = 0; bb < 4; bb++) {
                 const bool bit = (mk >> bb) & 1u;
                 const unsigned long long bm = __ballot(bit);
-                if (bit) s_list[4 * w + bb][len[bb] + (uint32_t)__popcll(bm & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
+                if (bit) s_list[4 * w + bb][len[bb] + (uint32_t)__popcll(bm & lt_mask)] = (uint16_t)(((64 * k + lane) * 16) | flag);
                 len[bb] += (uint32_t)__popcll(bm);
             }
         }
@@ -472,6 +512,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         FNX_BCLK(5)  // list build
         // entry q0 + slot lies in front of the pixel's last contributor <=> its LDS offset (16 slot) is below this bound
         const uint32_t lim_off = last_contributor > q0 ? min(last_contributor - q0, 4096u) << 4 : 0u;
+        const uint32_t lim_off1 = (DUAL && last1 > q0) ? min(last1 - q0, 4096u) << 4 : 0u;
         // Straight-line steps of kGroup entries (all LDS reads of a step issued together, no lane predicates): an entry
         // the pixel does not take has alpha = 0, which leaves T and the colour prefix exactly as they are (x * 1, + 0)
         // and zeroes every gradient term; the NULL record behind a list's end is such an entry for every pixel.
@@ -497,7 +538,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 float2 rc[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                     ra[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
                     rb[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
                     rc[k] = C == 3 ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(s_rc) + off)
@@ -505,13 +546,15 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const uint32_t raw = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const uint32_t off = raw & (DUAL ? kListOffMask : 0xFFFFu);
                     const float dx = ra[k].x - pxf, dy = ra[k].y - pyf;
                     const float u = __builtin_fmaf(ra[k].z, dx, ra[k].w * dy);
                     const float q = __builtin_fmaf(u, dx, (rb[k].x * dy) * dy);  // log2(e) * power
                     const float e = __builtin_amdgcn_exp2f(q + rb[k].y);         // o G
                     const float alpha = fminf(0.99f, e);
-                    const bool active = !(q > 0.0f) && !(alpha < 1.0f / 255.0f) && (off < lim_off);
+                    const bool hit = !(q > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    const bool active = hit && (off < lim_off);
                     const bool emits = active && (C == 3 ? rc[k].y : rb[k].w) != 0.0f;
                     const float a = active ? alpha : 0.0f;
                     const float one_m = 1 - a;
@@ -523,9 +566,23 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                     const float aT = a * Tb;
                     rest = __builtin_fmaf(-aT, c_dot, rest);
                     Tr = Tb * one_m;
-                    const float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
+                    float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
+                    if (DUAL) dL_dalpha = emits ? dL_dalpha : 0.0f;  // (the second image may emit where the first does not)
+                    bool emits1 = false;
+                    if (DUAL) {  // the second image's share: dynamic entries in front of ITS last contributor
+                        const bool active1 = hit && !(raw & kListStatic) && (off < lim_off1);
+                        const float a1 = active1 ? alpha : 0.0f;
+                        // (1 - alpha) is the same number in both images wherever both take the entry
+                        const float inv1 = active1 ? (active ? inv_1ma : __builtin_amdgcn_rcpf(1 - a1)) : 1.0f;
+                        const float Tb1 = Tr1, c_dot1 = rb[k].z * dL1;
+                        rest1 = __builtin_fmaf(-(a1 * Tb1), c_dot1, rest1);
+                        Tr1 = Tb1 * (1 - a1);
+                        const float dL_dalpha1 = __builtin_fmaf(Tb1, c_dot1, -(rest1 * inv1));
+                        emits1 = active1;  // a dynamic entry takes gradients (the forward's limit equals this call's)
+                        dL_dalpha += emits1 ? dL_dalpha1 : 0.0f;
+                    }
                     // G dL/dG = G o dL/dalpha = (o G) dL/dalpha: the clamp at 0.99 has no mask in the reference (A.10)
-                    const float wgt = (emits ? e : 0.0f) * dL_dalpha;
+                    const float wgt = ((emits || emits1) ? e : 0.0f) * dL_dalpha;
                     if constexpr (kLazy) {
                         w_[k] = wgt;
                         dx_[k] = dx;
@@ -547,13 +604,13 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                             for (int ch = 0; ch < C; ch++) valA[kAppearance && kCol + ch < kBlockA ? kCol + ch : 0][k] = dchannel_dcolor * dL_dpixel[ch];
                         }
                     }
-                    any_emit |= emits;
+                    any_emit |= emits || emits1;
                 }
                 if (FNX_ABLATE != 2 && __ballot(any_emit) != 0ull) {
                     // this quad's target: the slot of entry vq of the step (row-uniform), the NULL slot's sums are dropped
                     const uint32_t o01 = jw[0], o23 = jw[1];
                     const uint32_t osel = (vq & 2) ? o23 : o01;
-                    const uint32_t slot = ((osel >> (16 * (vq & 1))) & 0xFFFFu) >> 4;
+                    const uint32_t slot = ((osel >> (16 * (vq & 1))) & (DUAL ? kListOffMask : 0xFFFFu)) >> 4;
                     const int kq = lane & 3;
                     // value v of entry k: [w dx, w dy,] w dx dx, w dx dy, w dy dy [, w (the flush divides by o), alpha T dL_ch]
                     auto value = [&](int v, int k) -> float {
@@ -615,20 +672,22 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
             float4 ra[kGroup], rb[kGroup], rc[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                 ra[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
                 rb[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
                 rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
             }
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, slot = off >> 4;
+                const uint32_t raw = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t off = raw & (DUAL ? kListOffMask : 0xFFFFu), slot = off >> 4;
                 const float dx = ra[k].x - pxf, dy = ra[k].y - pyf;
                 const float power = -0.5f * (ra[k].z * dx * dx + rb[k].x * dy * dy) - ra[k].w * dx * dy;
                 const float G = exp_fixed_in_range(fmaxf(power, -87.0f));
                 const float alpha = fminf(0.99f, rb[k].y * G);
                 // the forward's decision (blend_forward_kernel), for the entries in front of the pixel's last contributor
-                const bool active = !(power > 0.0f) && !(alpha < 1.0f / 255.0f) && (off < lim_off);
+                const bool hit = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const bool active = hit && (off < lim_off);
                 const bool wants = rb[k].w != 0.0f;  // uniform within a row
                 const float a = active ? alpha : 0.0f;
                 // one hardware reciprocal (<= 1 ulp) serves both divisions by (1 - alpha) of backward.cu:482,510;
@@ -643,10 +702,21 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 rest = __builtin_fmaf(-(a * Tb), c_dot, rest);
                 Tr = Tb * one_m;  // the forward's test_T
                 const float dL_dalpha = __builtin_fmaf(Tb, c_dot, -(rest * inv_1ma));
-                const bool emits = active && wants;
-                const float dL_da = emits ? dL_dalpha : 0.0f;
+                bool emits = active && wants;
+                float dL_da = emits ? dL_dalpha : 0.0f;
+                bool active1 = false;
+                if (DUAL) {  // the second image's share (see the fast walk)
+                    active1 = hit && !(raw & kListStatic) && (off < lim_off1);
+                    const float a1 = active1 ? alpha : 0.0f;
+                    const float inv1 = active1 ? (active ? inv_1ma : __builtin_amdgcn_rcpf(1 - a1)) : 1.0f;
+                    const float Tb1 = Tr1, c_dot1 = col[0] * dL1;
+                    rest1 = __builtin_fmaf(-(a1 * Tb1), c_dot1, rest1);
+                    Tr1 = Tb1 * (1 - a1);
+                    dL_da += active1 ? __builtin_fmaf(Tb1, c_dot1, -(rest1 * inv1)) : 0.0f;
+                    emits = emits || active1;
+                }
                 const float dL_dG = rb[k].y * dL_da;
-                const float Gm = active ? G : 0.0f;  // power > 0 can push the range-limited exp out of range: never into a sum
+                const float Gm = (active || active1) ? G : 0.0f;  // power > 0 can push the range-limited exp out of range: never into a sum
                 // Per (pixel, entry) only the weighted moments of the offset are formed: w = G dL/dG,
                 // (w dx, w dy, w dx^2, w dx dy, w dy^2).  The entry's own constants -- its conic in dG/d(mean), the
                 // -1/2 of the conic gradients, the pixel scale -- multiply the SUMS once per entry when they are flushed.
@@ -703,6 +773,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 const float4 *nbs = reinterpret_cast<const float4 *>(
                     reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
                 ahead.stt = nbs[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
+            }
+            if (DUAL) {
+                const char *i1 = du.img1 + vb.img * (size_t)nv;
+                ahead.T_final1 = nin ? reinterpret_cast<const float *>(i1 + du.final_T)[npix] : 0.f;
+                ahead.last1 = nin ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[npix] : 0u;
+                ahead.dL1 = nin ? du.dL_dpix1[(size_t)nv * H * W + npix] : 0.f;
+                ahead.total1 = nin ? reinterpret_cast<const float *>(i1 + du.acc_final)[npix] : 0.f;
+                ahead.stt1 = make_float2(1.f, 0.f);
+                if (nb_)
+                    ahead.stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) +
+                                                                  du.bin_bstate1)[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
             }
         }
         // positions-only mode: the flush needs the splat's mean and world covariance; requested here, in front of the
@@ -797,6 +878,9 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                      "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                      "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                      "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nx2.item));
+        if (DUAL)
+            asm volatile("" ::"v"(ahead.T_final1), "v"(ahead.last1), "v"(ahead.dL1), "v"(ahead.total1), "v"(ahead.stt1.x),
+                         "v"(ahead.stt1.y));
         if (do_flush) {
             if (kFusedGeom) {
 #pragma unroll
@@ -1138,16 +1222,16 @@ geom_backward_kernel(int P, int D, int M, const float *__restrict__ means3D, con
 // ---------------------------------------------------------------------------------------------
 // The grid is exactly the workgroups that are resident at a time (the occupancy query: 4 per compute unit at the current register count): a larger grid
 // would run its surplus as a second, half-empty round.
-template <int C, int MODE, bool FAST, typename... A>
+template <int C, int MODE, bool FAST, bool DUAL = false, typename... A>
 static void launch_blend_backward_tf(int n_cu, hipStream_t s, A... args) {
     static int cache[kMaxDevices];  // resident workgroups per compute unit of THIS kernel variant, per device
     static std::mutex mu;
     const int per_cu = per_device_cached(cache, mu, [](int) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_kernel<C, MODE, FAST>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_kernel<C, MODE, FAST, DUAL>, 256, 0) != hipSuccess || n <= 0) n = 4;
         return n;
     });
-    hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+    hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST, DUAL>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
 }
 template <int C, int MODE, typename... A>
 static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, A... args) {
@@ -1162,18 +1246,23 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
                            float *dL_dopacity, float *dL_dcolors, const uint32_t *header, uint32_t capacity,
                            uint32_t grad_limit, int V, const ViewBatch &vb, const StaticRef &st, const float *means3D,
                            const float *cov3Ds, size_t cov3D_stride, const float *viewmatrix, const float *projmatrix,
-                           float *dL_dmean3D, int fast, uint32_t *status_out) {
+                           float *dL_dmean3D, int fast, uint32_t *status_out, const DualRef &du) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
     const int n_cu = device_cu_count();
-    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
-    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    if (du.img1) {  // dual mode (the caller has checked: 3 channels, positions only)
+        if (fast) launch_blend_backward_tf<3, 3, true, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+        else launch_blend_backward_tf<3, 3, false, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+        return;
+    }
+    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,

@@ -365,24 +365,33 @@ __device__ __forceinline__ float fast_alpha(const float4 ra, const float4 rb, fl
 
 // Full walk: `alive` is the WORKING transmittance (T while the pixel blends, 0 once it has stopped or if it lies
 // outside the image), Tr the pixel's transmittance, acc its colour, hit_off the LDS offset of the last entry taken.
-template <int C>
+// DUAL (fnx_raster_dual_t): a second, single-channel image over the DYNAMIC entries only, blended in the same walk.  A list
+// entry of a static splat carries bit 15 (kListStatic) on top of its LDS byte offset; for the second image such an entry
+// has alpha 0, everything else -- the entry's alpha, the order, the stop rule -- is the first image's arithmetic on the
+// second image's own transmittance, so its pixels equal a 1-channel render of the dynamic splats alone.
+constexpr uint32_t kListStatic = 0x8000u, kListOffMask = 0x1FFFu;
+struct DualPixel {
+    float acc, Tr, alive, Dm;
+    uint32_t hit_off;
+};
+template <int C, bool DUAL = false>
 __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
                                           const float4 *s_rc, float pxf, float pyf, float (&acc)[C], float &Tr,
-                                          float &alive, float &Dm, uint32_t &hit_off) {
+                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du = nullptr) {
     constexpr int kGroup = 4;
     // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
     // walk, and if T crosses 1/2 here the entry that took it across is mylist[n_half] (forward.cu:351-354)
-    uint32_t n_half = 0;
-    const float T_in = Tr;
+    uint32_t n_half = 0, n_half1 = 0;
+    const float T_in = Tr, T1_in = DUAL ? du->Tr : 0.f;
     for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
-        if (__all(alive == 0.0f)) break;
+        if (__all(alive == 0.0f && (!DUAL || du->alive == 0.0f))) break;
         uint32_t jw[kGroup / 2];
 #pragma unroll
         for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
         float a_h[kGroup], col[kGroup][3];
 #pragma unroll
         for (int k = 0; k < kGroup; k++) {
-            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
             const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
             const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
             col[k][0] = rb.z;
@@ -390,9 +399,25 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
             col[k][2] = C == 3 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off) : 0.f;
             a_h[k] = fast_alpha<C>(ra, rb, pxf, pyf);
         }
+        if (DUAL) {
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t raw = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, off = raw & kListOffMask;
+                const float a1 = (raw & kListStatic) ? 0.0f : a_h[k];
+                const float wq = a1 * du->alive;
+                const float t = du->alive - wq;
+                const bool stop = t < 0.0001f;
+                const float wgt = stop ? 0.0f : wq;
+                du->acc = __builtin_fmaf(col[k][0], wgt, du->acc);
+                du->Tr = stop ? du->Tr : t;
+                du->alive = stop ? 0.0f : t;
+                n_half1 += (du->Tr >= 0.5f) ? 1u : 0u;
+                du->hit_off = (wgt > 0.0f) ? off : du->hit_off;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kGroup; k++) {
-            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
             const float wq = a_h[k] * alive;      // alpha T (0 for a stopped pixel: its working T is 0)
             const float t = alive - wq;           // test_T
             const bool stop = t < 0.0001f;        // also true for every entry behind the one that stopped the pixel
@@ -407,9 +432,14 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
         }
     }
     if (T_in >= 0.5f && Tr < 0.5f) {
-        const uint32_t off = mylist[n_half];
+        const uint32_t off = mylist[n_half] & (DUAL ? kListOffMask : 0xFFFFu);
         Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
                     : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
+    }
+    if (DUAL && T1_in >= 0.5f && du->Tr < 0.5f) {
+        const uint32_t off = mylist[n_half1] & kListOffMask;
+        du->Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
+                        : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
     }
 }
 
@@ -614,7 +644,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 // sequence; T is updated as T - alpha T, the median depth is found from a per-batch count instead of per entry.
 // ~30 instead of ~54-65 VALU instructions per entry.  Pixels agree with the exact mode to ~1e-6 except where a rounding
 // moves an alpha across 1/255 or a T across 1e-4 (tests/test_fast_math_gpu.py states and checks the tolerance).
-template <int C, bool SPLIT, bool FAST>
+template <int C, bool SPLIT, bool FAST, bool DUAL = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
@@ -624,7 +654,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                      uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
-                     int skip_deep, uint32_t dyn_limit, const InvUpdate iu) {
+                     int skip_deep, uint32_t dyn_limit, const InvUpdate iu, const DualRef du) {
     const char *static_blob = nullptr;
     // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
     // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
@@ -665,6 +695,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             static_blob = st.base + st.stride * vw;
         }
     }
+    // DUAL: the second image's per-pixel arrays (an image blob of its own per view, same layout and stride)
+    char *img1 = DUAL ? du.img1 + vb.img * (size_t)wg_view : nullptr;
 #ifndef FNX_FWD_GROUP
 #define FNX_FWD_GROUP 4
 #endif
@@ -736,6 +768,13 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
     float Dm = 15.0f;  // median depth default (ch3 forward.cu:295)
+    DualPixel d1;  // DUAL: the second image's pixel (same conventions as alive / Tr / acc / Dm above)
+    d1.acc = 0.f;
+    d1.Tr = 1.0f;
+    d1.alive = inside ? 1.0f : 0.0f;
+    d1.Dm = 15.0f;
+    d1.hit_off = 0xFFFFFFFFu;
+    uint32_t last_contributor1 = 0;
     // Software pipeline over batches: the records of batch b+1 (and the list ids of batch b+2) are
     // requested from memory before batch b is blended, so only the first batch pays the two
     // dependent global-memory latencies (id -> record) on the tile's critical path.
@@ -822,6 +861,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     // forward -> backward hand-over (fnx_state.h, kBlendBatch): per-pixel state in front of every batch after the first
     float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
                      (size_t)(r0 >> 8) * 256 + tid;
+    float2 *bstate1 = DUAL ? reinterpret_cast<float2 *>(reinterpret_cast<char *>(point_list) + du.bin_bstate1) +
+                                 (size_t)(r0 >> 8) * 256 + tid : nullptr;
 #ifdef FNX_EXP_CLOCK
     const unsigned long long wg_t0 = wall_clock64();
     unsigned long long t_last = clock64();
@@ -835,7 +876,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         // each wave leaves its own answer in LDS before the barrier.  LDS-only barriers in this loop (lds_barrier): a
         // plain __syncthreads() also drains the wave's global stores (bstate, masks, point_list) and record prefetches,
         // an L2 round trip on the critical path of every batch, although no wave reads another's global data here.
-        const uint32_t wave_done = __all(alive == 0.0f) ? 1u : 0u;  // a vote of all 64 lanes: taken outside the branch
+        const uint32_t wave_done = __all(alive == 0.0f && (!DUAL || d1.alive == 0.0f)) ? 1u : 0u;  // a vote of all 64 lanes: taken outside the branch
         if (lane == 0) s_done[w] = wave_done;
         FNX_LOOP_BARRIER();
         const bool all_done = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
@@ -844,8 +885,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
-        if (blending && base != r0)
+        if (blending && base != r0) {
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
+            if (DUAL) bstate1[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float2(d1.Tr, d1.acc);
+        }
         const uint32_t cnt = min(256u, r1 - base);
         if (blending) staged += cnt;
         uint32_t qm = 0;
@@ -898,15 +941,17 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
         // a block whose 16 pixels have all stopped gets an empty list: the wave's step count is its longest list, and a
         // finished block must not be the one that keeps it walking
-        const unsigned long long live = __ballot(alive != 0.0f);
+        const unsigned long long live = __ballot(alive != 0.0f || (DUAL && d1.alive != 0.0f));
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
+            // DUAL: a static splat's entry is marked in its list word (staging wave k left the batch's dynamic flags)
+            const uint32_t flag = (DUAL && !((s_dynmask[k] >> lane) & 1ull)) ? kListStatic : 0u;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const bool bit = ((mk >> b) & 1u) && ((live >> (16 * b)) & 0xFFFFull) != 0ull;
                 const unsigned long long m = __ballot(bit);
-                if (bit) s_list[4 * w + b][len[b] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
+                if (bit) s_list[4 * w + b][len[b] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(((64 * k + lane) * 16) | flag);
                 len[b] += (uint32_t)__popcll(m);
             }
         }
@@ -951,11 +996,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         if (wg_rank == 0 && wg_view == 0 && lane == 0) { g_fwd_clock[16 * w + 8] += n_w; g_fwd_clock[16 * w + 9] += 1; }
 #endif
         uint32_t hit_off = 0xFFFFFFFFu;  // LDS offset of the last entry of this batch the pixel took
+        d1.hit_off = 0xFFFFFFFFu;
         if (FAST) {
-            fast_walk<C>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off);
+            fast_walk<C, DUAL>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off, &d1);
         } else
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
-            if (__all(alive == 0.0f)) break;
+            if (__all(alive == 0.0f && (!DUAL || d1.alive == 0.0f))) break;
             uint32_t jw[kGroup / 2];  // the next kGroup entries of this lane's list
 #pragma unroll
             for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
@@ -963,7 +1009,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             float4 rc[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                 const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
                 const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
                 rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off);
@@ -992,9 +1038,24 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 }
             }
 #endif
+            if (DUAL) {  // the second image: the same entries, static ones with alpha 0, its own T and stop rule
+#pragma unroll
+                for (int k = 0; k < kGroup; k++) {
+                    const uint32_t raw = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, off = raw & kListOffMask;
+                    const float ae = ((raw & kListStatic) ? 0.0f : a_h[k]) * d1.alive;
+                    const float test_T = d1.Tr * (1 - ae);
+                    const bool stop = test_T < 0.0001f;
+                    const float a_eff = stop ? 0.0f : ae;
+                    d1.acc = d1.acc + rc[k].x * a_eff * d1.Tr;
+                    d1.Dm = (d1.Tr > 0.5f && test_T < 0.5f) ? rc[k].w : d1.Dm;
+                    d1.Tr = stop ? d1.Tr : test_T;
+                    d1.hit_off = (a_eff > 0.0f) ? off : d1.hit_off;
+                    d1.alive = stop ? 0.0f : d1.alive;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                 const float ae = a_h[k] * alive;
                 const float test_T = Tr * (1 - ae);
                 const bool stop = test_T < 0.0001f;
@@ -1023,6 +1084,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             }
             const uint32_t d_all = dyn_at_or_below(255u);  // workgroup-uniform
             if (d_all != 0xFFFFFFFFu) dyn_before = pos0 + d_all;
+            if (DUAL && d1.hit_off != 0xFFFFFFFFu) last_contributor1 = pos0 + (d1.hit_off >> 4);
         }
         FNX_CLK(3)
     }
@@ -1036,10 +1098,20 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             acc_final[(size_t)ch * H * W + pix_id] = acc[ch];
         }
         out_depth[pix_id] = Dm;
+        if (DUAL) {  // the second image: every contributor of its is a dynamic entry, so both halves of n_contrib agree
+            reinterpret_cast<float *>(img1 + du.final_T)[pix_id] = d1.Tr;
+            uint32_t *nc1 = reinterpret_cast<uint32_t *>(img1 + du.n_contrib);
+            nc1[pix_id] = last_contributor1;
+            nc1[(size_t)W * H + pix_id] = last_contributor1;
+            reinterpret_cast<float *>(img1 + du.acc_final)[pix_id] = d1.acc;
+            du.out_color1[(size_t)wg_view * H * W + pix_id] = d1.acc + d1.Tr * du.bg1[0];
+            du.out_depth1[(size_t)wg_view * H * W + pix_id] = d1.Dm;
+        }
     }
     // one backward work item per batch that holds a DYNAMIC entry in front of some pixel's last contributor (the batches
     // behind hold nothing a backward pass within the gradient limit needs); qmax: how deep the tile went
-    uint32_t m = last_contributor, md = last_dyn;
+    uint32_t m = DUAL ? max(last_contributor, last_contributor1) : last_contributor;
+    uint32_t md = DUAL ? max(last_dyn, last_contributor1) : last_dyn;  // DUAL: the backward walks as far as either image needs
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         m = max(m, (uint32_t)__shfl_xor((int)m, off));
@@ -1151,7 +1223,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit, const InvUpdate &iu) {
+                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // static splats never take gradients: in static-split mode the limit is at most the first static id
     if (st.base && dyn_limit > st.id0) dyn_limit = st.id0;
@@ -1159,7 +1231,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     // A deep workgroup holds a whole compute unit at modest utilisation to cut the tile's LATENCY, which pays when the
     // launch is bound by its longest walks -- few views per launch (a rank's share of a sharded batch) -- and costs
     // throughput when thousands of other tiles wait for those compute units: deep = 1 (auto) uses it up to two views.
-    const int use_deep = (fast && depth_hint && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
+    const int use_deep = (fast && depth_hint && !du.img1 && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
     // the two kernels touch disjoint tiles: the deep one runs on a helper stream beside the per-tile kernel
     // (one helper per caller stream and device: two renders on two streams -- the 3-channel and the 1-channel one of a
     // dual-channel iteration -- may be in flight, or being captured into two branches of a graph, at the same time)
@@ -1217,18 +1289,24 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
         FNX_LAUNCH_BF_(CC, SS, true);                                                                                  \
     else                                                                                                               \
         FNX_LAUNCH_BF_(CC, SS, false)
-#define FNX_LAUNCH_BF_(CC, SS, FF)                                                                                     \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,      \
+#define FNX_LAUNCH_BF_(CC, SS, FF) FNX_LAUNCH_BF__(CC, SS, FF, false)
+#define FNX_LAUNCH_BF__(CC, SS, FF, DD)                                                                                \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF, DD>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,  \
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       use_deep, dyn_limit, iu)
+                       use_deep, dyn_limit, iu, du)
+    if (du.img1) {  // dual mode: 3 channels + the single-channel image of the per-call splats, static-split lists
+        if (fast) { FNX_LAUNCH_BF__(3, true, true, true); }
+        else { FNX_LAUNCH_BF__(3, true, false, true); }
+    } else
     if (C == 3 && st.base) { FNX_LAUNCH_BF(3, true); }
     else if (C == 3) { FNX_LAUNCH_BF(3, false); }
     else if (st.base) { FNX_LAUNCH_BF(1, true); }
     else { FNX_LAUNCH_BF(1, false); }
 #undef FNX_LAUNCH_BF
 #undef FNX_LAUNCH_BF_
+#undef FNX_LAUNCH_BF__
     if (use_deep && sd != s) {  // join
         (void)hipEventRecord(ev_join, sd);
         (void)hipStreamWaitEvent(s, ev_join, 0);

@@ -142,6 +142,9 @@ _GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
 _SINGLE_FORK = os.environ.get("FNX_SINGLE_FORK", "0") == "1"
 # The physical stage's targets as their grey means, formed once (FNX_GT_GREY=0: three planes, averaged per pixel and iteration)
 _GT_GREY = os.environ.get("FNX_GT_GREY", "1") == "1"
+# BASELINE config 5 (both rasterisers per view): the 1-channel fluid image out of the 3-channel rasteriser's own pass
+# (rasterizer dual mode, include/fnx_raster.h fnx_raster_dual_t) instead of a second render.  FNX_DUAL_FUSED=0: two renders.
+_DUAL_FUSED = os.environ.get("FNX_DUAL_FUSED", "1") != "0"
 _DIST_NOOP = os.environ.get("FNX_DIST_NOOP") == "1"  # probe: the distance branch without its kernels (WRONG gradients)
 _PHYS_NOOP = os.environ.get("FNX_PHYS_NOOP") == "1"  # probe: the physics branch without its kernels (WRONG gradients)
 
@@ -536,9 +539,13 @@ class HotLoop:
                         forked_d.append(1)
                 rasterizer.set_between_stages_hook(_hook)
             try:
+                from .renderer import pipes as _pipes
+                dual_fused = (self.dual_channel and _DUAL_FUSED and not _SCREEN_GRAD and _pipes._STATIC_SPLIT
+                              and gm.get_gs_xyz.shape[0] > 0)
                 pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
                                             GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
-                                            scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
+                                            scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD,
+                                            dual_bg=self.background[:1] if dual_fused else None)
             finally:
                 rasterizer.set_between_stages_hook(None)
         if not _PHYSICS_EARLY and not (_PHYSICS_AT_HOOK and mine) and not (single_fork and use_dist):
@@ -583,7 +590,13 @@ class HotLoop:
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
             outs, seeds = [pkg["render"]], [dimg]
-            if self.dual_channel:
+            if self.dual_channel and dual_fused:
+                # the 1-channel image of the fluid came out of the same pass (dual mode); its image term joins the backward
+                _, _, dimg1 = image_loss_value_and_grad(pkg["render1"].detach(), self._gt_stack(mine, "original_image_ch1"),
+                                                        c["lambda_dssim"], c["lambda_image"], grey=False)
+                outs.append(pkg["render1"])
+                seeds.append(dimg1)
+            elif self.dual_channel:
                 # the 1-channel render of the fluid (config 5) and its image term on their own stream, next to the
                 # 3-channel render: with few views per rank both blend forwards are bound by their deepest tiles' walks,
                 # not by throughput, and overlap almost entirely; autograd runs each backward on its forward's stream

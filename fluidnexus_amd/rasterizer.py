@@ -160,7 +160,7 @@ def get_blend_math() -> str:
     return ("exact", "fast")[_OPTS["blend_math"]]
 
 
-def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=None):
+def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=None, dual=None):
     """(fnx_raster_opts_t, dict) of one view-batched forward: module defaults overlaid with the instance's overrides."""
     o = dict(_OPTS)
     if overrides:
@@ -178,7 +178,7 @@ def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=N
     opts = _lib.make_opts(blend_math=o["blend_math"], lean_geometry=o["lean_geometry"], sort_mode=sort_mode,
                           deep_kernel=o["deep_kernel"],
                           grad_splat_limit=-1 if grad_splat_limit is None else int(grad_splat_limit),
-                          zero3=zero3, sort_state=state_ptr)
+                          zero3=zero3, sort_state=state_ptr, dual=dual)
     return opts, o
 
 
@@ -554,9 +554,10 @@ class StaticBin:
 
 
 def rasterize_gaussians_views(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                              view_batch, channels=3, grad_splat_limit=None, static_bin=None, options=None):
+                              view_batch, channels=3, grad_splat_limit=None, static_bin=None, options=None, dual_bg=None):
     return _RasterizeGaussiansViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit, static_bin, options)
+                                          cov3Ds_precomp, view_batch, channels, grad_splat_limit, static_bin, options,
+                                          dual_bg)
 
 
 class _RasterizeGaussiansViews(torch.autograd.Function):
@@ -567,7 +568,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch,
-                channels, grad_splat_limit=None, static_bin=None, options=None):
+                channels, grad_splat_limit=None, static_bin=None, options=None, dual_bg=None):
         lib = _lib.raster()
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -578,9 +579,13 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         V, P = vbatch.V, means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         Cn = int(channels)
+        ctx.dual = None
         if static_bin is not None:
             return _RasterizeGaussiansViews._forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations,
-                                                           cov3Ds_precomp, vbatch, Cn, grad_splat_limit, static_bin, options)
+                                                           cov3Ds_precomp, vbatch, Cn, grad_splat_limit, static_bin, options,
+                                                           dual_bg)
+        if dual_bg is not None:
+            raise ValueError("dual mode (dual_bg) needs a static_bin: the second image is the per-call splats'")
         means3D = _f32c(means3D)
         sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
@@ -654,9 +659,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def _forward_split(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, vbatch, Cn,
-                       grad_splat_limit, sb, options=None):
+                       grad_splat_limit, sb, options=None, dual_bg=None):
         """Static-split forward: the trailing sb.P splats were binned once (StaticBin); this call preprocesses, sorts
-        and bins only the leading ones and the blend kernel merges the two streams of every tile."""
+        and bins only the leading ones and the blend kernel merges the two streams of every tile.
+        dual_bg (f32[1]): DUAL mode (include/fnx_raster.h fnx_raster_dual_t) -- the same pass also blends a single-channel
+        image of the per-call splats alone (value = channel 0 of their colours, background dual_bg); two more outputs,
+        colour1 [V,1,H,W] and depth1 [V,1,H,W], and the backward differentiates both images at once."""
         lib = _lib.raster()
         dev = means3D.device
         rs = vbatch.settings[0]
@@ -686,9 +694,21 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         ctx.g_means3D_zeroed = None
         if _gradient_mode(ctx.needs_input_grad, M) == 3:
             ctx.g_means3D_zeroed = torch.empty(P_all, 3, dtype=torch.float32, device=dev)
+        dual = None
+        if dual_bg is not None:
+            if Cn != 3 or (grad_splat_limit is not None and int(grad_splat_limit) != P):
+                raise ValueError("dual mode: 3 channels, and every per-call splat takes gradients (grad_splat_limit = their count)")
+            if _gradient_mode(ctx.needs_input_grad, M) != 3 and any(ctx.needs_input_grad):
+                raise ValueError("dual mode: the backward is the positions-only one (means3D the only leaf, no screen-space gradient)")
+            img1 = torch.empty(V * ibytes, **u8)
+            color1 = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
+            depth1 = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
+            bg1 = _f32c(dual_bg).reshape(-1)[:1]
+            dual = _lib.make_dual(img1.data_ptr(), bg1.data_ptr(), color1.data_ptr(), depth1.data_ptr())
+            grad_splat_limit = P
         opts, ctx.options = _call_options(
             vbatch, Cn, P, options, grad_splat_limit=grad_splat_limit,
-            zero3=ctx.g_means3D_zeroed.data_ptr() if ctx.g_means3D_zeroed is not None else None)
+            zero3=ctx.g_means3D_zeroed.data_ptr() if ctx.g_means3D_zeroed is not None else None, dual=dual)
         ctx.status_ptr = None
         _lib.check(lib.fnx_forward_stage1_views_split_opts(
             Cn, V, geom.data_ptr(), img.data_ptr(), P, int(rs.sh_degree), M, W, H, means3D.data_ptr(), _ptr(sh),
@@ -710,7 +730,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         else:
             cap = known
             _capacity_hwm[key] = cap
-        binning = torch.empty(V * lib.fnx_binning_bytes_split(cap, sb.R_cap), **u8)
+        binning = torch.empty(V * (lib.fnx_binning_bytes_dual if dual is not None else lib.fnx_binning_bytes_split)(cap, sb.R_cap), **u8)
         if _between_stages_hook is not None:
             _between_stages_hook()
         status_ptr = None
@@ -732,18 +752,34 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         ctx.static_bin = sb
         ctx.grad_splat_limit = P if grad_splat_limit is None else int(grad_splat_limit)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
-        ctx.mark_non_differentiable(radii, depth)
         ctx.set_materialize_grads(False)
+        if dual is not None:
+            ctx.dual = (img1, bg1)
+            ctx.mark_non_differentiable(radii, depth, depth1)
+            return color, radii, depth, color1, depth1
+        ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
-        if grad_out_color is None:
-            return (None,) * 13
+    def backward(ctx, grad_out_color, _grad_radii, _grad_depth, grad_out_color1=None, _grad_depth1=None):
+        if grad_out_color is None and grad_out_color1 is None:
+            return (None,) * 14
         lib = _lib.raster()
         vbatch, Cn = ctx.vbatch, ctx.channels
+        if ctx.dual is not None:  # either image's gradient may be missing: zeros
+            rs0 = vbatch.settings[0]
+            shape = (vbatch.V, 1, int(rs0.image_height), int(rs0.image_width))
+            dev0 = ctx.saved_tensors[1].device
+            if grad_out_color is None:
+                grad_out_color = torch.zeros((vbatch.V, 3) + shape[2:], dtype=torch.float32, device=dev0)
+            if grad_out_color1 is None:
+                grad_out_color1 = torch.zeros(shape, dtype=torch.float32, device=dev0)
         # the backward runs with the options its forward ran with (blend arithmetic, lean geometry state)
-        bopts = _lib.make_opts(blend_math=ctx.options["blend_math"], lean_geometry=ctx.options["lean_geometry"])
+        dual = None
+        if ctx.dual is not None:
+            dL1 = _f32c(grad_out_color1)
+            dual = _lib.make_dual(ctx.dual[0].data_ptr(), ctx.dual[1].data_ptr(), dL_dpix1=dL1.data_ptr())
+        bopts = _lib.make_opts(blend_math=ctx.options["blend_math"], lean_geometry=ctx.options["lean_geometry"], dual=dual)
         static_args = (lambda sb: (sb.blob.data_ptr(), sb.P, sb.R_cap) if sb is not None else (None, 0, 0))
         rs = vbatch.settings[0]
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
@@ -770,7 +806,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             stream = torch.cuda.current_stream().cuda_stream
             _lib.check(lib.fnx_rasterize_backward_views_split_opts(*args, *static_args(sb), ctx.status_ptr,
                                                                    C.byref(bopts), stream))
-            return (g_means3D,) + (None,) * 12
+            return (g_means3D,) + (None,) * 13
+        if ctx.dual is not None:
+            raise RuntimeError("dual mode: only the positions-only backward is implemented (means3D the only leaf)")
         # per-view accumulators first, then the arrays summed over the views; one zero-filled slab
         widths = [V * 3, V * 4] + ([] if geometry_only == 1 else [V, V * Cn]) + [3, Cn, 1, 6, 3 * M, 3, 4]
         flat = torch.zeros(P * sum(widths), dtype=torch.float32, device=dev)
@@ -801,7 +839,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         if V == 1 and geometry_only != 1:  # a single view accumulates straight into its per-view arrays
             g_opacity, g_colors = g_opacity_v, g_colors_v
         return (g_means3D.view(P, 3), g_means2D.view(V, P, 3), g_sh.view(P, M, 3), g_colors.view(P, Cn),
-                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None, None)
+                g_opacity.view(P, 1), g_scales.view(P, 3), g_rot.view(P, 4), g_cov3D.view(P, 6), None, None, None, None, None,
+                None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -881,6 +920,9 @@ class GaussianRasterizerViews(nn.Module):
     grad_splat_limit = None
     static_bin = None  # a StaticBin over the trailing splats of the arrays passed to forward (static-split mode)
     options = None     # per-instance overrides of the module-level option defaults (keys of rasterizer._OPTS)
+    # f32[1]: DUAL mode (static_bin set, channels 3) -- forward also returns the single-channel image of the per-call
+    # splats alone (value = channel 0 of their colours, this background): (color, radii, depth, color1, depth1)
+    dual_bg = None
 
     def __init__(self, raster_settings_list, channels=None, options=None):
         super().__init__()
@@ -907,4 +949,4 @@ class GaussianRasterizerViews(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians_views(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                          cov3D_precomp, self.view_batch, self.channels, self.grad_splat_limit,
-                                         self.static_bin, self.options)
+                                         self.static_bin, self.options, self.dual_bg)

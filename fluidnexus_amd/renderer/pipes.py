@@ -225,7 +225,7 @@ def _zero_scalar(like):
 def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                           GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
                           gpf_only=False, gs_only=False, debug=False, means3D=None, attributes=None, screen_grad=True,
-                          **kwargs):
+                          dual_bg=None, **kwargs):
     """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
     reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
     per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
@@ -234,7 +234,12 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
     the pos_type lookup + scaling + concatenation done here; `attributes`: (opacity, scales, rotations, colours) of
     [fluid | background], activated by the caller (the visual-particle stage differentiates with respect to them);
     `screen_grad=False`: "viewspace_points" takes no gradient (a stage that neither optimises positions nor reads the
-    screen-space gradient lets the backward skip the 2D-mean sums)."""
+    screen-space gradient lets the backward skip the 2D-mean sums);
+    `dual_bg` (f32[1]): DUAL mode of the static-split rasteriser -- the same pass also renders what render_fluid_views
+    (the 1-channel rasteriser over the fluid particles alone, background dual_bg) would: "render1" [V,1,H,W] and
+    "depth1" [V,1,H,W] in the returned dict.  The fluid particles and every alpha are the same in both renders; a
+    configuration that runs both rasterisers per view (BASELINE configs[4]) otherwise pays a second preprocess / depth
+    sort / emission / pair of blend launches for them.  Needs grey fluid colours ([V,1], rendered as RGB here)."""
     from ..rasterizer import GaussianRasterizerViews
     if means3D is not None:
         assert not (gpf_only or gs_only)
@@ -273,11 +278,23 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
             with torch.no_grad():
                 rasterizer.static_bin = _static_bin(gm, rasterizer.view_batch, means3D, opacity, scales, rotations,
                                                     colors, n_fluid, rasterizer.channels)
-    image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
-                                     opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
-                                     cov3D_precomp=None)
+    extra = {}
+    if dual_bg is not None:
+        if rasterizer.static_bin is None or _attributes(gm, pos_type)[3].shape[1] != 1:
+            raise ValueError("dual_bg needs the static-split path (frozen background Gaussians behind the fluid ones) and "
+                             "grey fluid colours")
+        rasterizer.dual_bg = dual_bg
+        image, radii, depth, image1, depth1 = rasterizer(
+            means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(), opacities=opacity.float(),
+            scales=scales.float(), rotations=rotations.float(), cov3D_precomp=None)
+        extra = {"render1": image1, "depth1": depth1}
+    else:
+        image, radii, depth = rasterizer(means3D=means3D.float(), means2D=screen, shs=None, colors_precomp=colors.float(),
+                                         opacities=opacity.float(), scales=scales.float(), rotations=rotations.float(),
+                                         cov3D_precomp=None)
     pkg = _LazyPackage(_pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors,
                              scales, visibility=False))
+    pkg.update(extra)
     return pkg
 
 

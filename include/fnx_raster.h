@@ -49,8 +49,9 @@ typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
  * blob's n_contrib array doubled -- its second half is the backward's per-pixel walking limit, fnx_request_gradient_limit;
  * 4: per-call options fnx_raster_opts_t and the *_opts entry points, the process-wide setters and one-shot requests are
  * deprecated shims; culled splats keep their depth in the sort keys; image header grew to 16 words with the walked-entry
- * counters); a caller compares fnx_abi_version() with the FNX_ABI_VERSION it was compiled against before anything else. */
-#define FNX_ABI_VERSION 4
+ * counters; 5: fnx_raster_opts_t.dual, fnx_binning_bytes_dual); a caller compares fnx_abi_version() with the
+ * FNX_ABI_VERSION it was compiled against before anything else. */
+#define FNX_ABI_VERSION 5
 int fnx_abi_version(void);
 const char *fnx_last_error(void);
 
@@ -70,6 +71,26 @@ const char *fnx_last_error(void);
 #define FNX_SORT_FULL 0     /* 9-bit LSD radix passes; the fourth runs only when the key span needs it            */
 #define FNX_SORT_NARROW 1   /* the fourth pass is not launched; a view that needed it reports FNX_ERR_SORT_SPAN */
 #define FNX_SORT_COHERENT 2 /* one launch: repair of the previous call's order held in `sort_state` (see below) */
+/*
+ * Dual mode of the static-split view batch (ABI 5): a SECOND, single-channel image of the per-call splats alone, blended --
+ * and differentiated -- in the same pass over the same tile lists as the 3-channel image of all splats.  It is what a scene
+ * that runs the ch1 rasteriser over the fluid and the ch3 rasteriser over fluid + background per view (BASELINE configs[4])
+ * would otherwise pay a second preprocess, depth sort, emission and pair of blend launches for: the per-call splats, their
+ * depth order and every alpha are the same in both renders.  The second image's value per splat is CHANNEL 0 of the
+ * splat's colour; its pixels equal a 1-channel render of the per-call splats (bit for bit in the exact arithmetic).
+ * Stage 2 (channels = 3, static blobs given, grad_splat_limit = P_dyn or unset) writes out_color1 / out_depth1 and the
+ * second image's per-pixel state into image_buffers1; the backward (geometry_only = 3, grad_splat_limit = P_dyn) reads
+ * dL_dpix1 and adds both images' gradients into dL_dmean3D.  The binning blobs must be fnx_binning_bytes_dual() large.
+ */
+typedef struct fnx_raster_dual {
+    char *image_buffers1;     /* V * fnx_image_bytes(W, H) bytes, laid out like image_buffers: the second image's state  */
+    const float *background1; /* [1]                                                                                      */
+    float *out_color1;        /* stage 2: [V,1,H,W]                                                                       */
+    float *out_depth1;        /* stage 2: [V,1,H,W]                                                                       */
+    const float *dL_dpix1;    /* backward: [V,1,H,W]                                                                      */
+} fnx_raster_dual_t;
+size_t fnx_binning_bytes_dual(int64_t capacity, int64_t R_static_capacity);
+
 typedef struct fnx_raster_opts {
     uint32_t size;            /* sizeof(fnx_raster_opts_t) of the caller (checked)                                  */
     int32_t blend_math;       /* 0 exact / 1 fast (see fnx_set_blend_math); forward and backward must agree          */
@@ -88,6 +109,7 @@ typedef struct fnx_raster_opts {
                                  as a strictly increasing (depth bits, id) sequence on the device and a view that fails
                                  (new frame, large move, unseeded state) is sorted from scratch inside the same launch.
                                  With the other modes the radix sort leaves the state seeded.  NULL: no state.       */
+    const fnx_raster_dual_t *dual; /* stage 2 / backward of a static-split view batch: see fnx_raster_dual_t; NULL: off */
 } fnx_raster_opts_t;
 size_t fnx_sort_state_bytes(int P);
 /* Host read-back (blocking) of a view's counters in a sort state: out[0] = calls in coherent mode, out[1] = of those,
