@@ -491,7 +491,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
                           defer_visual_backward=True, capturable=graph, cfg=loop.cfg, batched_views=loop.batched_views,
                           fused_step=loop.fused_step, dual_channel=loop.dual_channel)
         done = 0
-        rasterizer.set_coherent_sort(a.sort == "coherent")
+        rasterizer.set_coherent_sort(a.coh)
         c0 = rasterizer.coherent_sort_counters()
         # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
         # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
@@ -530,7 +530,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     one_frame(False)  # untimed: first-use allocations of every stage
     sort_switched.clear()
     total = sum(one_frame(True) for _ in range(K))
-    rasterizer.set_coherent_sort(a.sort == "coherent")
+    rasterizer.set_coherent_sort(a.coh)
     per_frame = total / K
     return {"frames": K, "iters_per_frame": n, "seq_iters_per_s": K * n / total, "ms_per_frame": per_frame * 1e3,
             "frame_boundary_ms": (per_frame - n * steady_ms * 1e-3) * 1e3,
@@ -570,7 +570,7 @@ def main():
                          "bit-reproducible sequence the oracle repeats")
     ap.add_argument("--sort-four-passes", action="store_true",
                     help="always launch the fourth depth-sort pass (default: skipped once the warm-up has shown spans < 2^26 ulps)")
-    ap.add_argument("--sort", default="coherent", choices=["coherent", "radix"],
+    ap.add_argument("--sort", default="coherent", choices=["coherent", "coherent-always", "radix"],
                     help="depth sort of the per-call splats: coherent = one launch that repairs the previous iteration's order "
                          "(verified on the device, in-launch full sort when the check fails: exact by construction, "
                          "tests/test_coherent_sort_gpu.py); radix = the 9-bit LSD passes every call")
@@ -615,6 +615,10 @@ def main():
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
+    # coherent: where the repair launch fits one round of workgroups (rasterizer.coherent_sort_pays); -always: wherever it runs
+    a.coh = {"coherent": 1, "coherent-always": 2, "radix": 0}[a.sort]
+    if a.sort == "coherent-always":
+        a.sort = "coherent"
 
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -663,7 +667,7 @@ def main():
     _lib.raster()  # fail loudly if the HIP library is missing
     rasterizer.set_blend_math(a.blend_math)
     rasterizer.set_lean_geometry(not a.full_geometry)
-    rasterizer.set_coherent_sort(a.sort == "coherent")
+    rasterizer.set_coherent_sort(a.coh)
     if a.deep_kernel is not None:
         rasterizer.set_deep_kernel(a.deep_kernel)
     if a.no_static_split:

@@ -280,7 +280,8 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
                                                     colors, n_fluid, rasterizer.channels)
     extra = {}
     if dual_bg is not None:
-        if rasterizer.static_bin is None or _attributes(gm, pos_type)[3].shape[1] != 1:
+        fam = _ATTR.get(pos_type, "visual")  # (the raw tensor: no activation kernels for a shape check)
+        if rasterizer.static_bin is None or getattr(gm, f"_color_dummy" if fam == "dummy" else f"_{fam}_color").shape[1] != 1:
             raise ValueError("dual_bg needs the static-split path (frozen background Gaussians behind the fluid ones) and "
                              "grey fluid colours")
         rasterizer.dual_bg = dual_bg
