@@ -47,7 +47,7 @@ SIZE = 512
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 2 * 1.0  # 1024 SIMD-32s x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 VALU_MEASURED_WAVE_INSTR = 933e9                   # tools/micro/pk_rate.hip on this chip
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 CONFIGS = {
     2: dict(workload="BASELINE configs[1]: ScalarReal single frame, 100k grey Gaussians (gm_fluid / render_fluid / ch1), "
@@ -464,7 +464,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     solver_iterations = 3  # configs/fluid_nexus_smoke_dynamics.json
     optim = loop.optim_args
     graph = loop.capturable
-    gi = max(1, min(int(a.graph_iters), n))
+    gi = max(1, min(int(a.seq_graph_iters), n))
     seg = dict(simulate=0.0, setup=0.0, optimise=0.0, accept=0.0)
     counts, sort_switched = [], []
 
@@ -492,7 +492,8 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
                           fused_step=loop.fused_step, dual_channel=loop.dual_channel)
         done = 0
         rasterizer.set_coherent_sort(a.coh)
-        c0 = rasterizer.coherent_sort_counters()
+        P_frame = int(gm._visual_xyz.shape[0])  # the per-call splats of this frame: only their sort states count below
+        c0 = rasterizer.coherent_sort_counters(P_frame)
         # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
         # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
         for _ in range(4 if a.sort == "coherent" else 2):
@@ -500,8 +501,8 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             done += 1
         rasterizer.check_status()
         if a.sort == "coherent":
-            c1 = rasterizer.coherent_sort_counters()
-            if c1[1] - c0[1] > rasterizer.coherent_sort_states():
+            c1 = rasterizer.coherent_sort_counters(P_frame)
+            if c1[1] - c0[1] > rasterizer.coherent_sort_states(P_frame):
                 rasterizer.set_coherent_sort(False)
                 sort_switched.append(len(counts))
         if graph and n - done - 1 >= gi:
@@ -551,6 +552,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how many times the timed region (exactly --steps steps) is run: value = the median pass, `spread` = all")
     ap.add_argument("--config", default="auto", choices=["auto", "2", "3", "4", "5"],
                     help="BASELINE.json configuration (1-based); auto: 3 at 1-2 GPUs, 4 at 4 GPUs, 5 at 8 GPUs")
     ap.add_argument("--stage", default="physical", choices=["physical", "visual", "first"],
@@ -592,12 +595,16 @@ def main():
                     help="skip the `drop_in` leg (the reference's op sequence through the plug-in seam, ~1 s)")
     ap.add_argument("--no-exact-leg", action="store_true",
                     help="skip the `exact_mode` leg (the same loop re-captured with the bit-exact blend arithmetic, ~1 s)")
-    ap.add_argument("--frames", type=int, default=0,
+    ap.add_argument("--frames", type=int, default=-1,
                     help="also time a sequence of this many frames (config 3 / 5, physical stage): the reference's frame "
                          "boundary in its call order + --iters-per-frame optimisation iterations per frame, record key "
-                         "`sequence` (seq_iters_per_s, frame_boundary_ms); 0 = off")
-    ap.add_argument("--iters-per-frame", type=int, default=1000,
-                    help="optimisation iterations per frame of --frames (configs/fluid_nexus_smoke_dynamics.json: 1000)")
+                         "`sequence` (seq_iters_per_s, frame_boundary_ms); 0 = off; -1 (default) = 3 frames of 250 iterations "
+                         "in a single-GPU config-3 run (the reference's level-two stage runs 250 per frame: ~1 s), else off")
+    ap.add_argument("--iters-per-frame", type=int, default=0,
+                    help="optimisation iterations per frame of --frames (configs/fluid_nexus_smoke_dynamics.json: 1000; "
+                         "default: 1000 with an explicit --frames, 250 in the default leg)")
+    ap.add_argument("--seq-graph-iters", type=int, default=5,
+                    help="iterations per hipGraph inside the sequence leg (every frame re-captures: short graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")
     ap.add_argument("--image-loss", default="fused", choices=["torch", "fused"])
@@ -606,7 +613,7 @@ def main():
     ap.add_argument("--no-distance", action="store_true", help="drop the distance_loss term (round-1 behaviour)")
     ap.add_argument("--no-static-split", action="store_true", help="bin the static background Gaussians every iteration")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--graph-iters", type=int, default=5,
+    ap.add_argument("--graph-iters", type=int, default=20,
                     help="iterations recorded per hipGraph (reduced to a divisor of --steps; 1 in multi-GPU runs)")
     ap.add_argument("--views", default="batched", choices=["batched", "branches", "serial"],
                     help="the views of an iteration: one view-batched launch sequence (default), one rasteriser call "
@@ -615,6 +622,9 @@ def main():
     ap.add_argument("--unfused-physics", action="store_true",
                     help="physics terms as separate autograd nodes (the reference's op-by-op structure)")
     a = ap.parse_args()
+    default_seq = a.frames < 0
+    if a.iters_per_frame <= 0:
+        a.iters_per_frame = 250 if default_seq else 1000
     # coherent: where the repair launch fits one round of workgroups (rasterizer.coherent_sort_pays); -always: wherever it runs
     a.coh = {"coherent": 1, "coherent-always": 2, "radix": 0}[a.sort]
     if a.sort == "coherent-always":
@@ -728,32 +738,43 @@ def main():
             loop.use_graph(False)
             if hasattr(loop, "parallel_views"):
                 loop.parallel_views = False
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
     if not graph_mode:
         _lib.profile_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    steps_done = 0
-    while steps_done < a.steps:
-        if graph_mode and a.steps - steps_done < loop.iterations_per_call:
-            loop.use_graph(False)  # fewer steps left than one graph holds: the same iteration, launched eagerly
-        steps_done += loop.iterations_per_call
-        loop.iteration()
-    assert steps_done == a.steps
-    if graph_mode:
-        loop.use_graph(True)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if not a.host_sync:
-        rasterizer.check_status()  # raises if a replayed forward overflowed its binning capacity
-    if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed_pass():
+        """EXACTLY --steps steps between two barrier + synchronize brackets; max over the ranks."""
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps_done = 0
+        while steps_done < a.steps:
+            if graph_mode and a.steps - steps_done < loop.iterations_per_call:
+                loop.use_graph(False)  # fewer steps left than one graph holds: the same iteration, launched eagerly
+            steps_done += loop.iterations_per_call
+            loop.iteration()
+        assert steps_done == a.steps
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        d = time.perf_counter() - t0
+        if graph_mode:
+            loop.use_graph(True)
+        if not a.host_sync:
+            rasterizer.check_status()  # raises if a replayed forward overflowed its binning capacity
+        if use_dist:
+            tmax = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            d = float(tmax.item())
+        return d
+
+    # The timed region is run --repeats times (VERDICT r4: a 20-step region is 20 ms; one sample cannot show its own
+    # noise): `value` / `ms_per_step` are the MEDIAN pass, `spread` carries every pass.  Each pass times exactly --steps
+    # steps with the contract's brackets.
+    pass_s = [timed_pass() for _ in range(max(1, int(a.repeats)))]
+    dt = sorted(pass_s)[len(pass_s) // 2]
+    spread = {"repeats": len(pass_s), "iters_per_s": [a.steps / d for d in pass_s],
+              "min": a.steps / max(pass_s), "max": a.steps / min(pass_s), "value_is": "median pass"}
 
     # Roofline of the dominant kernel (blend backward), measured live with HIP events on its stream.  Events cannot
     # be read back from a replayed graph, so in graph mode the same iteration is run eagerly a few more times
@@ -832,23 +853,36 @@ def main():
                                               1 if os.environ.get("FNX_SCREEN_GRAD", "0") == "1" else 3)
     fast_s = 'true' if a.blend_math == 'fast' else 'false'
     split_s = 'true' if (pipes._STATIC_SPLIT and cfg_id != 2 and a.stage != "first") else 'false'
-    knames = {"blend_forward": f"fnx::blend_forward_kernel<{Cn}, {split_s}, {fast_s}>",
-              "blend_backward": f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}>"}
+    from fluidnexus_amd import harness as _Hn
+    dual_s = 'true' if (cfg_id == 5 and a.stage == "physical" and _Hn._DUAL_FUSED and split_s == 'true') else 'false'
+    knames = {"blend_forward": f"fnx::blend_forward_kernel<{Cn}, {split_s}, {fast_s}, {dual_s}>",
+              "blend_backward": f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}, {dual_s}>"}
     kname = knames[dom]
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
     counters = {}
+    # (the counter files are read from profiles/, not collected in this run -- they carry the hash of the
+    # kernel sources they were collected on, and a file whose hash differs from this checkout's is STALE: its numbers are
+    # left out and the record says so)
+    from fluidnexus_amd.build import csrc_hash
+    sha_now, traffic_stale = csrc_hash(), False
     for which, kn in knames.items():
         ent = {}
         try:
             with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{suffix}_pmc_traffic.json")) as f:
-                t = json.load(f).get("void " + kn)
+                tj = json.load(f)
+            t = tj.get("void " + kn)
+            if tj.get("_csrc_sha16") != sha_now:
+                t, traffic_stale = None, True
             if t:
                 ent["hbm_bytes_per_launch"] = t["fetch_bytes"] + t["write_bytes"]
         except OSError:
             pass
         try:
             with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{suffix}_sq_counters.json")) as f:
-                t = json.load(f).get("void " + kn)
+                tj = json.load(f)
+            t = tj.get("void " + kn)
+            if tj.get("_csrc_sha16") != sha_now:
+                t, traffic_stale = None, True
             if t:
                 ent["valu_wave_instructions_per_launch"] = t["SQ_INSTS_VALU"]
                 ent["counter_run_launch_us"] = t["us"]
@@ -873,6 +907,7 @@ def main():
                         "bytes they must touch are fewer: see `touched` (the kernels' own entry counts).  Neither kernel is "
                         "bound by HBM: the primary bound is the compute units' VALU / LDS pipelines, see `primary_bound`",
                 "traffic_source": src_note if traffic else None,
+                "traffic_stale": traffic_stale, "csrc_sha16": sha_now,
                 "hbm_traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic and avg_s > 0 else None,
                 "other_kernels_avg_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
     if touched:
@@ -925,7 +960,7 @@ def main():
     sort_fallbacks = None
     try:  # how often the coherent sort had to fall back to its in-launch full sort (per view batch: [calls, fallbacks] per view)
         from fluidnexus_amd.renderer.pipes import _VIEW_BATCH_CACHE
-        sort_fallbacks = [[list(c) for c in vb.sort_counters(*key)] for vb, _, _ in _VIEW_BATCH_CACHE.values()
+        sort_fallbacks = [[list(c) for c in vb.sort_counters(key[0], key[1], sort_key=key[2])] for vb, _, _ in _VIEW_BATCH_CACHE.values()
                           for key in list(vb._sort_state)]
     except Exception as e:
         print(f"[bench] sort counters unavailable: {type(e).__name__}: {e}", file=sys.stderr)
@@ -954,7 +989,7 @@ def main():
         "metric": metric,
         "value": value, "unit": "iters/s", "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
         "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "spread": spread, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": C["workload"] + stage_note, "baseline_config": cfg_id, "stage": a.stage,
                    "views_this_rank": len(loop_views), "global_views_per_step": len(cams), "image": f"{SIZE}x{SIZE}",
@@ -1045,6 +1080,9 @@ def main():
                                        "iters_per_s_with_model": 1.0 / (dt / a.steps + t_comm),
                                        "model": "10 us + 2 (n - 1) x (3 us + bytes / n / (0.8 x 153 GB/s)): ring over point-to-point "
                                                 "xGMI links; a bound, not a measurement"}
+    if default_seq:  # the default record carries a short sequence leg: single-GPU config 3, graph replay
+        a.frames = 3 if (cfg_id == 3 and world == 1 and graph_mode and a.stage == "physical" and a.emulate_world <= 1
+                         and a.views == "batched" and not a.no_distance) else 0
     if a.frames > 0 and cfg_id != 2 and a.stage == "physical" and a.emulate_world <= 1:
         try:
             out["sequence"] = sequence_timing(a, dev, cfg_id, rank, world, use_dist, dt / a.steps * 1e3)

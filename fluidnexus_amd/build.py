@@ -25,6 +25,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-unused-function", "-Wno-unused-value"]
 
 
+def csrc_hash() -> str:
+    """16 hex digits over every kernel source and header (and the compiler flags): what a counter profile under profiles/
+    was collected on.  bench.py compares it with the stamp tools/make_profiles.py leaves in the counter files and marks
+    them stale when the kernels have changed since."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = []
+    for d in (_CSRC, os.path.join(_CSRC, "lab"), os.path.join(_HERE, "..", "include")):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

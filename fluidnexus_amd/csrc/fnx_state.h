@@ -153,6 +153,12 @@ struct InvUpdate {
 };
 // the temporal-coherence records pack a tile rectangle into four bytes
 inline bool coherent_sort_supported(int W, int H) { return tiles_x(W) <= 255 && tiles_y(H) <= 255; }
+// Stamp of the records one call's preprocess writes for one view's sort state: the state's call counter mixed with a
+// per-state nonce (its address), so that a stale record left in the recycled geometry blob by ANOTHER state's call -- whose
+// counter may hold the same value -- cannot pass for one of this call's.
+__host__ __device__ inline uint32_t coh_stamp(const uint32_t *hdr) {
+    return hdr[COH_EPOCH] * 2654435761u + (uint32_t)((uintptr_t)hdr >> 8) * 0x9E3779B1u;
+}
 __host__ __device__ inline uint32_t coh_magic(int P) { return (0xC0DE0000u ^ ((uint32_t)P * 2654435761u)) | 1u; }
 inline int sort_blocks(int P) { return (P + kSortChunk - 1) / kSortChunk; }
 

@@ -515,7 +515,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
     for (int k = 0; k < kCohOut / kCohThreads; k++) s_out[k * kCohThreads + tid] = ~0ull;
     const uint32_t magic = coh_magic(P);
     const bool seeded = hdr[COH_MAGIC] == magic;  // written only by the workgroup that arrives last, after everyone read it
-    const uint32_t epoch = hdr[COH_EPOCH];        // the stamp this call's preprocess put on its records
+    const uint32_t epoch = coh_stamp(hdr);        // the stamp this call's preprocess put on its records
     uint32_t bad = 0;  // COH_WHY bits
     const int n_out = min(kCohOut, P - c * kCohOut);
     if (seeded) {
@@ -752,7 +752,12 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         s_last = (atomicAdd(&hdr[COH_ARRIVED], 1u) == (uint32_t)nc - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_last || tid >= 256) return;  // the tail below is the work of four waves
+    // The tail below is the work of four waves.  The other four END here, and the barriers of the tail are then between the
+    // remaining waves only: that is the documented behaviour of s_barrier on this ISA (terminated waves no longer count
+    // towards a workgroup's barrier), which this library -- gfx950 only -- relies on here and nowhere else; HIP's portable
+    // model would call a barrier behind a partial exit undefined.  Keeping eight waves alive through
+    // coh_fallback_sort / rank_hist_block would mean predicating every phase of those 256-thread routines.
+    if (!s_last || tid >= 256) return;
     // ---- the workgroup that arrives last: verify the chunk boundaries, repair by a full sort if need be, publish
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     uint32_t why = seeded ? 0u : 16u;
@@ -790,7 +795,7 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         ctl[SORT_CTL_OVERFLOW] = 0u;  // keys are compared whole: no span limit in this mode
         ctl[SORT_CTL_SPAN] = 0u;      // not measured here (the radix call that seeded the state reported it)
         hdr[COH_MAGIC] = magic;
-        hdr[COH_EPOCH] = epoch + 1u;
+        hdr[COH_EPOCH] = hdr[COH_EPOCH] + 1u;
         hdr[COH_ARRIVED] = 0u;
         hdr[COH_FAIL] = 0u;
         hdr[COH_REPAIRS] = hdr[COH_REPAIRS] + 1u;

@@ -311,7 +311,7 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
             const uint32_t slot = reinterpret_cast<const uint32_t *>(stv + coh.inv)[idx];
             if (slot < (uint32_t)P) {
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(stv + coh.hdr);
-                const uint32_t kbits = key & 0x7FFFFFFFu, epoch = hdr[COH_EPOCH];
+                const uint32_t kbits = key & 0x7FFFFFFFu, epoch = coh_stamp(hdr);
                 uint4 rec = make_uint4(kbits, (uint32_t)idx,
                                        visible ? ((uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24)) : 0u,
                                        epoch);

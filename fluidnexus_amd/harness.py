@@ -292,6 +292,16 @@ class HotLoop:
             self.iteration()
         torch.cuda.synchronize()
         self.gm.invalidate_caches()
+        # The fused step leaves the NEXT iteration's hidden-particle grid (and scaled positions) behind.  The recorded
+        # graph's first iteration may take them over instead of rebuilding the grid with five launches of its own (~28 us
+        # per replay, round 5): on every replay they are what the previous replay's last iteration -- or, the first time,
+        # the warm-up's -- left.  Particles moved between replays by anything else need a new capture (or use_graph(False)).
+        if self.fused_step and os.environ.get("FNX_CAPTURE_KEEP_GRID", "1") != "0":
+            gm, est = self.gm, self.gm._estimate_xyz_nn
+            key = (id(est), est._version)
+            grid, scaled = getattr(gm, "_step_grid", None), getattr(gm, "_est_scaled", None)
+            if grid is not None and scaled is not None and scaled[0] == key and grid.N == est.shape[0]:
+                gm._grid_cache["est"] = (key, grid)
         rasterizer._pending_status.clear()
         g = torch.cuda.CUDAGraph()
         self.graph_finish = None

@@ -56,7 +56,7 @@ def set_deep_variant(enabled: bool, min_depth: int | None = None):
 # forward to the library's deprecated process-wide setters, which only the single-view entry points still read.
 SORT_NARROW_MAX_BITS = 25   # widest depth-key span (bits) for which callers switch to the three-pass sort: two below the
                             # 27 bits three 9-bit passes order
-_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0)
+_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0, sort_key=None)
 
 
 def set_blend_math(mode: str):
@@ -112,15 +112,19 @@ def walked_entries():
 _VIEW_BATCHES = None  # weak set of the ViewBatch objects that hold a sort state
 
 
-def coherent_sort_counters():
-    """(calls in coherent mode, of those: in-launch full sorts) summed over every live sort state -- blocking.  A caller
+def coherent_sort_counters(P=None):
+    """(calls in coherent mode, of those: in-launch full sorts) summed over every live sort state (P: only the states of
+    this splat count) -- blocking.  A caller
     that sees the second number grow (a scene whose splats jump further than the repair window between calls: e.g.
     particles at the fringe of the velocity field's support) switches back with set_coherent_sort(False): the mode is
     exact either way, a fallback only costs time (~2 ms per view and call)."""
     calls = falls = 0
     for vb in list(_VIEW_BATCHES or ()):
-        for (ch, P) in list(vb._sort_state):
-            for c in vb.sort_counters(ch, P):
+        for key in list(vb._sort_state):
+            ch, kP = key[0], key[1]
+            if P is not None and kP != int(P):
+                continue
+            for c in vb.sort_counters(ch, kP, sort_key=key[2] if len(key) > 2 else None):
                 calls += c[0]
                 falls += c[1]
     return calls, falls
@@ -137,11 +141,12 @@ def coherent_sort_pays(P, V):
     return ((int(P) + 2047) // 2048) * int(V) <= COHERENT_MAX_WORKGROUPS
 
 
-def coherent_sort_states():
-    """How many (view, channel count, splat count) sort states are alive: a state's FIRST repair call may need the full
-    sort without that saying anything about the scene (the radix passes that seeded it order culled splats last, the
-    repair calls by depth), so a caller that judges the mode by coherent_sort_counters allows that many."""
-    return sum(vb.V * len(vb._sort_state) for vb in list(_VIEW_BATCHES or ()))
+def coherent_sort_states(P=None):
+    """How many (view, channel count, splat count) sort states are alive (P: of this splat count only): a state's FIRST
+    repair call may need the full sort without that saying anything about the scene (the radix passes that seeded it order
+    culled splats last, the repair calls by depth), so a caller that judges the mode by coherent_sort_counters allows that
+    many."""
+    return sum(vb.V * sum(1 for k in vb._sort_state if P is None or k[1] == int(P)) for vb in list(_VIEW_BATCHES or ()))
 
 
 def set_lean_geometry(enabled: bool):
@@ -170,7 +175,7 @@ def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=N
         o.update(overrides)
     sort_mode, state_ptr = (_lib.FNX_SORT_NARROW if o["sort_narrow"] else _lib.FNX_SORT_FULL), None
     if o["coherent_sort"] and P > 0 and (o["coherent_sort"] == 2 or coherent_sort_pays(P, vbatch.V)):
-        state, seeded = vbatch.sort_state(channels, P)
+        state, seeded = vbatch.sort_state(channels, P, o.get("sort_key"))
         if state is not None:
             state_ptr = state.data_ptr()
             if seeded:
@@ -265,7 +270,14 @@ def check_status():
         _capacity_hwm[key] = max(_capacity_hwm.get(key, 0), int(n * _CAP_SLACK) + 1024)
         max_sort_span_bits = max(max_sort_span_bits, (int(host[dev_index][slot][5]) >> 24) & 0xFF)
         if status == _lib.FNX_ERR_CAPACITY and err is None:
-            err = _lib.FnxError(status, f"binning capacity {cap} < num_rendered {n}")
+            if n > cap:
+                err = _lib.FnxError(status, f"binning capacity {cap} < num_rendered {n}")
+            else:  # written by a backward that found the blob laid out for another capacity than its own
+                err = _lib.FnxError(status, f"a backward pass ran with another binning capacity than its forward's ({cap}): "
+                                            "its gradients are zero")
+        if status == _lib.FNX_ERR_INVALID_ARG and err is None:
+            err = _lib.FnxError(status, "a backward pass asked for gradients beyond its forward's gradient limit "
+                                        "(grad_splat_limit / dual mode): refused, its gradients are zero")
         if status == _lib.FNX_ERR_SORT_SPAN and err is None:
             err = _lib.FnxError(status, "set_sort_narrow(True) but a view's depth keys span 2^27 ulps or more: the fourth "
                                         "sort pass was needed (set_sort_narrow(False) and render again)")
@@ -447,19 +459,33 @@ class ViewBatch:
         self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
         self._depth_hint = {}
         self._sort_state = {}
+        self._sort_pinned = set()  # keys handed out while a stream was capturing: a hipGraph holds their raw pointers
+        self._sort_tick = {}
 
-    def sort_state(self, channels, P):
+    def sort_state(self, channels, P, sort_key=None):
         """(u8 tensor [V * fnx_sort_state_bytes(P)], seeded) -- the persistent state of the temporal-coherence depth sort
-        for this camera batch, channel count and splat count (include/fnx_raster.h fnx_raster_opts_t.sort_state):
+        for this camera batch, channel count, splat count and `sort_key` (include/fnx_raster.h fnx_raster_opts_t.sort_state):
         zero-filled once; `seeded` is False for the one call whose radix passes seed it.  (None, False) while a graph is
-        being captured before any eager call allocated it."""
-        key = (int(channels), int(P))
+        being captured before any eager call allocated it.
+        ONE splat set per state: the state holds the previous call's depth order, so two different splat sets of the same
+        size rendered through the same cameras must not share it (each call would repair the other set's order, fail its
+        verification and pay the in-launch full sort: exact, but slow) -- give each its own `sort_key`
+        (GaussianRasterizerViews.options["sort_key"], any hashable).
+        The kernels receive the state as a RAW pointer, and a captured hipGraph keeps that pointer without a tensor
+        reference: states handed out during a capture stay until release_captured_sort_states(); otherwise the
+        least recently used states go once more than eight exist (splat counts of earlier frames)."""
+        key = (int(channels), int(P), sort_key)
+        self._sort_tick[key] = max(self._sort_tick.values(), default=0) + 1
         ent = self._sort_state.get(key)
+        if ent is not None and torch.cuda.is_current_stream_capturing():
+            self._sort_pinned.add(key)
         if ent is None:
             if torch.cuda.is_current_stream_capturing():
                 return None, False
-            if len(self._sort_state) > 8:  # splat counts of earlier frames
-                self._sort_state.clear()
+            for old in sorted((k for k in self._sort_state if k not in self._sort_pinned),
+                              key=lambda k: self._sort_tick.get(k, 0))[:max(0, len(self._sort_state) - len(self._sort_pinned) - 8)]:
+                del self._sort_state[old]
+                self._sort_tick.pop(old, None)
             n = _lib.raster().fnx_sort_state_bytes(int(P))
             ent = self._sort_state[key] = torch.zeros(self.V * n, dtype=torch.uint8, device=self.view.device)
             global _VIEW_BATCHES
@@ -470,10 +496,14 @@ class ViewBatch:
             return ent, False  # this call's radix passes seed it
         return ent, True
 
-    def sort_counters(self, channels, P, why=False, outliers=False):
+    def release_captured_sort_states(self):
+        """Un-pin the sort states a destroyed hipGraph referred to."""
+        self._sort_pinned.clear()
+
+    def sort_counters(self, channels, P, why=False, outliers=False, sort_key=None):
         """Per view (calls in coherent mode, of those: in-launch full sorts[, why: fnx_sort_state_read's bit mask][, splats
         taken as outliers so far: fnx_sort_state_outliers]) -- blocking read-back."""
-        ent = self._sort_state.get((int(channels), int(P)))
+        ent = self._sort_state.get((int(channels), int(P), sort_key))
         if ent is None:
             return []
         out, lib = [], _lib.raster()
@@ -635,9 +665,11 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             if _between_stages_hook is not None:
                 _between_stages_hook()
             status_ptr = None
+            ctx.status_rows = None
             if not synced:  # deferred status check: the forward's last kernel writes the headers into ring slots
                 ring, slot = _status_slots(dev, V, key)
                 status_ptr = ring[slot:slot + V].data_ptr()
+                ctx.status_rows = (dev.index, slot, V, key)
             ctx.status_ptr = status_ptr
             # (opts.grad_splat_limit: the backward will stop behind every pixel's last splat below the limit)
             _lib.check(lib.fnx_forward_stage2_views_split_opts(Cn, V, geom.data_ptr(), binning.data_ptr(), cap,
@@ -734,9 +766,11 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         if _between_stages_hook is not None:
             _between_stages_hook()
         status_ptr = None
+        ctx.status_rows = None
         if not synced:
             ring, slot = _status_slots(dev, V, key)
             status_ptr = ring[slot:slot + V].data_ptr()
+            ctx.status_rows = (dev.index, slot, V, key)
         ctx.status_ptr = status_ptr
         # (opts.grad_splat_limit; in split mode the library already stops at the first static id)
         _lib.check(lib.fnx_forward_stage2_views_split_opts(
@@ -775,6 +809,12 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             if grad_out_color1 is None:
                 grad_out_color1 = torch.zeros(shape, dtype=torch.float32, device=dev0)
         # the backward runs with the options its forward ran with (blend arithmetic, lean geometry state)
+        # a backward that refuses to run (capacity / gradient-limit mismatch) leaves its reason in the forward's status rows:
+        # look at them again at the next check_status(), even if the forward's own entry has been consumed since
+        rows = getattr(ctx, "status_rows", None)
+        if rows is not None and ctx.status_ptr is not None and not torch.cuda.is_current_stream_capturing():
+            for v in range(rows[2]):
+                _pending_status.append((rows[0], rows[1] + v, rows[3]))
         dual = None
         if ctx.dual is not None:
             dL1 = _f32c(grad_out_color1)

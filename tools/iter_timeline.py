@@ -16,6 +16,8 @@ for anchor in ('visual_backward', 'blend_backward_kernel<3, 3', 'blend_backward_
     if len(vb) > 2:
         break
 gaps = [(vb[i + 1][0] - vb[i][0]) / 1e6 for i in range(len(vb) - 1)]
+if len(sys.argv) > 3 and sys.argv[3] == "spacings":  # every iteration's length, in trace order (graph replays: k per replay)
+    print('iteration spacings (us):', ' '.join('%.0f' % (g * 1e3) for g in gaps))
 # the replayed iterations are the bulk of the anchors: take the window with the MEDIAN spacing (the shortest one may
 # belong to the rasteriser-only timing the bench runs afterwards, the longest to an eager or capturing iteration)
 i = sorted(range(len(gaps)), key=lambda k: gaps[k])[len(gaps) // 2]

@@ -9,6 +9,9 @@ ARGS = open(os.path.join(ROOT, "gpurun_out", TAG, "args.txt")).read().strip() if
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
+sys.path.insert(0, ROOT)
+from fluidnexus_amd.build import csrc_hash  # noqa: E402
+CSRC_SHA = csrc_hash()
 
 
 def short(name):
@@ -74,6 +77,7 @@ for k in fetch:
     if ("fnx::" in k or "kernel" in k) and "at::" not in k:
         traffic[k] = {"fetch_bytes": 2 * fetch[k].get("FETCH_SIZE", 0.0) * 1024,
                       "write_bytes": write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024}
+traffic["_csrc_sha16"] = CSRC_SHA  # the kernels these counters were collected on (bench.py: traffic_stale)
 json.dump(traffic, open(os.path.join(DST, f"{TAG}_pmc_traffic.json"), "w"), indent=1)
 
 # 5. SQ counters
@@ -111,6 +115,7 @@ sq_json = {"_note": "per-launch averages of the SQ counter pass (see the .md of 
                     "(us x 2.4 GHz x 1024 SIMDs), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; lds_busy (from the LDS pass) = "
                     "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES",
            **{k: _derived(k, c) for k, c in sq.items() if "fnx::" in k or ("kernel" in k and "at::" not in k)}}
+sq_json["_csrc_sha16"] = CSRC_SHA
 json.dump(sq_json, open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 # 6. LDS pipeline
 if os.path.exists(os.path.join(SRC, "pmc_lds", "r_counter_collection.csv")):
@@ -132,5 +137,6 @@ if os.path.exists(os.path.join(SRC, "pmc_lds", "r_counter_collection.csv")):
     for k, c in lds.items():
         if k in sq_json and c.get("SQ_BUSY_CU_CYCLES"):
             sq_json[k]["lds_busy"] = c.get("SQ_LDS_IDX_ACTIVE", 0.0) / c["SQ_BUSY_CU_CYCLES"]
+    sq_json["_csrc_sha16"] = CSRC_SHA
     json.dump(sq_json, open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(DST)))

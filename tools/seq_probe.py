@@ -26,4 +26,4 @@ print({k: v for k, v in out.items() if k != "note"})
 print("per-iteration ms (last 40 calls):", [f"{t:.2f}x{k}" for t, k in times[-40:]])
 for vb, _, _ in pipes._VIEW_BATCH_CACHE.values():
     for key in list(vb._sort_state):
-        print("sort state", key, vb.sort_counters(*key, why=True))
+        print("sort state", key, vb.sort_counters(key[0], key[1], why=True, sort_key=key[2]))

@@ -49,4 +49,4 @@ print(f"{done} iterations in {dt:.1f} s = {done / dt:.0f} it/s; finite {bool(tor
       f"memory {mem0 / 2**20:.0f} -> {torch.cuda.memory_allocated() / 2**20:.0f} MiB; step {float(gm.optimizer.state[gm._estimate_xyz_nn]['step']):.0f}")
 for vb in list(rasterizer._VIEW_BATCHES or ()):
     for key in list(vb._sort_state):
-        print("coherent sort, per view (calls, in-launch full sorts, why, outliers taken):", vb.sort_counters(*key, why=True, outliers=True))
+        print("coherent sort, per view (calls, in-launch full sorts, why, outliers taken):", vb.sort_counters(key[0], key[1], why=True, outliers=True, sort_key=key[2]))

@@ -15,4 +15,4 @@ with contextlib.redirect_stdout(buf):
     bench.main()
 for vb, _, _ in pipes._VIEW_BATCH_CACHE.values():
     for key in list(vb._sort_state):
-        print("sort state", key, vb.sort_counters(*key, why=True))
+        print("sort state", key, vb.sort_counters(key[0], key[1], why=True, sort_key=key[2]))
