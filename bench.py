@@ -354,12 +354,43 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
         e1.record()
         e1.synchronize()
         out[name] = e0.elapsed_time(e1) / 5 / V
-    _lib.profile_enable(True)
-    for _ in range(5):
-        radii = once(False)
-    torch.cuda.synchronize()
-    pre_ms, pre_n = _lib.profile_read(3)
-    _lib.profile_enable(False)
+    def pre_stage_us():
+        _lib.profile_enable(True)
+        for _ in range(5):
+            r = once(False)
+        torch.cuda.synchronize()
+        ms, n = _lib.profile_read(3)
+        _lib.profile_enable(False)
+        return r, ms, n
+
+    radii, pre_ms, pre_n = pre_stage_us()
+    # The SH colours of a view batch: on the matrix cores in the fast arithmetic (csrc/sh_mfma.h, v_mfma_f32_4x4x1_16B_f32:
+    # one Gaussian per 4 x 4 block, 16 per wave instruction), the scalar kernel in the exact one.  Both timed here, in the
+    # same process, by pinning the choice through the environment.
+    variants = {}
+    try:
+        screen = torch.zeros(V, P, 3, device=dev)
+        ims = {}
+        for name, env in (("scalar", "0"), ("mfma", "1")):
+            os.environ["FNX_LAB_SH_MFMA"] = env
+            with torch.no_grad():
+                ims[name] = rv(means3D=L["means3D"], means2D=screen, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                               rotations=L["rotations"])[0].clone()
+            _, m_ms, m_n = pre_stage_us()
+            variants[name] = m_ms / max(m_n, 1) * 1e3
+        n_mfma = ((P + 15) // 16) * ((V + 3) // 4) * 16  # wave-level v_mfma_f32_4x4x1_16B_f32 instructions per launch
+        variants = {"per_splat_stage_us": variants, "max_abs_image_difference": float((ims["mfma"] - ims["scalar"]).abs().max()),
+                    "mfma_wave_instructions_per_launch": n_mfma,
+                    # 8 cycles per instruction (2 passes) on one of 1024 matrix pipes at 2.4 GHz, over the stage's duration
+                    "mfma_pipe_busy_frac_computed": n_mfma * 8 / 1024 / 2.4e9 / (variants["mfma"] * 1e-6),
+                    "what": "per-splat stage = SH colour kernel + preprocess kernel; `mfma`: sh_colors_views_mfma_kernel (block = one "
+                            "Gaussian, rows = four views, columns = RGB, one v_mfma_f32_4x4x1_16B_f32 per SH coefficient), the "
+                            "fast arithmetic's kernel; `scalar`: sh_colors_views_kernel, the exact arithmetic's"}
+    except Exception as e:
+        print(f"[bench] SH variants failed: {type(e).__name__}: {e}", file=sys.stderr)
+        variants = None
+    finally:
+        os.environ.pop("FNX_LAB_SH_MFMA", None)
     p_vis = float((radii > 0).sum().item()) / V
     # per splat and view: reads xyz 12 + scale 12 + rotation 16 + opacity 4 + SH 16 x 12 = 236 B; a visible splat writes
     # the per-splat state of SURVEY 8(d) (60 B) + sort key 4 + rect 8 + blend record 64 + rgb 12 + clamped 3 = 151 B
@@ -376,12 +407,19 @@ def sh_timing(gm, cams, views, cfg_id, bg, degree, stage="physical"):
                            "moved_bytes_per_launch": int(moved),
                            "moved_frac_of_hbm_peak": moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
                            "bound": "hbm"},
-            "mfma_util": 0,
-            "why": "the SH contraction is a 1 x 16 . 16 x 3 product per (Gaussian, view) whose 16 x 3 operand is the "
-                   "Gaussian's own coefficients: no operand is shared between Gaussians, 192 B of coefficients feed 96 "
-                   "multiply-adds (0.5 flop/B against a machine balance of ~20), so the kernel is bound by reading the "
-                   "coefficients and the f32 matrix pipe has nothing to reuse; scalar FMAs in the preprocess kernel, "
-                   "no MFMA instruction in the library (DESIGN.md 4.8)"}
+            "mfma_util": (variants or {}).get("mfma_pipe_busy_frac_computed", 0) if rasterizer_fast() else 0,
+            "variants": variants,
+            "why": "the SH contraction is, per Gaussian, a (V x 16) . (16 x 3) product whose operands both belong to that "
+                   "Gaussian: 192 B of coefficients feed 96 multiply-adds per view (0.5 flop/B against a machine balance of ~20), so "
+                   "the stage is bound by reading the coefficients whatever evaluates them.  The batched outer-product instruction "
+                   "(16 Gaussians x 4 views x 4 channels per issue) still pays, through the LAYOUT it imposes: a wave's loads cover 16 "
+                   "Gaussians' coefficient rows and a lane evaluates one (Gaussian, view) basis -- see `variants`; the matrix pipe "
+                   "itself stays a few percent busy (DESIGN.md 4.8)"}
+
+
+def rasterizer_fast():
+    from fluidnexus_amd import rasterizer
+    return rasterizer.get_blend_math() == "fast"
 
 
 def drop_in_timing(a, dev, cfg_id, steps=8):

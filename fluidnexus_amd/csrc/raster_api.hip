@@ -20,7 +20,7 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        const float *proj, const float *campos, int W, int H, int *radii, float2 *means2D,
                        float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity, uint32_t *tiles_touched,
                        uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect, float4 *blend_rec, int prefiltered, int V,
-                       const ViewBatch &vb, const StaticRef &st, int lean, float *zero3, const CohRef &coh);
+                       const ViewBatch &vb, const StaticRef &st, int lean, float *zero3, const CohRef &coh, int fast_sh);
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
@@ -435,7 +435,7 @@ int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffer, 
                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, rad,
                            g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.sort_key0,
                            g.sort_hist + fnx::sort_scratch(P).kmin_blk, g.rect, g.blend_rec, prefiltered, V, vb, st,
-                           (op.lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0, op.zero3, coh);
+                           (op.lean_geometry && V > 1 && !cov3D_precomp) ? 1 : 0, op.zero3, coh, op.blend_math);
     }
     {
     ProfScope ps(2, s);

@@ -3,6 +3,7 @@
 // This file: per-splat preprocess (+ per-(splat block, tile) instance counts and depth-sort keys)
 // and the front-to-back blend.  The binning between them lives in raster_binning.hip.
 #include <mutex>
+#include <cstdlib>
 #include "fnx_device.h"
 #include "fnx_state.h"
 
@@ -116,6 +117,8 @@ sh_colors_views_kernel(int P, int D, int M, int V, const float *__restrict__ mea
         }
     }
 }
+
+#include "sh_mfma.h"  // the same colours through v_mfma_f32_4x4x1_16B_f32: the fast arithmetic's kernel
 
 // scale/rotation -> world covariance (ch3 forward.cu:113-145; quaternion used as given, :121).
 __device__ inline void cov3d_from_scale_rot(const float *scale, float mod, const float *rot, float *cov3D) {
@@ -1171,14 +1174,25 @@ static void launch_preprocess_c(hipStream_t s, int P, int D, int M, const float 
                                 float4 *conic_opacity, uint32_t *tiles_touched, uint32_t *sort_key,
                                 uint32_t *key_min_blk, uint2 *rect,
                                 float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
-                                float *zero3, const CohRef &coh) {
+                                float *zero3, const CohRef &coh, int fast_sh) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     // view batches with SH colours: every Gaussian's coefficients read once for all views (the SH pipe is 3-channel, and
     // its means3D / campos are the same arrays the preprocess reads)
     const int sh_pre = (C == 3 && V > 1 && colors_precomp == nullptr && shs != nullptr && campos != nullptr && M <= 16) ? 1 : 0;
-    if (sh_pre)
-        hipLaunchKernelGGL(sh_colors_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, campos, shs,
-                           clamped, rgb, vb.geom);
+    if (sh_pre) {
+        // The fast arithmetic (stated tolerance) evaluates the colours on the matrix cores (sh_mfma.h: 16 Gaussians per
+        // wave instruction, 102 -> 79 us for the per-splat stage of config 3's Gaussians x 5 views, colours equal to 2.4e-7);
+        // the exact arithmetic keeps the scalar kernel, whose expression order is the reference's.  FNX_LAB_SH_MFMA=0 / 1
+        // in the environment pins either (bench.py times one against the other).
+        const char *lab = getenv("FNX_LAB_SH_MFMA");
+        const bool mfma = lab ? lab[0] == '1' : fast_sh != 0;
+        if (mfma)
+            hipLaunchKernelGGL(sh_colors_views_mfma_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, M, V, means3D, campos,
+                               shs, clamped, rgb, vb.geom);
+        else
+            hipLaunchKernelGGL(sh_colors_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, campos, shs,
+                               clamped, rgb, vb.geom);
+    }
     const int blocks = (P + 255) / 256 + (st.base ? (st.P + 255) / 256 : 0);  // + copy of the static splats' radii
     hipLaunchKernelGGL((preprocess_kernel<C>), dim3(blocks, V), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, view, proj,
@@ -1193,17 +1207,17 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
                        float2 *means2D, float *depths, float *cov3Ds, float *rgb, float4 *conic_opacity,
                        uint32_t *tiles_touched, uint32_t *sort_key, uint32_t *key_min_blk, uint2 *rect,
                        float4 *blend_rec, int prefiltered, int V, const ViewBatch &vb, const StaticRef &st, int lean,
-                       float *zero3, const CohRef &coh) {
+                       float *zero3, const CohRef &coh, int fast_sh) {
     if (C == 3)
         launch_preprocess_c<3>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh, fast_sh);
     else
         launch_preprocess_c<1>(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
                                cov3D_precomp, colors_precomp, view, proj, campos, W, H, radii,
                                means2D, depths, cov3Ds, rgb, conic_opacity, tiles_touched, sort_key, key_min_blk, rect,
-                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh);
+                               blend_rec, prefiltered, V, vb, st, lean, zero3, coh, fast_sh);
 }
 
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
