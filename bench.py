@@ -1014,6 +1014,11 @@ def main():
                           "points_over_capacity_at_last_rebuild": sum(c[4] for c in cs), "slots_per_point": _ph.DIST_VERLET_K}
     except Exception as e:
         print(f"[bench] distance pair-list counters unavailable: {type(e).__name__}: {e}", file=sys.stderr)
+    knn_watch = None
+    if cfg_id != 2 and a.stage == "physical" and hasattr(gm, "check_knn_k") and getattr(gm, "_knn_flags", None) is not None:
+        gm.check_knn_k()  # raises if a fused search met a list longer than KNN_K anywhere in the run (device flag)
+        knn_watch = (f"armed: the fused density / interpolation kernels counted every query's neighbours in every iteration of "
+                     f"this run; no list exceeded KNN_K = {int(gm.KNN_K)} (gm.check_knn_k())")
     knn = None
     if cfg_id != 2 and a.stage == "physical":
         knn = gm.knn_k_report()  # outside the timed region: are the reference's neighbour lists below their cap here?
@@ -1061,7 +1066,7 @@ def main():
                    "views": {"batched": "one view-batched launch sequence per iteration (view = grid dimension y)",
                              "branches": "one rasteriser call per view, views as parallel graph branches",
                              "serial": "one rasteriser call per view, in series"}[view_mode],
-                   "knn_k": knn,
+                   "knn_k": knn, "knn_watch": knn_watch,
                    "physics": None if (cfg_id == 2 or a.stage != "physical") else
                    (("value and gradient evaluated once per iteration, the gradient added once per view "
                      "(equal to the reference's per-view evaluation, tpp:368-404)" if not a.physics_once

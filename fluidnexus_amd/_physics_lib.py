@@ -17,7 +17,7 @@ SYMBOLS = ("fnx_physics_abi_version", "fnx_physics_last_error", "fnx_grid_bytes"
            "fnx_visual_interp_forward_cells_div", "fnx_visual_interp_backward_cells_sum", "fnx_adam_step_grid",
            "fnx_visual_interp_forward_cells_vel", "fnx_distance_table_bytes", "fnx_distance_loss_lists", "fnx_stream_delay",
            "fnx_knn_cut", "fnx_density_forward_kcap", "fnx_density_backward_kcap", "fnx_visual_interp_forward_kcap",
-           "fnx_visual_interp_backward_kcap", "fnx_distance_verlet_bytes", "fnx_distance_loss_verlet")
+           "fnx_visual_interp_backward_kcap", "fnx_distance_verlet_bytes", "fnx_distance_loss_verlet", "fnx_knn_watch")
 
 
 def physics():
@@ -53,6 +53,8 @@ def physics():
     lib.fnx_distance_table_bytes.argtypes = [i]
     lib.fnx_distance_loss_lists.restype = i
     lib.fnx_distance_loss_lists.argtypes = [p, i, f, p, p, p, p]
+    lib.fnx_knn_watch.restype = i
+    lib.fnx_knn_watch.argtypes = [p, i]
     lib.fnx_distance_verlet_bytes.restype = C.c_size_t
     lib.fnx_distance_verlet_bytes.argtypes = [i, i]
     lib.fnx_distance_loss_verlet.restype = i

@@ -411,19 +411,30 @@ stage_points_kernel(const float *__restrict__ x_nn, int N, float sf, const float
 }
 
 // d_i = p_ratio_i - 1 and per-workgroup sums of d_i^2 -> term[blockIdx.x].  kDL lanes per particle.
+// WATCH (fnx_knn_watch): the reference's searches keep at most KNN_K neighbours per query (torch_cluster radius_graph /
+// radius with max_num_neighbors, gm_dynamics.py:1276,1302,1463); these kernels take every pair within H, which is the same
+// thing while no list is longer than K.  With a watch armed every query also counts its neighbours and raises `bit` in
+// the caller's flag word when the count exceeds K: the run no longer equals the reference's and must say so.
+template <bool WATCH>
 __global__ void __launch_bounds__(256)
 density_term_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ imass, float inv_cell, float H2,
                     float term1, float p0, uint32_t mask, const uint32_t *__restrict__ start,
-                    const float4 *__restrict__ rec, float *__restrict__ d_out, float *__restrict__ term) {
+                    const float4 *__restrict__ rec, float *__restrict__ d_out, float *__restrict__ term,
+                    uint32_t *__restrict__ knn_flags, float knn_k, uint32_t bit) {
     const int i = blockIdx.x * kDPerWg + (threadIdx.x / kDL), sub = threadIdx.x & (kDL - 1);
     const int ii = min(i, N - 1);
-    float acc = 0.f;
+    float acc = 0.f, cnt = 0.f;
     for_neighbours<kDL>(sub, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2], inv_cell, H2, mask, start, rec,
                        [&](uint32_t, uint32_t, float, float, float, float r2) {
                            const float t = H2 - r2;
                            acc += term1 * (t * t * t);
+                           if (WATCH) cnt += 1.0f;  // the list of radius_graph(loop = True): the particle itself included
                        });
     acc = density_lane_sum(acc);
+    if (WATCH) {
+        cnt = density_lane_sum(cnt);
+        if (sub == kDL - 1 && i < N && cnt > knn_k) atomicOr(knn_flags, bit);
+    }
     float d2 = 0.f;
     if (sub == kDL - 1 && i < N) {
         const float d = acc / imass[i] / p0 - 1.0f;
@@ -1007,13 +1018,15 @@ grid_cell_items_kernel(uint32_t M, const uint32_t *__restrict__ start, uint2 *__
     }
 }
 
+template <bool WATCH>
 __global__ void __launch_bounds__(64)
 visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float secs, float eps,
                             const float4 *__restrict__ vrec, const uint2 *__restrict__ items,
                             const uint32_t *__restrict__ n_items, uint32_t hmask,
                             const uint32_t *__restrict__ hstart, const float4 *__restrict__ hrec,
                             const float4 *__restrict__ u, float *__restrict__ out, float *__restrict__ sum_w,
-                            float *__restrict__ wvel, float *__restrict__ out_div, float divisor) {
+                            float *__restrict__ wvel, float *__restrict__ out_div, float divisor,
+                            uint32_t *__restrict__ knn_flags, float knn_k) {
     // a candidate = 24 bytes of LDS, read as 16 + 8 (position + u.x | u.y, u.z): the walk is bound by LDS cycles
     __shared__ float4 s_pos[kCellCand];
     __shared__ float2 s_vel[kCellCand];
@@ -1030,7 +1043,7 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
         const bool valid = pi < it.y;
         const float4 me = vrec[valid ? it.x + pi : it.x];
         const int3 c = cell_of(me.x, me.y, me.z, inv_cell);
-        float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        float S = 0.f, ax = 0.f, ay = 0.f, az = 0.f, cnt_n = 0.f;
         unsigned long long todo = __ballot(valid);
         while (todo) {  // one round per distinct cell among the lanes: one, unless cells collide in the bucket
             const int lead = __ffsll((long long)todo) - 1;
@@ -1080,6 +1093,7 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                         ax += q.w * w;
                         ay += uj.x * w;
                         az += uj.y * w;
+                        if (WATCH) cnt_n += (r2 < H2 && i < n) ? 1.0f : 0.0f;
                     }
                 }
                 __syncthreads();
@@ -1091,7 +1105,9 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
             ax += __shfl_xor(ax, (int)step);
             ay += __shfl_xor(ay, (int)step);
             az += __shfl_xor(az, (int)step);
+            if (WATCH) cnt_n += __shfl_xor(cnt_n, (int)step);
         }
+        if (WATCH && valid && slice == 0 && cnt_n > knn_k) atomicOr(knn_flags, 4u);  // radius(x = hidden, y = visual) list > K
         if (valid && slice == 0) {
             const uint32_t v = __float_as_uint(me.w);
             sum_w[v] = S;
@@ -1506,6 +1522,16 @@ int fnx_density_backward_kcap(const float *xyz, int N, const float *imass, float
     return hip_check("density_backward_kcap");
 }
 
+// K-cap watch (include/fnx_physics.h): per host thread, armed until cleared
+thread_local uint32_t *t_knn_flags = nullptr;
+thread_local int t_knn_k = 0;
+int fnx_knn_watch(uint32_t *flags, int K) {
+    if (flags && K < 1) return fail(FNX_ERR_INVALID_ARG, "knn_watch: K must be >= 1");
+    t_knn_flags = flags;
+    t_knn_k = flags ? K : 0;
+    return FNX_OK;
+}
+
 int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float *x_est, const float *x_prev,
                        const float *imass, const float *buoyancy, const float *force, float buoyancy_max_y, float H,
                        float p0, float secs, float lam_e, float lam_g, float lam_n, char *est_grid, int build_est_grid,
@@ -1525,16 +1551,24 @@ int fnx_physical_stage(const float *x_nn, int N, float scale_factor, const float
         if (build_est_grid)
             if (int rc = fnx_grid_build(x, N, H, est_grid, stream)) return rc;
         GridView g = carve(est_grid, N);
-        hipLaunchKernelGGL(density_term_kernel, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
-                           g.M - 1, g.start, g.rec, d1, part_g);
+        if (t_knn_flags)
+            hipLaunchKernelGGL(density_term_kernel<true>, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+                               g.M - 1, g.start, g.rec, d1, part_g, t_knn_flags, (float)t_knn_k, 1u);
+        else
+            hipLaunchKernelGGL(density_term_kernel<false>, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
+                               g.M - 1, g.start, g.rec, d1, part_g, (uint32_t *)nullptr, 0.f, 0u);
         hipLaunchKernelGGL(density_backward_kernel, dim3(nb_d), dim3(256), 0, s, x, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d1, 2.0f * lam_g / (float)N, dx_est);
     }
     if (lam_n > 0.f) {
         if (int rc = fnx_grid_build(xg, N, H, guess_grid, stream)) return rc;
         GridView g = carve(guess_grid, N);
-        hipLaunchKernelGGL(density_term_kernel, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
-                           g.M - 1, g.start, g.rec, d2, part_n);
+        if (t_knn_flags)
+            hipLaunchKernelGGL(density_term_kernel<true>, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+                               g.M - 1, g.start, g.rec, d2, part_n, t_knn_flags, (float)t_knn_k, 2u);
+        else
+            hipLaunchKernelGGL(density_term_kernel<false>, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
+                               g.M - 1, g.start, g.rec, d2, part_n, (uint32_t *)nullptr, 0.f, 0u);
         hipLaunchKernelGGL(density_backward_kernel, dim3(nb_d), dim3(256), 0, s, xg, N, imass, inv, H2, t1, p0,
                            g.M - 1, g.start, g.rec, d2, 2.0f * lam_n / (float)N, dg);
     }
@@ -2197,9 +2231,16 @@ int fnx_visual_interp_forward_cells_vel(const float *visual, int V, const float 
     // one-wave workgroups that stride over the items; 20 of them fit a CU (8 KiB of LDS each)
     const size_t bound = (size_t)V + (size_t)V / 64 + 1;
     const unsigned wgs = (unsigned)(bound < 5120 ? bound : 5120);
-    hipLaunchKernelGGL(visual_forward_cells_kernel, dim3(wgs), dim3(64), 0, (hipStream_t)stream, V, 1.0f / H, H * H,
-                       poly6_term1(H), secs, eps, gv.rec, (const uint2 *)(visual_items + 64),
-                       (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel, out_div, divisor);
+    if (t_knn_flags)
+        hipLaunchKernelGGL(visual_forward_cells_kernel<true>, dim3(wgs), dim3(64), 0, (hipStream_t)stream, V, 1.0f / H, H * H,
+                           poly6_term1(H), secs, eps, gv.rec, (const uint2 *)(visual_items + 64),
+                           (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel, out_div, divisor,
+                           t_knn_flags, (float)t_knn_k);
+    else
+        hipLaunchKernelGGL(visual_forward_cells_kernel<false>, dim3(wgs), dim3(64), 0, (hipStream_t)stream, V, 1.0f / H, H * H,
+                           poly6_term1(H), secs, eps, gv.rec, (const uint2 *)(visual_items + 64),
+                           (const uint32_t *)visual_items, g.M - 1, g.start, g.rec, g.aux0, out, sum_w, wvel, out_div, divisor,
+                           (uint32_t *)nullptr, 0.f);
     return hip_check("visual_interp_forward_cells");
 }
 

@@ -812,6 +812,39 @@ class GaussianModel:
             raise RuntimeError(f"neighbour lists exceed KNN_K: {rep}; the reference truncates them, the fused kernels do not")
         return rep
 
+    # K-cap watch on the FUSED path (round 5): the fused stage and the cell-by-cell interpolation take every pair within H;
+    # armed, they count every query's neighbours on their way and raise a device flag when a list exceeds KNN_K -- no
+    # host synchronisation inside the loop, check_knn_k() reads the word when the caller likes (bench.py: after the timed
+    # region; the loops: at every frame boundary).
+    _KNN_BITS = {1: "hidden particles at the optimised positions (get_gas_constraints_from_exyz_nn)",
+                 2: "hidden particles at the guessed positions (get_gas_constraints_from_vel_nn_guess)",
+                 4: "visual particles over the hidden ones (get_visual_xyz_from_nn)"}
+
+    def arm_knn_watch(self):
+        """Have the fused physics / interpolation kernels of this host thread flag neighbour lists longer than KNN_K."""
+        if getattr(self, "_knn_flags", None) is None or self._knn_flags.device != self._xyz.device:
+            self._knn_flags = torch.zeros(4, dtype=torch.int32, device=self._xyz.device)
+        physics.PL.check(physics.PL.physics().fnx_knn_watch(self._knn_flags.data_ptr(), int(self.KNN_K)))
+        return self._knn_flags
+
+    def disarm_knn_watch(self):
+        physics.PL.check(physics.PL.physics().fnx_knn_watch(None, 0))
+
+    def check_knn_k(self):
+        """Blocking read of the watch's flag word: raises if any fused search met a list longer than KNN_K since the last
+        call (the reference would have truncated it, gm_dynamics.py:1276,1302,1463: this run no longer equals it --
+        set_knn_cap(True) reproduces the truncation through the per-particle kernels)."""
+        flags = getattr(self, "_knn_flags", None)
+        if flags is None:
+            return 0
+        word = int(flags[0].item())
+        if word:
+            flags.zero_()
+            which = "; ".join(v for k, v in self._KNN_BITS.items() if word & k)
+            raise RuntimeError(f"a neighbour list exceeded KNN_K = {int(self.KNN_K)} on the fused path: {which}.  The reference "
+                               "truncates such lists (max_num_neighbors); the fused kernels do not: gm.set_knn_cap(True)")
+        return 0
+
     # -- optimiser set-up and gradient caches ----------------------------------------------------------
     def _lr_schedule(self, a):
         return get_expon_lr_func(lr_init=a.position_lr_init * self.spatial_lr_scale,

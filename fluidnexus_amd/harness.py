@@ -183,6 +183,10 @@ class HotLoop:
             raise ValueError("gm.knn_cap (max_num_neighbors mode) runs through the per-term physics methods: "
                              "HotLoop(fused_physics=False, defer_visual_backward=False)")
         self.force_all_reduce = force_all_reduce
+        # the fused kernels take every pair within H: have them flag lists longer than the reference's cap
+        if (fused_physics or defer_visual_backward) and not getattr(gm, "knn_cap", False) and \
+                os.environ.get("FNX_KNN_WATCH", "1") != "0" and gm._xyz.is_cuda:
+            gm.arm_knn_watch()
         gm.defer_visual_backward = bool(defer_visual_backward)
         dev = gm._xyz.device
         self.background = torch.zeros(3, device=dev)

@@ -194,6 +194,14 @@ int fnx_distance_loss(const float *xyz, int N, float threshold, char *grid, floa
 /* Scheduling aid: one sleeping wave on `stream` for about `microseconds` (a side branch of a captured graph can only fork
  * at a kernel boundary of the main chain; this moves its start INTO the kernel that follows the fork point). */
 int fnx_stream_delay(float microseconds, fnx_stream_t stream);
+/* K-cap watch.  The reference's three neighbour searches keep at most KNN_K neighbours per query (torch_cluster
+ * radius_graph(loop = True) / radius with max_num_neighbors = KNN_K, gm_dynamics.py:1276,1302,1463); the fused stage and the
+ * cell-by-cell interpolation take every pair within H -- identical while no list is longer than K.  With a watch armed
+ * (per host thread, until fnx_knn_watch(NULL, 0)) fnx_physical_stage and fnx_visual_interp_forward_cells* count every
+ * query's neighbours on their way and OR into flags[0]: 1 = a hidden-particle list at the optimised positions exceeds K,
+ * 2 = one at the guessed positions, 4 = a visual particle's list of hidden particles.  No host synchronisation: the
+ * caller owns the word (zero it once) and reads it when it likes; launches recorded into a hipGraph keep the pointer. */
+int fnx_knn_watch(uint32_t *flags, int K);
 size_t fnx_distance_table_bytes(int N);
 int fnx_distance_loss_lists(const float *xyz, int N, float threshold, char *table, float *grad, float *loss_out,
                             fnx_stream_t stream);
