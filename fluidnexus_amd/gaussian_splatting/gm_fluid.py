@@ -4,7 +4,7 @@ separate background set, rendered through render_fluid and the 1-channel rasteri
 The reference's gm_fluid.py is a sibling copy of gm_dynamics.py; a normalised diff of the two leaves these
 differences, which is all this subclass states: no `_gs_*` background group and no load_ply; the first-frame particle
 clouds have hard-coded geometry (`create_particles_visual()` :468-487, `create_particles_hidden()` :490-528);
-`load_visual` has no colour replication flag; `save_all` has no re-simulation flag; `record_time` times a solver step
+`prepare_emitter_points()` takes no arguments (hard-coded nozzle, :594-632); `load_visual` has no colour replication flag; `save_all` has no re-simulation flag; `record_time` times a solver step
 with device events (:898-900, 988-995).  Physics terms, PBF solver, gradient caches and checkpoint formats are the
 shared implementation of .gm_dynamics."""
 from __future__ import annotations
@@ -40,6 +40,18 @@ class GaussianModel(_DynamicsModel):
         self.init_hidden_velocity = 0.0
         self._init_hidden_state(self._pillar_lattice(g["x_mid"], g["z_mid"], g["radius_max"], g["y_min"], g["y_max"],
                                                      g["delta"]))
+
+    # hard-coded nozzle of the ScalarReal scenes (gm_fluid.py:594-632): the dynamics model reads it from model_args
+    EMITTER = dict(emitter_hidden_delta=0.015, emitter_visual_delta=0.00625, init_x_mid=0.34, init_z_mid=-0.225,
+                   emitter_center_y_hidden=-0.02, emitter_center_y_visual=-0.01, emitter_visual_radius_ratio=4,
+                   emitter_hidden_radius_ratio=6)
+
+    @torch.no_grad()
+    def prepare_emitter_points(self):
+        """:594-632: NO arguments in this model (entries_scalar_real/train_physical_particle.py calls it so) -- the same
+        one-layer disc lattices as the dynamics model's, from the constants above."""
+        from types import SimpleNamespace
+        return super().prepare_emitter_points(SimpleNamespace(**self.EMITTER))
 
     def load_visual(self, checkpoint_path, frame_idx, scale=True, device="cuda"):
         return super().load_visual(checkpoint_path, frame_idx, scale=scale, color_3ch=False, device=device)

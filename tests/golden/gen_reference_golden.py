@@ -546,6 +546,13 @@ def gen_emitter():
         rlen = torch.norm(r, dim=1)
         out["spiky_r"], out["spiky_grad"] = r.numpy().copy(), gm.spiky_grad(r, rlen).numpy().copy()
         np.savez(os.path.join(OUT, "emitter.npz"), **out)
+        # the ScalarReal model's emitter (gm_fluid.py:594-632): no arguments, hard-coded nozzle geometry
+        import gaussian_splatting.gm_fluid as gmf
+        gf = gmf.GaussianModel()
+        gf.emit_ratio_visual, gf.emit_ratio_hidden = 1.0, 1.0  # only printed
+        gf.prepare_emitter_points()
+        np.savez(os.path.join(OUT, "emitter_fluid.npz"), emit_visual=gf.visual_emitter_points.numpy().copy(),
+                 emit_hidden=gf.hidden_emitter_points.numpy().copy())
     finally:
         for n, f in zip(names, saved[:-1]):
             setattr(torch, n, f)
@@ -574,6 +581,33 @@ def gen_entry_surface():
         names[os.path.relpath(pth, REF)] = sorted(set(re.findall(r"\bgaussians\.([A-Za-z_]\w*)", code)))
     with open(os.path.join(OUT, "entry_script_names.json"), "w") as f:
         json.dump(names, f, indent=0, sort_keys=True)
+    # (1b) what KIND of thing each name is on the reference's class the script's shipped configuration selects, and for
+    # methods their parameter names (with "=" behind those that have a default): a stub attribute, or a method with
+    # another signature, must not pass for the real thing.  Names and parameter lists only.
+    import inspect
+    import gaussian_splatting.gm_background as gmb
+    import gaussian_splatting.gm_fluid as gmf
+    cls_of = {"entries_fluid_nexus/train_background.py": gmb.GaussianModel,
+              "entries_fluid_nexus/train_physical_particle.py": gmd.GaussianModel,
+              "entries_fluid_nexus/train_visual_particle.py": gmd.GaussianModel,
+              "entries_scalar_real/train_physical_particle.py": gmf.GaussianModel,
+              "entries_scalar_real/train_visual_particle.py": gmf.GaussianModel}
+    sigs = {}
+    for script, cls in cls_of.items():
+        ent = {}
+        for n in names[script]:
+            a = inspect.getattr_static(cls, n, None)
+            if isinstance(a, property):
+                ent[n] = {"kind": "property"}
+            elif inspect.isfunction(a):
+                ps = [p for p in inspect.signature(a).parameters.values() if p.name != "self"]
+                ent[n] = {"kind": "method", "params": [("**" if p.kind is p.VAR_KEYWORD else "*" if p.kind is p.VAR_POSITIONAL else "")
+                                                       + p.name + ("=" if p.default is not inspect.Parameter.empty else "") for p in ps]}
+            else:
+                ent[n] = {"kind": "attribute"}  # set on the instance (in __init__ or by a set-up method)
+        sigs[script] = ent
+    with open(os.path.join(OUT, "entry_script_signatures.json"), "w") as f:
+        json.dump(sigs, f, indent=0, sort_keys=True)
 
     rng = np.random.RandomState(31)
     f32 = lambda *s: torch.tensor(rng.normal(size=s).astype(np.float32))  # noqa: E731
