@@ -731,6 +731,13 @@ def main():
     nominal_views = C["views"]
     n_views = nominal_views * world if scaling == "weak" else nominal_views
     shard_world = world
+    graph_ar = None
+    if use_dist:
+        # multi-rank: the all-reduce goes INSIDE the hipGraph (one launch gap per k iterations instead of a replay + an eager
+        # collective + an eager step per iteration) if a captured collective completes on every rank: tried first on a
+        # throw-away process group, with a deadline (harness.graph_allreduce_self_test)
+        from fluidnexus_amd import harness as _H
+        graph_ar = _H.graph_allreduce_self_test(dev) if _H._GRAPH_ALLREDUCE == "auto" else _H._GRAPH_ALLREDUCE == "1"
     gm, cams, loop = build_workload(cfg_id, n_views, dev, rank, world, a, use_dist)
     loop_views = shard_views(len(cams), rank, world)
     if a.emulate_world > 1:
@@ -1040,6 +1047,12 @@ def main():
                    "parallelism": (f"views sharded round-robin over {shard_world} rank(s)"
                                    + (f" (emulated: rank {a.emulate_rank}'s share, no communication)" if a.emulate_world > 1 else "")
                                    + ", RCCL all-reduce of the leaf gradient"),
+                   "all_reduce": (None if not use_dist else
+                                  ("inside the hipGraph (local phase | RCCL all-reduce | fused step, k iterations per graph); a captured "
+                                   "collective was first replayed on a throw-away process group with a deadline on every rank"
+                                   if (graph_ar and getattr(loop, "graph_finish", "x") is None and graph_mode) else
+                                   "eager, between a graph replay of the local phase and the eager fused step"
+                                   + ("" if graph_ar else " (the captured-collective self-test did not pass or is switched off)"))),
                    "shared_terms": ("physics terms + distance loss on every rank, added once per local view"
                                     if getattr(loop, "shared_terms_rank", None) is None else
                                     f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "

@@ -163,6 +163,11 @@ __global__ void __launch_bounds__(1024)
 grid_scan_kernel(uint32_t M, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
                  uint32_t *__restrict__ cursor) {
     __shared__ uint32_t s_wave[kScanChunks][16];
+    // One workgroup, pure latency (two barriers per 32 768 buckets): alone it takes 5-7 us, but as a side-branch kernel under
+    // the rasteriser's blend forward its 16 waves waited behind four throughput-bound waves per SIMD and took 65 us (config 3)
+    // / 212 us (config 5) -- raised wave priority instead of more workgroups: a multi-workgroup scan of 8 chunks would add a
+    // look-back chain to a kernel that is already nothing but latency, and the starvation is what costs (round 5).
+    __builtin_amdgcn_s_setprio(3);
     grid_scan_block(M, count, start, cursor, s_wave);
 }
 

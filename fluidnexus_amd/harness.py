@@ -136,7 +136,62 @@ _DIST_DELAY_US = float(os.environ.get("FNX_DIST_DELAY_US", "0"))
 # graph) instead of replaying the local phase and issuing the collective and the step eagerly.  Opt-in: it could only be
 # tried with one rank on the builder's single-GPU box (bench.py FNX_FORCE_DIST=1), and a collective that hangs inside a
 # graph on a multi-GPU node cannot be caught from here; if the capture raises, the eager path is used.
-_GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "0") == "1"
+# Round 5: the DEFAULT of a multi-rank run once graph_allreduce_self_test() has shown, on a process group of its own, that
+# this RCCL completes a captured collective on every rank within a deadline ("auto").  FNX_GRAPH_ALLREDUCE=1 forces it,
+# =0 keeps the eager collective.
+_GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "auto")
+_GRAPH_ALLREDUCE_OK = None  # result of the self-test (None: not run)
+
+
+def graph_allreduce_self_test(dev, timeout_s=20.0):
+    """Can this process group replay an all-reduce that was recorded into a hipGraph?  Every rank records one small
+    all-reduce on a process group OF ITS OWN (a collective that hangs inside a replayed graph cannot be cancelled; it must
+    not wedge the communicator the run needs), replays it and polls a completion event against a deadline -- no blocking
+    wait -- then the ranks agree through the main group: True only if every rank finished in time with the right sum.
+    A rank that timed out leaves a spinning collective behind on its side stream; the run goes on with the eager
+    collective and says so.  Collective: every rank must call it."""
+    global _GRAPH_ALLREDUCE_OK
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    import time
+    ok = 0
+    try:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        grp = dist.new_group(ranks=list(range(world)))
+        x = torch.full((1024,), float(rank + 1), device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            dist.all_reduce(x, group=grp)  # eager: sets the communicator up outside the capture
+            side.synchronize()
+            x.fill_(float(rank + 1))
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                dist.all_reduce(x, group=grp)
+            g.replay()
+            done = torch.cuda.Event()
+            done.record(side)
+        deadline = time.monotonic() + float(timeout_s)
+        while not done.query() and time.monotonic() < deadline:
+            time.sleep(0.005)
+        if done.query():
+            ok = int(abs(float(x[0].item()) - world * (world + 1) / 2.0) < 1e-3)
+    except Exception as e:  # e.g. a backend that cannot be captured (gloo)
+        print(f"[harness] all-reduce self-test inside a hipGraph: {type(e).__name__}: {e}", flush=True)
+        ok = 0
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # the main group, eagerly: every rank learns the common verdict
+    _GRAPH_ALLREDUCE_OK = bool(int(flag.item()))
+    return _GRAPH_ALLREDUCE_OK
+
+
+def _graph_allreduce_wanted():
+    if _GRAPH_ALLREDUCE == "1":
+        return True
+    if _GRAPH_ALLREDUCE == "0":
+        return False
+    return bool(_GRAPH_ALLREDUCE_OK)  # auto: only after a passed self-test
 # One fork point for both side branches (the rasteriser's between-stages hook) instead of two: every fork / join of the
 # captured graph costs the main chain ~5 us in front of the kernel behind it
 _SINGLE_FORK = os.environ.get("FNX_SINGLE_FORK", "0") == "1"
@@ -316,7 +371,7 @@ class HotLoop:
             # "write access to a read-only page".  A 0.3 MB all-reduce costs one launch either way.
             self._reduce_buf = torch.zeros_like(self.gm._estimate_xyz_nn.detach())
             torch.cuda.synchronize()
-            if _GRAPH_ALLREDUCE and self.fused_step:
+            if _graph_allreduce_wanted() and self.fused_step:
                 try:
                     itr0, tot0 = self.itr, self.gm.total_iterations
                     with torch.cuda.graph(g, stream=self.stream):
