@@ -422,7 +422,7 @@ def rasterizer_fast():
     return rasterizer.get_blend_math() == "fast"
 
 
-def drop_in_timing(a, dev, cfg_id, steps=8):
+def drop_in_timing(a, dev, cfg_id, steps=8, auto=False):
     """What a FluidNexus user gets from `PYTHONPATH=<this repo>` alone: the reference's own op sequence
     through the plug-in seam -- one GaussianRasterizer autograd node per view (train_physical_particle.py:338-405), the
     image / physics / distance terms as separate autograd nodes, gm.cache_gradient_current per view, torch.optim.Adam,
@@ -432,15 +432,20 @@ def drop_in_timing(a, dev, cfg_id, steps=8):
     from types import SimpleNamespace
     from fluidnexus_amd import rasterizer
     from fluidnexus_amd.renderer import pipes
+    import fluidnexus_amd
     keep = dict(rasterizer._OPTS)
     keep_sync, keep_split, keep_cudnn = rasterizer._HOST_SYNC, pipes._STATIC_SPLIT, torch.backends.cudnn.enabled
+    keep_auto = fluidnexus_amd.auto_enabled()
     try:
         rasterizer.set_blend_math("exact")
         rasterizer.set_lean_geometry(False)
         rasterizer.set_sort_narrow(False)
         rasterizer.set_coherent_sort(False)
         rasterizer.set_host_sync(True)
-        pipes.set_static_split(False)
+        pipes.set_static_split(bool(auto))
+        # `auto`: the SAME loop -- the reference's per-view op sequence, torch.optim.Adam, exact arithmetic -- with the
+        # library-side automation of the seam switched on (FNX_AUTO=1 for a user): nothing in the calling code changes
+        fluidnexus_amd.set_auto(bool(auto))
         torch.backends.cudnn.enabled = False  # utils.loss_utils.ssim's conv2d on ATen's own kernels (MIOpen's cold find step)
         b = SimpleNamespace(**vars(a))
         b.no_graph, b.host_sync, b.image_loss, b.unfused_physics, b.torch_adam, b.views = True, True, "torch", True, True, "serial"
@@ -454,6 +459,14 @@ def drop_in_timing(a, dev, cfg_id, steps=8):
             loop.iteration()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        if auto:
+            rasterizer.check_status()
+            return {"drop_in_iters_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                    "what": "the same per-view op sequence and the same calling code as `drop_in` with fluidnexus_amd's automation of "
+                            "the seam on (FNX_AUTO=1): render_dynamics(camera, ...) routes through the view-batched rasteriser with one "
+                            "view (background binned once per camera, no host sync per forward, positions-only backward, coherent "
+                            "depth sort per camera), utils.loss_utils.ssim runs the fused kernel; exact blend arithmetic, torch.optim.Adam, "
+                            "per-view physics / distance autograd nodes, per-view gradient cache"}
         return {"drop_in_iters_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps,
                 "what": "reference op sequence through the plug-in seam: per-view rasteriser autograd nodes, torch image / "
                         "physics / distance terms, per-view gradient cache, torch.optim.Adam, host sync per forward, exact "
@@ -466,6 +479,7 @@ def drop_in_timing(a, dev, cfg_id, steps=8):
         rasterizer.set_coherent_sort(bool(keep["coherent_sort"]))
         rasterizer.set_host_sync(keep_sync)
         pipes.set_static_split(keep_split)
+        fluidnexus_amd.set_auto(keep_auto)
         torch.backends.cudnn.enabled = keep_cudnn
 
 
@@ -1122,6 +1136,7 @@ def main():
     if not a.no_drop_in and cfg_id in (3, 4) and a.stage == "physical" and world == 1 and a.emulate_world <= 1:
         try:
             out["drop_in"] = drop_in_timing(a, dev, cfg_id)
+            out["drop_in_auto"] = drop_in_timing(a, dev, cfg_id, steps=24, auto=True)
         except Exception as e:
             import traceback
             traceback.print_exc()

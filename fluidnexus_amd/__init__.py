@@ -3,3 +3,24 @@ hot path: the differentiable 3D-Gaussian rasteriser (ch3 / ch1) and the physics-
 particle losses, behind the reference's own Python plug-in interface.  See DESIGN.md.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# Library-side automation of the PER-VIEW plug-in seam (round 5).  The reference's entry scripts call render_dynamics(camera,
+# ...) once per view, utils.loss_utils per view, loss.backward() per view: with `auto` on, those same calls -- no script
+# edit -- get what the harness uses under the hood: the per-view pipe routes through the view-batched rasteriser with one
+# view (frozen background binned once per camera, no host sync per forward, positions-only backward while only positions
+# are optimised, the temporal-coherence depth sort per camera), utils.loss_utils.ssim runs the fused kernel on device
+# tensors.  Off by default (the reference's op-by-op behaviour); FNX_AUTO=1 in the environment or set_auto(True).
+# What changes for a caller: "viewspace_points" takes no gradient while only positions are optimised (the background
+# stage, which reads it, is unaffected), and a binning overflow is reported by the next call instead of this one.
+_AUTO = _os.environ.get("FNX_AUTO", "0") == "1"
+
+
+def set_auto(enabled: bool):
+    global _AUTO
+    _AUTO = bool(enabled)
+
+
+def auto_enabled() -> bool:
+    return _AUTO

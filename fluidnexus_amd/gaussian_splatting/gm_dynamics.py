@@ -743,7 +743,11 @@ class GaussianModel:
         x = self._scaled_estimate()
         if self._visual_memo[0] != key:
             self.flush_deferred_gradients()
-            self._visual_memo = (key, {"defer": True} if self.defer_visual_backward else {})
+            # (with the seam's automation on -- fluidnexus_amd.set_auto -- the per-view backward passes are deferred as
+            # well: the interpolation is linear in the rendered positions' gradient, one backward per iteration on the sum
+            # of the views' gradients, added to the gradient cache by set_batch_gradient_current / flush_deferred_gradients)
+            from .. import auto_enabled
+            self._visual_memo = (key, {"defer": True} if (self.defer_visual_backward or auto_enabled()) else {})
         if getattr(self, "_render_means_request", None) is not None:
             self._visual_memo[1]["out_div"] = self._render_means_request
         else:

@@ -348,12 +348,25 @@ def physical_stage_loss(gm, lam_exyz, lam_gas, lam_next, memo=None):
     return _PhysicalStageLoss.apply(gm._estimate_xyz_nn, gm, float(lam_exyz), float(lam_gas), float(lam_next), memo)
 
 
+_DIST_MEMO = [None]  # (state key, threshold, loss, grad) of the latest tagged evaluation
+
+
 class _DistanceLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, positions, threshold):
-        loss, grad = distance_loss_value_and_grad(positions.detach(), threshold)
+        # The reference evaluates the term once per VIEW on the same rendered positions (train_physical_particle.py:365-366).
+        # The automated per-view pipe tags its positions with the particle state they were computed from (`_fnx_state`):
+        # a second evaluation for the same state and threshold reuses value and gradient instead of searching again.
+        key = getattr(positions, "_fnx_state", None)
+        hit = _DIST_MEMO[0]
+        if key is not None and hit is not None and hit[0] == key and hit[1] == float(threshold) and hit[3].shape == positions.shape:
+            loss, grad = hit[2], hit[3]
+        else:
+            loss, grad = distance_loss_value_and_grad(positions.detach(), threshold)
+            if key is not None:
+                _DIST_MEMO[0] = (key, float(threshold), loss, grad)
         ctx.save_for_backward(grad)
-        return loss
+        return loss.clone() if key is not None else loss
 
     @staticmethod
     def backward(ctx, g):

@@ -125,6 +125,9 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
                     GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None, gpf_only=False, gs_only=False,
                     debug=False, **kwargs):
     """Fluid particles (+ static background Gaussians) through the 3-channel rasteriser."""
+    from .. import auto_enabled
+    if auto_enabled() and not (gpf_only or gs_only or debug) and override_color is None and _auto_applies(gm, pos_type):
+        return _render_dynamics_auto(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier, GRsetting, GRzer, pos_type, scale)
     raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
     if gpf_only:
         means3D = render_xyz
@@ -148,6 +151,47 @@ def render_dynamics(viewpoint_camera, gm, pipe_args, bg_color, scaling_modifier=
                                      colors_precomp=colors.float(), opacities=opacity.float(), scales=scales.float(),
                                      rotations=rotations.float(), cov3D_precomp=None)
     return _pack(image, radii, depth, screen, opacity, render_xyz, raw_render_xyz, means3D, rotations, colors, scales)
+
+
+def _auto_applies(gm, pos_type):
+    """The automated per-view path covers the position stages: nothing but positions is optimised (no attribute of the
+    fluid or the background Gaussians requires grad), device tensors."""
+    fam = _ATTR.get(pos_type, "visual")
+    if fam == "dummy":
+        return False
+    names = [f"_{fam}_{n}" for n in ("opacity", "scales", "rotation", "color")] + [f"_gs_{n}" for n in ("xyz", "opacity", "scales", "rotation", "color")]
+    ts = [getattr(gm, n, None) for n in names]
+    return all(t is not None and t.is_cuda and not t.requires_grad for t in ts)
+
+
+_AUTO_HOST_SYNC_WARNED = []
+
+
+def _render_dynamics_auto(cam, gm, pipe_args, bg_color, scaling_modifier, GRsetting, GRzer, pos_type, scale):
+    """render_dynamics(camera, ...) of a position stage through the view-batched machinery with ONE view (fluidnexus_amd.
+    set_auto): same arguments, same return keys and shapes.  Per camera: the frozen background is binned once (StaticBin,
+    keyed by the background tensors' versions), the depth sort repairs the previous call's order (its own state per
+    camera), the forward reads nothing back (binning capacity from a high-water mark; an overflow is reported by
+    rasterizer.check_status() / the next check), and the backward is the positions-only one: "viewspace_points" is
+    returned without a gradient."""
+    from .. import rasterizer as _rz
+    if _rz._HOST_SYNC:  # the automation's forward is the sync-free one
+        _rz.set_host_sync(False)
+    raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
+    means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
+    pkg = render_dynamics_views([cam], gm, pipe_args, bg_color, scaling_modifier, GRsetting=GRsetting, GRzer=GRzer,
+                                pos_type=pos_type, scale=scale, means3D=means3D, screen_grad=False,
+                                options=dict(coherent_sort=2, sort_key=id(cam)))
+    out = dict(pkg)
+    for k in ("render", "radii", "depth", "viewspace_points"):
+        out[k] = pkg[k][0]
+    out["means2D"] = out["viewspace_points"]
+    out["visibility_filter"] = out["radii"] > 0
+    out["render_xyz"], out["raw_render_xyz"] = render_xyz, raw_render_xyz
+    if pos_type == "guess_visual_nn":  # the state the positions were interpolated from (physics._DistanceLoss reuses on it)
+        est = gm._estimate_xyz_nn
+        render_xyz._fnx_state = (id(gm), id(est), est._version, id(gm._visual_xyz), bool(scale))
+    return out
 
 
 class _LazyPackage(dict):
@@ -195,18 +239,22 @@ def set_static_split(enabled: bool):
 
 
 def _static_bin(gm, vbatch, means3D, opacity, scales, rotations, colors, n_fluid, channels):
-    """StaticBin over the background rows [n_fluid:] of the concatenated arrays, rebuilt when the camera batch or any
-    raw background tensor changes (object or version).  The entry holds the objects it is keyed on."""
+    """StaticBin over the background rows [n_fluid:] of the concatenated arrays, per (model, camera batch): rebuilt when a
+    raw background tensor changes (object or version) or the split does.  The entry holds the objects it is keyed on.
+    (Per camera batch since round 5: the automated per-view path cycles through one single-view batch per camera.)"""
     from ..rasterizer import StaticBin
     raws = [getattr(gm, f"_gs_{n}") for n in ("xyz", "opacity", "scales", "rotation", "color")]
     versions = tuple(t._version for t in raws)
-    hit = _STATIC_BIN_CACHE.get(id(gm))
+    key = (id(gm), id(vbatch))
+    hit = _STATIC_BIN_CACHE.get(key)
     if (hit is not None and hit[0] is gm and hit[1] is vbatch and hit[3] == versions and hit[4] == (n_fluid, channels)
             and all(a is b for a, b in zip(hit[2], raws))):
         return hit[5]
+    if len(_STATIC_BIN_CACHE) > 64:
+        _STATIC_BIN_CACHE.clear()
     sb = StaticBin(vbatch, means3D[n_fluid:], opacity[n_fluid:], n_fluid, colors_precomp=colors[n_fluid:],
                    scales=scales[n_fluid:], rotations=rotations[n_fluid:], channels=channels)
-    _STATIC_BIN_CACHE[id(gm)] = (gm, vbatch, raws, versions, (n_fluid, channels), sb)
+    _STATIC_BIN_CACHE[key] = (gm, vbatch, raws, versions, (n_fluid, channels), sb)
     return sb
 
 
@@ -225,7 +273,7 @@ def _zero_scalar(like):
 def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_modifier=1.0, override_color=None,
                           GRsetting=None, GRzer=None, pos_type="visual", scale=False, prev_visual_xyz=None,
                           gpf_only=False, gs_only=False, debug=False, means3D=None, attributes=None, screen_grad=True,
-                          dual_bg=None, **kwargs):
+                          dual_bg=None, options=None, **kwargs):
     """render_dynamics for all cameras of a training batch in one rasteriser call (extension: the
     reference loops over the views, train_physical_particle.py:338-352).  Same keyword arguments; the
     per-view entries of the returned dict carry a leading view dimension ("render" [V,3,H,W], "radii"
@@ -269,7 +317,8 @@ def render_dynamics_views(viewpoint_cameras, gm, pipe_args, bg_color, scaling_mo
     if screen_grad:
         screen = screen.requires_grad_()
     rasterizer = GaussianRasterizerViews(_view_batch(GRsetting, viewpoint_cameras, bg_color, scaling_modifier,
-                                                     gm.active_sh_degree), channels=getattr(GRzer, "channels", 3))
+                                                     gm.active_sh_degree), channels=getattr(GRzer, "channels", 3),
+                                         options=options)
     if not (gpf_only or gs_only) and not any(
             getattr(gm, f"_gs_{n}").requires_grad for n in ("xyz", "opacity", "scales", "rotation", "color")):
         n_fluid = render_xyz.shape[0]

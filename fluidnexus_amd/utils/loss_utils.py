@@ -51,6 +51,16 @@ def _ssim_map(img1, img2, window, pad, channel):
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
+    """loss_utils.py:33-64.  With the per-view automation on (fluidnexus_amd.set_auto), device tensors of the default form (11-tap window, mean over the image, [C,H,W] or [N,C,H,W])
+    go through the fused kernel (fluidnexus_amd.losses.fused_l1_ssim: separable windows in LDS, one launch forward and one
+    backward instead of ~25 + ~40 -- pinned against this very expression by tests/golden/loss_utils.npz); anything else
+    takes the reference's own op sequence below."""
+    if img1.is_cuda and img2.is_cuda and window_size == 11 and size_average and img1.dim() == 3 and img1.shape == img2.shape \
+            and img1.dtype == torch.float32:
+        from .. import auto_enabled
+        if auto_enabled():  # part of the per-view seam's automation (fluidnexus_amd.set_auto / FNX_AUTO=1)
+            from ..losses import fused_l1_ssim
+            return fused_l1_ssim(img1, img2)[1]
     channel = img1.size(-3)
     window = create_window(window_size, channel).to(device=img1.device, dtype=img1.dtype)
     m = _ssim_map(img1, img2, window, window_size // 2, channel)
