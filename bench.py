@@ -548,18 +548,33 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         c0 = rasterizer.coherent_sort_counters(P_frame)
         # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
         # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
-        for _ in range(4 if a.sort == "coherent" else 2):
+        for _ in range(2):
             loop.iteration()
             done += 1
         rasterizer.check_status()
+        captured = False
+        if graph and n - done - 1 >= gi:
+            loop.capture(warmup=1, iterations=gi)
+            done += 1
+            captured = True
         if a.sort == "coherent":
+            # does the frame stay inside the coherent sort's reach?  Judged on the first replay (round 5: two eager iterations
+            # fewer per frame than judging before the capture); a frame that does not is re-captured on the radix passes
+            if captured and n - done >= gi:
+                loop.iteration()
+                done += gi
+            else:
+                for _ in range(min(2, n - done)):
+                    loop.iteration()
+                    done += loop.iterations_per_call
             c1 = rasterizer.coherent_sort_counters(P_frame)
             if c1[1] - c0[1] > rasterizer.coherent_sort_states(P_frame):
                 rasterizer.set_coherent_sort(False)
                 sort_switched.append(len(counts))
-        if graph and n - done - 1 >= gi:
-            loop.capture(warmup=1, iterations=gi)
-            done += 1
+                if captured and n - done - 1 >= gi:
+                    loop.use_graph(False)
+                    loop.capture(warmup=1, iterations=gi)
+                    done += 1
         t2 = tick()
         while done < n:
             if loop.iterations_per_call > n - done:
@@ -592,9 +607,9 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             "particles_last_frame": {"hidden": counts[-1][0], "visual": counts[-1][1]},
             "emitted_per_frame": {"hidden": int(hid.shape[0]), "visual": int(vis.shape[0])},
             "frames_on_radix_sort": len(sort_switched),
-            "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, four eager "
-                    "iterations (two with --sort radix; the first seeds the depth sort's state, the others show whether the frame "
-                    "stays inside the coherent sort's reach), static background re-binned, hipGraph re-captured (setup: its iterations count towards n) | "
+            "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, two eager "
+                    "iterations (the first seeds the depth sort's state), static background re-binned, hipGraph re-captured, its first "
+                    "replay shows whether the frame stays inside the coherent sort's reach (setup: its iterations count towards n) | "
                     "replayed iterations | confirm + advect + confirm; frame_boundary_ms = ms_per_frame - n x the steady-state "
                     "ms_per_step of this record; a host sync at each segment boundary (4 per frame)"}
 
