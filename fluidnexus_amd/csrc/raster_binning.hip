@@ -916,6 +916,17 @@ constexpr int kEmitMaskWords = FNX_EMIT_MASK_WORDS;    // per-tile bitmask: 32 r
 constexpr int kEmitSpan = 32 * kEmitMaskWords;         // ranks per sub-batch
 constexpr int kEmitTileWindow = kEmitMaskWords <= 8 ? 2048 : (kEmitMaskWords <= 16 ? 1792 : 960);  // <= kEmitStage: one splat never overflows a sub-batch; window x (words + 1) x 4 B of LDS
 static_assert(kSplatBlock == 1024, "emit packs the rank-in-block into 10 bits");
+// Round 5: the COUNTING form of an item (default; FNX_EMIT_COUNTING=0 keeps only the bitmask form, which also serves
+// images whose bands do not fit one tile window).  Instead of 256-rank sub-batches with a bitmask per tile, a chunk of
+// up to 6 x the tile window instances (a whole rank block of config 3) is placed by a counting sort over the tiles held in
+// LDS: one LDS atomic per instance hands out a slot inside its tile's segment (arrival order), an exclusive scan of the
+// per-tile counts places the segments, and every staged entry then counts the entries of its own segment with a lower rank
+// -- its place in the tile's list -- and goes straight out.  Six barriers per ~4 600 instances instead of four per ~1 100,
+// no per-sub-batch pass over all tiles' mask words.  Deterministic (the count fixes the order), bit-identical lists.
+#ifndef FNX_EMIT_COUNTING
+#define FNX_EMIT_COUNTING 1
+#endif
+constexpr int kCountPer = 12;          // instances per thread and chunk at most (registers)
 static_assert(kEmitTileWindow <= kEmitStage && kEmitTileWindow <= (1 << 22), "entry packing");
 
 // Cursor over the instances of a rank block in (splat, tile row, tile column) order, restricted to
@@ -1098,11 +1109,7 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         const int tw1 = min(band_t1, tw0 + TW);
         const bool whole = (tw0 == band_t0 && tw1 == band_t1);
         lds_barrier();
-        for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
-            s_cur[i] = starts[tw0 + i] + rel[tw0 + i];
-#pragma unroll
-            for (int q = 0; q < kEmitMaskWords; q++) s_mask[q * TW + i] = 0u;  // word-major: lanes = tiles, no bank conflicts
-        }
+        for (int i = tid; i < tw1 - tw0; i += kEmitThreads) s_cur[i] = starts[tw0 + i] + rel[tw0 + i];
         // per-splat instance counts inside this tile window, and their prefix over the block
         uint32_t c[kEmitPer], run = 0;
 #pragma unroll
@@ -1139,6 +1146,105 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         const uint32_t total = s_pre[kSplatBlock - 1];
         FNX_PH(1)
         uint32_t done = 0;  // instances of splats < l0
+        if (FNX_EMIT_COUNTING && whole && FNX_EXP_EMIT == 0) {
+            // ---- counting form (see FNX_EMIT_COUNTING): s_dyn = counts [TW] | segment starts [TW] | staged entries [6 TW] | s_cur [TW]
+            const int ntw = tw1 - tw0;
+            uint32_t *s_cnt = s_dyn, *s_off = s_dyn + TW, *s_stage = s_dyn + 2 * (size_t)TW;
+            const uint32_t cap = min((uint32_t)(6 * TW), (uint32_t)(kCountPer * kEmitThreads));
+            for (int l0 = 0; done < total;) {
+                // chunk [l0, l1): as many ranks as fit `cap` instances (at least one splat: a single splat's instances never
+                // exceed the window, and TW <= cap)
+                int lo = l0, hi = kSplatBlock;
+                if (s_pre[hi - 1] - done <= cap) {
+                    lo = hi;
+                } else {
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pre[mid] - done > cap) hi = mid; else lo = mid + 1;
+                    }
+                }
+                const int l1 = lo;
+                const uint32_t batch = s_pre[l1 - 1] - done;
+                for (int i = tid; i < ntw; i += kEmitThreads) s_cnt[i] = 0u;
+                lds_barrier();
+                // the chunk's instances in (splat, row, column) order, dealt out in equal contiguous runs; one atomic per
+                // instance: its slot inside the tile's segment (arrival order)
+                const uint32_t run = (batch + (uint32_t)kEmitThreads - 1u) / (uint32_t)kEmitThreads;
+                const uint32_t i0 = min(batch, (uint32_t)tid * run), i1 = min(batch, i0 + run);
+                uint32_t ent[kCountPer], slot[kCountPer];
+                {
+                    InstanceWalk wk;
+                    wk.load(s_rect, l0);
+                    if (i0 < i1) wk.seek(s_pre, s_rect, l0, l1 - 1, done + i0, gx, tw0, tw1, true);
+#pragma unroll
+                    for (int k = 0; k < kCountPer; k++) {
+                        ent[k] = 0xFFFFFFFFu;
+                        slot[k] = 0u;
+                        if (i0 + k < i1) {
+                            const uint32_t t = (uint32_t)(wk.tile(gx) - tw0);
+                            slot[k] = atomicAdd(&s_cnt[t], 1u);
+                            ent[k] = (t << 10) | (uint32_t)wk.l;
+                            if (i0 + k + 1 < i1) wk.next(s_rect, gx, tw0, tw1, true);
+                        }
+                    }
+                }
+                lds_barrier();
+                // exclusive scan of the counts over the window's tiles -> segment starts (consecutive tiles per thread)
+                {
+                    const int per = (ntw + kEmitThreads - 1) / kEmitThreads;
+                    const int b0 = tid * per, b1 = min(ntw, b0 + per);
+                    uint32_t sum = 0;
+                    for (int i = b0; i < b1; i++) sum += s_cnt[i];
+                    uint32_t inc = sum;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+                        if (lane >= off) inc += v;
+                    }
+                    if (lane == 63) s_wsum[w] = inc;
+                    lds_barrier();
+                    uint32_t at = inc - sum;
+                    for (int k = 0; k < w; k++) at += s_wsum[k];
+                    for (int i = b0; i < b1; i++) {
+                        s_off[i] = at;
+                        at += s_cnt[i];
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < kCountPer; k++)
+                    if (ent[k] != 0xFFFFFFFFu) s_stage[s_off[ent[k] >> 10] + slot[k]] = ent[k];
+                lds_barrier();
+                // an entry's place inside its segment = the number of the segment's entries with a lower rank (they share the
+                // tile bits: whole words compare): counted by the entry's own thread, so a long segment -- a tile that takes
+                // dozens of consecutive ranks -- costs every one of its entries a pass over it instead of one thread a
+                // quadratic sort.  Consecutive threads hold consecutive staged entries: a segment goes out to one stretch of
+                // its tile's list.
+                for (uint32_t i = tid; i < batch; i += kEmitThreads) {
+                    const uint32_t e = s_stage[i], t = e >> 10, l = e & 1023u;
+                    const uint32_t b0 = s_off[t], n = s_cnt[t];
+                    uint32_t r = 0;
+                    for (uint32_t k = 0; k < n; k++) r += s_stage[b0 + k] < e ? 1u : 0u;
+                    const uint32_t pos = s_cur[t] + r;
+                    if (PAIRS) pair_list[pos] = make_uint2(s_key[PAIRS ? l : 0], s_id[l]);
+                    else point_list[pos] = s_id[l];
+                }
+                lds_barrier();
+                for (int i = tid; i < ntw; i += kEmitThreads) s_cur[i] += s_cnt[i];
+                done += batch;
+                l0 = l1;
+#ifdef FNX_EXP_CLOCK
+                n_sub++;
+                n_inst += batch;
+#endif
+            }
+            continue;  // the window (= the item's band) is done
+        }
+        // ---- bitmask form
+        for (int i = tid; i < tw1 - tw0; i += kEmitThreads) {
+#pragma unroll
+            for (int q = 0; q < kEmitMaskWords; q++) s_mask[q * TW + i] = 0u;  // word-major: lanes = tiles, no bank conflicts
+        }
+        lds_barrier();
         for (int l0 = 0; done < total;) {
             // sub-batch [l0, l1): at most kEmitSpan ranks and kEmitStage instances
             int lo = l0, hi = min(kSplatBlock, l0 + kEmitSpan);  // l1 = first l with s_pre[l] - done > kEmitStage
