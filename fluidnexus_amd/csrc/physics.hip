@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/fnx_physics.h"
 #include "../../include/fnx_raster.h"
@@ -1709,6 +1710,16 @@ inline DistTable carve_dist(char *blob, int N) {
     return t;
 }
 constexpr uint32_t kDistNone = 0xFFFFFFFFu;
+// Publish one workgroup's partial sum for the workgroup that arrives last, WITHOUT a release fence: __threadfence() is
+// `buffer_wbl2` -- it writes back everything the XCD's L2 holds dirty (these kernels have just stored 2.4 MB of gradients),
+// once per workgroup, 782 times per launch: 10 of the 29 us of the list-mode kernel (round 5, FNX_LAB_VERLET=1).  The
+// partial goes out as a device-scope atomic exchange instead (performed at the coherent level), its return is waited for,
+// then the arrival counter is bumped; the last workgroup invalidates its L2 (acquire fence) and reads the partials.
+__device__ __forceinline__ bool publish_partial_and_arrive(float *partial, float value, uint32_t *arrived, uint32_t n_wg) {
+    const uint32_t old = atomicExch(reinterpret_cast<uint32_t *>(partial), __float_as_uint(value));
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+    return atomicAdd(arrived, 1u) == n_wg - 1u;
+}
 
 __global__ void __launch_bounds__(256)
 distance_build_kernel(const float *__restrict__ xyz, int N, float inv_cell, uint32_t mask, const uint32_t *__restrict__ hdr,
@@ -1793,11 +1804,8 @@ distance_lists_kernel(int N, float inv_cell, float thr, uint32_t mask, uint32_t 
     acc = wave_sum63(acc);
     if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-        __threadfence();
-        s_last = atomicAdd(&hdr[1], 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
+    if (threadIdx.x == 0)
+        s_last = publish_partial_and_arrive(&partial[blockIdx.x], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), &hdr[1], gridDim.x) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     // the workgroup that arrives last: the loss (partial sums in workgroup order), the next call's stamp
@@ -2020,9 +2028,10 @@ distance_verlet_kernel(const float *__restrict__ xyz, int N, float inv_cell, flo
                 for (int k = 0; k < 4; k++) j[k] = k0 + k < n ? nbr[(size_t)(k0 + k) * N + i] : (uint32_t)i;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    qx[k] = xyz[3 * (size_t)j[k]];
-                    qy[k] = xyz[3 * (size_t)j[k] + 1];
-                    qz[k] = xyz[3 * (size_t)j[k] + 2];
+                    const size_t jj = (size_t)j[k];
+                    qx[k] = xyz[3 * jj];
+                    qy[k] = xyz[3 * jj + 1];
+                    qz[k] = xyz[3 * jj + 2];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -2043,11 +2052,9 @@ distance_verlet_kernel(const float *__restrict__ xyz, int N, float inv_cell, flo
     acc = wave_sum63(acc);
     if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-        __threadfence();
-        s_last = atomicAdd(&hdr[VL_ARRIVED], 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
+    if (threadIdx.x == 0)
+        s_last = publish_partial_and_arrive(&partial[blockIdx.x], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), &hdr[VL_ARRIVED],
+                                            gridDim.x) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     // the workgroup that arrives last: the loss (partial sums in workgroup order), the state's bookkeeping
