@@ -141,6 +141,7 @@ _DIST_DELAY_US = float(os.environ.get("FNX_DIST_DELAY_US", "0"))
 # =0 keeps the eager collective.
 _GRAPH_ALLREDUCE = os.environ.get("FNX_GRAPH_ALLREDUCE", "auto")
 _GRAPH_ALLREDUCE_OK = None  # result of the self-test (None: not run)
+_TEST_GRAPH_AR_FAIL = os.environ.get("FNX_TEST_GRAPH_AR_FAIL", "")  # tests only: make the in-graph capture fail
 
 
 def graph_allreduce_self_test(dev, timeout_s=20.0):
@@ -166,8 +167,9 @@ def graph_allreduce_self_test(dev, timeout_s=20.0):
             side.synchronize()
             x.fill_(float(rank + 1))
             side.synchronize()
+            _drain_collective_watchdog()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):  # see HotLoop.capture
                 dist.all_reduce(x, group=grp)
             g.replay()
             done = torch.cuda.Event()
@@ -184,6 +186,24 @@ def graph_allreduce_self_test(dev, timeout_s=20.0):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # the main group, eagerly: every rank learns the common verdict
     _GRAPH_ALLREDUCE_OK = bool(int(flag.item()))
     return _GRAPH_ALLREDUCE_OK
+
+
+def _drain_collective_watchdog(seconds=0.35):
+    """Call before a capture that records a collective.  The process group's watchdog thread polls the completion events
+    of earlier EAGER collectives every 100 ms until they have completed; recording a collective pulls the group's
+    internal stream into the capture, and on this HIP an event query on ANY event of a stream that is capturing fails
+    (hipErrorCapturedEvent) -- the watchdog thread dies with it and takes the process down (3 of 24 runs).  With the
+    device idle, one polling period retires every outstanding work and the watchdog has nothing left to ask."""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("FNX_WATCHDOG_DRAIN_S", seconds)))
+
+
+def _leak(obj):
+    """One reference that is never given back.  For a torch.cuda.CUDAGraph whose capture was invalidated: its destructor
+    raises a c10::Error on this torch (-> std::terminate), at the rebinding of the name or at interpreter exit."""
+    import ctypes
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(obj))
 
 
 def _graph_allreduce_wanted():
@@ -335,6 +355,17 @@ class HotLoop:
             loss = loss + c["lambda_next_gas_constraints"] * l2_loss(pn, torch.ones_like(pn))
         return loss
 
+    def _fresh_streams(self):
+        """New streams for everything the loop launches on (after a failed capture, see capture())."""
+        dev = self.gm._xyz.device
+        if self.stream is not None:
+            self.stream = torch.cuda.Stream(device=dev)
+        for name in ("side_stream", "dist_stream", "ch1_stream"):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, torch.cuda.Stream(device=dev))
+        if getattr(self, "view_streams", None):
+            self.view_streams = [torch.cuda.Stream(device=dev) for _ in self.view_streams]
+
     def capture(self, warmup=3, iterations=1):
         """Record one whole iteration (all views forward + losses + backward + gradient mean + Adam) as a
         hipGraph; later iteration() calls replay it.  Needs the sync-free rasteriser mode with a seeded
@@ -374,21 +405,44 @@ class HotLoop:
             if _graph_allreduce_wanted() and self.fused_step:
                 try:
                     itr0, tot0 = self.itr, self.gm.total_iterations
-                    with torch.cuda.graph(g, stream=self.stream):
-                        for _ in range(int(iterations)):
+                    _drain_collective_watchdog()
+                    # thread_local: calls of other threads (the process group's watchdog, the allocator) do not
+                    # invalidate this capture
+                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                        for k in range(int(iterations)):
                             self._iteration_body_batched(phase="local")
                             dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
                             self._finish_step(len(self.cams), grad=self._reduce_buf)
+                            if k == 0 and _TEST_GRAPH_AR_FAIL == "raise":  # tests: the fallback below
+                                raise RuntimeError("injected failure inside the capture")
+                            if k == 0 and _TEST_GRAPH_AR_FAIL == "sync":  # tests: a call that invalidates the capture
+                                torch.cuda.synchronize()
                     self.itr, self.gm.total_iterations = itr0, tot0
                     self.graph, self.graph_iterations, self._replay, self.graph_finish = g, int(iterations), True, None
                     return g
                 except Exception as e:  # the collective refused to be captured: the eager path below
                     print(f"[harness] all-reduce inside the graph failed ({type(e).__name__}: {e}); eager collective", flush=True)
                     self.itr, self.gm.total_iterations = itr0, tot0
+                    # a graph object whose capture was invalidated must never be destroyed: its destructor raises (this
+                    # torch: c10 check inside ~CUDAGraph -> std::terminate).  One leaked reference keeps it alive to the end.
+                    _leak(g)
                     g = torch.cuda.CUDAGraph()
-                    torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=self.stream):
-                self._iteration_body_batched(phase="local")
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:  # the invalidated capture's error, reported once more
+                        torch.cuda.synchronize()
+                    # ... and on this HIP the streams that took part keep the status "invalidated" behind the failed
+                    # hipStreamEndCapture: the loop goes on with streams of its own making
+                    self._fresh_streams()
+                    self.gm.invalidate_caches()
+                    rasterizer._pending_status.clear()
+            try:
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._iteration_body_batched(phase="local")
+            except Exception:
+                _leak(g)
+                self._fresh_streams()
+                raise
             if self.fused_step:
                 # batch mean + Adam step is ONE kernel (fnx_adam_step): launched eagerly behind the all-reduce, it
                 # costs a kernel launch instead of the ~27 us start-up gap of a second graph

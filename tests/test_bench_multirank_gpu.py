@@ -42,3 +42,11 @@ def test_one_rank_through_rccl_takes_the_all_reduce_into_the_graph():
     assert d["ranks"] == 1 and d["config"]["all_reduce"].startswith("inside the hipGraph"), d["config"]["all_reduce"]
     d0 = _bench({"FNX_FORCE_DIST": "1", "FNX_GRAPH_ALLREDUCE": "0", "MASTER_PORT": "29534"})
     assert d0["config"]["all_reduce"].startswith("eager")
+
+
+def test_a_failed_capture_of_the_collective_falls_back_to_the_eager_one():
+    """The capture with the all-reduce inside raises (injected, HotLoop.capture): the run goes on with the local phase
+    replayed and the collective issued eagerly, and still prints its one record."""
+    d = _bench({"FNX_FORCE_DIST": "1", "FNX_TEST_GRAPH_AR_FAIL": "raise", "MASTER_PORT": "29535"})
+    assert d["ranks"] == 1 and d["config"]["all_reduce"].startswith("eager"), d["config"]["all_reduce"]
+    assert d["value"] > 0 and d["config"]["launch"].startswith("hipGraph")
