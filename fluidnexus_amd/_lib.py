@@ -59,16 +59,17 @@ class RasterOpts(C.Structure):
     _fields_ = [("size", C.c_uint32), ("blend_math", C.c_int32), ("lean_geometry", C.c_int32), ("sort_mode", C.c_int32),
                 ("deep_kernel", C.c_int32), ("grad_splat_limit", C.c_int32), ("deep_threshold", C.c_uint32),
                 ("reserved0", C.c_uint32), ("zero3", c_void_p), ("sort_state", c_void_p),
-                ("dual", C.POINTER(RasterDual))]
+                ("dual", C.POINTER(RasterDual)), ("segment_scratch", c_void_p)]
 
 
 def make_opts(blend_math=0, lean_geometry=0, sort_mode=FNX_SORT_FULL, deep_kernel=0, grad_splat_limit=-1,
-              deep_threshold=0, zero3=None, sort_state=None, dual=None) -> RasterOpts:
+              deep_threshold=0, zero3=None, sort_state=None, dual=None, segment_scratch=None) -> RasterOpts:
     o = RasterOpts()
     o.size = C.sizeof(RasterOpts)
     o.blend_math, o.lean_geometry, o.sort_mode, o.deep_kernel = int(blend_math), int(lean_geometry), int(sort_mode), int(deep_kernel)
     o.grad_splat_limit, o.deep_threshold = int(grad_splat_limit), int(deep_threshold)
     o.zero3, o.sort_state = zero3, sort_state
+    o.segment_scratch = segment_scratch
     if dual is not None:  # a RasterDual the caller keeps alive for the duration of the call
         o.dual = C.pointer(dual)
     return o
@@ -93,11 +94,12 @@ SYMBOLS = (
     "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
     "fnx_forward_stage1_views_split_opts", "fnx_forward_stage2_views_split_opts", "fnx_rasterize_backward_views_split_opts",
     "fnx_sort_state_bytes", "fnx_sort_state_read", "fnx_sort_state_outliers", "fnx_binning_bytes_dual",
+    "fnx_segment_scratch_bytes", "fnx_segment_scratch_read",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
 # scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def raster_path() -> str:
@@ -195,6 +197,10 @@ def raster():
     lib.fnx_forward_stage2_views_split_opts.argtypes = lib.fnx_forward_stage2_views_split.argtypes[:-1] + [op, p]
     lib.fnx_rasterize_backward_views_split_opts.restype = i
     lib.fnx_rasterize_backward_views_split_opts.argtypes = lib.fnx_rasterize_backward_views_split.argtypes[:-1] + [p, op, p]
+    lib.fnx_segment_scratch_bytes.restype = c_size_t
+    lib.fnx_segment_scratch_bytes.argtypes = [i, i]
+    lib.fnx_segment_scratch_read.restype = i
+    lib.fnx_segment_scratch_read.argtypes = [p, i, i, i, p, C.POINTER(C.c_uint32)]
     lib.fnx_sort_state_bytes.restype = c_size_t
     lib.fnx_sort_state_bytes.argtypes = [i]
     lib.fnx_sort_state_outliers.restype = i

@@ -282,6 +282,63 @@ struct DualRef {
     size_t bin_bstate1;                    // byte offset of the second image's per-batch state inside a binning blob
 };
 
+// Segmented blend forward (fnx_raster_opts_t.segment_scratch, round 5): the list of a DEEP tile is cut into segments of
+// kSegBatches batches (the first: kSegBatches0) that independent workgroups blend at the same time, each from
+// transmittance 1 and colour 0; the workgroup of a tile that finishes last puts the segments together per pixel
+// (colour += T_in colour_s, T_in *= T_s), checks that no decision of a segment's walk depends on the T_in it did not know
+// (the stop rule T < 1e-4, the median-depth entry) and blends the rest of the list again from the first segment where
+// one does (raster_forward.hip).  Per view: a control block, the work list of the blend launch (segments of the
+// segmented tiles first, then the other tiles in tile order), per tile the first record slot and an arrival counter,
+// per segment a record per pixel.
+#ifndef FNX_SEG_BATCHES
+#define FNX_SEG_BATCHES 4
+#endif
+#ifndef FNX_SEG_BATCHES0
+#define FNX_SEG_BATCHES0 8
+#endif
+constexpr uint32_t kSegBatches = FNX_SEG_BATCHES, kSegBatches0 = FNX_SEG_BATCHES0;
+constexpr uint32_t kSegMax = 2048;      // segments per view (record slots); tiles beyond the budget stay whole
+constexpr uint32_t kSegPerTileMax = 255;
+// work item of the blend forward: tile | segment << 14 | segments of the tile << 24 (0: the whole tile)
+enum { SEG_CTL_WORK = 0, SEG_CTL_SEGMENTS = 1, SEG_CTL_TILES = 2, SEG_CTL_REPAIRED = 3, SEG_CTL_REPAIR_BATCHES = 4,
+       SEG_CTL_PARITY = 5, SEG_CTL_WORDS = 16 };
+// What a segment's walk cannot know is the transmittance T_in in front of it.  It starts from a HINT: the T_in the same
+// pixel had at the same segment boundary in the previous forward of this view batch (kept in the scratch, two generations:
+// a call reads the previous one's while it writes its own); without one (first call, a tile not cut last time) from 1.
+// The hint only has to be good enough that a pixel hinted as stopped is stopped and that the walk sees T cross 1/2 in the
+// segment where it does; everything else is scaled to the true T_in afterwards.
+struct SegLayout {
+    size_t ctl, items, tile_slot, arrive, meta, rec_a, rec_b, hint, total;  // byte offsets inside a view's scratch
+};
+__host__ __device__ inline SegLayout seg_layout(int T) {
+    SegLayout o;
+    size_t off = 0, t = (size_t)T;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    o.ctl = off;       off = up(off + SEG_CTL_WORDS * 4);
+    o.items = off;     off = up(off + (t + kSegMax) * 4);
+    o.tile_slot = off; off = up(off + 2 * t * 4);  // [generation][tile]: first record slot | segments << 16 (0xFFFFFFFF: whole)
+    o.arrive = off;    off = up(off + t * 4);
+    o.meta = off;      off = up(off + (size_t)kSegMax * 16);
+    o.rec_a = off;     off = up(off + (size_t)kSegMax * 256 * 16);
+    o.rec_b = off;     off = up(off + (size_t)kSegMax * 256 * 16);
+    o.hint = off;      off = up(off + 2 * (size_t)kSegMax * 256 * 4);  // [generation][slot][pixel]: working T in front of the segment
+    o.total = off + 256;
+    return o;
+}
+struct SegRef {
+    char *base;     // aligned start of view 0's scratch (nullptr: off)
+    size_t stride;  // bytes between consecutive views' scratch
+    SegLayout L;
+};
+// first batch of segment s of a tile, and the segments a list of `len` entries is cut into (0: not worth cutting)
+__host__ __device__ inline uint32_t seg_first_batch(uint32_t s) { return s == 0 ? 0u : kSegBatches0 + (s - 1u) * kSegBatches; }
+__host__ __device__ inline uint32_t seg_count_for(uint32_t len) {
+    const uint32_t nb = (len + 255u) >> 8;
+    if (nb < kSegBatches0 + kSegBatches) return 0u;
+    const uint32_t n = 1u + (nb - kSegBatches0 + kSegBatches - 1u) / kSegBatches;
+    return n > kSegPerTileMax ? 0u : n;
+}
+
 // header words inside the image blob
 // HDR_BIN_CAPACITY: the binning capacity stage 2 ran with (the binning blob's layout depends on it): the backward pass
 // refuses a view whose stored value differs from its own argument (status FNX_ERR_CAPACITY)

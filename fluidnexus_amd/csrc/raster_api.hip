@@ -24,7 +24,7 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
-                      const StaticRef &st);
+                      const StaticRef &st, const SegRef &sg);
 void launch_tile_colscan(hipStream_t s, int T, int P, const uint16_t *blk_hist, uint32_t *blk_rel,
                          uint32_t *tile_count, int V, const ViewBatch &vb);
 void launch_depth_sort(hipStream_t s, int P, const uint32_t *raw_keys, uint2 *pairs_a, uint2 *pairs_b,
@@ -47,7 +47,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du);
+                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du, const SegRef &sg);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
@@ -85,6 +85,17 @@ int hip_check(const char *what) {
 }
 
 char *aligned(char *p) { return (char *)(((uintptr_t)p + fnx::kAlign - 1) / fnx::kAlign * fnx::kAlign); }
+// the segment scratch of a view batch (fnx_raster_opts_t.segment_scratch); off when the tile grid does not fit a work item
+fnx::SegRef make_seg_ref(char *scratch, int width, int height) {
+    fnx::SegRef sg;
+    memset(&sg, 0, sizeof(sg));
+    const int T = fnx::tiles_x(width) * fnx::tiles_y(height);
+    if (!scratch || T > fnx::kMaxTiles) return sg;
+    sg.L = fnx::seg_layout(T);
+    sg.stride = sg.L.total;
+    sg.base = aligned(scratch);
+    return sg;
+}
 const char *aligned(const char *p) { return aligned(const_cast<char *>(p)); }
 
 struct Geom {
@@ -266,6 +277,7 @@ struct Opts {
     float *zero3;
     char *sort_state;
     const fnx_raster_dual_t *dual;
+    char *segment_scratch;
 };
 int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pending_limit, Opts *out) {
     out->blend_math = g_blend_math;
@@ -277,6 +289,7 @@ int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pend
     out->zero3 = pending_zero3;
     out->sort_state = nullptr;
     out->dual = nullptr;
+    out->segment_scratch = nullptr;
     if (!o) return FNX_OK;
     if (o->size != sizeof(fnx_raster_opts_t))
         return fail(FNX_ERR_INVALID_ARG, "fnx_raster_opts_t.size is %u, this library's is %u (ABI %d)", o->size,
@@ -292,6 +305,7 @@ int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pend
     out->zero3 = o->zero3;
     out->sort_state = o->sort_state;
     out->dual = o->dual;
+    out->segment_scratch = o->segment_scratch;
     if (out->blend_math != 0 && out->blend_math != 1) return fail(FNX_ERR_INVALID_ARG, "blend_math must be 0 (exact) or 1 (fast)");
     if (out->sort_mode < FNX_SORT_FULL || out->sort_mode > FNX_SORT_COHERENT) return fail(FNX_ERR_INVALID_ARG, "bad sort_mode");
     if (out->sort_mode == FNX_SORT_COHERENT && !out->sort_state)
@@ -449,7 +463,8 @@ int fnx_forward_stage1_views_split_opts(int channels, int V, char *geom_buffer, 
                               V, vb);
     fnx::launch_tile_colscan(s, T, P, g.blk_hist, g.blk_rel, img.tile_count, V, vb);
     fnx::launch_tile_scan(s, T, img.tile_count, img.ranges, img.dyn_start, img.header, P, height, g.sort_hist, depth_hint,
-                          op.deep_min, img.tile_order, img.tile_deep, V, vb, st);
+                          op.deep_min, img.tile_order, img.tile_deep, V, vb, st,
+                          make_seg_ref(op.segment_scratch, width, height));
     }
     return hip_check("stage1");
 }
@@ -580,7 +595,8 @@ int fnx_forward_stage2_views_split_opts(int channels, int V, char *geom_buffer, 
         fnx::launch_blend_forward(channels, s, width, height, img.ranges, bin.point_list, g.blend_rec, background,
                                   img.final_T, img.n_contrib, out_color, out_depth, img.header, cap, status_out,
                                   img.tile_count, img.dyn_start, img.acc_final, img.tile_order, img.tile_deep, depth_hint,
-                                  st, materialize_all, V, vb, op.blend_math, op.deep_kernel, op.grad_limit, iu, du);
+                                  st, materialize_all, V, vb, op.blend_math, op.deep_kernel, op.grad_limit, iu, du,
+                                  make_seg_ref(op.segment_scratch, width, height));
     }
     return hip_check("stage2");
 }
@@ -843,6 +859,18 @@ int fnx_request_gradient_limit(int grad_splat_limit) {
     return FNX_OK;
 }
 size_t fnx_sort_state_bytes(int P) { return fnx::sort_state_layout(P).total; }
+size_t fnx_segment_scratch_bytes(int width, int height) {
+    return fnx::seg_layout(fnx::tiles_x(width) * fnx::tiles_y(height)).total;
+}
+int fnx_segment_scratch_read(const char *scratch, int width, int height, int view, fnx_stream_t stream, uint32_t out[16]) {
+    if (!scratch || !out || view < 0) return fail(FNX_ERR_INVALID_ARG, "bad argument");
+    const fnx::SegLayout L = fnx::seg_layout(fnx::tiles_x(width) * fnx::tiles_y(height));
+    const char *src = aligned(const_cast<char *>(scratch)) + L.total * (size_t)view + L.ctl;
+    hipError_t e = hipMemcpyAsync(out, src, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(FNX_ERR_HIP, "segment_scratch_read: %s", hipGetErrorString(e));
+    return FNX_OK;
+}
 int fnx_sort_state_read(const char *sort_state, int P, int view, fnx_stream_t stream, uint32_t out[3]) {
     if (!sort_state || !out || P < 0 || view < 0) return fail(FNX_ERR_INVALID_ARG, "bad argument");
     const fnx::SortStateLayout SL = fnx::sort_state_layout(P);

@@ -23,7 +23,18 @@ __device__ unsigned long long g_fwd_clock[64];
 extern "C" int fnx_debug_fwd_clock(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_clock), sizeof(g_fwd_clock));
 }
-__device__ unsigned long long g_fwd_wg[3 * 8192];  // per workgroup (view * T + blockIdx.x): wall start, wall end, list length
+__device__ unsigned long long g_fwd_wg[4 * 16384];
+__device__ unsigned long long g_fwd_wg2[16384];  // segmented tiles: when the last segment to arrive started putting them together
+extern "C" int fnx_debug_fwd_wg_reset() {
+    void *a = nullptr, *b = nullptr;
+    (void)hipGetSymbolAddress(&a, HIP_SYMBOL(g_fwd_wg));
+    (void)hipGetSymbolAddress(&b, HIP_SYMBOL(g_fwd_wg2));
+    (void)hipMemset(a, 0, sizeof(g_fwd_wg));
+    return (int)hipMemset(b, 0, sizeof(g_fwd_wg2));
+}
+extern "C" int fnx_debug_fwd_wg2(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_wg2), (size_t)n * 8);
+}  // per workgroup (view * T + rank): wall start, wall end, depth << 32 | list length, staged entries
 extern "C" int fnx_debug_fwd_wg(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_wg), (size_t)n * 8);
 }
@@ -377,10 +388,12 @@ struct DualPixel {
     float acc, Tr, alive, Dm;
     uint32_t hit_off;
 };
-template <int C, bool DUAL = false>
+// REC (segmented tiles): vstop keeps the test value of the entry that stopped the pixel (T (1 - alpha) < 1e-4; 0: none yet).
+template <int C, bool DUAL = false, bool REC = false>
 __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
                                           const float4 *s_rc, float pxf, float pyf, float (&acc)[C], float &Tr,
-                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du = nullptr) {
+                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du = nullptr,
+                                          float *vstop = nullptr) {
     constexpr int kGroup = 4;
     // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
     // walk, and if T crosses 1/2 here the entry that took it across is mylist[n_half] (forward.cu:351-354)
@@ -424,6 +437,7 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
             const float wq = a_h[k] * alive;      // alpha T (0 for a stopped pixel: its working T is 0)
             const float t = alive - wq;           // test_T
             const bool stop = t < 0.0001f;        // also true for every entry behind the one that stopped the pixel
+            if (REC) *vstop = fmaxf(*vstop, stop ? t : 0.0f);  // (behind the stop the working T is 0: t = 0)
             const float wgt = stop ? 0.0f : wq;
             acc[0] = __builtin_fmaf(col[k][0], wgt, acc[0]);
             if (C > 1) acc[C > 1 ? 1 : 0] = __builtin_fmaf(col[k][1], wgt, acc[C > 1 ? 1 : 0]);
@@ -510,11 +524,14 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
                  uint32_t *__restrict__ emit_items, size_t geom_stride, uint32_t *__restrict__ depth_hint,
                  uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
-                 const StaticRef st, const uint32_t *__restrict__ sort_ctl) {
+                 const StaticRef st, const uint32_t *__restrict__ sort_ctl, const SegRef sg) {
     constexpr int kDeepSorted = 1024;
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_deep_n;
     __shared__ uint2 s_deep[kDeepSorted];  // (depth hint, tile) of the deep tiles
+    __shared__ uint2 s_sorted[kDeepSorted];    // ... deepest first (segmented launch)
+    __shared__ uint32_t s_before[kDeepSorted];  // cut tiles in front of a sorted rank
+    __shared__ uint32_t s_tot;
     if (threadIdx.x == 0) s_deep_n = 0;
     tile_order = view_at(tile_order, img_stride, blockIdx.y);
     tile_deep = view_at(tile_deep, img_stride, blockIdx.y);
@@ -569,6 +586,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                 rank += (ot.x > me.x || (ot.x == me.x && ot.y < me.y)) ? 1u : 0u;
             }
             tile_order[rank] = me.y;
+            s_sorted[rank] = me;
         }
     }
     __syncthreads();
@@ -585,6 +603,57 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         __syncthreads();
         // + the bit length of the view's depth-key span in the top byte (the host learns whether three sort passes suffice)
         if (tid == 0) header[HDR_DEEP_COUNT] = min(nd, 0xFFFFFFu) | (view_at(sort_ctl, geom_stride, blockIdx.y)[SORT_CTL_SPAN] << 24);
+    }
+    if (sg.base) {
+        // Work list of the segmented blend launch (fnx_state.h): the deep tiles, deepest first, are cut into segments as far
+        // as the previous forward consumed their lists (+ a batch; what lies behind is taken up by the workgroup that puts
+        // the segments together, if a pixel still blends there), while the record slots last; the segments lead the list,
+        // the other tiles follow in tile order.
+        char *sc = sg.base + sg.stride * blockIdx.y;
+        uint32_t *sctl = reinterpret_cast<uint32_t *>(sc + sg.L.ctl), *items = reinterpret_cast<uint32_t *>(sc + sg.L.items);
+        const uint32_t gen = (sctl[SEG_CTL_PARITY] & 1u) ^ 1u;  // this call's generation of tile_slot / hints
+        uint32_t *tile_slot = reinterpret_cast<uint32_t *>(sc + sg.L.tile_slot) + (size_t)gen * T;
+        uint32_t *arrive = reinterpret_cast<uint32_t *>(sc + sg.L.arrive);
+        __syncthreads();  // ranges / tile_order of this block are written (and every thread has read the generation)
+        const uint32_t nds = min(s_deep_n, (uint32_t)kDeepSorted);
+        uint32_t my_n = 0, my_tile = 0;
+        if ((uint32_t)tid < nds) {
+            const uint2 me = s_sorted[tid];  // (depth the tile's list was consumed to, tile)
+            my_tile = me.y;
+            const uint32_t len = ranges[2 * my_tile + 1] - ranges[2 * my_tile];
+            my_n = seg_count_for(min(len, me.x + 256u));
+        }
+        // the budget of record slots goes to the deepest tiles: a tile is cut if it and everything in front of it fit
+        const uint32_t want_inc = block_scan_1024(my_n, s_wave);
+        if (want_inc > kSegMax) my_n = 0;
+        const uint32_t packed = my_n | (my_n ? 1u << 16 : 0u);  // (segments | tiles cut): both sums stay below 2^16
+        const uint32_t inc = block_scan_1024(packed, s_wave);
+        const uint32_t at = (inc - packed) & 0xFFFFu;
+        if (tid < kDeepSorted) s_before[tid] = (inc - packed) >> 16;
+        if (tid == 1023) s_tot = inc;
+        for (int i = b; i < e; i++) {
+            tile_slot[i] = 0xFFFFFFFFu;
+            arrive[i] = 0u;
+        }
+        __syncthreads();
+        const uint32_t n_segs = s_tot & 0xFFFFu, n_cut = s_tot >> 16;
+        if (my_n) {
+            tile_slot[my_tile] = at | (my_n << 16);
+            for (uint32_t j = 0; j < my_n; j++) items[at + j] = my_tile | (j << kItemTileBits) | (my_n << 24);
+        }
+        __syncthreads();
+        for (int q = b; q < e; q++) {  // the tiles that stay whole, in tile order
+            const uint32_t t = tile_order[q];
+            if (tile_slot[t] != 0xFFFFFFFFu) continue;
+            const uint32_t cut_before = (uint32_t)q < nds ? s_before[q] : n_cut;
+            items[n_segs + (uint32_t)q - cut_before] = t;
+        }
+        if (tid == 0) {
+            sctl[SEG_CTL_WORK] = n_segs + (uint32_t)T - n_cut;
+            sctl[SEG_CTL_SEGMENTS] = n_segs;
+            sctl[SEG_CTL_TILES] = n_cut;
+            sctl[SEG_CTL_PARITY] = gen;
+        }
     }
     if (tid == 1023) {
         header[HDR_NUM_RENDERED] = run;  // thread 1023 owns the last chunk of tiles: its running sum is the total
@@ -647,7 +716,50 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 // sequence; T is updated as T - alpha T, the median depth is found from a per-batch count instead of per entry.
 // ~30 instead of ~54-65 VALU instructions per entry.  Pixels agree with the exact mode to ~1e-6 except where a rounding
 // moves an alpha across 1/255 or a T across 1e-4 (tests/test_fast_math_gpu.py states and checks the tolerance).
-template <int C, bool SPLIT, bool FAST, bool DUAL = false>
+//
+// SEG (fnx_raster_opts_t.segment_scratch; FAST, not DUAL): the launch takes its work from the list tile_scan_kernel laid down
+// in the segment scratch -- segments of the deep tiles first, then the other tiles whole.  A segment is blended like a
+// tile that starts at its first batch with transmittance 1 and colour 0; the segment of a tile that arrives last puts
+// the segments together (fnx_state.h), and where a pixel's walk did depend on the transmittance in front of its segment
+// -- the stop rule fires inside it, the median-depth entry lies in it -- the rest of the tile's list is blended again,
+// by this workgroup, from the first such segment and from the true state in front of it.
+// Stores / loads at device scope (sc1: past the XCD's L2), for data another workgroup -- on another XCD -- reads within
+// the same launch behind an arrival counter.  A release fence instead (__threadfence: buffer_wbl2) writes back EVERYTHING
+// dirty in the XCD's L2 -- during a kernel that streams megabytes of stores it took tens of microseconds per workgroup.
+__device__ __forceinline__ void store_dev(float4 *p, const float4 v) {
+    float *f = reinterpret_cast<float *>(p);
+    __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_dev(uint4 *p, const uint4 v) {
+    uint32_t *f = reinterpret_cast<uint32_t *>(p);
+    __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_dev(const float4 *p) {
+    float *f = const_cast<float *>(reinterpret_cast<const float *>(p));
+    return make_float4(__hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ uint4 load_dev(const uint4 *p) {
+    uint32_t *f = const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(p));
+    return make_uint4(__hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+#ifdef FNX_EXP_SEG_WHY  // developer counters: pixels whose segment walk was not trusted, by reason (ctl words 6 .. 10)
+#define FNX_SEG_WHY(i) atomicAdd(&sctl[i], 1u);
+#else
+#define FNX_SEG_WHY(i)
+#endif
+template <int C, bool SPLIT, bool FAST, bool DUAL = false, bool SEG = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
 blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                      int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
@@ -657,7 +769,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                      const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                      const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                      uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
-                     int skip_deep, uint32_t dyn_limit, const InvUpdate iu, const DualRef du) {
+                     int skip_deep, uint32_t dyn_limit, const InvUpdate iu, const DualRef du, const SegRef sg) {
+    static_assert(!SEG || (FAST && !DUAL), "segmented tiles: fast arithmetic, one image");
     const char *static_blob = nullptr;
     // Workgroup -> (view, rank in the view's tile order).  The hardware dispatches workgroups in linear order
     // (x fastest), and each view's order starts with its deep tiles: with the view as the slow grid dimension the
@@ -666,8 +779,8 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     // built for), and the deep tiles of ALL views lead the launch.
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x, n_views = gridDim.y;
     const int wg_view = (wg_linear >> 3) % n_views, wg_rank = ((wg_linear >> 3) / n_views) * 8 + (wg_linear & 7);
-    if (wg_rank >= T) return;  // gridDim.x is T rounded up to a multiple of 8
-    if (iu.pairs) {
+    if (!SEG && wg_rank >= T) return;  // gridDim.x is T rounded up to a multiple of 8
+    if (iu.pairs && wg_rank < T) {
         // temporal-coherence depth sort (raster_binning.hip): the rank every splat has in this call's order, for the next
         // call's preprocess.  The T workgroups of a view share the P ranks.
         const uint2 *pr = view_at(iu.pairs, vb.geom, wg_view);
@@ -733,7 +846,29 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
     // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
-    const int tile = (int)tile_order[wg_rank];
+    uint32_t seg = 0, nseg = 0;  // SEG: this workgroup's segment of the tile and the tile's segment count (0: the whole tile)
+    // ... generation of this call's hints / slots, the tile's first record slot, its slot | segments << 16 of the previous call
+    uint32_t seg_gen = 0, seg_slot0 = 0, seg_old = 0xFFFFFFFFu;
+    char *seg_scratch = nullptr;
+    int tile_ = 0;
+    if (SEG) {
+        seg_scratch = sg.base + sg.stride * (size_t)wg_view;
+        const uint32_t *sctl = reinterpret_cast<const uint32_t *>(seg_scratch + sg.L.ctl);
+        if ((uint32_t)wg_rank >= sctl[SEG_CTL_WORK]) return;
+        const uint32_t item = reinterpret_cast<const uint32_t *>(seg_scratch + sg.L.items)[wg_rank];
+        tile_ = (int)(item & kItemTileMask);
+        seg = (item >> kItemTileBits) & 0x3FFu;
+        nseg = item >> 24;
+        if (nseg) {
+            seg_gen = sctl[SEG_CTL_PARITY] & 1u;
+            const uint32_t *ts = reinterpret_cast<const uint32_t *>(seg_scratch + sg.L.tile_slot);
+            seg_slot0 = ts[(size_t)seg_gen * T + tile_] & 0xFFFFu;
+            seg_old = ts[(size_t)(seg_gen ^ 1u) * T + tile_];
+        }
+    } else {
+        tile_ = (int)tile_order[wg_rank];
+    }
+    const int tile = tile_;
     if (tile_deep[tile]) {
         if (skip_deep) return;  // blend_forward_deep_kernel takes the tiles that went deep in the previous forward
         __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
@@ -754,12 +889,36 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     const float pxf = (float)px, pyf = (float)py;
     const float tile_x0 = (float)(tx * FNX_TILE_X), tile_y0 = (float)(ty * FNX_TILE_Y);
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    // the part of the list this workgroup blends: all of it, or (SEG) a segment's batches
+    uint32_t b_lo = r0, b_hi = r1;
+    if (SEG && nseg) {
+        b_lo = r0 + 256u * seg_first_batch(seg);
+        b_hi = min(r1, r0 + 256u * seg_first_batch(seg + 1u));
+    }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // 1 while the pixel is still blending, 0 once it has stopped (T would drop below 1e-4) or if it is outside the image:
     // an arithmetic mask instead of a predicate, so that the recurrence below needs no lane-mask logic.
     // FAST: `alive` is the WORKING transmittance (T while blending, 0 once stopped / outside), Tr the pixel's T.
     float alive = inside ? 1.0f : 0.0f;
     float Tr = 1.0f;
+    const uint32_t nseg_t = nseg;  // segments of this workgroup's tile (nseg is cleared once they have been put together)
+    // SEG: the working T the walk of segment s2 of this tile starts from (fnx_state.h)
+    auto seg_hint = [&](uint32_t s2) -> float {
+        if (!inside) return 0.0f;
+        if (s2 == 0u || seg_old == 0xFFFFFFFFu || s2 >= (seg_old >> 16)) return 1.0f;
+        const float h = reinterpret_cast<const float *>(seg_scratch + sg.L.hint)[((size_t)(seg_gen ^ 1u) * kSegMax +
+                                                                                  (seg_old & 0xFFFFu) + s2) * 256 + threadIdx.x];
+        return fminf(1.0f, h);
+    };
+    float *hint_new = SEG ? reinterpret_cast<float *>(seg_scratch + sg.L.hint) + ((size_t)seg_gen * kSegMax + seg_slot0) * 256 + threadIdx.x
+                          : nullptr;
+    // second round of a cut tile: the segment this pixel joins at (0xFFFF: it does not, 0xFFFE: it has)
+    uint32_t my_act = 0xFFFFu;
+    float seg_vstop = 0.0f;  // a segment's walk: the test value of the entry that stopped the pixel (fast_walk REC)
+    if (SEG && nseg && seg) {
+        alive = seg_hint(seg);
+        Tr = alive;
+    }
     uint32_t last_contributor = 0;
     // Splats with id >= dyn_limit take no gradient (the frozen background of the position stages).  A backward pass that
     // differentiates only ids below it needs nothing from the entries BEHIND a pixel's last such ("dynamic") entry: what
@@ -822,6 +981,11 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         return id;
     };
+    uint32_t staged = 0;   // list entries of the batches this workgroup blended
+#ifdef FNX_EXP_CLOCK
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
+again:  // (SEG: the workgroup that put a tile's segments together comes back here to blend the rest of the list again)
     if (SPLIT) {
         const uint32_t *starts = reinterpret_cast<const uint32_t *>(static_blob + st.starts);
         const uint32_t s0 = starts[tile];
@@ -830,11 +994,32 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         rec_s = reinterpret_cast<const float4 *>(static_blob + st.rec);
         nf = tile_count[tile];
         fp = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(point_list) + vb.bin_pairs) + dyn_start[tile];
-        // batch 0: merge, request its records, prefetch the windows behind it
+        si = fj = 0;
+        if (SEG && b_lo != r0) {
+            // where the two streams stand behind the first d merged entries: merge path, 64 probes per round (one wave)
+            const uint32_t d = b_lo - r0;
+            if (w == 0) {
+                uint32_t lo = d > nf ? d - nf : 0u, hi = min(d, ns);
+                while (lo < hi) {
+                    const uint32_t step = (hi - lo + 63u) / 64u, m = lo + (uint32_t)lane * step;
+                    const bool p = m < hi && sp[m].x < fp[d - m - 1u].x;  // static entry m lies in front of merged position d
+                    const uint32_t c = (uint32_t)__popcll(__ballot(p));   // the probes that hold form a prefix
+                    const uint32_t nlo = c ? lo + (c - 1u) * step + 1u : lo;
+                    hi = (c < 64u && lo + c * step < hi) ? lo + c * step : hi;
+                    lo = nlo;
+                }
+                if (lane == 0) s_adv = lo;
+            }
+            __syncthreads();
+            si = s_adv;
+            fj = d - si;
+            __syncthreads();
+        }
+        // first batch: merge, request its records, prefetch the windows behind it
         load_windows();
         store_windows();
         __syncthreads();
-        const uint32_t cnt0 = min(256u, r1 - r0);
+        const uint32_t cnt0 = min(256u, b_hi - b_lo);
         my_id = merge_batch(cnt0);
         __syncthreads();
         if (cnt0) {
@@ -851,15 +1036,15 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         load_windows();
     } else {
-        if (r0 + (uint32_t)tid < r1) {
-            my_id = point_list[r0 + tid];
+        if (b_lo + (uint32_t)tid < b_hi) {
+            my_id = point_list[b_lo + tid];
             const float4 *rec = blend_rec + 4 * (size_t)my_id;
             pa = rec[0];
             pb = rec[1];
             pc = rec[2];
             if (C > 2) pd = rec[3].x;
         }
-        if (r0 + 256u + (uint32_t)tid < r1) id_ahead = point_list[r0 + 256u + tid];
+        if (b_lo + 256u + (uint32_t)tid < b_hi) id_ahead = point_list[b_lo + 256u + tid];
     }
     // forward -> backward hand-over (fnx_state.h, kBlendBatch): per-pixel state in front of every batch after the first
     float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
@@ -867,19 +1052,30 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     float2 *bstate1 = DUAL ? reinterpret_cast<float2 *>(reinterpret_cast<char *>(point_list) + du.bin_bstate1) +
                                  (size_t)(r0 >> 8) * 256 + tid : nullptr;
 #ifdef FNX_EXP_CLOCK
-    const unsigned long long wg_t0 = wall_clock64();
     unsigned long long t_last = clock64();
     if (wg_rank == 0 && wg_view == 0 && lane == 0) { for (int i = 0; i < 16; i++) g_fwd_clock[16 * w + i] = 0; g_fwd_clock[16 * w + 15] = r1 - r0; }
 #endif
     bool blending = true;  // SPLIT + materialize_all: false once every pixel is done (merging and writing go on)
-    uint32_t staged = 0;   // list entries of the batches this tile blended
-    for (uint32_t base = r0; base < r1; base += 256) {
+    for (uint32_t base = b_lo; base < b_hi; base += 256) {
         FNX_CLK(0)
         // barrier between the previous batch's walk and this batch's staging, and "has every pixel stopped?" in one:
         // each wave leaves its own answer in LDS before the barrier.  LDS-only barriers in this loop (lds_barrier): a
         // plain __syncthreads() also drains the wave's global stores (bstate, masks, point_list) and record prefetches,
         // an L2 round trip on the critical path of every batch, although no wave reads another's global data here.
-        const uint32_t wave_done = __all(alive == 0.0f && (!DUAL || d1.alive == 0.0f)) ? 1u : 0u;  // a vote of all 64 lanes: taken outside the branch
+        if (SEG && nseg_t && !nseg) {
+            // second round of a cut tile (see behind the loop): a pixel joins at the first batch of the segment its walk was not
+            // trusted from, with the state the segments in front of it add up to; the hints of the boundaries it passes
+            const uint32_t j = (base - r0) >> 8;
+            if (j >= kSegBatches0 && (j - kSegBatches0) % kSegBatches == 0u) {
+                const uint32_t s2 = 1u + (j - kSegBatches0) / kSegBatches;
+                if (my_act == s2) {  // its registers hold the state in front of this segment; it was only kept from blending
+                    alive = Tr;
+                    my_act = 0xFFFEu;
+                }
+                if (s2 < nseg_t && alive != 0.0f) hint_new[(size_t)s2 * 256] = alive;
+            }
+        }
+        const uint32_t wave_done = __all(alive == 0.0f && (!DUAL || d1.alive == 0.0f) && (!SEG || my_act >= 0xFFFEu)) ? 1u : 0u;  // a vote of all 64 lanes: taken outside the branch
         if (lane == 0) s_done[w] = wave_done;
         FNX_LOOP_BARRIER();
         const bool all_done = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
@@ -888,11 +1084,14 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
-        if (blending && base != r0) {
+        if (blending && base != r0 && !(SEG && nseg_t && !nseg && alive == 0.0f)) {  // (second round of a cut tile: the pixels it blends)
+            if (SEG && nseg)  // a segment: the workgroup that puts the tile together reads it in this launch
+                store_dev(&bstate[(size_t)(((base - r0) >> 8) - 1) * 256], make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]));
+            else
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
             if (DUAL) bstate1[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float2(d1.Tr, d1.acc);
         }
-        const uint32_t cnt = min(256u, r1 - base);
+        const uint32_t cnt = min(256u, b_hi - base);
         if (blending) staged += cnt;
         uint32_t qm = 0;
         {  // which staged entries are dynamic: one ballot per wave (slot = thread), read back behind the walk
@@ -922,7 +1121,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
             store_windows();
         } else {
-            if (base + 256u + (uint32_t)tid < r1) {  // next batch's records: in flight while this batch is blended
+            if (base + 256u + (uint32_t)tid < b_hi) {  // next batch's records: in flight while this batch is blended
                 my_id = id_ahead;
                 const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
                 pa = rec[0];
@@ -930,7 +1129,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
                 pc = rec[2];
                 if (C > 2) pd = rec[3].x;
             }
-            if (base + 512u + (uint32_t)tid < r1) id_ahead = point_list[base + 512u + tid];
+            if (base + 512u + (uint32_t)tid < b_hi) id_ahead = point_list[base + 512u + tid];
         }
         s_mask[tid] = (uint16_t)qm;
         if ((uint32_t)tid < cnt && blending)  // the backward pass builds its lists from the same masks
@@ -960,7 +1159,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         uint32_t next_cnt = 0, next_id = 0;
         if (SPLIT) {
-            next_cnt = base + 256u < r1 ? min(256u, r1 - base - 256u) : 0u;
+            next_cnt = base + 256u < b_hi ? min(256u, b_hi - base - 256u) : 0u;
             next_id = merge_batch(next_cnt);
         }
         FNX_LOOP_BARRIER_BC();
@@ -1001,6 +1200,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         uint32_t hit_off = 0xFFFFFFFFu;  // LDS offset of the last entry of this batch the pixel took
         d1.hit_off = 0xFFFFFFFFu;
         if (FAST) {
+            if (SEG && nseg)
+                fast_walk<C, false, true>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off, nullptr, &seg_vstop);
+            else
             fast_walk<C, DUAL>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off, &d1);
         } else
         for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
@@ -1091,6 +1293,160 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
         }
         FNX_CLK(3)
     }
+    if (SEG && nseg) {
+        // ---- a segment of a cut tile: leave the pixels' record, arrive; the last one to arrive goes on ----
+        uint32_t *sctl = reinterpret_cast<uint32_t *>(seg_scratch + sg.L.ctl);
+        float4 *rec_a = reinterpret_cast<float4 *>(seg_scratch + sg.L.rec_a) + (size_t)seg_slot0 * 256 + tid;
+        uint4 *rec_b = reinterpret_cast<uint4 *>(seg_scratch + sg.L.rec_b) + (size_t)seg_slot0 * 256 + tid;
+        uint4 *meta = reinterpret_cast<uint4 *>(seg_scratch + sg.L.meta) + seg_slot0;
+        // (T behind the segment -- in front of the entry that stopped the pixel, if one did --, colour taken in it, both on the
+        //  hint's scale | last contributor, last dynamic entry at or in front of it (0: none in this segment), median depth,
+        //  working T behind the segment (0: stopped))
+        store_dev(&rec_a[(size_t)seg * 256], make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]));
+        store_dev(&rec_b[(size_t)seg * 256], make_uint4(last_contributor, last_dyn, __float_as_uint(Dm), __float_as_uint(seg_vstop)));
+        if (tid == 0) {
+            store_dev(&meta[seg], make_uint4(dyn_before, 0u, 0u, 0u));
+            if (staged) atomicAdd(&header[HDR_FWD_ENTRIES], staged);
+        }
+        staged = 0;
+        // the record and this segment's hand-over records (device-scope stores, all of them) have been written when their
+        // stores have returned: then the arrival
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_adv = atomicAdd(reinterpret_cast<uint32_t *>(seg_scratch + sg.L.arrive) + tile, 1u);
+        __syncthreads();
+        const bool last_to_arrive = s_adv == nseg - 1u;
+        __syncthreads();
+        if (!last_to_arrive) {
+#ifdef FNX_EXP_CLOCK
+            if (tid == 0) {
+                const int wg = wg_view * (T + (int)kSegMax) + wg_rank;
+                if (wg < 16384) {
+                    g_fwd_wg[4 * wg] = wg_t0;
+                    g_fwd_wg[4 * wg + 1] = wall_clock64();
+                    g_fwd_wg[4 * wg + 2] = r1 - r0;
+                    g_fwd_wg[4 * wg + 3] = ((unsigned long long)(seg | (nseg_t << 8)) << 48);
+                }
+            }
+#endif
+            return;
+        }
+#ifdef FNX_EXP_CLOCK
+        if (tid == 0 && wg_view * (T + (int)kSegMax) + wg_rank < 16384) g_fwd_wg2[wg_view * (T + (int)kSegMax) + wg_rank] = wall_clock64();
+#endif
+        const uint32_t nb_t = (r1 - r0 + 255u) >> 8;  // batches of the tile
+        // One pass per pixel over the tile's segments, in order, with the true state (T, colour, last contributor ...) in
+        // front of each: with rho = true T_in / the hint the walk started from, every T of the walk is rho times what the walk
+        // saw and the colour it took rho times its colour.  A segment's walk stands for the pixel if none of its decisions
+        // depended on T_in: it did not stop the pixel, the smallest T its stop rule accepted -- the last: T only falls --
+        // times rho is still >= 1e-4, and walk and truth agree on whether T crosses 1/2 in it (the median-depth entry is then
+        // taken from the walk; it may be a neighbour of the true one: stated tolerance of this mode).  The first segment whose
+        // walk does not stand is where the pixel is blended AGAIN, from the true state, in a second round by this workgroup
+        // (the stop rule fires in that segment or soon behind it: a pixel's second round is about a segment long).  The first
+        // segment starts from the truth and always stands.
+        uint32_t first_bad = 0xFFFFu;
+        {
+            float T = 1.0f;
+            bool live = inside;
+            float ca[3] = {0.f, 0.f, 0.f};
+            uint32_t lc = 0, ld = 0, db = 0;
+            float dm = 15.0f;
+            for (uint32_t s2 = 0; s2 < nseg; s2++) {
+                const float4 a = load_dev(&rec_a[(size_t)s2 * 256]);
+                const uint4 b = load_dev(&rec_b[(size_t)s2 * 256]);
+                const uint32_t mdyn = load_dev(&meta[s2]).x;
+                const float h = seg_hint(s2);
+                const uint32_t j0 = seg_first_batch(s2), j1 = min(seg_first_batch(s2 + 1u), nb_t);
+                if (first_bad == 0xFFFFu) {
+                    hint_new[(size_t)s2 * 256] = live ? T : 0.0f;
+                    float rho = 0.0f;
+                    bool cross = false;
+                    if (live) {
+                        const float vstop = __uint_as_float(b.w);  // > 0: the walk stopped the pixel, at an entry with this test value
+                        rho = h > 0.0f ? T / h : 0.0f;
+                        const float t_end = rho * a.x;
+                        cross = T >= 0.5f && t_end < 0.5f;
+                        const bool cross_h = h >= 0.5f && a.x < 0.5f;
+                        // the entry that stopped the pixel must stop it under the true T as well; the median-depth entry is
+                        // only taken from a walk that saw T within 2 % of the truth
+                        const bool stop_moves = vstop > 0.0f && !(rho * vstop < 0.0001f);
+                        const bool depth_off = cross != cross_h || (cross && fabsf(rho - 1.0f) > 0.02f);
+                        if (s2 > 0 && (h == 0.0f || stop_moves || t_end < 0.0001f || depth_off)) {
+                            first_bad = s2;
+                            FNX_SEG_WHY(h == 0.0f ? 6 : stop_moves ? 8 : t_end < 0.0001f ? 7 : 9)
+                        }
+                    }
+                    if (first_bad == 0xFFFFu) {
+                        if (s2 > 0) {
+                            // the hand-over records of the segment's batches: "hint's scale, colour from 0" -> the tile's own
+                            bstate[(size_t)(j0 - 1u) * 256] = make_float4(T, ca[0], ca[1], ca[2]);
+                            for (uint32_t j = j0 + 1u; j < j1; j++) {
+                                const float4 q = load_dev(&bstate[(size_t)(j - 1u) * 256]);
+                                bstate[(size_t)(j - 1u) * 256] =
+                                    live ? make_float4(rho * q.x, __builtin_fmaf(rho, q.y, ca[0]), __builtin_fmaf(rho, q.z, ca[1]),
+                                                       __builtin_fmaf(rho, q.w, ca[2]))
+                                         : make_float4(T, ca[0], ca[1], ca[2]);
+                            }
+                        }
+                        if (live) {
+                            if (cross) dm = __uint_as_float(b.z);
+                            ca[0] = __builtin_fmaf(rho, a.y, ca[0]);
+                            ca[1] = __builtin_fmaf(rho, a.z, ca[1]);
+                            ca[2] = __builtin_fmaf(rho, a.w, ca[2]);
+                            if (b.x) {
+                                lc = b.x;
+                                ld = b.y ? b.y : db;
+                            }
+                            live = __uint_as_float(b.w) == 0.0f;  // (no entry stopped it)
+                            T = rho * a.x;
+                        }
+                        db = max(db, mdyn);
+                    }
+                } else {
+                    hint_new[(size_t)s2 * 256] = 0.0f;  // (what the second round passes overwrites it)
+                }
+            }
+            // the list goes on behind the segments (they cover what the tile consumed last time): pixels still blending go on
+            if (first_bad == 0xFFFFu && live && seg_first_batch(nseg) < nb_t) {
+                first_bad = nseg;
+                FNX_SEG_WHY(10)
+            }
+            Tr = T;
+            alive = live ? T : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) acc[ch] = ca[ch];
+            last_contributor = lc;
+            last_dyn = ld;
+            Dm = dm;
+            dyn_before = db;  // (per pixel here; made the tile's below)
+        }
+        if (tid == 0) s_adv = 0xFFFFu;
+        __syncthreads();
+        if (first_bad != 0xFFFFu) atomicMin(&s_adv, first_bad);
+        __syncthreads();
+        const uint32_t s_first = s_adv;  // the first segment any pixel joins the second round at
+        __syncthreads();
+        nseg = 0;
+        if (s_first != 0xFFFFu) {
+            // Second round: the batches from segment s_first on, once more, as ONE list; a pixel takes part from the segment
+            // its walk was not trusted from (its state waits in the scratch until the loop reaches that segment) until the stop
+            // rule -- applied to the true T now -- ends it.  A pixel's registers hold its state in front of that segment (the
+            // final one, for a pixel that does not take part): a working T of 0 keeps it from blending until then.
+            my_act = first_bad;
+            alive = 0.0f;
+            // the last dynamic list position in front of segment s_first (the tile's, not the pixel's)
+            uint32_t db = 0;
+            for (uint32_t s2 = 0; s2 < min(s_first, nseg_t); s2++) db = max(db, load_dev(&meta[s2]).x);
+            dyn_before = db;
+            b_lo = r0 + 256u * seg_first_batch(s_first);
+            b_hi = r1;
+            if (tid == 0) {
+                atomicAdd(&sctl[SEG_CTL_REPAIRED], 1u);
+                atomicAdd(&sctl[SEG_CTL_REPAIR_BATCHES], (r1 - min(b_lo, r1) + 255u) >> 8);
+            }
+            if (b_lo < r1) goto again;
+        }
+    }
     if (inside) {
         final_T[pix_id] = Tr;
         n_contrib[pix_id] = last_contributor;
@@ -1137,11 +1493,12 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     if (tid == 0 && staged) atomicAdd(&header[HDR_FWD_ENTRIES], staged);
 #ifdef FNX_EXP_CLOCK
     if (tid == 0) {
-        const int wg = wg_view * T + wg_rank;
-        if (wg < 8192) {
-            g_fwd_wg[3 * wg] = wg_t0;
-            g_fwd_wg[3 * wg + 1] = wall_clock64();
-            g_fwd_wg[3 * wg + 2] = ((unsigned long long)qmax << 32) | (r1 - r0);
+        const int wg = wg_view * (T + (SEG ? (int)kSegMax : 0)) + wg_rank;
+        if (wg < 16384) {
+            g_fwd_wg[4 * wg] = wg_t0;
+            g_fwd_wg[4 * wg + 1] = wall_clock64();
+            g_fwd_wg[4 * wg + 2] = ((unsigned long long)qmax << 32) | (r1 - r0);
+            g_fwd_wg[4 * wg + 3] = ((unsigned long long)(seg | (nseg_t << 8)) << 48) | ((unsigned long long)(nb & 0xFFFFu) << 32) | staged;
         }
     }
 #endif
@@ -1223,12 +1580,12 @@ void launch_preprocess(int C, hipStream_t s, int P, int D, int M, const float *m
 void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t *ranges, uint32_t *dyn_start,
                       uint32_t *header, int P, int H, uint32_t *sort_scratch_words, uint32_t *depth_hint,
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
-                      const StaticRef &st) {
+                      const StaticRef &st, const SegRef &sg) {
     const SortScratch L = sort_scratch(P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
                        sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, tile_order, tile_deep, st,
-                       sort_scratch_words + L.ctl);
+                       sort_scratch_words + L.ctl, sg);
 }
 
 void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ranges, uint32_t *point_list,
@@ -1237,7 +1594,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           uint32_t *status_out, const uint32_t *tile_count, const uint32_t *dyn_start,
                           float *acc_final, const uint32_t *tile_order, const uint8_t *tile_deep, uint32_t *depth_hint,
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
-                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du) {
+                          uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du, const SegRef &sg) {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // static splats never take gradients: in static-split mode the limit is at most the first static id
     if (st.base && dyn_limit > st.id0) dyn_limit = st.id0;
@@ -1309,7 +1666,20 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       use_deep, dyn_limit, iu, du)
+                       use_deep, dyn_limit, iu, du, sg)
+    // segmented deep tiles (the work list tile_scan_kernel left in the segment scratch): fast arithmetic, one image
+    const bool use_seg = sg.base && fast && !du.img1 && !materialize_all && !use_deep && depth_hint;
+#define FNX_LAUNCH_SEG(CC, SS)                                                                                         \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, true, false, true>), dim3((T + (int)kSegMax + 7) & ~7, V), dim3(256), \
+                       0, s, T, gx, ranges, point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth,  \
+                       header, capacity, status_out, tile_count, dyn_start, acc_final, tile_order, tile_deep,           \
+                       depth_hint, st, materialize_all, vb, use_deep, dyn_limit, iu, du, sg)
+    if (use_seg) {
+        if (C == 3 && st.base) { FNX_LAUNCH_SEG(3, true); }
+        else if (C == 3) { FNX_LAUNCH_SEG(3, false); }
+        else if (st.base) { FNX_LAUNCH_SEG(1, true); }
+        else { FNX_LAUNCH_SEG(1, false); }
+    } else
     if (du.img1) {  // dual mode: 3 channels + the single-channel image of the per-call splats, static-split lists
         if (fast) { FNX_LAUNCH_BF__(3, true, true, true); }
         else { FNX_LAUNCH_BF__(3, true, false, true); }
@@ -1321,6 +1691,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
 #undef FNX_LAUNCH_BF
 #undef FNX_LAUNCH_BF_
 #undef FNX_LAUNCH_BF__
+#undef FNX_LAUNCH_SEG
     if (use_deep && sd != s) {  // join
         (void)hipEventRecord(ev_join, sd);
         (void)hipStreamWaitEvent(s, ev_join, 0);

@@ -17,6 +17,7 @@ There is no CPU path: tensors must live on a HIP device and the HIP library must
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple
 
 import torch
@@ -56,7 +57,8 @@ def set_deep_variant(enabled: bool, min_depth: int | None = None):
 # forward to the library's deprecated process-wide setters, which only the single-view entry points still read.
 SORT_NARROW_MAX_BITS = 25   # widest depth-key span (bits) for which callers switch to the three-pass sort: two below the
                             # 27 bits three 9-bit passes order
-_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0, sort_key=None)
+_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0, sort_key=None,
+             segments=1 if os.environ.get("FNX_SEG_FORWARD", "0") == "1" else 0)
 
 
 def set_blend_math(mode: str):
@@ -156,6 +158,27 @@ def set_lean_geometry(enabled: bool):
     _lib.check(_lib.raster().fnx_set_lean_geometry(_OPTS["lean_geometry"]))
 
 
+def set_segmented_forward(enabled: bool):
+    """View batches, fast arithmetic, one image: the blend forward cuts the lists of deep tiles into segments that are
+    blended at the same time and put together per pixel (include/fnx_raster.h fnx_raster_opts_t.segment_scratch)."""
+    _OPTS["segments"] = 1 if enabled else 0
+
+
+def segmented_forward_counters():
+    """Per view batch and view: (work items of the last blend launch, of those segments, tiles cut, running total of tiles
+    blended on as one list behind some segment, running total of the batches that took) -- blocking read-back."""
+    out = []
+    for vb in list(_VIEW_BATCHES or ()):
+        for ch, t in vb._seg_scratch.items():
+            rs = vb.settings[0]
+            for v in range(vb.V):
+                w = (C.c_uint32 * 16)()
+                _lib.check(_lib.raster().fnx_segment_scratch_read(t.data_ptr(), int(rs.image_width), int(rs.image_height), v,
+                                                                  torch.cuda.current_stream().cuda_stream, w))
+                out.append(tuple(int(x) for x in w[:5]) + ((tuple(int(x) for x in w[6:11]),) if any(w[6:11]) else ()))
+    return out
+
+
 def set_deep_kernel(mode: int):
     _OPTS["deep_kernel"] = int(mode)
     _lib.check(_lib.raster().fnx_set_deep_kernel(int(mode)))
@@ -180,10 +203,13 @@ def _call_options(vbatch, channels, P, overrides, zero3=None, grad_splat_limit=N
             state_ptr = state.data_ptr()
             if seeded:
                 sort_mode = _lib.FNX_SORT_COHERENT  # else: this call's radix passes leave the state seeded
+    seg_ptr = None
+    if o["segments"] and o["blend_math"] == 1 and dual is None and P > 0:
+        seg_ptr = vbatch.segment_scratch(channels).data_ptr()
     opts = _lib.make_opts(blend_math=o["blend_math"], lean_geometry=o["lean_geometry"], sort_mode=sort_mode,
                           deep_kernel=o["deep_kernel"],
                           grad_splat_limit=-1 if grad_splat_limit is None else int(grad_splat_limit),
-                          zero3=zero3, sort_state=state_ptr, dual=dual)
+                          zero3=zero3, sort_state=state_ptr, dual=dual, segment_scratch=seg_ptr)
     return opts, o
 
 
@@ -458,9 +484,26 @@ class ViewBatch:
         self.tan_x = (C.c_float * self.V)(*[float(rs.tan_fov_x) for rs in settings_list])
         self.tan_y = (C.c_float * self.V)(*[float(rs.tan_fov_y) for rs in settings_list])
         self._depth_hint = {}
+        self._seg_scratch = {}
         self._sort_state = {}
         self._sort_pinned = set()  # keys handed out while a stream was capturing: a hipGraph holds their raw pointers
         self._sort_tick = {}
+
+    def segment_scratch(self, channels):
+        """u8 tensor [V * fnx_segment_scratch_bytes(W, H)], zero-filled once: the segmented blend forward's work list and
+        per-segment records (fnx_raster_opts_t.segment_scratch).  Like the depth hints, one per channel count: it lives as
+        long as the camera batch, so a captured graph's raw pointer stays valid."""
+        t = self._seg_scratch.get(int(channels))
+        if t is None:
+            rs = self.settings[0]
+            n = _lib.raster().fnx_segment_scratch_bytes(int(rs.image_width), int(rs.image_height))
+            t = self._seg_scratch[int(channels)] = torch.zeros(self.V * n + 256, dtype=torch.uint8, device=self.view.device)
+            global _VIEW_BATCHES
+            if _VIEW_BATCHES is None:
+                import weakref
+                _VIEW_BATCHES = weakref.WeakSet()
+            _VIEW_BATCHES.add(self)
+        return t
 
     def sort_state(self, channels, P, sort_key=None):
         """(u8 tensor [V * fnx_sort_state_bytes(P)], seeded) -- the persistent state of the temporal-coherence depth sort

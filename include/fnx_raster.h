@@ -51,7 +51,7 @@ typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
  * deprecated shims; culled splats keep their depth in the sort keys; image header grew to 16 words with the walked-entry
  * counters; 5: fnx_raster_opts_t.dual, fnx_binning_bytes_dual); a caller compares fnx_abi_version() with the
  * FNX_ABI_VERSION it was compiled against before anything else. */
-#define FNX_ABI_VERSION 5
+#define FNX_ABI_VERSION 6
 int fnx_abi_version(void);
 const char *fnx_last_error(void);
 
@@ -110,8 +110,21 @@ typedef struct fnx_raster_opts {
                                  (new frame, large move, unseeded state) is sorted from scratch inside the same launch.
                                  With the other modes the radix sort leaves the state seeded.  NULL: no state.       */
     const fnx_raster_dual_t *dual; /* stage 2 / backward of a static-split view batch: see fnx_raster_dual_t; NULL: off */
+    char *segment_scratch;    /* stage 1 + stage 2 (ABI 6), fast arithmetic, no dual image: V * fnx_segment_scratch_bytes(W, H)
+                                 bytes, ZERO-FILLED ONCE, the same pointer in both stages of a call.  The blend forward then
+                                 cuts the lists of DEEP tiles (thousands of contributing entries per pixel: the launch ends
+                                 when the longest sequential walk ends) into segments that independent workgroups blend at
+                                 the same time, each from transmittance 1, and puts them together per pixel; a segment whose
+                                 walk depended on the transmittance in front of it (the stop rule fires in it, the median-depth
+                                 entry lies in it) is blended again from the true state.  Pixels differ from the one-list walk
+                                 by the association of that product (the fast arithmetic's stated tolerance).  NULL: off. */
 } fnx_raster_opts_t;
 size_t fnx_sort_state_bytes(int P);
+size_t fnx_segment_scratch_bytes(int width, int height);
+/* Host read-back (blocking) of a view's counters in a segment scratch: out[0] = work items of the last blend launch,
+ * out[1] = of those, segments, out[2] = tiles cut into segments, out[3] = running total of tiles whose list was blended
+ * on as one list behind some segment, out[4] = running total of the batches that took, out[5 .. 15] = reserved. */
+int fnx_segment_scratch_read(const char *scratch, int width, int height, int view, fnx_stream_t stream, uint32_t out[16]);
 /* Host read-back (blocking) of a view's counters in a sort state: out[0] = calls in coherent mode, out[1] = of those,
  * calls that fell back to the in-launch full sort, out[2] = why they did, OR-ed over the calls (1: a record not written
  * by the call's preprocess, 2: a sample-sort bucket overflowed, 4: a chunk not strictly increasing, 8: a chunk boundary out

@@ -52,9 +52,9 @@ if hasattr(lib, "fnx_debug_fwd_stats"):
 if hasattr(lib, "fnx_debug_fwd_wg"):
     import numpy as np
     n = 5 * 1024
-    buf = (C.c_ulonglong * (3 * n))()
-    lib.fnx_debug_fwd_wg(buf, 3 * n)
-    a = np.array(buf[:], dtype=np.uint64).reshape(n, 3)
+    buf = (C.c_ulonglong * (4 * n))()
+    lib.fnx_debug_fwd_wg(buf, 4 * n)
+    a = np.array(buf[:], dtype=np.uint64).reshape(n, 4)
     t0, t1 = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64)
     depth, length = (a[:, 2] >> np.uint64(32)).astype(np.int64), (a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     base = t0.min()

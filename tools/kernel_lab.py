@@ -82,3 +82,29 @@ if hasattr(lib, "fnx_debug_emit_clock"):
     for off, label in ((0, "wg 0 (heavy)"), (8, "wg 200")):
         ph = [big[4 * 16000 + off + i] for i in range(8)]
         print(" ", label, "phase cycles:", {n: int(v) for n, v in zip(names, ph)}, "total", sum(ph))
+if hasattr(lib, "fnx_debug_fwd_wg"):  # -DFNX_EXP_CLOCK builds: per-workgroup timeline of the LAST blend forward
+    n = a.views * 1024
+    buf = (C.c_ulonglong * (4 * n))()
+    lib.fnx_debug_fwd_wg(buf, 4 * n)
+    arr = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
+    t0, t1 = arr[:, 0].astype(np.float64), arr[:, 1].astype(np.float64)
+    depth, length = (arr[:, 2] >> np.uint64(32)).astype(np.int64), (arr[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    nbwd, staged = (arr[:, 3] >> np.uint64(32)).astype(np.int64), (arr[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    ok = t1 > 0
+    s, e = (t0 - t0[ok].min()) * 0.01, (t1 - t0[ok].min()) * 0.01
+    dur = e - s
+    print(f"fwd: launch span {e[ok].max():.1f} us, last start {s[ok].max():.1f} us, sum of durations {dur[ok].sum() / 1e3:.2f} ms "
+          f"= {dur[ok].sum() / e[ok].max():.0f} workgroups busy on average")
+    print(f"fwd: list entries {length.sum()}, staged {staged.sum()}, deepest contributor sum {depth.sum()}, "
+          f"batches staged {((staged + 255) // 256).sum()}, batches holding a contributor {((depth + 255) // 256).sum()}, "
+          f"backward items {nbwd.sum()}")
+    for q in (0.5, 0.8, 0.9, 0.95, 0.99, 1.0):
+        print(f"   {q:4.2f} of the workgroups ended by {np.quantile(e[ok], q):7.1f} us")
+    for lo, hi in ((0, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 4096), (4096, 1 << 30)):
+        m = ok & (staged >= lo) & (staged < hi)
+        if m.sum():
+            print(f"   staged in [{lo}, {hi}): {m.sum():5d} tiles, mean duration {dur[m].mean():7.1f} us, per staged batch "
+                  f"{dur[m].sum() / np.maximum(1, ((staged[m] + 255) // 256).sum()):6.2f} us, total {dur[m].sum() / 1e3:6.2f} ms")
+    for i in np.argsort(-e)[:6]:
+        print(f"   wg {i % 1024:4d} view {i // 1024}: start {s[i]:7.1f} end {e[i]:7.1f} dur {dur[i]:7.1f} us, staged {staged[i]:5d} "
+              f"of {length[i]:5d}, deepest contributor {depth[i]:5d}")
