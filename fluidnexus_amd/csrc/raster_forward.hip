@@ -399,11 +399,25 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
     // walk, and if T crosses 1/2 here the entry that took it across is mylist[n_half] (forward.cu:351-354)
     uint32_t n_half = 0, n_half1 = 0;
     const float T_in = Tr, T1_in = DUAL ? du->Tr : 0.f;
+#if FNX_WALK_LIST_AHEAD
+    // the list words of the NEXT group are requested in front of this group's records: a deep tile's wave runs all but alone on
+    // its SIMD and waits out every LDS round trip itself -- list word -> records are two dependent ones per group
+    uint32_t jn[kGroup / 2];
+#pragma unroll
+    for (int k = 0; k < kGroup / 2; k++) jn[k] = reinterpret_cast<const uint32_t *>(mylist)[k];
+#endif
     for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
         if (__all(alive == 0.0f && (!DUAL || du->alive == 0.0f))) break;
         uint32_t jw[kGroup / 2];
+#if FNX_WALK_LIST_AHEAD
+#pragma unroll
+        for (int k = 0; k < kGroup / 2; k++) jw[k] = jn[k];
+#pragma unroll
+        for (int k = 0; k < kGroup / 2; k++) jn[k] = reinterpret_cast<const uint32_t *>(mylist + i0 + kGroup)[k];  // (the lists are padded)
+#else
 #pragma unroll
         for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
+#endif
         float a_h[kGroup], col[kGroup][3];
 #pragma unroll
         for (int k = 0; k < kGroup; k++) {
@@ -706,6 +720,12 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
 // prefetched.  Ties in depth go to the per-call stream (lower ids), as in the reference's stable sort of ids
 // emitted in id order.  The merged ids of every batch that is blended are written to point_list (the backward
 // pass walks exactly that prefix); `materialize_all` keeps merging and writing after the pixels are done.
+#ifndef FNX_WALK_LIST_AHEAD
+#define FNX_WALK_LIST_AHEAD 0  // measured: 1022 / 1014 / 1016 against 1010 / 1016 / 1020 it/s (config 3), 527 against 529 (config 5): nothing
+#endif
+#ifndef FNX_MERGE_FAST_PATH
+#define FNX_MERGE_FAST_PATH 1
+#endif
 #ifndef FNX_FWD_WAVES
 #define FNX_FWD_WAVES 4  // waves per SIMD the register allocation of the blend forward aims at (4: 469 us, 3: 486 us on config 3)
 #endif
@@ -969,6 +989,18 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             const uint32_t nsw = min(256u, ns - si), nfw = min(256u, nf - fj);
             const uint32_t *ks = s_wk[0], *kf = s_wk[SPLIT ? 1 : 0];
             const uint32_t t = (uint32_t)tid;
+#if FNX_MERGE_FAST_PATH
+            // One stream alone fills the batch (inside a plume: per-call entries only, the frozen background lies behind it):
+            // two window reads instead of the search's ~9 dependent pairs -- a tenth of a deep tile's chain per batch.
+            if (nfw >= cnt_next && (nsw == 0u || kf[cnt_next - 1u] <= ks[0])) {
+                if (t == 0u) s_adv = 0u;
+                return s_wi[SPLIT ? 1 : 0][t];
+            }
+            if (nsw >= cnt_next && (nfw == 0u || ks[cnt_next - 1u] < kf[0])) {
+                if (t == 0u) s_adv = cnt_next;
+                return s_wi[0][t];
+            }
+#endif
             uint32_t lo = t > nfw ? t - nfw : 0u, hi = min(t, nsw);
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -1139,7 +1171,9 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
             for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
         }
+        FNX_CLK(4)
         FNX_LOOP_BARRIER_BC();
+        FNX_CLK(5)
         uint32_t len[4] = {0u, 0u, 0u, 0u};  // wave-uniform lengths of the wave's lists
         // a block whose 16 pixels have all stopped gets an empty list: the wave's step count is its longest list, and a
         // finished block must not be the one that keeps it walking
@@ -1157,12 +1191,15 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
                 len[b] += (uint32_t)__popcll(m);
             }
         }
+        FNX_CLK(6)
         uint32_t next_cnt = 0, next_id = 0;
         if (SPLIT) {
             next_cnt = base + 256u < b_hi ? min(256u, b_hi - base - 256u) : 0u;
             next_id = merge_batch(next_cnt);
         }
+        FNX_CLK(7)
         FNX_LOOP_BARRIER_BC();
+        FNX_CLK(10)
         if (SPLIT) {
             if (next_cnt) {
                 const uint32_t a = s_adv;
@@ -1170,12 +1207,21 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
                 fj += next_cnt - a;
             }
             my_id = next_id;
-            if ((uint32_t)tid < next_cnt) {  // next batch's records: in flight while this batch is blended
+            {
+                // next batch's records: in flight while this batch is blended.  UNCONDITIONAL loads (a thread beyond the batch
+                // reads the record of splat 0, which it never stages): under `if (tid < next_cnt)` the compiler merged the loaded
+                // values into the loop-carried registers with copies right behind the loads -- s_waitcnt vmcnt in front of the
+                // walk, a memory round trip on the critical path of every batch (round 5).
+#ifdef FNX_EXP_COND_PREFETCH  // timing experiment: the loads under the condition, as they were
+                if ((uint32_t)tid < next_cnt)
+#endif
+                {
                 const float4 *rec = record_of(my_id);
                 pa = rec[0];
                 pb = rec[1];
                 pc = rec[2];
                 if (C > 2) pd = rec[3].x;
+                }
             }
             load_windows();
             if (!blending) continue;

@@ -38,7 +38,7 @@ if hasattr(lib, "fnx_debug_fwd_clock"):
     lib.fnx_debug_fwd_clock(buf)
     for w in range(4):
         v = [int(x) for x in buf[16 * w:16 * w + 16]]
-        print("wave", w, dict(loop_top=v[0], all_done_barrier=v[1], stage_merge=v[2], blend_loop=v[3], sum_n_w=v[8], batches=v[9], list_length=v[15]))
+        print("wave", w, dict(loop_top=v[0], all_done_barrier=v[1], masks_and_stores=v[4], barrier_b=v[5], list_build=v[6], merge_search=v[7], barrier_c=v[10], fetch_next=v[2], blend_loop=v[3], sum_n_w=v[8], batches=v[9], list_length=v[15]))
 if hasattr(lib, "fnx_debug_fwd_stats"):
     buf = (C.c_ulonglong * 8)()
     lib.fnx_debug_fwd_stats(buf, 1)
