@@ -530,15 +530,20 @@ sort_repair_kernel(int P, const uint32_t *__restrict__ raw_keys, const uint4 *__
         for (int k = 0; k < kCohPer; k++) {
             const long long g = gt + k;
             real[k] = g >= 0 && g < (long long)P;
-            rec[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (real[k]) rec[k] = krec[g];
+            // UNCONDITIONAL loads (an index outside the array reads the nearest record, dropped below): under `if (real[k])`
+            // every load sat in a branch of its own with s_waitcnt vmcnt(0) behind it -- eight memory round trips in a row at
+            // the head of a latency-bound kernel (round 5)
+            rec[k] = krec[min(max(g, 0ll), (long long)P - 1)];
         }
+
         // the call's outliers (records the preprocess kept out of the slots of their previous ranks): every workgroup
         // takes all of them, one per thread; those its window has no place for only count (below) or drop out (above)
         const uint32_t n_outl = min(hdr[COH_NOUT], (uint32_t)kCohOutlierCap);  // (candidates beyond the list's size stayed in their slots)
         real[kCohPer] = (uint32_t)tid < n_outl;
-        rec[kCohPer] = make_uint4(0u, 0u, 0u, 0u);
-        if (real[kCohPer]) rec[kCohPer] = olist[tid];
+        rec[kCohPer] = olist[min((uint32_t)tid, (uint32_t)kCohOutlierCap - 1u)];  // (unconditional, as above)
+#pragma unroll
+        for (int k = 0; k < kCohE; k++)
+            if (!real[k]) rec[k] = make_uint4(0u, 0u, 0u, 0u);
         uint32_t holes_part = 0;  // holes in front of the window's first rank (a multiple of 1024): that many fewer elements there
         for (int b = tid, nb = (int)(max(0ll, (long long)c * kCohOut - kCohMargin) >> 10); b < nb; b += kCohThreads)
             holes_part += holes[b];
