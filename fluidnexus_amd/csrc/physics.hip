@@ -787,21 +787,37 @@ adam_count_scan_kernel(float *__restrict__ x, int N, const float *__restrict__ g
         const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
         const float step_size = lr / bc1;
         float sx[3];
+        // every input of the particle is requested up front, unconditionally (an absent gradient term reads another term's
+        // array and is not used): with the loads under `if (g1)` ... each sat in front of its own s_waitcnt vmcnt(0) -- a dozen
+        // memory round trips in a row in the first kernel of every iteration (round 5)
+        const float *any = g0 ? g0 : (g1 ? g1 : (g2 ? g2 : m));
+        const float *q0 = g0 ? g0 : any, *q1 = g1 ? g1 : any, *q2 = g2 ? g2 : any;
+        float a0[3], a1[3], a2[3], mo[3], vo[3], xo[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = 3 * p + k;
+            a0[k] = q0[i];
+            a1[k] = q1[i];
+            a2[k] = q2[i];
+            mo[k] = m[i];
+            vo[k] = v[i];
+            xo[k] = x[i];
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int i = 3 * p + k;
             float g = 0.f;
-            if (g0) g = g + g0[i] * s0;
-            if (g1) g = g + g1[i] * s1;
-            if (g2) g = g + g2[i] * s2;
+            if (g0) g = g + a0[k] * s0;
+            if (g1) g = g + a1[k] * s1;
+            if (g2) g = g + a2[k] * s2;
             g = g * inv_batch;
             if (grad_out) grad_out[i] = g;
-            const float mi = m[i] + omb1 * (g - m[i]);
-            const float vi = b2 * v[i] + omb2 * g * g;
+            const float mi = mo[k] + omb1 * (g - mo[k]);
+            const float vi = b2 * vo[k] + omb2 * g * g;
             m[i] = mi;
             v[i] = vi;
             const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-            const float xn = x[i] - step_size * (mi / denom);
+            const float xn = xo[k] - step_size * (mi / denom);
             x[i] = xn;
             sx[k] = xn * scale;
             scaled_out[i] = sx[k];
@@ -1076,9 +1092,10 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                 for (uint32_t j = par; j < cnt; j += 4) {  // stage the part of this bucket that falls into the round
                     const uint32_t i0 = first + j, i1 = i0 + 2;
                     const bool in0 = i0 >= base && i0 < base + n, in1 = j + 2 < cnt && i1 >= base && i1 < base + n;
-                    float4 p0, v0, p1, v1;
-                    if (in0) { p0 = hrec[s0 + j]; v0 = u[s0 + j]; }
-                    if (in1) { p1 = hrec[s0 + j + 2]; v1 = u[s0 + j + 2]; }
+                    // (unconditional loads, all four in flight together: under `if (in0)` / `if (in1)` the second pair was
+                    //  requested only when the first had returned)
+                    const uint32_t j1 = j + 2 < cnt ? j + 2 : j;
+                    const float4 p0 = hrec[s0 + j], v0 = u[s0 + j], p1 = hrec[s0 + j1], v1 = u[s0 + j1];
                     if (in0) { s_pos[i0 - base] = make_float4(p0.x, p0.y, p0.z, v0.x); s_vel[i0 - base] = make_float2(v0.y, v0.z); }
                     if (in1) { s_pos[i1 - base] = make_float4(p1.x, p1.y, p1.z, v1.x); s_vel[i1 - base] = make_float2(v1.y, v1.z); }
                 }
