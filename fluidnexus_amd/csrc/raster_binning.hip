@@ -1066,16 +1066,26 @@ emit_kernel(int P, int T, const uint2 *__restrict__ sorted3_all, const uint2 *__
         uint32_t id[kEmitPer], key[kEmitPer];
         uint2 rc[kEmitPer];
         uint32_t have = 0;
+        // unconditional loads at clamped ranks, all of the thread's in flight together (cf. sort_repair_kernel); the empty asm
+        // keeps the compiler from sinking them back into the branches that use them, one memory round trip each
+        uint2 kv_[kEmitPer], rect_[kEmitPer];
+#pragma unroll
+        for (int k = 0; k < kEmitPer; k++) {
+            const int rank = min(blk * kSplatBlock + kEmitPer * tid + k, P - 1);
+            kv_[k] = sorted_ids[rank];
+            rect_[k] = rect_sorted[rank];
+        }
+#pragma unroll
+        for (int k = 0; k < kEmitPer; k++) asm volatile("" : "+v"(kv_[k].x), "+v"(kv_[k].y), "+v"(rect_[k].x), "+v"(rect_[k].y));
 #pragma unroll
         for (int k = 0; k < kEmitPer; k++) {
             const int rank = blk * kSplatBlock + kEmitPer * tid + k;
             id[k] = key[k] = 0;
             rc[k] = make_uint2(0u, 0u);
+            const uint2 kv = kv_[k], rect = rect_[k];
             if (rank < P) {
-                const uint2 kv = sorted_ids[rank];
                 id[k] = kv.y;
                 key[k] = kv.x + kmin;
-                const uint2 rect = rect_sorted[rank];
                 // clip the tile rows to the band
                 const uint32_t y0 = max(rect.y & 0xFFFFu, (uint32_t)ry0), y1 = min(rect.y >> 16, (uint32_t)ry1);
                 if (y1 > y0 && (rect.x >> 16) > (rect.x & 0xFFFFu)) {
