@@ -172,25 +172,36 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     // the workgroups that are resident at a time (launch_blend_backward).  Handing the items out in queue order through
     // an atomic ticket measured 7 % slower (neighbouring tiles' batches then run at the same time and meet on the same
     // splats' accumulators).  A view whose forward overflowed its binning capacity contributes no items.
+    // (thread v reads view v's header words, all five in flight together, thread 0 adds the views up behind a barrier: read
+    //  by one thread, view after view, with the short-circuit conditions below, they were twenty-five memory round trips in a
+    //  row at the head of every workgroup -- round 5)
+    __shared__ uint32_t s_view_items[kMaxViews];
+    if (tid < n_views) {
+        const int v = tid;
+        const uint32_t *h = view_at(header, vb.img, v);
+        const uint32_t h_limit = h[HDR_DYN_LIMIT], h_cap = h[HDR_BIN_CAPACITY], h_nr = h[HDR_NUM_RENDERED],
+                       h_status = h[HDR_STATUS], h_items = h[HDR_BWD_ITEMS];
+        // a view whose forward overflowed, or ran with another binning capacity than this call's (the blob's layout
+        // depends on it), contributes nothing; the mismatch is left in the view's status word (fnx_read_status)
+        // ... or whose forward laid the work items and walking limits down for a SMALLER gradient limit than this call's
+        // (fnx_request_gradient_limit; HDR_DYN_LIMIT): splats this call differentiates would be cut off
+        // (dual mode: the second image was blended over ids < HDR_DYN_LIMIT; this call must differentiate exactly those)
+        const bool cut = grad_limit > h_limit || (DUAL && grad_limit != h_limit);
+        const bool mismatch = h_cap != capacity || cut;
+        if (mismatch && blockIdx.x == 0) {
+            const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+            // ... and in the caller's status row of the view, where a deferred check looks (a refused backward
+            // returns zero gradients: it must not pass unnoticed)
+            if (status_out) status_out[8 * v + HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+        }
+        s_view_items[v] = (mismatch || h_nr > capacity || h_status != 0u) ? 0u : h_items;
+    }
+    __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
         for (int v = 0; v < n_views; v++) {
-            const uint32_t *h = view_at(header, vb.img, v);
             s_first[v] = run;
-            // a view whose forward overflowed, or ran with another binning capacity than this call's (the blob's layout
-            // depends on it), contributes nothing; the mismatch is left in the view's status word (fnx_read_status)
-            // ... or whose forward laid the work items and walking limits down for a SMALLER gradient limit than this call's
-            // (fnx_request_gradient_limit; HDR_DYN_LIMIT): splats this call differentiates would be cut off
-            // (dual mode: the second image was blended over ids < HDR_DYN_LIMIT; this call must differentiate exactly those)
-            const bool cut = grad_limit > h[HDR_DYN_LIMIT] || (DUAL && grad_limit != h[HDR_DYN_LIMIT]);
-            const bool mismatch = h[HDR_BIN_CAPACITY] != capacity || cut;
-            if (mismatch && blockIdx.x == 0) {
-                const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
-                // ... and in the caller's status row of the view, where a deferred check looks (a refused backward
-                // returns zero gradients: it must not pass unnoticed)
-                if (status_out) status_out[8 * v + HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
-            }
-            if (!(mismatch || h[HDR_NUM_RENDERED] > capacity || h[HDR_STATUS] != 0u)) run += h[HDR_BWD_ITEMS];
+            run += s_view_items[v];
         }
         s_first[n_views] = run;
     }
