@@ -553,14 +553,14 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         c0 = rasterizer.coherent_sort_counters(P_frame)
         # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
         # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
-        for _ in range(2):
+        for _ in range(max(1, int(a.seq_eager))):
             loop.iteration()
             done += 1
         rasterizer.check_status()
         captured = False
         if graph and n - done - 1 >= gi:
-            loop.capture(warmup=1, iterations=gi)
-            done += 1
+            loop.capture(warmup=int(a.seq_capture_warmup), iterations=gi)
+            done += int(a.seq_capture_warmup)
             captured = True
         if a.sort == "coherent":
             # does the frame stay inside the coherent sort's reach?  Judged on the first replay (round 5: two eager iterations
@@ -675,7 +675,11 @@ def main():
     ap.add_argument("--iters-per-frame", type=int, default=0,
                     help="optimisation iterations per frame of --frames (configs/fluid_nexus_smoke_dynamics.json: 1000; "
                          "default: 1000 with an explicit --frames, 250 in the default leg)")
-    ap.add_argument("--seq-graph-iters", type=int, default=5,
+    ap.add_argument("--seq-eager", type=int, default=2,
+                    help="sequence leg: eager iterations of a frame in front of its capture (the first sizes the binning buffers and "
+                         "seeds the depth sort's state)")
+    ap.add_argument("--seq-capture-warmup", type=int, default=0, help="sequence leg: eager iterations inside HotLoop.capture")
+    ap.add_argument("--seq-graph-iters", type=int, default=3,
                     help="iterations per hipGraph inside the sequence leg (every frame re-captures: short graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sync", action="store_true", help="reference behaviour: read num_rendered every forward")

@@ -169,7 +169,7 @@ def graph_allreduce_self_test(dev, timeout_s=20.0):
             side.synchronize()
             _drain_collective_watchdog()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):  # see HotLoop.capture
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):  # (the self-test keeps torch's own context)  # see HotLoop.capture
                 dist.all_reduce(x, group=grp)
             g.replay()
             done = torch.cuda.Event()
@@ -197,6 +197,28 @@ def _drain_collective_watchdog(seconds=0.35):
     import time
     torch.cuda.synchronize()
     time.sleep(float(os.environ.get("FNX_WATCHDOG_DRAIN_S", seconds)))
+
+
+class _graph_capture:
+    """`with torch.cuda.graph(g, stream=...)` without its `torch.cuda.empty_cache()`: handing every cached block back to the
+    driver in front of EVERY capture costs ~4 ms by itself and turns the allocations of the iterations that follow into
+    hipMalloc calls -- per frame of a sequence (bench.py --frames), where the loop is re-captured 120 times."""
+
+    def __init__(self, g, stream, pool=None, capture_error_mode="global"):
+        self.g, self.pool, self.mode = g, pool, capture_error_mode
+        self.stream_ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self.stream_ctx.__enter__()
+        if self.pool is None:
+            self.g.capture_begin(capture_error_mode=self.mode)
+        else:
+            self.g.capture_begin(self.pool, capture_error_mode=self.mode)
+
+    def __exit__(self, *args):
+        self.g.capture_end()
+        self.stream_ctx.__exit__(*args)
 
 
 def _leak(obj):
@@ -408,7 +430,7 @@ class HotLoop:
                     _drain_collective_watchdog()
                     # thread_local: calls of other threads (the process group's watchdog, the allocator) do not
                     # invalidate this capture
-                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                    with _graph_capture(g, self.stream, capture_error_mode="thread_local"):
                         for k in range(int(iterations)):
                             self._iteration_body_batched(phase="local")
                             dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
@@ -437,7 +459,7 @@ class HotLoop:
                     self.gm.invalidate_caches()
                     rasterizer._pending_status.clear()
             try:
-                with torch.cuda.graph(g, stream=self.stream):
+                with _graph_capture(g, self.stream):
                     self._iteration_body_batched(phase="local")
             except Exception:
                 _leak(g)
@@ -449,13 +471,13 @@ class HotLoop:
                 self.graph_finish = "eager"
             else:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self.stream, pool=g.pool()):
+                with _graph_capture(g2, self.stream, pool=g.pool()):
                     self._finish_step(len(self.cams), grad=self._reduce_buf)
                 self.graph_finish = g2
             iterations = 1
         else:
             itr0, tot0 = self.itr, self.gm.total_iterations
-            with torch.cuda.graph(g, stream=self.stream):
+            with _graph_capture(g, self.stream):
                 for _ in range(int(iterations)):
                     self._iteration_body()
             self.itr, self.gm.total_iterations = itr0, tot0  # recording is not running
@@ -1002,7 +1024,7 @@ class HotLoopLevelTwo:
         rasterizer._pending_status.clear()
         g = torch.cuda.CUDAGraph()
         tot0 = self.gm.total_iterations
-        with torch.cuda.graph(g, stream=self.stream):
+        with _graph_capture(g, self.stream):
             for _ in range(int(iterations)):
                 self._body_batched()
         self.gm.total_iterations = tot0
@@ -1225,7 +1247,7 @@ class FirstFrameLoop:
         rasterizer._pending_status.clear()
         g = torch.cuda.CUDAGraph()
         itr0, tot0 = self.itr, self.gm.total_iterations
-        with torch.cuda.graph(g, stream=self.stream):
+        with _graph_capture(g, self.stream):
             if self.multi:  # local gradient | all-reduce outside the graph | one-kernel step launched eagerly
                 self._body(phase="local")
                 iterations = 1
