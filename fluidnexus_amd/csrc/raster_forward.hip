@@ -1116,13 +1116,6 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             if (!SPLIT || !materialize_all) break;
             blending = false;
         }
-        if (blending && base != r0 && !(SEG && nseg_t && !nseg && alive == 0.0f)) {  // (second round of a cut tile: the pixels it blends)
-            if (SEG && nseg)  // a segment: the workgroup that puts the tile together reads it in this launch
-                store_dev(&bstate[(size_t)(((base - r0) >> 8) - 1) * 256], make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]));
-            else
-            bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
-            if (DUAL) bstate1[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float2(d1.Tr, d1.acc);
-        }
         const uint32_t cnt = min(256u, b_hi - base);
         if (blending) staged += cnt;
         uint32_t qm = 0;
@@ -1150,7 +1143,6 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             }
         }
         if (SPLIT) {
-            if ((uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
             store_windows();
         } else {
             if (base + 256u + (uint32_t)tid < b_hi) {  // next batch's records: in flight while this batch is blended
@@ -1164,8 +1156,6 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             if (base + 512u + (uint32_t)tid < b_hi) id_ahead = point_list[base + 512u + tid];
         }
         s_mask[tid] = (uint16_t)qm;
-        if ((uint32_t)tid < cnt && blending)  // the backward pass builds its lists from the same masks
-            reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks)[base + tid] = (uint16_t)qm;
         {  // this wave's four lists start out as NULL pointers (slot 256) from end to end
             const uint4 nul = make_uint4(0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u);
             uint4 *mine = reinterpret_cast<uint4 *>(&s_list[4 * w][0]);
@@ -1198,6 +1188,21 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             next_id = merge_batch(next_cnt);
         }
         FNX_CLK(7)
+        // The batch's global STORES go out here, behind everything that waits for a load: s_waitcnt vmcnt counts loads and
+        // stores in order, so a store issued in front of the mask computation (which waits for the batch's records) or of the
+        // windows' LDS copies (which wait for the windows) was waited for as well -- a store's round trip on the chain of
+        // every batch (round 5).  Nothing waits on vmcnt between here and the next batch's staging.
+        if (blending && base != r0 && !(SEG && nseg_t && !nseg && alive == 0.0f)) {  // (second round of a cut tile: the pixels it blends)
+            // hand-over record: the pixel's state in front of this batch (the walk below changes it)
+            if (SEG && nseg)  // a segment: the workgroup that puts the tile together reads it in this launch
+                store_dev(&bstate[(size_t)(((base - r0) >> 8) - 1) * 256], make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]));
+            else
+            bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
+            if (DUAL) bstate1[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float2(d1.Tr, d1.acc);
+        }
+        if (SPLIT && (uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
+        if ((uint32_t)tid < cnt && blending)  // the backward pass builds its lists from the same masks
+            reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks)[base + tid] = (uint16_t)qm;
         FNX_LOOP_BARRIER_BC();
         FNX_CLK(10)
         if (SPLIT) {
