@@ -319,6 +319,54 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         float2 stt1;
     } ahead;
     ahead.valid = false;
+    auto load_ahead = [&](const Fetched &f) {  // the pixel inputs of item f (valid)
+        const int nv = f.vw, ntile = (int)(f.item & kItemTileMask);
+        const uint32_t nb_ = f.item >> kItemTileBits;
+        const int npx = (ntile % gx) * FNX_TILE_X + blend_pixel_x(w, lane), npy = (ntile / gx) * FNX_TILE_Y + blend_pixel_y(w, lane);
+        const bool nin = npx < W && npy < H;
+        const uint32_t npix = (uint32_t)W * npy + npx;
+        ahead.T_final = nin ? view_at(final_Ts, vb.img, nv)[npix] : 0.f;
+        ahead.last_contributor = nin ? (view_at(n_contrib, vb.img, nv) + (size_t)W * H)[npix] : 0u;
+        const float *nacc = view_at(acc_final, vb.img, nv), *ndl = dL_dpixels + (size_t)nv * C * H * W;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+            ahead.dL[ch] = nin ? ndl[(size_t)ch * H * W + npix] : 0.f;
+            ahead.total[ch] = nin ? nacc[(size_t)ch * H * W + npix] : 0.f;
+        }
+        ahead.stt = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (nb_) {
+            const float4 *nbs = reinterpret_cast<const float4 *>(
+                reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
+            ahead.stt = nbs[((size_t)(f.r0 >> 8) + nb_ - 1) * 256 + tid];
+        }
+        if (DUAL) {
+            const char *i1 = du.img1 + vb.img * (size_t)nv;
+            ahead.T_final1 = nin ? reinterpret_cast<const float *>(i1 + du.final_T)[npix] : 0.f;
+            ahead.last1 = nin ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[npix] : 0u;
+            ahead.dL1 = nin ? du.dL_dpix1[(size_t)nv * H * W + npix] : 0.f;
+            ahead.total1 = nin ? reinterpret_cast<const float *>(i1 + du.acc_final)[npix] : 0.f;
+            ahead.stt1 = make_float2(1.f, 0.f);
+            if (nb_)
+                ahead.stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) +
+                                                              du.bin_bstate1)[((size_t)(f.r0 >> 8) + nb_ - 1) * 256 + tid];
+        }
+    };
+    // The FIRST item's pixels are requested here, like every later item's behind the walk of the one before: a load of them
+    // left inside the loop "for the first item only" gave every item an s_waitcnt vmcnt(0) at its head -- behind the
+    // previous item's flush atomics (the phase clocks' "item head": 17 % of a workgroup's time, round 5).
+    ahead.valid = cur.item != kNoItem;
+    if (ahead.valid) load_ahead(cur);
+    // ... and everything the first item was requested is waited for HERE: the compiler's wait-count pass merges the loop's two
+    // entries, and a register that is still in flight on the way in costs every iteration an s_waitcnt vmcnt(0) at its first
+    // use -- on the way round that is a wait for the flush atomics.
+    asm volatile("" ::"v"(cur.id), "v"(cur.qm), "v"(cur.ra.x), "v"(cur.ra.y), "v"(cur.ra.z), "v"(cur.ra.w), "v"(cur.rbx),
+                 "v"(cur.rby), "v"(cur.rcz), "v"(cur.rcw), "v"(cur.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                 "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
+                 "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
+                 "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nxt.item));
+    if (DUAL)
+        asm volatile("" ::"v"(ahead.T_final1), "v"(ahead.last1), "v"(ahead.dL1), "v"(ahead.total1), "v"(ahead.stt1.x),
+                     "v"(ahead.stt1.y));
 #ifdef FNX_EXP_BCLK
     unsigned long long t_last = clock64();
 #endif
@@ -345,26 +393,16 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #endif
         fetch_range(nxt);
         // per-view scratch, pixel gradients and screen-space accumulators of the item's view
-        const float *final_Ts_v = view_at(final_Ts, vb.img, vw);
-        // the pixel's walking limit: the forward's last DYNAMIC contributor (second half of the n_contrib array; equal to the
-        // last contributor when the forward ran without a gradient limit) -- nothing behind it is differentiated
-        const uint32_t *n_contrib_v = view_at(n_contrib, vb.img, vw) + (size_t)W * H;
-        const float *acc_final_v = view_at(acc_final, vb.img, vw);
-        const uint32_t *point_list_v = view_at(point_list, vb.bin, vw);
-        const float *dL_dpixels_v = dL_dpixels + (size_t)vw * C * H * W;
         float *dL_dmean2D_v = dL_dmean2D + (size_t)vw * P * 3;
         float *dL_dconic_v = dL_dconic + (size_t)vw * P * 4;
         float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)vw * P : nullptr;
         float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)vw * P * C : nullptr;
-        const float4 *bstate_all = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(point_list_v) + vb.bin_bstate);
         const uint32_t item = cur.item;
         const int tile = (int)(item & kItemTileMask);
         const uint32_t b = item >> kItemTileBits;
         const int tx = tile % gx, ty = tile / gx;
         const int row = lane >> 4;
         const int px = tx * FNX_TILE_X + blend_pixel_x(w, lane), py = ty * FNX_TILE_Y + blend_pixel_y(w, lane);
-        const bool inside = px < W && py < H;
-        const uint32_t pix_id = (uint32_t)W * py + px;
         const float pxf = (float)px, pyf = (float)py;
         const uint32_t r0 = cur.r0;
         const uint32_t q0 = b << 8;  // list position of the batch's first entry
@@ -373,7 +411,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         float T_final, dL_dpixel[C], total[C];
         uint32_t last_contributor;
         float4 stt = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (ahead.valid) {
+        {  // (always prefetched: before the loop for the first item, behind the previous item's walk otherwise)
             T_final = ahead.T_final;
             last_contributor = ahead.last_contributor;
 #pragma unroll
@@ -382,35 +420,17 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
                 total[ch] = ahead.total[ch];
             }
             stt = ahead.stt;
-        } else {
-            T_final = inside ? final_Ts_v[pix_id] : 0.f;
-            last_contributor = inside ? n_contrib_v[pix_id] : 0u;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                dL_dpixel[ch] = inside ? dL_dpixels_v[(size_t)ch * H * W + pix_id] : 0.f;
-                total[ch] = inside ? acc_final_v[(size_t)ch * H * W + pix_id] : 0.f;
-            }
-            if (b) stt = bstate_all[((size_t)(r0 >> 8) + b - 1) * 256 + tid];  // state in front of the batch, as the forward left it
         }
         // DUAL: the second image's pixel (final T, last contributor, dL/dpixel, accumulated value, state in front of the batch)
         float T_final1 = 0.f, dL1 = 0.f, total1 = 0.f;
         uint32_t last1 = 0;
         float2 stt1 = make_float2(1.f, 0.f);
         if (DUAL) {
-            if (ahead.valid) {
-                T_final1 = ahead.T_final1;
-                dL1 = ahead.dL1;
-                total1 = ahead.total1;
-                last1 = ahead.last1;
-                stt1 = ahead.stt1;
-            } else {
-                const char *i1 = du.img1 + vb.img * (size_t)vw;
-                T_final1 = inside ? reinterpret_cast<const float *>(i1 + du.final_T)[pix_id] : 0.f;
-                last1 = inside ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[pix_id] : 0u;
-                dL1 = inside ? du.dL_dpix1[(size_t)vw * H * W + pix_id] : 0.f;
-                total1 = inside ? reinterpret_cast<const float *>(i1 + du.acc_final)[pix_id] : 0.f;
-                if (b) stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(point_list_v) + du.bin_bstate1)[((size_t)(r0 >> 8) + b - 1) * 256 + tid];
-            }
+            T_final1 = ahead.T_final1;
+            dL1 = ahead.dL1;
+            total1 = ahead.total1;
+            last1 = ahead.last1;
+            stt1 = ahead.stt1;
         }
         float Tr1 = b ? stt1.x : 1.0f;
         // what lies behind the entry, second image: (total1 - prefix1) dL1 + its background's share
@@ -765,38 +785,7 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
 #endif
         fetch_records(nxt);  // in flight while the accumulators are flushed
         ahead.valid = nxt.item != kNoItem;
-        if (ahead.valid) {  // ... and so are the next item's pixels
-            const int nv = nxt.vw, ntile = (int)(nxt.item & kItemTileMask);
-            const uint32_t nb_ = nxt.item >> kItemTileBits;
-            const int npx = (ntile % gx) * FNX_TILE_X + blend_pixel_x(w, lane), npy = (ntile / gx) * FNX_TILE_Y + blend_pixel_y(w, lane);
-            const bool nin = npx < W && npy < H;
-            const uint32_t npix = (uint32_t)W * npy + npx;
-            ahead.T_final = nin ? view_at(final_Ts, vb.img, nv)[npix] : 0.f;
-            ahead.last_contributor = nin ? (view_at(n_contrib, vb.img, nv) + (size_t)W * H)[npix] : 0u;
-            const float *nacc = view_at(acc_final, vb.img, nv), *ndl = dL_dpixels + (size_t)nv * C * H * W;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                ahead.dL[ch] = nin ? ndl[(size_t)ch * H * W + npix] : 0.f;
-                ahead.total[ch] = nin ? nacc[(size_t)ch * H * W + npix] : 0.f;
-            }
-            ahead.stt = make_float4(1.f, 0.f, 0.f, 0.f);
-            if (nb_) {
-                const float4 *nbs = reinterpret_cast<const float4 *>(
-                    reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
-                ahead.stt = nbs[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
-            }
-            if (DUAL) {
-                const char *i1 = du.img1 + vb.img * (size_t)nv;
-                ahead.T_final1 = nin ? reinterpret_cast<const float *>(i1 + du.final_T)[npix] : 0.f;
-                ahead.last1 = nin ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[npix] : 0u;
-                ahead.dL1 = nin ? du.dL_dpix1[(size_t)nv * H * W + npix] : 0.f;
-                ahead.total1 = nin ? reinterpret_cast<const float *>(i1 + du.acc_final)[npix] : 0.f;
-                ahead.stt1 = make_float2(1.f, 0.f);
-                if (nb_)
-                    ahead.stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) +
-                                                                  du.bin_bstate1)[((size_t)(nxt.r0 >> 8) + nb_ - 1) * 256 + tid];
-            }
-        }
+        if (ahead.valid) load_ahead(nxt);  // ... and so are the next item's pixels
         // positions-only mode: the flush needs the splat's mean and world covariance; requested here, in front of the
         // barrier (the waves wait for the slowest walk anyway), instead of as a round trip inside the flush
         float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
