@@ -1017,6 +1017,9 @@ visual_forward_kcap_kernel(const float *__restrict__ visual, int V, float inv_ce
 // of one or two cells -- stages the hidden particles of the cell's 27-neighbourhood (position + velocity, ~200
 // candidates) in LDS ONCE and every lane walks them with broadcast LDS reads.  The particle-centric kernel above
 // re-reads start / records from L2 for every particle in arbitrary order; this one reads them once per cell.
+#ifndef FNX_VFC_FMA
+#define FNX_VFC_FMA 1  // fused multiply-adds in the interpolation forward walk (0: plain multiplies and adds; A/B in DESIGN 4.9)
+#endif
 constexpr int kCellCand = 256;  // staged candidates per round (2 x 4 KiB of LDS per one-wave workgroup)
 // Work items of a grid for cell-by-cell kernels: every non-empty bucket becomes ceil(count / 64) items
 // (first slot, slots), so that one wave handles particles of ONE cell (up to hash collisions) -- a wave that
@@ -1109,13 +1112,23 @@ visual_forward_cells_kernel(int V, float inv_cell, float H2, float term1, float 
                         const float4 q = s_pos[ic];
                         const float2 uj = s_vel[ic];
                         const float ex = me.x - q.x, ey = me.y - q.y, ez = me.z - q.z;
+#if FNX_VFC_FMA
+                        const float r2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+#else
                         const float r2 = ex * ex + ey * ey + ez * ez;
+#endif
                         const float t = H2 - r2;
                         const float w = (r2 < H2 && i < n) ? term1 * (t * t * t) : 0.0f;  // +0 terms leave the sums unchanged
                         S += w;
+#if FNX_VFC_FMA
+                        ax = __builtin_fmaf(q.w, w, ax);
+                        ay = __builtin_fmaf(uj.x, w, ay);
+                        az = __builtin_fmaf(uj.y, w, az);
+#else
                         ax += q.w * w;
                         ay += uj.x * w;
                         az += uj.y * w;
+#endif
                         if (WATCH) cnt_n += (r2 < H2 && i < n) ? 1.0f : 0.0f;
                     }
                 }
@@ -1404,17 +1417,19 @@ visual_backward_cells_kernel(float inv_cell, float H2, float term1, float secs, 
 #pragma unroll
                         for (int k = 0; k < kBwdGroup; k++) {
                             if (k < ng) {  // wave-uniform
+                                // fused multiply-adds, spelled out (the library is built with -ffp-contract=off): the kernel is
+                                // bound by its VALU instructions (82 % busy), 37 per (candidate, hidden particle) without them
                                 const float ex = hx[k] - q[u].x, ey = hy[k] - q[u].y, ez = hz[k] - q[u].z;
-                                const float r2 = ex * ex + ey * ey + ez * ez;
+                                const float r2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
                                 if (in[u] && r2 < H2) {
-                                    const float t = H2 - r2;
-                                    const float wgt = term1 * (t * t * t);
-                                    const float dW = -3.0f * term1 * (t * t);
-                                    const float dLdw = secs * (G[u].x * vx[k] + G[u].y * vy[k] + G[u].z * vz[k]) - G[u].w;
-                                    const float kk = dLdw * dW * 2.0f;
-                                    ax[k] += wgt * G[u].x + kk * ex;
-                                    ay[k] += wgt * G[u].y + kk * ey;
-                                    az[k] += wgt * G[u].z + kk * ez;
+                                    const float t = H2 - r2, t2 = t * t;
+                                    const float wgt = term1 * (t2 * t);
+                                    const float dW2 = (-6.0f * term1) * t2;  // 2 dW/dr2
+                                    const float dot = __builtin_fmaf(G[u].z, vz[k], __builtin_fmaf(G[u].y, vy[k], G[u].x * vx[k]));
+                                    const float kk = __builtin_fmaf(secs, dot, -G[u].w) * dW2;
+                                    ax[k] = __builtin_fmaf(kk, ex, __builtin_fmaf(wgt, G[u].x, ax[k]));
+                                    ay[k] = __builtin_fmaf(kk, ey, __builtin_fmaf(wgt, G[u].y, ay[k]));
+                                    az[k] = __builtin_fmaf(kk, ez, __builtin_fmaf(wgt, G[u].z, az[k]));
                                 }
                             }
                         }
