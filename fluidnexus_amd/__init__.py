@@ -13,13 +13,17 @@ import os as _os
 # are optimised, the temporal-coherence depth sort per camera), utils.loss_utils.ssim runs the fused kernel on device
 # tensors.  Off by default (the reference's op-by-op behaviour); FNX_AUTO=1 in the environment or set_auto(True).
 # What changes for a caller: "viewspace_points" takes no gradient while only positions are optimised (the background
-# stage, which reads it, is unaffected), and a binning overflow is reported by the next call instead of this one.
+# stage, which reads it, is unaffected), and a binning overflow is reported by a later call instead of this one (the automated path reads the status ring every 32
+# views and when it is switched off; rasterizer.check_status() reads it at once).
 _AUTO = _os.environ.get("FNX_AUTO", "0") == "1"
 
 
 def set_auto(enabled: bool):
     global _AUTO
-    _AUTO = bool(enabled)
+    was, _AUTO = _AUTO, bool(enabled)
+    if was and not _AUTO:  # pending status rows are read, the host-sync mode the automation changed is restored
+        from .renderer import pipes as _pipes
+        _pipes.auto_off()
 
 
 def auto_enabled() -> bool:

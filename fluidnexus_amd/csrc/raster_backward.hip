@@ -28,6 +28,10 @@
 #define FNX_FLUSH_ADD(p, v) unsafeAtomicAdd((p), (v))
 #endif
 #include "lab/fnx_lab.h"  // experiment switches (all off in the production build)
+#include <cstdlib>
+#ifndef FNX_BWD_FORM_DEFAULT
+#define FNX_BWD_FORM_DEFAULT 0
+#endif
 
 #ifdef FNX_EXP_BCLK  // developer timing: per-phase cycles of wave 0 / lane 0 of every workgroup, summed over the launch
 __device__ unsigned long long g_bwd_clock[16];
@@ -1155,6 +1159,10 @@ __device__ inline void geom_backward_view(const float3 mean, const float *cov3D,
     gm[2] = gm2 + dmz;
 }
 
+}  // namespace fnx
+#include "raster_backward_lanes.h"
+namespace fnx {
+
 // One thread per splat, all views of the batch in turn (a splat's result is a sum over the views
 // that see it, formed in view order in registers and written once): conic gradient -> cov2D ->
 // cov3D and mean, view-dependent colour (SH), then scale / rotation from the summed cov3D gradient
@@ -1233,10 +1241,35 @@ static void launch_blend_backward_tf(int n_cu, hipStream_t s, A... args) {
     });
     hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST, DUAL>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
 }
+// entries-as-lanes form (raster_backward_lanes.h); takes the row form's arguments without the dual reference
+template <int C, int MODE, bool FAST, typename... A>
+static void launch_blend_backward_lanes_tf(int n_cu, hipStream_t s, A... args) {
+    static int cache[kMaxDevices];
+    static std::mutex mu;
+    const int per_cu = per_device_cached(cache, mu, [](int) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_lanes_kernel<C, MODE, FAST>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        return n;
+    });
+    hipLaunchKernelGGL((blend_backward_lanes_kernel<C, MODE, FAST>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+}
+int g_backward_form = -1;  // fnx_set_backward_form: 0 = one pixel per lane (rows), 1 = one entry per lane; -1: FNX_BWD_FORM or the default
+static int backward_form() {
+    if (g_backward_form < 0) {
+        const char *e = getenv("FNX_BWD_FORM");
+        g_backward_form = e ? (atoi(e) != 0) : FNX_BWD_FORM_DEFAULT;
+    }
+    return g_backward_form;
+}
 template <int C, int MODE, typename... A>
-static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, A... args) {
-    if (fast) launch_blend_backward_tf<C, MODE, true>(n_cu, s, args...);
-    else launch_blend_backward_tf<C, MODE, false>(n_cu, s, args...);
+static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, const DualRef &du, A... args) {
+    if (backward_form() == 1) {
+        if (fast) launch_blend_backward_lanes_tf<C, MODE, true>(n_cu, s, args...);
+        else launch_blend_backward_lanes_tf<C, MODE, false>(n_cu, s, args...);
+        return;
+    }
+    if (fast) launch_blend_backward_tf<C, MODE, true>(n_cu, s, args..., du);
+    else launch_blend_backward_tf<C, MODE, false>(n_cu, s, args..., du);
 }
 
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
@@ -1255,14 +1288,14 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
         else launch_blend_backward_tf<3, 3, false, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
         return;
     }
-    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
-    else launch_blend_backward_t<1, 1>(fast, n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+    if (C == 3 && mode == 3) launch_blend_backward_t<3, 3>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 3) launch_blend_backward_t<1, 3>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3 && mode == 2) launch_blend_backward_t<3, 2>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 2) launch_blend_backward_t<1, 2>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3 && mode == 0) launch_blend_backward_t<3, 0>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (C == 3) launch_blend_backward_t<3, 1>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else if (mode == 0) launch_blend_backward_t<1, 0>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
+    else launch_blend_backward_t<1, 1>(fast, n_cu, s, du, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out);
 }
 
 void launch_geom_backward(int C, hipStream_t s, int P, int D, int M, const float *means3D, const int *radii,

@@ -1,0 +1,555 @@
+// Blend backward, ENTRIES-AS-LANES form (round 6; included by raster_backward.hip behind blend_backward_kernel, whose
+// work items, staging formats, flush and ticket protocol it shares).
+//
+// blend_backward_kernel walks four block lists per wave, one 4x4 block per 16-lane row, a LANE = a PIXEL: every lane is
+// a serial chain over its block's entries (T <- T (1 - alpha), "what lies behind" <- ...), every (pixel, entry) reads the
+// entry's record from LDS, every per-entry sum is a cross-lane fold + an LDS atomic, a wave lasts as long as the longest of
+// its four lists and a workgroup as long as its slowest quadrant (VALU 31 % of the issue rate, LDS pipe 51 %
+// busy at 12 cycles per instruction, 41 % of the wave cycles waiting).
+//
+// Here a wave takes ONE block at a time with all 64 lanes: lane (r, e) = row r of the block's pixels x entry e of a
+// CHUNK of 16 consecutive entries of the block's list.  The lane keeps its entry's record in registers and steps over the
+// four pixels j of its row:
+//   * alpha(entry e, pixel (j, r)) -- the forward's arithmetic, operation for operation (decisions are bit-equal);
+//   * the transmittance in front of the entry is the pixel's carry times the EXCLUSIVE PRODUCT of (1 - alpha) over the
+//     chunk's earlier lanes: a 16-lane multiplicative scan, four DPP row shifts (the reference's recurrence
+//     ch3 backward.cu:446-535 re-associated; the forward's recurrence forward.cu:297-361);
+//   * "what lies behind the entry" = carry - the INCLUSIVE SUM of alpha T (c . dL): an additive scan of the same shape;
+//   * the per-entry sums stay in the lane: over its four pixels dy is one number, so three sums (w, w dx, w dx^2) carry
+//     all five moments; the four rows' sums of an entry are folded with v_permlane{32,16}_swap and reach the
+//     workgroup's accumulators with one LDS atomic per four values and chunk.
+// The four pixels of a step are independent of each other (only the carries chain, from chunk to chunk), the inner loop
+// reads no LDS, and the blocks of a tile are dealt to the waves across the quadrants, one block of each quadrant per wave.
+// Sums are re-associated against both the reference and blend_backward_kernel: gradients agree within the backward's
+// stated fp32 bound; integer decisions (which entries a pixel takes) are the forward's.
+#pragma once
+#include "raster_backward_lanes_prims.h"
+
+namespace fnx {
+
+#ifndef FNX_BWDL_WAVES
+#define FNX_BWDL_WAVES 4  // waves per SIMD the register allocation aims at
+#endif
+
+template <int C, int MODE, bool FAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWDL_WAVES, FNX_BWDL_WAVES)))
+blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
+                            int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
+                            const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
+                            const float *__restrict__ acc_final, const float *__restrict__ dL_dpixels,
+                            float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
+                            float *__restrict__ dL_dcolors, const uint32_t *__restrict__ header, uint32_t capacity,
+                            uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb,
+                            const float *__restrict__ means3D, const float *__restrict__ cov3Ds, size_t cov3D_stride,
+                            const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
+                            float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out) {
+    constexpr bool kMeans = MODE != 2, kAppearance = MODE == 0 || MODE == 2, kFusedGeom = MODE == 3;
+    constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums (as the row form)
+    constexpr int NV = kAppearance ? kCol + C : kOpac;
+    constexpr int kListStride = 272;  // 256 entries + a chunk of NULL pointers
+    constexpr uint32_t kNullOff = 256u * 16u;
+    // staged batch (same records as blend_backward_kernel): slot 256 is a NULL record (alpha = 0)
+    __shared__ uint32_t s_id[256];
+    __shared__ float4 s_ra[257];  // x, y, conic a, conic b   (FAST: the conic pre-scaled by -log2(e) / 2, -log2(e))
+    __shared__ float4 s_rb[257];  // conic c, opacity (FAST: log2 opacity), FAST: colour 0, colour 1 | wants; exact: -, wants
+    __shared__ float4 s_rc[257];  // FAST C = 3: colour 2, wants; exact: colour
+    __shared__ float4 s_rd[FAST ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush
+    constexpr int kAccStride = 272;
+    __shared__ float s_acc[NV][kAccStride];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][kListStride];  // the list of the block a wave is walking
+    __shared__ uint16_t s_mask[256];
+    __shared__ uint32_t s_bmax[16];
+    // the pixels' state in front of the batch, index 16 block + 4 row + column (= the staging thread's index)
+    __shared__ __attribute__((aligned(16))) float s_pT[256], s_pR[256], s_pD[C][256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pL[256];
+    __shared__ uint32_t s_first[kMaxViews + 1];
+    __shared__ uint32_t s_view_items[kMaxViews];
+    __shared__ uint32_t s_tk;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
+    if (tid == 0) {
+        s_ra[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rb[256] = FAST ? make_float4(0.f, -200.0f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rc[256] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < n_views) {  // (as blend_backward_kernel: which views contribute items)
+        const int v = tid;
+        const uint32_t *h = view_at(header, vb.img, v);
+        const uint32_t h_limit = h[HDR_DYN_LIMIT], h_cap = h[HDR_BIN_CAPACITY], h_nr = h[HDR_NUM_RENDERED],
+                       h_status = h[HDR_STATUS], h_items = h[HDR_BWD_ITEMS];
+        const bool cut = grad_limit > h_limit;
+        const bool mismatch = h_cap != capacity || cut;
+        if (mismatch && blockIdx.x == 0) {
+            const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+            if (status_out) status_out[8 * v + HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
+        }
+        s_view_items[v] = (mismatch || h_nr > capacity || h_status != 0u) ? 0u : h_items;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int v = 0; v < n_views; v++) {
+            s_first[v] = run;
+            run += s_view_items[v];
+        }
+        s_first[n_views] = run;
+    }
+    struct Fetched {
+        uint32_t item;
+        int vw;
+        uint32_t r0, r1;
+        uint32_t id, qm;
+        float4 ra;
+        float rbx, rby, rcz, rcw, rdx;
+    };
+    constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+    auto fetch_item = [&](uint32_t t, Fetched &f) {
+        f.item = kNoItem;
+        f.vw = 0;
+        if (t < s_first[n_views]) {
+            while (t >= s_first[f.vw + 1]) f.vw++;
+            const uint32_t *items = reinterpret_cast<const uint32_t *>(
+                reinterpret_cast<const char *>(view_at(point_list, vb.bin, f.vw)) + vb.bin_items);
+            f.item = items[t - s_first[f.vw]];
+        }
+    };
+    auto fetch_range = [&](Fetched &f) {
+        f.r0 = f.r1 = 0;
+        if (f.item != kNoItem) {
+            const uint2 rg = reinterpret_cast<const uint2 *>(view_at(ranges, vb.img, f.vw))[f.item & kItemTileMask];
+            f.r0 = rg.x;
+            f.r1 = rg.y;
+        }
+    };
+    auto fetch_ids = [&](Fetched &f) {
+        f.id = 0;
+        f.qm = 0;
+        const uint32_t pos = f.r0 + ((f.item >> kItemTileBits) << 8) + (uint32_t)tid;
+        if (f.item != kNoItem && pos < f.r1) {
+            const uint32_t *pl = view_at(point_list, vb.bin, f.vw);
+            f.id = pl[pos];
+            f.qm = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(pl) + vb.bin_masks)[pos];
+        }
+    };
+    auto fetch_records = [&](Fetched &f) {
+        const uint32_t pos = f.r0 + ((f.item >> kItemTileBits) << 8) + (uint32_t)tid;
+        if (f.item != kNoItem && pos < f.r1) {
+            const float4 *rec = (st.base && f.id >= st.id0)
+                ? reinterpret_cast<const float4 *>(st.base + st.stride * f.vw + st.rec) + 4 * (size_t)(f.id - st.id0)
+                : view_at(blend_rec, vb.geom, f.vw) + 4 * (size_t)f.id;
+            const float4 rb = rec[1], rc = rec[2];
+            f.ra = rec[0];
+            f.rbx = rb.x;
+            f.rby = rb.y;
+            f.rcz = rc.z;
+            f.rcw = rc.w;
+            f.rdx = C > 2 ? rec[3].x : 0.f;
+        }
+    };
+    __syncthreads();  // s_first is written
+    // tickets: as blend_backward_kernel (the first two items of a workgroup are fixed, the rest drawn from a device
+    // counter, scrambled so that workgroups running at the same time work far apart in the queue)
+    const uint32_t n_all = max(s_first[n_views], 1u);
+    const unsigned long long mult = (n_all % 7919u) ? 7919ull : 7927ull;
+    auto scramble = [&](uint32_t t) -> uint32_t { return t < n_all ? (uint32_t)(((unsigned long long)t * mult) % n_all) : 0xFFFFFFF0u; };
+    uint32_t dyn_next = 0xFFFFFFF0u;
+    auto ticket_of = [&](uint32_t sidx) -> uint32_t {
+        return sidx < 2 ? scramble(blockIdx.x + sidx * gridDim.x) : scramble(dyn_next);
+    };
+    uint32_t walked = 0u;
+    Fetched cur, nxt;
+    fetch_item(ticket_of(0), cur);
+    fetch_item(ticket_of(1), nxt);
+    fetch_range(cur);
+    fetch_ids(cur);
+    fetch_records(cur);
+    // the staging thread's pixel (tid = 16 block + 4 row + column, the forward's lane order: fnx_device.h blend_pixel_*)
+    struct PixelsAhead {
+        float T_final;
+        uint32_t last_contributor;
+        float dL[C], total[C];
+        float4 stt;
+    } ahead;
+    auto load_ahead = [&](const Fetched &f) {
+        const int nv = f.vw, ntile = (int)(f.item & kItemTileMask);
+        const uint32_t nb_ = f.item >> kItemTileBits;
+        const int npx = (ntile % gx) * FNX_TILE_X + blend_pixel_x(w, lane), npy = (ntile / gx) * FNX_TILE_Y + blend_pixel_y(w, lane);
+        const bool nin = npx < W && npy < H;
+        const uint32_t npix = (uint32_t)W * npy + npx;
+        ahead.T_final = nin ? view_at(final_Ts, vb.img, nv)[npix] : 0.f;
+        ahead.last_contributor = nin ? (view_at(n_contrib, vb.img, nv) + (size_t)W * H)[npix] : 0u;
+        const float *nacc = view_at(acc_final, vb.img, nv), *ndl = dL_dpixels + (size_t)nv * C * H * W;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+            ahead.dL[ch] = nin ? ndl[(size_t)ch * H * W + npix] : 0.f;
+            ahead.total[ch] = nin ? nacc[(size_t)ch * H * W + npix] : 0.f;
+        }
+        ahead.stt = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (nb_) {
+            const float4 *nbs = reinterpret_cast<const float4 *>(
+                reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
+            ahead.stt = nbs[((size_t)(f.r0 >> 8) + nb_ - 1) * 256 + tid];
+        }
+    };
+    if (cur.item != kNoItem) load_ahead(cur);
+    // everything the first item was requested is waited for here (see blend_backward_kernel: a register in flight on the
+    // way into the loop costs every iteration a vmcnt(0) at its first use)
+    asm volatile("" ::"v"(cur.id), "v"(cur.qm), "v"(cur.ra.x), "v"(cur.ra.y), "v"(cur.ra.z), "v"(cur.ra.w), "v"(cur.rbx),
+                 "v"(cur.rby), "v"(cur.rcz), "v"(cur.rcw), "v"(cur.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                 "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
+                 "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
+                 "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nxt.item));
+    const int r = lane >> 4, e = lane & 15;
+    for (uint32_t sidx = 0;; sidx++) {
+        if (cur.item == kNoItem) break;
+        const int vw = cur.vw;
+        Fetched nx2;
+        uint32_t drawn = 0;
+        if (tid == 0) {  // the ticket for the item after next (see blend_backward_kernel on why this is an instruction)
+            uint32_t *tk = const_cast<uint32_t *>(header) + HDR_BWD_TICKET;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(tk), "v"(one) : "memory");
+        }
+        fetch_range(nxt);
+        float *dL_dmean2D_v = dL_dmean2D + (size_t)vw * P * 3;
+        float *dL_dconic_v = dL_dconic + (size_t)vw * P * 4;
+        float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)vw * P : nullptr;
+        float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)vw * P * C : nullptr;
+        const uint32_t item = cur.item;
+        const int tile = (int)(item & kItemTileMask);
+        const uint32_t b = item >> kItemTileBits;
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t q0 = b << 8;
+        const uint32_t cnt = min(256u, cur.r1 - cur.r0 - q0);  // entries of the batch
+        walked += cnt;
+
+        // ---- staging: this thread's pixel, this thread's entry -------------------------------------------------------
+        {
+            const float T_final = ahead.T_final;
+            const uint32_t last_contributor = ahead.last_contributor;
+            float bg_dot = 0.f, total_dot = 0.f, pre_dot = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                bg_dot += bg[ch] * ahead.dL[ch];
+                total_dot += ahead.total[ch] * ahead.dL[ch];
+            }
+            const float pre[3] = {b ? ahead.stt.y : 0.f, b ? ahead.stt.z : 0.f, b ? ahead.stt.w : 0.f};
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) pre_dot += pre[ch] * ahead.dL[ch];
+            // what lies behind the batch's first entry: (total - prefix) . dL + the background's share
+            s_pT[tid] = b ? ahead.stt.x : 1.0f;
+            s_pR[tid] = (total_dot - pre_dot) + T_final * bg_dot;
+            // entry q0 + slot lies in front of the pixel's last contributor <=> its LDS offset (16 slot) is below this
+            s_pL[tid] = last_contributor > q0 ? min(last_contributor - q0, 256u) << 4 : 0u;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) s_pD[ch][tid] = ahead.dL[ch];
+            uint32_t m = last_contributor;  // a block needs nothing behind its own deepest contributor
+            for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+            if (e == 0) s_bmax[tid >> 4] = m;
+        }
+        if ((uint32_t)tid < cnt) {
+            const uint32_t id = cur.id;
+            s_id[tid] = id;
+            const float wants_f = id < grad_limit ? 1.0f : 0.0f;
+            if (FAST) {
+                constexpr float kL2e = 1.44269504088896341f;
+                s_ra[tid] = make_float4(cur.ra.x, cur.ra.y, (-0.5f * kL2e) * cur.ra.z, (-kL2e) * cur.ra.w);
+                s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), cur.rcz,
+                                        C == 3 ? cur.rcw : wants_f);
+                if (C == 3) s_rc[tid] = make_float4(cur.rdx, wants_f, 0.f, 0.f);
+                s_rd[FAST ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
+            } else {
+                s_ra[tid] = cur.ra;
+                s_rb[tid] = make_float4(cur.rbx, cur.rby, 0.f, wants_f);
+                s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
+        s_mask[tid] = (uint16_t)((uint32_t)tid < cnt ? cur.qm : 0u);
+        fnx::lds_barrier();  // B: the batch is staged
+
+        fetch_ids(nxt);  // in flight during the walk
+        // ---- walk: one block of every quadrant per wave ----------------------------------------------------------------
+#pragma unroll 1
+        for (int qi = 0; qi < 4; qi++) {
+            const int bsub = (w + qi) & 3;
+            const int k = 4 * qi + bsub;  // bit of the block in the entries' masks (fnx_device.h block_mask_exact)
+            const uint32_t bm_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bmax[k]);
+            const uint32_t nlim = bm_ > q0 ? min(bm_ - q0, 256u) : 0u;
+            if (nlim == 0u) continue;
+            uint16_t *mylist = s_list[w];
+            uint32_t len = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint32_t slot = 64 * kk + lane;
+                const bool bit = (((uint32_t)s_mask[slot] >> k) & 1u) && slot < nlim;
+                const unsigned long long bmk = __ballot(bit);
+                if (bit) mylist[len + (uint32_t)__popcll(bmk & lt_mask)] = (uint16_t)(slot * 16);
+                len += (uint32_t)__popcll(bmk);
+            }
+            if (len == 0u) continue;
+            if (lane < 16) mylist[len + lane] = (uint16_t)kNullOff;  // the last chunk's tail points to the NULL record
+            const uint32_t nchunks = (len + 15u) >> 4;
+            // the row's four pixels
+            const float4 T4 = reinterpret_cast<const float4 *>(s_pT)[4 * k + r];
+            const float4 R4 = reinterpret_cast<const float4 *>(s_pR)[4 * k + r];
+            const uint4 L4 = reinterpret_cast<const uint4 *>(s_pL)[4 * k + r];
+            float Tc[4] = {T4.x, T4.y, T4.z, T4.w}, Rc[4] = {R4.x, R4.y, R4.z, R4.w};
+            const uint32_t Lj[4] = {L4.x, L4.y, L4.z, L4.w};
+            float dLj[C][4];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                const float4 d4 = reinterpret_cast<const float4 *>(s_pD[ch])[4 * k + r];
+                dLj[ch][0] = d4.x;
+                dLj[ch][1] = d4.y;
+                dLj[ch][2] = d4.z;
+                dLj[ch][3] = d4.w;
+            }
+            const float pxf0 = (float)(tx * FNX_TILE_X + 8 * (qi & 1) + 4 * (bsub & 1));
+            const float pyf = (float)(ty * FNX_TILE_Y + 8 * (qi >> 1) + 4 * (bsub >> 1) + r);
+            // the chunk's records are requested one chunk ahead
+            uint32_t off_n = mylist[e];
+            float4 ra_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off_n);
+            float4 rb_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off_n);
+            float4 rc_n = (!FAST || C == 3) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off_n)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+            for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t off = off_n;
+                const float4 ra = ra_n, rb = rb_n, rc = rc_n;
+                if (c + 1 < nchunks) {
+                    off_n = mylist[16 * (c + 1) + e];
+                    ra_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off_n);
+                    rb_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off_n);
+                    if (!FAST || C == 3) rc_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off_n);
+                }
+                const bool wants = (FAST ? (C == 3 ? rc.y : rb.w) : rb.w) != 0.0f;
+                float col[3];
+                if (FAST) {
+                    col[0] = rb.z;
+                    col[1] = C > 1 ? rb.w : 0.f;
+                    col[2] = C > 2 ? rc.x : 0.f;
+                } else {
+                    col[0] = rc.x;
+                    col[1] = rc.y;
+                    col[2] = rc.z;
+                }
+                const float dy = ra.y - pyf;
+                // per chunk: the terms of the exponent that do not depend on the column
+                const float k1 = FAST ? ra.w * dy : 0.f;                    // FAST: (-log2e b) dy
+                const float k0 = (rb.x * dy) * dy;                          // (c dy) dy, FAST: pre-scaled
+                float dx[4], ev[4], a[4], om[4], inv[4], cd[4];
+                bool emits[4];
+                bool any_emit = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    dx[j] = ra.x - (pxf0 + (float)j);
+                    float alpha;
+                    bool hit;
+                    if (FAST) {
+                        const float u = __builtin_fmaf(ra.z, dx[j], k1);
+                        const float q = __builtin_fmaf(u, dx[j], k0);  // log2(e) * power
+                        ev[j] = __builtin_amdgcn_exp2f(q + rb.y);      // o G
+                        alpha = fminf(0.99f, ev[j]);
+                        hit = !(q > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    } else {
+                        const float power = -0.5f * (ra.z * dx[j] * dx[j] + k0) - ra.w * dx[j] * dy;
+                        const float G = exp_fixed_in_range(fmaxf(power, -87.0f));
+                        alpha = fminf(0.99f, rb.y * G);
+                        hit = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                        ev[j] = G;
+                    }
+                    const bool active = hit && (off < Lj[j]);
+                    emits[j] = active && wants;
+                    any_emit |= emits[j];
+                    a[j] = active ? alpha : 0.0f;
+                    if (!FAST) ev[j] = active ? ev[j] : 0.0f;  // power > 0 can push the range-limited exp out of range
+                    om[j] = 1 - a[j];
+                    inv[j] = __builtin_amdgcn_rcpf(om[j]);
+                    float cdot = col[0] * dLj[0][j];
+                    if (C > 1) cdot = __builtin_fmaf(col[1], dLj[C > 1 ? 1 : 0][j], cdot);
+                    if (C > 2) cdot = __builtin_fmaf(col[2], dLj[C > 2 ? 2 : 0][j], cdot);
+                    cd[j] = cdot;
+                }
+                // transmittance behind every entry of the chunk: the carry times the inclusive product of (1 - alpha)
+                float Tn[4] = {om[0], om[1], om[2], om[3]};
+                row_scan_mul4(Tn);
+                float Tb[4], aT[4], term[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    Tn[j] = Tc[j] * Tn[j];
+                    Tb[j] = row_prev(Tn[j], Tc[j]);  // transmittance in FRONT of the entry
+                    aT[j] = a[j] * Tb[j];
+                    term[j] = aT[j] * cd[j];
+                }
+                // what lies behind the entry: the carry minus alpha T (c . dL) of the entries up to and including it
+                row_scan_add4(term);
+                float S0 = 0.f, S1 = 0.f, S2 = 0.f, SO = 0.f, SC[C];  // SO: exact arithmetic's opacity sum (G dL/dalpha)
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) SC[ch] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float rest = Rc[j] - term[j];
+                    const float dL_dalpha = __builtin_fmaf(Tb[j], cd[j], -(rest * inv[j]));
+                    // FAST: G dL/dG = (o G) dL/dalpha; exact: G (o dL/dalpha) (ch3 backward.cu:505-512)
+                    const float Ge = emits[j] ? ev[j] : 0.0f;
+                    const float wgt = FAST ? Ge * dL_dalpha : Ge * (rb.y * dL_dalpha);
+                    if (!FAST && kAppearance) SO = __builtin_fmaf(Ge, dL_dalpha, SO);
+                    S0 += wgt;
+                    S1 = __builtin_fmaf(wgt, dx[j], S1);
+                    S2 = __builtin_fmaf(wgt * dx[j], dx[j], S2);
+                    if (kAppearance) {
+                        const float dch = emits[j] ? aT[j] : 0.0f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) SC[ch] = __builtin_fmaf(dch, dLj[ch][j], SC[ch]);
+                    }
+                    Tc[j] = row_last(Tn[j]);
+                    Rc[j] = row_last(rest);
+                }
+                if (__ballot(any_emit) != 0ull) {
+                    // the lane's sums over its four pixels -> the entry's moments (dy is the row's)
+                    float m[NV];
+                    const float S0y = S0 * dy;
+                    if (kMeans) {
+                        m[0] = S1;
+                        m[kMeans ? 1 : 0] = S0y;
+                    }
+                    m[kConic] = S2;
+                    m[kConic + 1] = S1 * dy;
+                    m[kConic + 2] = S0y * dy;
+                    if (kAppearance) {
+                        // the row form sums w = (o G) dL/dalpha and divides by o at the flush (FAST); exact: G dL/dalpha
+                        m[kAppearance ? kOpac : 0] = FAST ? S0 : SO;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) m[kAppearance ? kCol + ch : 0] = SC[ch];
+                    }
+                    const uint32_t slot = off >> 4;
+                    const int vq = ((r & 1) << 1) | (r >> 1);  // which value of a group of four this row ends up with
+#pragma unroll
+                    for (int g = 0; g < NV; g += 4) {
+                        auto mv = [&](int i) -> float { return i < NV ? m[i < NV ? i : 0] : 0.0f; };
+                        const float t = rows_fold4(mv(g), mv(g + 1), mv(g + 2), mv(g + 3));
+                        if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
+                    }
+                }
+            }
+        }
+        // the ticket drawn at the top has long arrived (published before the prefetches below are issued)
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_tk = 2u * gridDim.x + drawn;
+        }
+        fetch_records(nxt);  // in flight while the accumulators are flushed
+        if (nxt.item != kNoItem) load_ahead(nxt);
+        float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kFusedGeom && (uint32_t)tid < cnt) {
+            const uint32_t gid = s_id[tid];
+            if (gid < grad_limit) {
+                const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) gmean[kx] = means3D[3 * (size_t)gid + kx];
+#pragma unroll
+                for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
+            }
+        }
+        fnx::lds_barrier();  // C: every block of the batch is walked
+        dyn_next = s_tk;
+        fetch_item(ticket_of(sidx + 2), nx2);
+        // ---- flush: thread t turns the sums of entry t into gradients (as blend_backward_kernel) ----------------------
+        constexpr int kFl = kFusedGeom ? 3 : (kMeans ? 2 : 0) + 3 + (kAppearance ? 1 + C : 0);
+        float fl[kFl];
+#pragma unroll
+        for (int kx = 0; kx < kFl; kx++) fl[kx] = 0.f;
+        bool do_flush = false;
+        uint32_t fid = 0;
+        if ((uint32_t)tid < cnt) {
+            const uint32_t id = s_id[tid];
+            float a[NV];
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                a[v] = s_acc[v][tid];
+                any |= (a[v] != 0.f);
+            }
+            if (any) {
+                do_flush = true;
+                fid = id;
+                float4 ra = s_ra[tid];
+                float cc = s_rb[tid].x;
+                if (FAST) {
+                    const float4 rd = s_rd[FAST ? tid : 0];
+                    ra.z = rd.x;
+                    ra.w = rd.y;
+                    cc = rd.z;
+                    if (kAppearance) a[kAppearance ? kOpac : 0] = a[kAppearance ? kOpac : 0] / rd.w;
+                }
+                const float g0 = kMeans ? -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx : 0.f;
+                const float g1 = kMeans ? -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy : 0.f;
+                if (kFusedGeom) {
+                    const float3 mean = make_float3(gmean[0], gmean[1], gmean[2]);
+                    float gv[3];
+                    geom_backward_view<false>(mean, gcov, viewmatrix + 16 * vw, projmatrix + 16 * vw, vb.focal_x[vw],
+                                              vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw], -0.5f * a[kConic],
+                                              -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, nullptr);
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) fl[kx < kFl ? kx : 0] = gv[kx];
+                } else {
+                    int o = 0;
+                    if (kMeans) {
+                        fl[o++ < kFl ? o - 1 : 0] = g0;
+                        fl[o++ < kFl ? o - 1 : 0] = g1;
+                    }
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic];
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 1];
+                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 2];
+                    if (kAppearance) {
+                        fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kOpac : 0];
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kCol + ch : 0];
+                    }
+                }
+            }
+        }
+        // every prefetched register is waited for in front of the atomics (vmcnt counts in order)
+        asm volatile("" ::"v"(nxt.id), "v"(nxt.qm), "v"(nxt.ra.x), "v"(nxt.ra.y), "v"(nxt.ra.z), "v"(nxt.ra.w), "v"(nxt.rbx),
+                     "v"(nxt.rby), "v"(nxt.rcz), "v"(nxt.rcw), "v"(nxt.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                     "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
+                     "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
+                     "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nx2.item));
+        if (do_flush) {
+            if (kFusedGeom) {
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)fid + kx], fl[kx < kFl ? kx : 0]);
+            } else {
+                int o = 0;
+                if (kMeans) {
+                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
+                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
+                }
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
+                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 3], fl[o++ < kFl ? o - 1 : 0]);
+                if (kAppearance) {
+                    FNX_FLUSH_ADD(&dL_dopacity_v[fid], fl[o++ < kFl ? o - 1 : 0]);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)fid * C + ch], fl[o++ < kFl ? o - 1 : 0]);
+                }
+            }
+        }
+        cur = nxt;
+        nxt.item = nx2.item;
+        nxt.vw = nx2.vw;
+    }
+    if (tid == 0 && walked) atomicAdd(const_cast<uint32_t *>(header) + HDR_BWD_ENTRIES, walked);
+    if (tid == 0) {  // the last workgroup re-arms the counters (as blend_backward_kernel)
+        uint32_t *h0 = const_cast<uint32_t *>(header);
+        if (atomicAdd(h0 + HDR_BWD_DONE, 1u) == gridDim.x - 1u) {
+            __hip_atomic_store(h0 + HDR_BWD_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(h0 + HDR_BWD_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace fnx

@@ -931,6 +931,9 @@ static_assert(kSplatBlock == 1024, "emit packs the rank-in-block into 10 bits");
 #ifndef FNX_EMIT_COUNTING
 #define FNX_EMIT_COUNTING 1
 #endif
+// the counting form lays counts [TW] | starts [TW] | staged [6 TW] into the dynamic LDS and expects s_cur at 8 TW
+// (= TW * kEmitMaskWords): fewer mask words would put the staging area over s_cur and past the allocation
+static_assert(!FNX_EMIT_COUNTING || FNX_EMIT_MASK_WORDS >= 8, "the counting emit needs FNX_EMIT_MASK_WORDS >= 8");
 constexpr int kCountPer = 12;          // instances per thread and chunk at most (registers)
 static_assert(kEmitTileWindow <= kEmitStage && kEmitTileWindow <= (1 << 22), "entry packing");
 

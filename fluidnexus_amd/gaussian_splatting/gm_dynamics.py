@@ -665,6 +665,7 @@ class GaussianModel:
         self._grid_cache.update(keep)
         self._state_memos.clear()
         self._visual_memo = (None, {})
+        physics._DIST_MEMO[0] = None  # (module-level: keyed on tensor ids / versions a raw-pointer write does not move)
 
     def _cached_grid(self, slot, xyz):
         """Neighbour grids depend only on the current value of _estimate_xyz_nn: rebuild when the
@@ -829,10 +830,15 @@ class GaussianModel:
         if getattr(self, "_knn_flags", None) is None or self._knn_flags.device != self._xyz.device:
             self._knn_flags = torch.zeros(4, dtype=torch.int32, device=self._xyz.device)
         physics.PL.check(physics.PL.physics().fnx_knn_watch(self._knn_flags.data_ptr(), int(self.KNN_K)))
+        # the library keeps the raw device pointer (per host thread) until it is re-armed or disarmed: the module holds the
+        # flag tensor for as long, so a model or loop that is dropped while armed cannot leave later physics launches (or
+        # captured graphs) writing into freed allocator memory
+        _KNN_ARMED[0] = self._knn_flags
         return self._knn_flags
 
     def disarm_knn_watch(self):
         physics.PL.check(physics.PL.physics().fnx_knn_watch(None, 0))
+        _KNN_ARMED[0] = None
 
     def check_knn_k(self):
         """Blocking read of the watch's flag word: raises if any fused search met a list longer than KNN_K since the last
@@ -1067,6 +1073,9 @@ class GaussianModel:
     def set_batch_gradient_current_level_two(self, batch_size):
         for n in self._l2_active():
             getattr(self, f"_visual_{n}").grad = self._l2_grad[n] * (1.0 / batch_size)
+
+
+_KNN_ARMED = [None]  # the flag tensor the physics library's K-cap watch currently points at (kept alive while armed)
 
 
 def _group_properties():

@@ -544,12 +544,25 @@ def adam_step(param, optimizer, terms, batch_size, grad_out=None, scaled_out=Non
                                         st["fnx_arrived"].data_ptr(), float(grid.cell), grid.blob.data_ptr(), ptr(prev),
                                         float(secs) if secs is not None else 1.0, _stream()))
         grid.velocity_of = (prev.data_ptr(), float(secs)) if prev is not None else None
+        _raw_write_done(param)
         return
     PL.check(lib.fnx_adam_step(x.data_ptr(), x.numel(), ptr(ts[0]), sc[0], ptr(ts[1]), sc[1], ptr(ts[2]), sc[2],
                                1.0 / float(batch_size), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                st["step"].data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                ptr(grad_out), ptr(scaled_out), float(scale), st["fnx_arrived"].data_ptr(),
                                _stream()))
+    _raw_write_done(param)
+
+
+def _raw_write_done(param):
+    """The library's optimiser steps write `param.data` through raw pointers: autograd's version counter -- what every
+    per-state memo in this package is keyed on -- does not move by itself (the distance-loss memo then served
+    the previous iteration's value and gradient).  Bump it like an in-place torch op would, and drop the module-level memo."""
+    _DIST_MEMO[0] = None
+    try:
+        torch._C._autograd._unsafe_set_version_counter((param,), (param._version + 1,))
+    except Exception:  # an older torch without the hook: the memos are cleared explicitly above / by invalidate_caches()
+        pass
 
 
 def knn_mean_dist2(points):

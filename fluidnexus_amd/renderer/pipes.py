@@ -164,7 +164,22 @@ def _auto_applies(gm, pos_type):
     return all(t is not None and t.is_cuda and not t.requires_grad for t in ts)
 
 
-_AUTO_HOST_SYNC_WARNED = []
+_AUTO_RESTORE: list = []   # non-empty: the automated path switched the rasteriser's host sync off and owes a restore
+_AUTO_CALLS = 0
+_AUTO_CHECK_EVERY = 32
+
+
+def auto_off():
+    """fluidnexus_amd.set_auto(False): read the status rows the automated forwards left (raises on an overflow / a refused
+    backward) and give the rasteriser back the host-sync mode it had."""
+    from .. import rasterizer as _rz
+    try:
+        if not torch.cuda.is_current_stream_capturing():
+            _rz.check_status()
+    finally:
+        if _AUTO_RESTORE:
+            _AUTO_RESTORE.clear()
+            _rz.set_host_sync(True)
 
 
 def _render_dynamics_auto(cam, gm, pipe_args, bg_color, scaling_modifier, GRsetting, GRzer, pos_type, scale):
@@ -175,8 +190,17 @@ def _render_dynamics_auto(cam, gm, pipe_args, bg_color, scaling_modifier, GRsett
     rasterizer.check_status() / the next check), and the backward is the positions-only one: "viewspace_points" is
     returned without a gradient."""
     from .. import rasterizer as _rz
-    if _rz._HOST_SYNC:  # the automation's forward is the sync-free one
+    global _AUTO_CALLS
+    if _rz._HOST_SYNC:  # the automation's forward is the sync-free one; set_auto(False) restores the caller's mode
+        _AUTO_RESTORE.append(True)
         _rz.set_host_sync(False)
+    # Nothing else on this path reads the status ring: without this an unmodified entry script would never see a binning
+    # overflow or a refused backward (such a view contributes no gradient), and the capacity high-water mark -- refreshed
+    # by check_status() only -- would stay at 1.3 x the first call's count (ADVICE r5).  One small blocking read every
+    # _AUTO_CHECK_EVERY calls, well inside the ring (256 rows): an overflow is reported at most that many views late.
+    _AUTO_CALLS += 1
+    if _AUTO_CALLS % _AUTO_CHECK_EVERY == 0 and not torch.cuda.is_current_stream_capturing():
+        _rz.check_status()
     raw_render_xyz, render_xyz = _positions(gm, pos_type, scale)
     means3D = torch.cat([render_xyz, gm.get_gs_xyz], dim=0)
     pkg = render_dynamics_views([cam], gm, pipe_args, bg_color, scaling_modifier, GRsetting=GRsetting, GRzer=GRzer,
@@ -190,7 +214,7 @@ def _render_dynamics_auto(cam, gm, pipe_args, bg_color, scaling_modifier, GRsett
     out["render_xyz"], out["raw_render_xyz"] = render_xyz, raw_render_xyz
     if pos_type == "guess_visual_nn":  # the state the positions were interpolated from (physics._DistanceLoss reuses on it)
         est = gm._estimate_xyz_nn
-        render_xyz._fnx_state = (id(gm), id(est), est._version, id(gm._visual_xyz), bool(scale))
+        render_xyz._fnx_state = (id(gm), id(est), est._version, id(gm._visual_xyz), gm._visual_xyz._version, bool(scale))
     return out
 
 

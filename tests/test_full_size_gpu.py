@@ -205,3 +205,142 @@ def test_full_size_config3_view_against_the_oracle(oracle):
     assert int((d > 2e-5).sum()) <= int(1e-4 * d.size) and d.max() <= 2e-3
     assert np.abs(itf["color"].astype(np.float64) - f["color"]).mean() <= 1e-5  # north_star: rendered L1 within 1e-5
     assert n_nc <= int(1e-3 * d.size)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size GRADIENTS against the oracle: one view each of config 3 / 4, config 2 and config 5's
+# colour rasteriser -- the oracle's backward (all host cores, under a second per view) against the C ABI's, in both blend
+# arithmetics, all gradients and the positions-only mode; then the view-batched static-split positions-only backward that
+# bench.py times (gradient limit = the fluid's splats) against the oracle's dL/dmeans3D summed over the views.
+def _bound_ratio(ref, got, rel=1e-3, abs_of_max=2e-5):
+    """worst per-element err / (rel |ref| + abs_of_max max|ref|), the number of elements above the bound, a message"""
+    ref = ref.astype(np.float64)
+    got = got.reshape(ref.shape).astype(np.float64)
+    err = np.abs(got - ref)
+    bound = rel * np.abs(ref) + abs_of_max * np.abs(ref).max()
+    ratio = err / np.maximum(bound, 1e-300)
+    i = np.unravel_index(np.argmax(ratio), ref.shape)
+    return float(ratio[i]), int((ratio > 1.0).sum()), (f"worst element {i}: ref {ref[i]:.6e} got {got[i]:.6e} err {err[i]:.3e} "
+                                                         f"bound {bound[i]:.3e} (max|ref| {np.abs(ref).max():.3e})")
+
+
+def _check_full_size_grads(tag, ref, got, keys, fast):
+    """Exact arithmetic: every element inside the mixed bound.  Fast arithmetic: a rounding that moves one alpha across
+    1 / 255 is a DISCONTINUITY of the reference's own function, so entries fed by a flipped (pixel, entry) pair
+    may leave the bound: counted, at most max(2, 1e-5 of the array), each within 50 bounds."""
+    bad = []
+    for k in keys:
+        if ref[k].size == 0:
+            continue
+        worst, n_over, msg = _bound_ratio(ref[k], got[k])
+        print(f"[full-size grads {tag}] {k}: worst err / bound {worst:.3f}, elements over the bound {n_over} of {ref[k].size}; {msg}")
+        allowed = max(2, int(1e-5 * ref[k].size)) if fast else 0
+        if n_over > allowed or worst > (50.0 if fast else 1.0):
+            bad.append(f"{k}: {n_over} over (allowed {allowed}), {msg}")
+    assert not bad, "\n".join(bad)
+
+
+_ALL_KEYS = ("dL_dmeans3D", "dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dcov3D", "dL_dscales", "dL_drotations")
+
+
+@pytest.mark.parametrize("name,view", [("smoke_ch3", 2), ("scalar_real_ch1", 1), ("ball_ch3", 3)])
+def test_full_size_gradients_against_the_oracle(oracle, name, view):
+    import os
+    from fluidnexus_amd import rasterizer
+    from tests.hip_harness import HipRun, scene_kwargs
+    sc = _Scene(name)
+    cam = sc.cams[view]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    kw = scene_kwargs(sc.g, cam, SIZE, SIZE, 0.8)
+    extra = dict(colors_precomp=sc.g["colors"], scales=sc.g["scales"], rotations=sc.g["rotations"])
+    oracle.set_threads(os.cpu_count() or 1)
+    f = oracle.forward(kw["means3D"], kw["opacities"], bg, kw["view"], kw["proj"], kw["campos"], SIZE, SIZE, kw["tanx"],
+                       kw["tany"], channels=sc.C, **extra)
+    dL = np.random.RandomState(11).normal(size=(sc.C, SIZE, SIZE)).astype(np.float32)
+    ref = oracle.backward(f, dL)
+    assert np.abs(ref["dL_dmeans3D"]).max() > 0
+    for math_mode in ("exact", "fast"):
+        rasterizer.set_blend_math(math_mode)
+        try:
+            h = HipRun(bg=bg, channels=sc.C, **kw, **extra)
+            assert h.R == f["num_rendered"]
+            full = h.backward(dL)
+            pos = h.backward(dL, geometry_only=3)
+            lim = sc.P // 2
+            pos_lim = h.backward(dL, grad_splat_limit=lim, geometry_only=3)
+        finally:
+            rasterizer.set_blend_math("exact")
+        fast = math_mode == "fast"
+        _check_full_size_grads(f"{name} {math_mode} all", ref, full, _ALL_KEYS, fast)
+        _check_full_size_grads(f"{name} {math_mode} positions-only", ref, pos, ("dL_dmeans3D",), fast)
+        # a gradient limit: rows below it as the full backward's (same bound, against the FULL array's magnitude), the rest zero
+        got = pos_lim["dL_dmeans3D"].reshape(sc.P, 3)
+        r3 = ref["dL_dmeans3D"].reshape(sc.P, 3)
+        assert (got[lim:] == 0).all()
+        err = np.abs(got[:lim].astype(np.float64) - r3[:lim])
+        bound = 1e-3 * np.abs(r3[:lim]) + 2e-5 * np.abs(r3).max()
+        n_over = int((err > bound).sum())
+        print(f"[full-size grads {name} {math_mode} limit {lim}] worst err / bound {(err / bound).max():.3f}, over {n_over}")
+        assert n_over <= (max(2, int(1e-5 * err.size)) if fast else 0)
+
+
+@pytest.mark.parametrize("math_mode", ["exact", "fast"])
+def test_full_size_view_batched_static_split_positions_only_against_the_oracle(oracle, math_mode):
+    """What bench.py's config 3 times, at its size: 5 views in one launch sequence, the background binned once (static
+    split), gradient limit = the fluid's splats, positions-only backward (fnx_rasterize_backward_views_split_opts,
+    geometry_only = 3) -- against the oracle's dL/dmeans3D of the five views added up in float64."""
+    import os
+    from fluidnexus_amd import rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews, StaticBin, ViewBatch
+    from tests.hip_harness import scene_kwargs
+    sc = _Scene("smoke_ch3")
+    P_dyn, V = 200_000, 5
+    dev = torch.device("cuda")
+    bg_np = np.array([0.1, 0.2, 0.3], np.float32)
+    rng = np.random.RandomState(12)
+    dL_np = rng.normal(size=(V, 3, SIZE, SIZE)).astype(np.float32)
+    oracle.set_threads(os.cpu_count() or 1)
+    extra = dict(colors_precomp=sc.g["colors"], scales=sc.g["scales"], rotations=sc.g["rotations"])
+    want = np.zeros((sc.P, 3), np.float64)
+    for v in range(V):
+        kw = scene_kwargs(sc.g, sc.cams[v], SIZE, SIZE, 0.8)
+        f = oracle.forward(kw["means3D"], kw["opacities"], bg_np, kw["view"], kw["proj"], kw["campos"], SIZE, SIZE, kw["tanx"],
+                           kw["tany"], channels=3, **extra)
+        want += oracle.backward(f, dL_np[v])["dL_dmeans3D"].reshape(sc.P, 3).astype(np.float64)
+    bg = torch.tensor(bg_np, device=dev)
+    tan = math.tan(0.4)
+    gcams = S.arc_cameras(V, SIZE, SIZE, device=dev)
+    vb = ViewBatch([GaussianRasterizationSettings(image_height=SIZE, image_width=SIZE, tan_fov_x=tan, tan_fov_y=tan, bg=bg,
+                                                  scale_modifier=1.0, view_matrix=c.world_view_transform,
+                                                  proj_matrix=c.full_proj_transform, sh_degree=0, campos=c.camera_center,
+                                                  prefiltered=False) for c in gcams])
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.g.items()}
+    rasterizer.set_blend_math(math_mode)
+    try:
+        with torch.no_grad():
+            sb = StaticBin(vb, t["means3D"][P_dyn:], t["opacities"][P_dyn:], P_dyn, colors_precomp=t["colors"][P_dyn:],
+                           scales=t["scales"][P_dyn:], rotations=t["rotations"][P_dyn:], channels=3)
+        rv = GaussianRasterizerViews(vb, channels=3)
+        rv.grad_splat_limit = P_dyn
+        rv.static_bin = sb
+        leaf = t["means3D"].clone().requires_grad_(True)
+        # only means3D asks for a gradient: autograd's needs_input_grad selects geometry_only = 3
+        im, _, _ = rv(means3D=leaf, means2D=torch.zeros(V, sc.P, 3, device=dev), opacities=t["opacities"],
+                      colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+        (im * torch.tensor(dL_np, device=dev)).sum().backward()
+        torch.cuda.synchronize()
+        rasterizer.check_status()
+    finally:
+        rasterizer.set_blend_math("exact")
+    got = leaf.grad.cpu().numpy()
+    assert (got[P_dyn:] == 0).all()
+    r = want[:P_dyn]
+    err = np.abs(got[:P_dyn].astype(np.float64) - r)
+    bound = 1e-3 * np.abs(r) + 2e-5 * np.abs(r).max()
+    ratio = err / bound
+    i = np.unravel_index(np.argmax(ratio), ratio.shape)
+    n_over = int((ratio > 1.0).sum())
+    print(f"[full-size bench path {math_mode}] dL/dmeans3D of {P_dyn} fluid splats over {V} views: worst err / bound "
+          f"{ratio[i]:.3f} at {i} (ref {r[i]:.6e} got {got[i]:.6e}), elements over the bound {n_over}")
+    fast = math_mode == "fast"
+    assert n_over <= (max(2, int(1e-5 * err.size)) if fast else 0) and ratio[i] <= (50.0 if fast else 1.0)
