@@ -34,10 +34,10 @@
 #endif
 
 #ifdef FNX_EXP_BCLK  // developer timing: per-phase cycles of wave 0 / lane 0 of every workgroup, summed over the launch
-__device__ unsigned long long g_bwd_clock[16];
+__device__ unsigned long long g_bwd_clock[32];
 extern "C" int fnx_debug_bwd_clock(unsigned long long *host, int reset) {
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_clock), z, sizeof(z));
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_clock), sizeof(g_bwd_clock));

@@ -27,6 +27,24 @@
 
 namespace fnx {
 
+#ifdef FNX_EXP_BCLK  // developer timing (tools/bwd_phases.py --lanes): lane 0 of EVERY wave, g_bwd_clock of raster_backward.hip
+// (summed in registers, one set of atomics per wave at the end of the kernel: an atomic per phase and item made the
+//  instrumented kernel 16 x slower and charged its own round trips to whichever phase waited for memory next)
+#define FNX_LCLK(i) { const unsigned long long tn = clock64(); lclk[i] += tn - t_last; t_last = tn; }
+#define FNX_LCNT(i, n) { lclk[i] += (unsigned long long)(n); }
+#define FNX_LSUB0() { t_sub = clock64(); }
+#define FNX_LSUB(i) { const unsigned long long tn = clock64(); lclk[i] += tn - t_sub; t_sub = tn; }
+#else
+#define FNX_LCLK(i)
+#define FNX_LCNT(i, n)
+#define FNX_LSUB0()
+#define FNX_LSUB(i)
+#endif
+// timing experiments (results WRONG): bit 1 no global flush atomics, 2 no mean / covariance gathers, 4 no pixel loads,
+// 8 no geometry in the flush, 16 no walk, 32 no record loads, 64 no LDS atomics in the walk
+#ifndef FNX_LABLATE
+#define FNX_LABLATE 0
+#endif
 #ifndef FNX_BWDL_WAVES
 #define FNX_BWDL_WAVES 4  // waves per SIMD the register allocation aims at
 #endif
@@ -104,14 +122,25 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         float rbx, rby, rcz, rcw, rdx;
     };
     constexpr uint32_t kNoItem = 0xFFFFFFFFu;
-    auto fetch_item = [&](uint32_t t, Fetched &f) {
+    __syncthreads();  // s_first is written
+    const uint32_t n_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[n_views]);
+    // The descriptor and the tile range of an item are the same for every thread: the ticket is made wave-uniform
+    // (v_readfirstlane), so these are SCALAR loads -- they count against lgkmcnt, not against vmcnt, i.e. they are not
+    // queued behind the flush's global atomics (vmcnt retires in order: a vector load issued behind the atomics is only
+    // seen when they have all returned, and the ablations priced that at a third of the kernel).
+    auto fetch_item = [&](uint32_t t_, Fetched &f) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_);
         f.item = kNoItem;
         f.vw = 0;
-        if (t < s_first[n_views]) {
-            while (t >= s_first[f.vw + 1]) f.vw++;
+        if (t < n_total) {
+            uint32_t first = 0;
+            for (int v = 1; v < n_views; v++) {
+                const uint32_t fv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[v]);
+                if (t >= fv) f.vw = v, first = fv;
+            }
             const uint32_t *items = reinterpret_cast<const uint32_t *>(
                 reinterpret_cast<const char *>(view_at(point_list, vb.bin, f.vw)) + vb.bin_items);
-            f.item = items[t - s_first[f.vw]];
+            f.item = items[t - first];
         }
     };
     auto fetch_range = [&](Fetched &f) {
@@ -134,7 +163,10 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     };
     auto fetch_records = [&](Fetched &f) {
         const uint32_t pos = f.r0 + ((f.item >> kItemTileBits) << 8) + (uint32_t)tid;
-        if (f.item != kNoItem && pos < f.r1) {
+        if (FNX_LABLATE & 32) {
+            f.ra = make_float4(100.f, 100.f, 1.f, 0.f);
+            f.rbx = 1.f, f.rby = 0.5f, f.rcz = f.rcw = f.rdx = 0.3f;
+        } else if (f.item != kNoItem && pos < f.r1) {
             const float4 *rec = (st.base && f.id >= st.id0)
                 ? reinterpret_cast<const float4 *>(st.base + st.stride * f.vw + st.rec) + 4 * (size_t)(f.id - st.id0)
                 : view_at(blend_rec, vb.geom, f.vw) + 4 * (size_t)f.id;
@@ -147,10 +179,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             f.rdx = C > 2 ? rec[3].x : 0.f;
         }
     };
-    __syncthreads();  // s_first is written
     // tickets: as blend_backward_kernel (the first two items of a workgroup are fixed, the rest drawn from a device
     // counter, scrambled so that workgroups running at the same time work far apart in the queue)
-    const uint32_t n_all = max(s_first[n_views], 1u);
+    const uint32_t n_all = max(n_total, 1u);
     const unsigned long long mult = (n_all % 7919u) ? 7919ull : 7927ull;
     auto scramble = [&](uint32_t t) -> uint32_t { return t < n_all ? (uint32_t)(((unsigned long long)t * mult) % n_all) : 0xFFFFFFF0u; };
     uint32_t dyn_next = 0xFFFFFFF0u;
@@ -162,6 +193,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     fetch_item(ticket_of(0), cur);
     fetch_item(ticket_of(1), nxt);
     fetch_range(cur);
+    fetch_range(nxt);
     fetch_ids(cur);
     fetch_records(cur);
     // the staging thread's pixel (tid = 16 block + 4 row + column, the forward's lane order: fnx_device.h blend_pixel_*)
@@ -172,6 +204,13 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         float4 stt;
     } ahead;
     auto load_ahead = [&](const Fetched &f) {
+        if (FNX_LABLATE & 4) {
+            ahead.T_final = 0.5f;
+            ahead.last_contributor = 0xFFFFu;
+            for (int ch = 0; ch < C; ch++) ahead.dL[ch] = 0.1f, ahead.total[ch] = 0.2f;
+            ahead.stt = make_float4(1.f, 0.f, 0.f, 0.f);
+            return;
+        }
         const int nv = f.vw, ntile = (int)(f.item & kItemTileMask);
         const uint32_t nb_ = f.item >> kItemTileBits;
         const int npx = (ntile % gx) * FNX_TILE_X + blend_pixel_x(w, lane), npy = (ntile / gx) * FNX_TILE_Y + blend_pixel_y(w, lane);
@@ -201,7 +240,68 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                  "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                  "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nxt.item));
     const int r = lane >> 4, e = lane & 15;
+#ifdef FNX_EXP_BCLK
+    unsigned long long lclk[32];
+    for (int i = 0; i < 32; i++) lclk[i] = 0;
+    unsigned long long t_last = clock64(), t_sub = t_last;
+#endif
+    // The gradients of an item are ADDED at the top of the NEXT iteration, behind the request for the ids of the item after
+    // it: from there the atomics have a whole staging + walk to retire before anything is waited for (the first wait is for
+    // those ids, behind the walk), and every other wait of an iteration is for a load that was issued in front of them.
+    // Issued at the end of their own iteration they sat in front of the next item's first loads: 100 of 304 us (ablation).
+    constexpr int kFl = kFusedGeom ? 3 : (kMeans ? 2 : 0) + 3 + (kAppearance ? 1 + C : 0);
+    float pf_fl[kFl];
+    bool pf_do = false;
+    uint32_t pf_id = 0;
+    int pf_vw = 0;
+    // Positions-only mode: the three components of a splat's gradient go out in ONE instruction, not three.  A global fp32
+    // atomic is priced per memory REQUEST (a 128-byte line per instruction), not per lane -- tools/micro/atomic_rate.hip:
+    // 4.7 M atomics at random splats 233 us (20 G/s), at consecutive addresses 46 us -- and a tile's entries hit 64 different
+    // splats per wave: with lane l adding component l % 3 of entry l / 3 an instruction touches 22 lines instead of 64, a
+    // third of the requests for the same sums.  The values change lanes through a wave-private strip of LDS (in-order per
+    // wave: no barrier).
+    __shared__ float s_pfv[4][192];
+    __shared__ uint32_t s_pfi[4][64];
+    auto issue_pending = [&]() {
+        if (kFusedGeom) {
+            if (__ballot(pf_do) == 0ull) return;
+            s_pfi[w][lane] = pf_do ? pf_id : 0xFFFFFFFFu;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) s_pfv[w][3 * lane + kx] = pf_fl[kx < kFl ? kx : 0];
+#pragma unroll
+            for (int rnd = 0; rnd < 3; rnd++) {
+                const int v = 64 * rnd + lane;
+                const uint32_t id_ = s_pfi[w][v / 3];
+                const float val = s_pfv[w][v];
+                if (id_ != 0xFFFFFFFFu) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)id_ + (v % 3)], val);
+            }
+            pf_do = false;
+            return;
+        }
+        if (!pf_do) return;
+        {
+            float *dL_dmean2D_v = dL_dmean2D + (size_t)pf_vw * P * 3;
+            float *dL_dconic_v = dL_dconic + (size_t)pf_vw * P * 4;
+            float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)pf_vw * P : nullptr;
+            float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)pf_vw * P * C : nullptr;
+            int o = 0;
+            if (kMeans) {
+                FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)pf_id + 0], pf_fl[o++ < kFl ? o - 1 : 0]);
+                FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)pf_id + 1], pf_fl[o++ < kFl ? o - 1 : 0]);
+            }
+            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 0], pf_fl[o++ < kFl ? o - 1 : 0]);
+            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 1], pf_fl[o++ < kFl ? o - 1 : 0]);
+            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 3], pf_fl[o++ < kFl ? o - 1 : 0]);
+            if (kAppearance) {
+                FNX_FLUSH_ADD(&dL_dopacity_v[pf_id], pf_fl[o++ < kFl ? o - 1 : 0]);
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)pf_id * C + ch], pf_fl[o++ < kFl ? o - 1 : 0]);
+            }
+        }
+        pf_do = false;
+    };
     for (uint32_t sidx = 0;; sidx++) {
+        FNX_LCLK(0)  // loop back-edge
         if (cur.item == kNoItem) break;
         const int vw = cur.vw;
         Fetched nx2;
@@ -211,11 +311,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             const uint32_t one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(tk), "v"(one) : "memory");
         }
-        fetch_range(nxt);
-        float *dL_dmean2D_v = dL_dmean2D + (size_t)vw * P * 3;
-        float *dL_dconic_v = dL_dconic + (size_t)vw * P * 4;
-        float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)vw * P : nullptr;
-        float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)vw * P * C : nullptr;
+        fetch_ids(nxt);   // (its range was requested at the end of the previous iteration)
+        issue_pending();  // the previous item's gradients
+        FNX_LCLK(7)       // ids request + flush atomics
         const uint32_t item = cur.item;
         const int tile = (int)(item & kItemTileMask);
         const uint32_t b = item >> kItemTileBits;
@@ -268,12 +366,14 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
         s_mask[tid] = (uint16_t)((uint32_t)tid < cnt ? cur.qm : 0u);
+        FNX_LCLK(1)  // staging
         fnx::lds_barrier();  // B: the batch is staged
+        FNX_LCLK(2)  // wait at barrier B
+        if (w == 0) { FNX_LCNT(8, 1) FNX_LCNT(9, cnt) }
 
-        fetch_ids(nxt);  // in flight during the walk
         // ---- walk: one block of every quadrant per wave ----------------------------------------------------------------
 #pragma unroll 1
-        for (int qi = 0; qi < 4; qi++) {
+        for (int qi = 0; qi < ((FNX_LABLATE & 16) ? 0 : 4); qi++) {
             const int bsub = (w + qi) & 3;
             const int k = 4 * qi + bsub;  // bit of the block in the entries' masks (fnx_device.h block_mask_exact)
             const uint32_t bm_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bmax[k]);
@@ -292,6 +392,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             if (len == 0u) continue;
             if (lane < 16) mylist[len + lane] = (uint16_t)kNullOff;  // the last chunk's tail points to the NULL record
             const uint32_t nchunks = (len + 15u) >> 4;
+            FNX_LCNT(10, len) FNX_LCNT(11, nchunks) FNX_LCNT(12, 1)
             // the row's four pixels
             const float4 T4 = reinterpret_cast<const float4 *>(s_pT)[4 * k + r];
             const float4 R4 = reinterpret_cast<const float4 *>(s_pR)[4 * k + r];
@@ -409,6 +510,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                     Rc[j] = row_last(rest);
                 }
                 if (__ballot(any_emit) != 0ull) {
+                    FNX_LCNT(13, 1)
                     // the lane's sums over its four pixels -> the entry's moments (dy is the row's)
                     float m[NV];
                     const float S0y = S0 * dy;
@@ -431,22 +533,33 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                     for (int g = 0; g < NV; g += 4) {
                         auto mv = [&](int i) -> float { return i < NV ? m[i < NV ? i : 0] : 0.0f; };
                         const float t = rows_fold4(mv(g), mv(g + 1), mv(g + 2), mv(g + 3));
-                        if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
+                        if (FNX_LABLATE & 64) {
+                            asm volatile("" ::"v"(t));
+                        } else if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
                     }
                 }
             }
         }
+        FNX_LCLK(3)  // walk (list builds + chunks)
         // the ticket drawn at the top has long arrived (published before the prefetches below are issued)
+        FNX_LSUB0()
         if (tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_tk = 2u * gridDim.x + drawn;
         }
-        fetch_records(nxt);  // in flight while the accumulators are flushed
-        if (nxt.item != kNoItem) load_ahead(nxt);
+        FNX_LSUB(16)
+#ifdef FNX_EXP_BCLK
+        asm volatile("" ::"v"(nxt.id), "v"(nxt.qm));
+        FNX_LSUB(17)  // wait for the next item's ids
+#endif
+        // this item's mean / covariance first: the flush wants them first, and vmcnt retires in order
         float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (kFusedGeom && (uint32_t)tid < cnt) {
             const uint32_t gid = s_id[tid];
-            if (gid < grad_limit) {
+            if (FNX_LABLATE & 2) {
+                gmean[0] = 0.1f, gmean[1] = 0.2f, gmean[2] = -0.3f;
+                gcov[0] = gcov[3] = gcov[5] = 1e-4f;
+            } else if (gid < grad_limit) {
                 const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) gmean[kx] = means3D[3 * (size_t)gid + kx];
@@ -454,16 +567,21 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
             }
         }
+        fetch_records(nxt);  // in flight while the accumulators are flushed
+        FNX_LSUB(18)
+        if (nxt.item != kNoItem) load_ahead(nxt);
+        FNX_LSUB(19)
+        FNX_LSUB(20)  // gather requests
+        FNX_LCLK(4)  // prefetch requests
         fnx::lds_barrier();  // C: every block of the batch is walked
+        FNX_LCLK(5)  // wait at barrier C
+        FNX_LSUB0()
         dyn_next = s_tk;
         fetch_item(ticket_of(sidx + 2), nx2);
-        // ---- flush: thread t turns the sums of entry t into gradients (as blend_backward_kernel) ----------------------
-        constexpr int kFl = kFusedGeom ? 3 : (kMeans ? 2 : 0) + 3 + (kAppearance ? 1 + C : 0);
-        float fl[kFl];
+        FNX_LSUB(21)
+        // ---- flush: thread t turns the sums of entry t into gradients (as blend_backward_kernel); added at the next top ----
 #pragma unroll
-        for (int kx = 0; kx < kFl; kx++) fl[kx] = 0.f;
-        bool do_flush = false;
-        uint32_t fid = 0;
+        for (int kx = 0; kx < kFl; kx++) pf_fl[kx] = 0.f;
         if ((uint32_t)tid < cnt) {
             const uint32_t id = s_id[tid];
             float a[NV];
@@ -474,8 +592,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 any |= (a[v] != 0.f);
             }
             if (any) {
-                do_flush = true;
-                fid = id;
+                pf_do = !(FNX_LABLATE & 1);
+                pf_id = id;
+                pf_vw = vw;
                 float4 ra = s_ra[tid];
                 float cc = s_rb[tid].x;
                 if (FAST) {
@@ -487,61 +606,61 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 }
                 const float g0 = kMeans ? -(ra.z * a[0] + ra.w * a[kMeans ? 1 : 0]) * ddelx_dx : 0.f;
                 const float g1 = kMeans ? -(cc * a[kMeans ? 1 : 0] + ra.w * a[0]) * ddely_dy : 0.f;
-                if (kFusedGeom) {
+                if (kFusedGeom && (FNX_LABLATE & 8)) {
+                    pf_fl[0] = g0 + gmean[0] + gcov[0], pf_fl[1 < kFl ? 1 : 0] = g1 + gmean[1] + gcov[3], pf_fl[2 < kFl ? 2 : 0] = a[kConic] + gmean[2] + gcov[5];
+                } else if (kFusedGeom) {
                     const float3 mean = make_float3(gmean[0], gmean[1], gmean[2]);
                     float gv[3];
                     geom_backward_view<false>(mean, gcov, viewmatrix + 16 * vw, projmatrix + 16 * vw, vb.focal_x[vw],
                                               vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw], -0.5f * a[kConic],
                                               -0.5f * a[kConic + 1], -0.5f * a[kConic + 2], g0, g1, gv, nullptr);
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++) fl[kx < kFl ? kx : 0] = gv[kx];
+                    for (int kx = 0; kx < 3; kx++) pf_fl[kx < kFl ? kx : 0] = gv[kx];
                 } else {
                     int o = 0;
                     if (kMeans) {
-                        fl[o++ < kFl ? o - 1 : 0] = g0;
-                        fl[o++ < kFl ? o - 1 : 0] = g1;
+                        pf_fl[o++ < kFl ? o - 1 : 0] = g0;
+                        pf_fl[o++ < kFl ? o - 1 : 0] = g1;
                     }
-                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic];
-                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 1];
-                    fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 2];
+                    pf_fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic];
+                    pf_fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 1];
+                    pf_fl[o++ < kFl ? o - 1 : 0] = -0.5f * a[kConic + 2];
                     if (kAppearance) {
-                        fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kOpac : 0];
+                        pf_fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kOpac : 0];
 #pragma unroll
-                        for (int ch = 0; ch < C; ch++) fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kCol + ch : 0];
+                        for (int ch = 0; ch < C; ch++) pf_fl[o++ < kFl ? o - 1 : 0] = a[kAppearance ? kCol + ch : 0];
                     }
                 }
             }
         }
-        // every prefetched register is waited for in front of the atomics (vmcnt counts in order)
+        if (FNX_LABLATE & 1) {
+            float sink = 0.f;
+            for (int kx = 0; kx < kFl; kx++) sink += pf_fl[kx];
+            asm volatile("" ::"v"(sink));
+        }
+        FNX_LSUB(22)  // sums -> gradients (incl. the wait for the gathered mean / covariance)
+        // the next item's records and pixels (requested in front of barrier C) are waited for here, with no atomic between
+        // their request and this wait
         asm volatile("" ::"v"(nxt.id), "v"(nxt.qm), "v"(nxt.ra.x), "v"(nxt.ra.y), "v"(nxt.ra.z), "v"(nxt.ra.w), "v"(nxt.rbx),
                      "v"(nxt.rby), "v"(nxt.rcz), "v"(nxt.rcw), "v"(nxt.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
                      "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                      "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
-                     "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nx2.item));
-        if (do_flush) {
-            if (kFusedGeom) {
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)fid + kx], fl[kx < kFl ? kx : 0]);
-            } else {
-                int o = 0;
-                if (kMeans) {
-                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
-                    FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
-                }
-                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);
-                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 1], fl[o++ < kFl ? o - 1 : 0]);
-                FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)fid + 3], fl[o++ < kFl ? o - 1 : 0]);
-                if (kAppearance) {
-                    FNX_FLUSH_ADD(&dL_dopacity_v[fid], fl[o++ < kFl ? o - 1 : 0]);
-#pragma unroll
-                    for (int ch = 0; ch < C; ch++) FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)fid * C + ch], fl[o++ < kFl ? o - 1 : 0]);
-                }
-            }
-        }
+                     "v"(ahead.stt.z), "v"(ahead.stt.w));
+        FNX_LSUB(23)  // wait for the next item's records / pixels
+        FNX_LCLK(6)   // flush: sums -> gradients (+ the wait for the prefetched registers)
+        FNX_LCNT(14, __popcll(__ballot(pf_do)))
+        fetch_range(nx2);  // scalar; the descriptor was requested behind barrier C
         cur = nxt;
         nxt.item = nx2.item;
         nxt.vw = nx2.vw;
+        nxt.r0 = nx2.r0;
+        nxt.r1 = nx2.r1;
     }
+    issue_pending();  // the last item's gradients
+#ifdef FNX_EXP_BCLK
+    if (lane == 0)
+        for (int i = 0; i < 32; i++) atomicAdd(&g_bwd_clock[i], lclk[i]);
+#endif
     if (tid == 0 && walked) atomicAdd(const_cast<uint32_t *>(header) + HDR_BWD_ENTRIES, walked);
     if (tid == 0) {  // the last workgroup re-arms the counters (as blend_backward_kernel)
         uint32_t *h0 = const_cast<uint32_t *>(header);

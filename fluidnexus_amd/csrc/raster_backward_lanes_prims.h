@@ -47,6 +47,14 @@ __device__ __forceinline__ float row_last(float v) {
 // row 2 of b, row 3 of d (per lane of the row).  v_permlane32_swap exchanges the upper half of its first operand with the
 // lower half of its second, v_permlane16_swap the odd rows of the first with the even rows of the second (gfx950).
 __device__ __forceinline__ float rows_fold4(float a, float b, float c, float d) {
+#ifdef FNX_EXP_FOLD_BUILTIN  // timing experiment, WRONG sums (see below): the builtin form
+    const auto ab = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const auto cd = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d), false, false);
+    const float s1 = __builtin_bit_cast(float, ab[0]) + __builtin_bit_cast(float, ab[1]);
+    const float s2 = __builtin_bit_cast(float, cd[0]) + __builtin_bit_cast(float, cd[1]);
+    const auto t = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2), false, false);
+    return __builtin_bit_cast(float, t[0]) + __builtin_bit_cast(float, t[1]);
+#endif
     // (written as instructions: with hipcc 7.2 both elements of __builtin_amdgcn_permlane32_swap's result came out as the
     //  FIRST one -- v_add v1, v1, v1 behind the swap, tools/micro/lanes_prims.hip.  A swap reads its operands two wait
     //  states behind a VALU write at the earliest.)

@@ -14,7 +14,7 @@ bg = torch.zeros(3, device="cuda")
 rasterizer.set_host_sync(False)
 rasterizer.set_blend_math("fast")
 lib = _lib.raster()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for it in range(4):
     if it == 3:
         torch.cuda.synchronize()
@@ -24,6 +24,22 @@ for it in range(4):
     gm.optimizer.zero_grad()
 torch.cuda.synchronize()
 lib.fnx_debug_bwd_clock(buf, 0)
+if "--lanes" in sys.argv:  # the entries-as-lanes form (FNX_BWD_FORM=1): lane 0 of every wave
+    names = ["flush: global atomics (to loop top)", "staging", "wait barrier B", "walk (list builds + chunks)", "prefetch requests",
+             "wait barrier C", "flush: sums -> gradients"]
+    tot = sum(int(buf[i]) for i in range(7))
+    for i, n in enumerate(names):
+        print(f"{n:36s} {int(buf[i]) / 4096 / 100:8.1f} us per wave  {100 * int(buf[i]) / tot:5.1f} %")
+    for i, n in ((16, "  ticket wait (wave 0)"), (17, "  wait for the next item's ids"), (18, "  record requests"), (19, "  pixel requests"),
+                 (20, "  mean / covariance gather requests"), (21, "  next-next item descriptor"), (22, "  sums -> gradients (+ gather wait)"),
+                 (23, "  wait for the next item's records / pixels")):
+        print(f"{n:46s} {100 * int(buf[i]) / tot:5.1f} %")
+    items, ents, ln, ch, nb, em = (int(buf[i]) for i in range(8, 14))
+    print(f"total {tot / 4096 / 100:.1f} us per wave if the counter runs at 100 MHz (4096 waves)")
+    print(f"items {items}, staged entries {ents} ({ents / max(items, 1):.1f} per item); walked blocks {nb} ({nb / max(items, 1):.2f} per item), "
+          f"list entries {ln} ({ln / max(nb, 1):.1f} per walked block, {ln / max(ents, 1):.2f} blocks per staged entry), chunks {ch} "
+          f"(lane fill {ln / max(16 * ch, 1):.3f}), chunks with a gradient {em} ({em / max(ch, 1):.3f}); flushed entries {int(buf[14])} ({int(buf[14]) / max(ents, 1):.3f} of the staged)")
+    sys.exit(0)
 names = ["flush (to loop top)", "item head (pixel inputs, maxima)", "wait barrier A", "staging writes", "wait barrier B", "list build",
          "walk", "prefetch + wait barrier C"]
 tot = sum(int(buf[i]) for i in range(8))
