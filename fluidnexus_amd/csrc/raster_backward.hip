@@ -30,7 +30,7 @@
 #include "lab/fnx_lab.h"  // experiment switches (all off in the production build)
 #include <cstdlib>
 #ifndef FNX_BWD_FORM_DEFAULT
-#define FNX_BWD_FORM_DEFAULT 0
+#define FNX_BWD_FORM_DEFAULT 1  // 1: entries as lanes (raster_backward_lanes.h), 0: pixels as lanes (this file); the dual mode always takes 0
 #endif
 
 #ifdef FNX_EXP_BCLK  // developer timing: per-phase cycles of wave 0 / lane 0 of every workgroup, summed over the launch
@@ -162,6 +162,8 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
     __shared__ uint16_t s_mask[256];
     __shared__ __attribute__((aligned(16))) uint32_t s_max[16];
     __shared__ uint32_t s_first[kMaxViews + 1];  // ticket of every view's first work item; [n_views] = all items
+    __shared__ float s_pfv[kFusedGeom ? 4 : 1][192];   // positions-only flush: the gradients change lanes here
+    __shared__ uint32_t s_pfi[kFusedGeom ? 4 : 1][64];
     __shared__ unsigned long long s_dynmask[DUAL ? 4 : 1];  // DUAL: per staging wave, which slots hold dynamic entries
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -885,11 +887,24 @@ blend_backward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const 
         if (DUAL)
             asm volatile("" ::"v"(ahead.T_final1), "v"(ahead.last1), "v"(ahead.dL1), "v"(ahead.total1), "v"(ahead.stt1.x),
                          "v"(ahead.stt1.y));
-        if (do_flush) {
-            if (kFusedGeom) {
+        if (kFusedGeom) {
+            // one atomic instruction for the three components of a splat's gradient (lane l: component l % 3 of entry l / 3,
+            // through a wave-private strip of LDS): a global fp32 atomic is priced per memory request, and an instruction then
+            // touches 22 lines instead of 64 (raster_backward_lanes.h, tools/micro/atomic_rate.hip)
+            if (__ballot(do_flush) != 0ull) {
+                s_pfi[w][lane] = do_flush ? fid : 0xFFFFFFFFu;
 #pragma unroll
-                for (int k = 0; k < 3; k++) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)fid + k], fl[k < kFl ? k : 0]);
-            } else {
+                for (int k = 0; k < 3; k++) s_pfv[w][3 * lane + k] = fl[k < kFl ? k : 0];
+#pragma unroll
+                for (int rnd = 0; rnd < 3; rnd++) {
+                    const int v = 64 * rnd + lane;
+                    const uint32_t id_ = s_pfi[w][v / 3];
+                    const float val = s_pfv[w][v];
+                    if (id_ != 0xFFFFFFFFu) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)id_ + (v % 3)], val);
+                }
+            }
+        } else if (do_flush) {
+            {
                 int o = 0;
                 if (kMeans) {
                     FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)fid + 0], fl[o++ < kFl ? o - 1 : 0]);

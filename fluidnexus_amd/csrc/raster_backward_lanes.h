@@ -45,6 +45,9 @@ namespace fnx {
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
+#ifndef FNX_LANES_EARLY_GATHER
+#define FNX_LANES_EARLY_GATHER 0  // 1: in front of the walk -- nine more live registers there, spills: 249 against 240 us
+#endif
 #ifndef FNX_BWDL_WAVES
 #define FNX_BWDL_WAVES 4  // waves per SIMD the register allocation aims at
 #endif
@@ -371,6 +374,24 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         FNX_LCLK(2)  // wait at barrier B
         if (w == 0) { FNX_LCNT(8, 1) FNX_LCNT(9, cnt) }
 
+#if FNX_LANES_EARLY_GATHER
+        // this item's mean / covariance for the flush: requested HERE, in front of the walk (9 registers that the walk must
+        // leave alone) -- requested behind the walk their round trip sat in front of every flush (ablation: 18 of 239 us)
+        float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kFusedGeom && (uint32_t)tid < cnt) {
+            const uint32_t gid = cur.id;
+            if (FNX_LABLATE & 2) {
+                gmean[0] = 0.1f, gmean[1] = 0.2f, gmean[2] = -0.3f;
+                gcov[0] = gcov[3] = gcov[5] = 1e-4f;
+            } else if (gid < grad_limit) {
+                const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) gmean[kx] = means3D[3 * (size_t)gid + kx];
+#pragma unroll
+                for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
+            }
+        }
+#endif
         // ---- walk: one block of every quadrant per wave ----------------------------------------------------------------
 #pragma unroll 1
         for (int qi = 0; qi < ((FNX_LABLATE & 16) ? 0 : 4); qi++) {
@@ -552,7 +573,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         asm volatile("" ::"v"(nxt.id), "v"(nxt.qm));
         FNX_LSUB(17)  // wait for the next item's ids
 #endif
-        // this item's mean / covariance first: the flush wants them first, and vmcnt retires in order
+#if !FNX_LANES_EARLY_GATHER
+        // this item's mean / covariance for the flush: requested HERE, in front of the walk (9 registers that the walk must
+        // leave alone) -- requested behind the walk their round trip sat in front of every flush (ablation: 18 of 239 us)
         float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (kFusedGeom && (uint32_t)tid < cnt) {
             const uint32_t gid = s_id[tid];
@@ -567,6 +590,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
             }
         }
+#endif
         fetch_records(nxt);  // in flight while the accumulators are flushed
         FNX_LSUB(18)
         if (nxt.item != kNoItem) load_ahead(nxt);
@@ -639,6 +663,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             asm volatile("" ::"v"(sink));
         }
         FNX_LSUB(22)  // sums -> gradients (incl. the wait for the gathered mean / covariance)
+        fetch_range(nx2);  // scalar; the descriptor was requested behind barrier C.  In front of the wait below: they overlap
         // the next item's records and pixels (requested in front of barrier C) are waited for here, with no atomic between
         // their request and this wait
         asm volatile("" ::"v"(nxt.id), "v"(nxt.qm), "v"(nxt.ra.x), "v"(nxt.ra.y), "v"(nxt.ra.z), "v"(nxt.ra.w), "v"(nxt.rbx),
@@ -649,7 +674,6 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         FNX_LSUB(23)  // wait for the next item's records / pixels
         FNX_LCLK(6)   // flush: sums -> gradients (+ the wait for the prefetched registers)
         FNX_LCNT(14, __popcll(__ballot(pf_do)))
-        fetch_range(nx2);  // scalar; the descriptor was requested behind barrier C
         cur = nxt;
         nxt.item = nx2.item;
         nxt.vw = nx2.vw;

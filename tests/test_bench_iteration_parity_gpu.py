@@ -18,39 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _host_iteration(oracle, po, st, x, cams, cfg, V):
-    """d (sum over the views of the per-view loss) / d x on the host; x: float64 leaf [N, 3] (world units)."""
-    from fluidnexus_amd.utils.loss_utils import l1_loss, l2_loss, ssim
-    from oracle.physics_oracle import distance_loss_oracle
-    sf = po.scale_factor
-    n_fluid = st["visual_xyz"].shape[0]
-    visual = po.visual_xyz_from_nn(x, st["x_prev"], st["visual_xyz"])       # simulation units, [n_fluid, 3]
-    render_xyz = visual / sf
-    means = np.concatenate([render_xyz.detach().numpy().astype(np.float32), st["gs_xyz"]], 0)
-    g_means = np.zeros((n_fluid, 3), np.float64)
-    for cam in cams:
-        f = oracle.forward(means, st["opacity"], st["bg"], cam["view"], cam["proj"], cam["campos"], st["W"], st["H"],
-                           cam["tan"], cam["tan"], colors_precomp=st["colors"], scales=st["scales"],
-                           rotations=st["rotations"], channels=3)
-        img = torch.tensor(f["color"], dtype=torch.float64, requires_grad=True)
-        gt = cam["gt"]
-        gt3 = torch.cat([torch.mean(gt, dim=0, keepdim=True)] * 3, dim=0)              # tpp:356-360
-        im3 = torch.cat([torch.mean(img, dim=0, keepdim=True)] * 3, dim=0)
-        loss = ((1.0 - cfg["lambda_dssim"]) * l1_loss(im3, gt3) + cfg["lambda_dssim"] * (1.0 - ssim(im3, gt3))) * cfg["lambda_image"]
-        dimg, = torch.autograd.grad(loss, img)
-        g = oracle.backward(f, dimg.numpy().astype(np.float32))
-        g_means += g["dL_dmeans3D"][:n_fluid].astype(np.float64)
-    # the view-independent terms, once per view (tpp:365-404): distance loss on the rendered positions, physics terms on x
-    _, gd = distance_loss_oracle(render_xyz.detach().numpy(), cfg["distance_threshold_visual"])
-    g_means += V * cfg["lambda_current_distance"] * gd
-    phys = cfg["lambda_exyz"] * l2_loss(x * sf, st["estimate_xyz"])
-    pr = po.gas_constraints_from_exyz_nn(x, st["imass"])
-    phys = phys + cfg["lambda_gas_constraints"] * l2_loss(pr, torch.ones_like(pr))
-    pn = po.gas_constraints_from_vel_nn_guess(x, st["x_prev"], st["imass"], st["buoyancy"], st["force"])
-    phys = phys + cfg["lambda_next_gas_constraints"] * l2_loss(pn, torch.ones_like(pn))
-    total = V * phys + (render_xyz * torch.from_numpy(g_means)).sum()   # the rasteriser's gradient enters as a cotangent
-    gx, = torch.autograd.grad(total, x)
-    return gx / V  # set_batch_gradient_current (gm_dynamics.py:461-472)
+from oracle.host_iteration import host_iteration as _host_iteration  # noqa: E402  (the host composition, shared with bench.py's cpu_baseline)
 
 
 def _mixed(got, ref, rel, abs_of_max):
@@ -92,15 +60,8 @@ def test_bench_iteration_against_the_host_composition(oracle):
             return dict(x=p.detach().double().cpu().clone(), m=s["exp_avg"].double().cpu().clone(),
                         v=s["exp_avg_sq"].double().cpu().clone(), step=float(s["step"]))
 
-        cpu = lambda t: t.detach().double().cpu()  # noqa: E731
-        from fluidnexus_amd.renderer.pipes import _static_attributes
-        opac, scales, rots, cols = (t.detach().float().cpu().numpy() for t in _static_attributes(gm, "guess_visual_nn", False))
-        st = dict(x_prev=cpu(gm._xyz), visual_xyz=cpu(gm._visual_xyz), estimate_xyz=cpu(gm._estimate_xyz), imass=cpu(gm._imass),
-                  buoyancy=cpu(gm._buoyancy), force=cpu(gm._force), gs_xyz=gm._gs_xyz.detach().float().cpu().numpy(),
-                  opacity=opac, scales=scales, rotations=rots, colors=cols, bg=np.zeros(3, np.float32), W=size, H=size)
-        hc = [dict(view=c.world_view_transform.cpu().numpy(), proj=c.full_proj_transform.cpu().numpy(),
-                   campos=c.camera_center.cpu().numpy(), tan=math.tan(c.FoVx * 0.5), gt=c.original_image.double().cpu())
-              for c in cams]
+        from oracle.host_iteration import frame_state
+        st, hc = frame_state(gm, cams, size)
         po = PhysicsOracle(H=cfg["H"], p0=cfg["p0"], secs=cfg["secs"], scale_factor=gm.scale_factor,
                            buoyancy_max_y=gm.buoyancy_max_y)
         lr = float(gm.optimizer.param_groups[0]["lr"])
