@@ -47,7 +47,7 @@ SIZE = 512
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_SPEC_WAVE_INSTR = 256 * 4 * 2.4e9 / 2 * 1.0  # 1024 SIMD-32s x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 VALU_MEASURED_WAVE_INSTR = 933e9                   # tools/micro/pk_rate.hip on this chip
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 CONFIGS = {
     2: dict(workload="BASELINE configs[1]: ScalarReal single frame, 100k grey Gaussians (gm_fluid / render_fluid / ch1), "
@@ -186,13 +186,18 @@ def cpu_baseline_whole_iteration(gm, cams, cfg, views):
     and its image gradient with the torch-CPU utils.loss_utils, the hidden -> visual interpolation, the distance loss and the
     exyz / gas / next-gas terms with oracle/physics_oracle.py on k-d tree neighbour lists (oracle/host_iteration.py; same
     edge rule as the brute-force oracle, tests/test_host_iteration.py), torch.optim.Adam -- 1 warm-up, then the median of
-    5 iterations (3 when the warm-up took more than 8 s: the sample is bounded to about half a minute)."""
+    5 iterations (of 2 when the warm-up took more than 8 s: the sample is bounded to about half a minute of CPU work)."""
     import statistics
     from oracle import raster_oracle as O
     from oracle.host_iteration import KdPhysicsOracle, distance_loss_kdtree, frame_state, host_iteration
     O.build()
-    cores = os.cpu_count() or 1
+    # two OpenMP pools (the oracle's and torch's) that alternate: beyond a few dozen threads each they only fight each other
+    # (their idle threads spin) -- the first whole-iteration sample ran 90 s per iteration with 256 + 256 threads, as the
+    # config-1 sample had found before (12.8 s against 27 ms); both pools are held to 32 threads and the record says so
+    cores = min(os.cpu_count() or 1, 32)
     O.set_threads(cores)
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
     st, hc = frame_state(gm, cams[:views], SIZE)
     po = KdPhysicsOracle(H=cfg["H"], p0=cfg["p0"], secs=cfg["secs"], scale_factor=gm.scale_factor,
                          buoyancy_max_y=gm.buoyancy_max_y)
@@ -207,12 +212,13 @@ def cpu_baseline_whole_iteration(gm, cams, cfg, views):
         opt.step()
         dt = time.perf_counter() - t0
         if it == 0 and dt > 8.0:
-            n_timed = 3
+            n_timed = 2
         if it:
             times.append(dt)
         it += 1
+    torch.set_num_threads(torch_threads)
     med = statistics.median(times)
-    return {"value": 1.0 / med, "unit": "iters/s", "cores": cores, "kind": "port", "scope": "whole iteration",
+    return {"value": 1.0 / med, "unit": "iters/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port", "scope": "whole iteration",
             "statistic": f"median of {len(times)} iterations after 1 warm-up (BASELINE.md section 2)",
             "seconds_per_iteration": {"median": round(med, 3), "min": round(min(times), 3), "max": round(max(times), 3)},
             "sample": f"{views} views x (oracle/raster_oracle.c forward + backward, OpenMP {cores} threads; torch-CPU grey-mean "
@@ -520,13 +526,13 @@ def drop_in_timing(a, dev, cfg_id, steps=6, auto=False):
                         "blend arithmetic, no static split / view batching / graph (bench.py --views serial --no-graph "
                         "--image-loss torch --torch-adam --unfused-physics --host-sync --blend-math exact --no-static-split)"}
     finally:
+        fluidnexus_amd.set_auto(keep_auto)  # (first: switching the automation off restores the host-sync mode IT found)
         rasterizer.set_blend_math(("exact", "fast")[keep["blend_math"]])
         rasterizer.set_lean_geometry(bool(keep["lean_geometry"]))
         rasterizer.set_sort_narrow(bool(keep["sort_narrow"]))
         rasterizer.set_coherent_sort(bool(keep["coherent_sort"]))
         rasterizer.set_host_sync(keep_sync)
         pipes.set_static_split(keep_split)
-        fluidnexus_amd.set_auto(keep_auto)
         torch.backends.cudnn.enabled = keep_cudnn
 
 
@@ -980,8 +986,10 @@ def main():
     split_s = 'true' if (pipes._STATIC_SPLIT and cfg_id != 2 and a.stage != "first") else 'false'
     from fluidnexus_amd import harness as _Hn
     dual_s = 'true' if (cfg_id == 5 and a.stage == "physical" and _Hn._DUAL_FUSED and split_s == 'true') else 'false'
+    lanes = rasterizer.get_backward_form() == "lanes" and dual_s == 'false'
     knames = {"blend_forward": f"fnx::blend_forward_kernel<{Cn}, {split_s}, {fast_s}, {dual_s}, false>",
-              "blend_backward": f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}, {dual_s}>"}
+              "blend_backward": (f"fnx::blend_backward_lanes_kernel<{Cn}, {bwd_mode}, {fast_s}>" if lanes else
+                                 f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}, {dual_s}>")}
     kname = knames[dom]
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")
     counters = {}

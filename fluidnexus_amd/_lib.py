@@ -94,7 +94,7 @@ SYMBOLS = (
     "fnx_set_deep_threshold", "fnx_set_blend_math", "fnx_get_blend_math", "fnx_set_deep_kernel", "fnx_set_lean_geometry", "fnx_set_sort_narrow", "fnx_request_zero3", "fnx_request_gradient_limit",
     "fnx_forward_stage1_views_split_opts", "fnx_forward_stage2_views_split_opts", "fnx_rasterize_backward_views_split_opts",
     "fnx_sort_state_bytes", "fnx_sort_state_read", "fnx_sort_state_outliers", "fnx_binning_bytes_dual",
-    "fnx_segment_scratch_bytes", "fnx_segment_scratch_read",
+    "fnx_segment_scratch_bytes", "fnx_segment_scratch_read", "fnx_set_backward_form", "fnx_get_backward_form",
 )
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
@@ -188,6 +188,9 @@ def raster():
     lib.fnx_set_sort_narrow.argtypes = [i]
     lib.fnx_set_lean_geometry.argtypes = [i]
     lib.fnx_set_deep_kernel.argtypes = [i]
+    lib.fnx_set_backward_form.restype = i
+    lib.fnx_set_backward_form.argtypes = [i]
+    lib.fnx_get_backward_form.restype = i
     lib.fnx_rasterize_backward_views_split.restype = i
     lib.fnx_rasterize_backward_views_split.argtypes = lib.fnx_rasterize_backward_views.argtypes[:-1] + [p, i, c_int64, p]
     op = C.POINTER(RasterOpts)

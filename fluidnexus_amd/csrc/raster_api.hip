@@ -49,6 +49,8 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                           const StaticRef &st, int materialize_all, int V, const ViewBatch &vb, int fast, int deep,
                           uint32_t dyn_limit, const InvUpdate &iu, const DualRef &du, const SegRef &sg);
 void launch_mark_visible(hipStream_t s, int P, const float *means3D, const float *view, uint8_t *present);
+void set_backward_form(int form);
+int get_backward_form();
 void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, const uint32_t *ranges,
                            const uint32_t *point_list, const float *bg, const float4 *blend_rec, const float *final_Ts,
                            const uint32_t *n_contrib, const float *acc_final, const float *dL_dpixels,
@@ -906,6 +908,13 @@ int fnx_set_deep_kernel(int mode) {
     g_deep_kernel = mode;
     return FNX_OK;
 }
+
+int fnx_set_backward_form(int form) {
+    if (form != 0 && form != 1) return fail(FNX_ERR_INVALID_ARG, "backward form must be 0 (pixels as lanes) or 1 (entries as lanes)");
+    fnx::set_backward_form(form);
+    return FNX_OK;
+}
+int fnx_get_backward_form(void) { return fnx::get_backward_form(); }
 
 int fnx_profile_enable(int on) {
     g_prof_on = on != 0;

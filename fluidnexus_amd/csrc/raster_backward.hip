@@ -1276,6 +1276,8 @@ static int backward_form() {
     }
     return g_backward_form;
 }
+void set_backward_form(int form) { g_backward_form = form ? 1 : 0; }
+int get_backward_form() { return backward_form(); }
 template <int C, int MODE, typename... A>
 static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, const DualRef &du, A... args) {
     if (backward_form() == 1) {

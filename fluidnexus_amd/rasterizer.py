@@ -184,6 +184,17 @@ def set_deep_kernel(mode: int):
     _lib.check(_lib.raster().fnx_set_deep_kernel(int(mode)))
 
 
+def set_backward_form(form: str | int):
+    """Which form of the blend backward runs: "lanes" / 1 = a lane per list entry (default), "rows" / 0 = a lane per pixel
+    (include/fnx_raster.h fnx_set_backward_form; the dual mode always runs the latter)."""
+    f = {"rows": 0, "lanes": 1}.get(form, form)
+    _lib.check(_lib.raster().fnx_set_backward_form(int(f)))
+
+
+def get_backward_form() -> str:
+    return ("rows", "lanes")[_lib.raster().fnx_get_backward_form()]
+
+
 def get_blend_math() -> str:
     return ("exact", "fast")[_OPTS["blend_math"]]
 

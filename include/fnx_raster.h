@@ -365,6 +365,14 @@ int fnx_get_blend_math(void);
  * workgroups wait for an empty compute unit behind the per-tile kernel's workgroups and the iteration gets slower
  * (config 3, 2 of 5 views: 1251 -> 1216 it/s), so it is opt-in. */
 int fnx_set_deep_kernel(int mode);
+/* Which form of the blend BACKWARD the next calls run (process-wide; both are parity-tested against the oracle, same work
+ * items, same staging, same gradients within the backward's stated fp32 bound -- the sums are associated differently):
+ *   0  a lane = a PIXEL: every 16-lane row walks the list of one 4x4 block entry by entry (rounds 1-5);
+ *   1  a lane = a LIST ENTRY (default, round 6): a wave takes one block with 4 pixel rows x 16 entries, the transmittance in
+ *      front of an entry is a 16-lane product scan, the per-entry sums stay in the lane (csrc/raster_backward_lanes.h).
+ * The dual mode (fnx_raster_dual_t) always runs form 0.  FNX_BWD_FORM in the environment sets the initial value. */
+int fnx_set_backward_form(int form);
+int fnx_get_backward_form(void);
 /* View-batched entry points (V > 1): 1 = the per-view copies of the reference's GeometryState that this library never
  * reads back (means2D, depths, conic_opacity, tiles_touched: 32 of the 136 bytes a visible splat writes per view) are
  * not written, and the world covariance -- identical for every view -- is written for view 0 only and read at stride 0

@@ -9,7 +9,7 @@ def nm(r):
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), nm(r), r.get('Queue_Id', '')) for r in rows)
 # anchor: a kernel that runs once per iteration (the loops differ: hidden<-visual backward, else the blend backward)
 vb = []
-for anchor in ('visual_backward', 'blend_backward_kernel<3, 3', 'blend_backward_kernel<1, 3', 'blend_backward_kernel<3, 1',
+for anchor in ('visual_backward', 'blend_backward_lanes_kernel<3, 3', 'blend_backward_lanes_kernel<1, 3', 'blend_backward_lanes_kernel<3, 2', 'blend_backward_lanes_kernel', 'blend_backward_kernel<3, 3', 'blend_backward_kernel<1, 3', 'blend_backward_kernel<3, 1',
                'blend_backward_kernel<1, 1', 'blend_backward_kernel<3, 2',
                'blend_backward_kernel<3, 0'):
     vb = [e for e in ev if anchor in e[2]]
