@@ -571,7 +571,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     graph = loop.capturable
     gi = max(1, min(int(a.seq_graph_iters), n))
     seg = dict(simulate=0.0, setup=0.0, optimise=0.0, accept=0.0)
-    counts, sort_switched = [], []
+    counts, sort_switched, frame_s, knn_checked, setup_s = [], [], [], [], []
 
     def tick():
         torch.cuda.synchronize()
@@ -635,6 +635,9 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             done += loop.iterations_per_call
             loop.iteration()
         rasterizer.check_status()
+        if getattr(gm, "_knn_flags", None) is not None:
+            gm.check_knn_k()  # raises when a fused neighbour search of this frame met a list longer than KNN_K (device flag)
+            knn_checked.append(1)
         t3 = tick()
         gm.confirm_guess_hidden_particles_from_nn()
         gm.update_visual_xyz_from_nn()
@@ -646,10 +649,13 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             seg["optimise"] += t3 - t2
             seg["accept"] += t4 - t3
             counts.append((int(gm._xyz.shape[0]), int(gm._visual_xyz.shape[0])))
+            frame_s.append(t4 - t0)
+            setup_s.append(t2 - t1)
         return t4 - t0
 
     one_frame(False)  # untimed: first-use allocations of every stage
     sort_switched.clear()
+    knn_checked.clear()
     total = sum(one_frame(True) for _ in range(K))
     rasterizer.set_coherent_sort(a.coh)
     per_frame = total / K
@@ -660,6 +666,13 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             "particles_last_frame": {"hidden": counts[-1][0], "visual": counts[-1][1]},
             "emitted_per_frame": {"hidden": int(hid.shape[0]), "visual": int(vis.shape[0])},
             "frames_on_radix_sort": len(sort_switched),
+            "per_frame_iters_per_s": {"min": n / max(frame_s), "median": n / sorted(frame_s)[len(frame_s) // 2], "max": n / min(frame_s),
+                                      "first": n / frame_s[0], "last": n / frame_s[-1]},
+            "particles_first_frame": {"hidden": counts[0][0], "visual": counts[0][1]},
+            "setup_ms_by_frame": [round(x * 1e3, 1) for x in setup_s],
+            "frames_switched_to_radix": list(sort_switched),
+            "knn_watch": (f"checked at every frame boundary ({len(knn_checked)} frames): no fused neighbour search met a list longer "
+                          f"than KNN_K = {int(gm.KNN_K)}") if knn_checked else None,
             "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, two eager "
                     "iterations (the first seeds the depth sort's state), static background re-binned, hipGraph re-captured, its first "
                     "replay shows whether the frame stays inside the coherent sort's reach (setup: its iterations count towards n) | "
@@ -723,7 +736,7 @@ def main():
     ap.add_argument("--iters-per-frame", type=int, default=0,
                     help="optimisation iterations per frame of --frames (configs/fluid_nexus_smoke_dynamics.json: 1000; "
                          "default: 1000 with an explicit --frames, 250 in the default leg)")
-    ap.add_argument("--seq-eager", type=int, default=2,
+    ap.add_argument("--seq-eager", type=int, default=1,
                     help="sequence leg: eager iterations of a frame in front of its capture (the first sizes the binning buffers and "
                          "seeds the depth sort's state)")
     ap.add_argument("--seq-capture-warmup", type=int, default=0, help="sequence leg: eager iterations inside HotLoop.capture")

@@ -6,6 +6,8 @@ loaded, every entry point raises.
 from __future__ import annotations
 
 import ctypes as C
+
+import torch
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -82,6 +84,13 @@ def make_dual(image_buffers1, background1, out_color1=None, out_depth1=None, dL_
     return d
 
 # every symbol include/fnx_raster.h declares (tests check the library exports all of them)
+def raw_stream() -> int:
+    """hipStream_t of torch's current stream as an integer.  torch.cuda.current_stream().cuda_stream builds a Stream object
+    and walks through torch.cuda.is_available() on the way (4-5 us a call, sixteen calls per loop iteration: a fifth of the
+    host time of an eager iteration, tools/iter_host_profile.py); the two private getters below take 0.3 us."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 SYMBOLS = (
     "fnx_abi_version", "fnx_last_error", "fnx_geom_bytes", "fnx_image_bytes", "fnx_binning_bytes",
     "fnx_rasterize_forward", "fnx_forward_stage1", "fnx_read_num_rendered", "fnx_forward_stage2", "fnx_read_status",

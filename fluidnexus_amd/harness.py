@@ -20,6 +20,8 @@ from types import SimpleNamespace
 import numpy as np
 import os
 import torch
+
+from ._lib import raw_stream as _lib_raw_stream
 import torch.distributed as dist
 
 from . import synthetic as S
@@ -656,7 +658,7 @@ class HotLoop:
                     from . import _physics_lib as _PL
                     if getattr(self, "_gp_zero", None) is None:
                         self._gp_zero = torch.zeros_like(gm._estimate_xyz_nn)
-                    _PL.check(_PL.physics().fnx_stream_delay(1.0, torch.cuda.current_stream().cuda_stream))
+                    _PL.check(_PL.physics().fnx_stream_delay(1.0, _lib_raw_stream()))
                     gp = self._gp_zero
                 elif self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
                     from .physics import physical_stage_value_and_grad
@@ -712,13 +714,13 @@ class HotLoop:
                 with torch.cuda.stream(self.dist_stream):
                     if _DIST_DELAY_US > 0:
                         from . import _physics_lib as _PL
-                        _PL.check(_PL.physics().fnx_stream_delay(_DIST_DELAY_US, torch.cuda.current_stream().cuda_stream))
+                        _PL.check(_PL.physics().fnx_stream_delay(_DIST_DELAY_US, _lib_raw_stream()))
                     n_vis = gm._visual_xyz.shape[0]
                     if _DIST_NOOP:  # developer probe: the branch's fork / join without its work
                         from . import _physics_lib as _PL
                         if getattr(self, "_gd_zero", None) is None:
                             self._gd_zero = torch.zeros(n_vis, 3, device=means3D.device)
-                        _PL.check(_PL.physics().fnx_stream_delay(1.0, torch.cuda.current_stream().cuda_stream))
+                        _PL.check(_PL.physics().fnx_stream_delay(1.0, _lib_raw_stream()))
                         self.last_distance, gd = None, self._gd_zero
                     else:
                         self.last_distance, gd = distance_loss_value_and_grad(means3D.detach()[:n_vis],

@@ -11,6 +11,8 @@ import os
 
 import torch
 
+from ._lib import raw_stream as _lib_raw_stream
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 SYMBOLS = ("fnx_losses_abi_version", "fnx_losses_last_error", "fnx_l1_ssim_tiles", "fnx_l1_ssim_forward",
@@ -67,7 +69,7 @@ class _L1SSIM(torch.autograd.Function):
         nt = L.fnx_l1_ssim_tiles(Cn, H, W, int(grey))
         partials = torch.empty(N, nt, 2, dtype=torch.float32, device=img.device)
         dmaps = torch.empty(N, 3, Ce, H, W, dtype=torch.float32, device=img.device)
-        s = torch.cuda.current_stream().cuda_stream
+        s = _lib_raw_stream()
         _check(L.fnx_l1_ssim_forward_batch(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey),
                                            partials.data_ptr(), dmaps.data_ptr(), s))
         sums = partials.sum(dim=1) / float(Ce * H * W)  # [N, 2]
@@ -86,7 +88,7 @@ class _L1SSIM(torch.autograd.Function):
         g_l1 = g_l1.float().contiguous()
         g_ssim = g_ssim.float().contiguous()
         out = torch.empty_like(img)
-        s = torch.cuda.current_stream().cuda_stream
+        s = _lib_raw_stream()
         _check(L.fnx_l1_ssim_backward_batch(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(ctx.grey),
                                             dmaps.data_ptr(), g_l1.data_ptr(), g_ssim.data_ptr(), out.data_ptr(), s))
         return out, None, None
@@ -122,7 +124,7 @@ class _ImageLoss(torch.autograd.Function):
         dmaps = torch.empty(N, 3, Ce, H, W, dtype=torch.float32, device=img.device)
         _check(L.fnx_image_loss_forward(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
                                         partials.data_ptr(), dmaps.data_ptr(), per_image.data_ptr(), loss.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream))
+                                        _lib_raw_stream()))
         ctx.save_for_backward(img, gt, dmaps)
         ctx.consts = (float(w_l1), float(w_dssim), bool(grey))
         per_image = per_image.view(N, 2)
@@ -139,7 +141,7 @@ class _ImageLoss(torch.autograd.Function):
         out = torch.empty_like(img)
         _check(L.fnx_image_loss_backward(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
                                          dmaps.data_ptr(), g.data_ptr(), out.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream))
+                                         _lib_raw_stream()))
         return out, None, None, None, None
 
 
@@ -174,7 +176,7 @@ def image_loss_value_and_grad(img, gt, lambda_dssim, lambda_image=1.0, grey=True
     w_l1, w_dssim = (1.0 - float(lambda_dssim)) * float(lambda_image), float(lambda_dssim) * float(lambda_image)
     _check(L.fnx_image_loss_value_and_grad(img.data_ptr(), gt.data_ptr(), N, Cn, H, W, int(grey), w_l1, w_dssim,
                                            partials.data_ptr(), dmaps.data_ptr(), per_image.data_ptr(), loss.data_ptr(),
-                                           one.data_ptr(), dimg.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                           one.data_ptr(), dimg.data_ptr(), _lib_raw_stream()))
     return loss.view(()), per_image.view(N, 2), dimg
 
 
@@ -215,7 +217,7 @@ def level2_activate(raw, out):
     n = raw["color"].shape[0]
     args = [_l2_ptr(raw[k], n, _L2_WIDTH[k], f"raw {k}") for k in _L2_ORDER]
     args += [_l2_ptr(out[k], n, 3 if k == "color" else _L2_WIDTH[k], f"activated {k}") for k in _L2_ORDER]
-    _check(lib().fnx_level2_activate(*args[:4], n, *args[4:], torch.cuda.current_stream().cuda_stream))
+    _check(lib().fnx_level2_activate(*args[:4], n, *args[4:], _lib_raw_stream()))
 
 
 def level2_backward(raw, prev, g, d, lambdas, lambda_reg, reg_threshold, reg_count, scale):
@@ -232,4 +234,4 @@ def level2_backward(raw, prev, g, d, lambdas, lambda_reg, reg_threshold, reg_cou
         p4(*[_l2_ptr(g[k], n, 3 if k == "color" else _L2_WIDTH[k], f"gradient {k}") for k in _L2_ORDER]),
         p4(*[_l2_ptr(d.get(k), n, _L2_WIDTH[k], f"output {k}") for k in _L2_ORDER]),
         n, n_prev, f4(*[float(lambdas[k]) for k in _L2_ORDER]), float(lambda_reg), float(reg_threshold), float(reg_count),
-        float(scale), torch.cuda.current_stream().cuda_stream))
+        float(scale), _lib_raw_stream()))

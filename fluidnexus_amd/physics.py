@@ -11,11 +11,13 @@ import os
 
 import torch
 
+from ._lib import raw_stream as _lib_raw_stream
+
 from . import _physics_lib as PL
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib_raw_stream()
 
 
 def _req(t: torch.Tensor) -> torch.Tensor:

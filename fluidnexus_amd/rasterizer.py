@@ -174,7 +174,7 @@ def segmented_forward_counters():
             for v in range(vb.V):
                 w = (C.c_uint32 * 16)()
                 _lib.check(_lib.raster().fnx_segment_scratch_read(t.data_ptr(), int(rs.image_width), int(rs.image_height), v,
-                                                                  torch.cuda.current_stream().cuda_stream, w))
+                                                                  _lib.raw_stream(), w))
                 out.append(tuple(int(x) for x in w[:5]) + ((tuple(int(x) for x in w[6:11]),) if any(w[6:11]) else ()))
     return out
 
@@ -372,7 +372,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
         bg, view, proj, campos = _f32c(rs.bg), _f32c(rs.view_matrix), _f32c(rs.proj_matrix), _f32c(rs.campos)
         M = sh.shape[1] if sh.numel() else 0
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.raw_stream()
         u8 = dict(dtype=torch.uint8, device=dev)
         geom = torch.empty(lib.fnx_geom_bytes(P, W, H), **u8)
         img = torch.empty(lib.fnx_image_bytes(W, H), **u8)
@@ -450,7 +450,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_means3D, g_means2D, g_colors, g_conic, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
         if P != 0:
             dL = _f32c(grad_out_color)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.raw_stream()
             # skip what autograd would throw away: opacity / colour / SH gradients nobody asked for, and
             # splats the caller declared gradient-free (GaussianRasterizer.grad_splat_limit)
             need = ctx.needs_input_grad  # (means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, ...)
@@ -568,7 +568,7 @@ class ViewBatch:
             h = ent.view(self.V, n)[:, :64].contiguous().view(torch.int32).cpu().numpy().view("uint32")
             return [(int(r[5]), int(r[4])) + ((int(r[6]),) if why else ()) + ((int(r[9]),) if outliers else ()) for r in h]
         out, lib = [], _lib.raster()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.raw_stream()
         for v in range(self.V):
             pair = (C.c_uint32 * 3)()
             _lib.check(lib.fnx_sort_state_read(ent.data_ptr(), int(P), v, stream, pair))
@@ -622,7 +622,7 @@ class StaticBin:
         means3D, opacities = f(means3D), f(opacities)
         shs, colors_precomp, scales, rotations, cov3D_precomp = f(shs), f(colors_precomp), f(scales), f(rotations), f(cov3D_precomp)
         M = shs.shape[1] if shs.numel() else 0
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.raw_stream()
         u8 = dict(dtype=torch.uint8, device=dev)
         gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
         geom, img = torch.empty(V * gbytes, **u8), torch.empty(V * ibytes, **u8)
@@ -681,7 +681,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
         M = sh.shape[1] if sh.numel() else 0
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.raw_stream()
         u8 = dict(dtype=torch.uint8, device=dev)
         gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
         geom = torch.empty(V * gbytes, **u8)
@@ -772,7 +772,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         sh, colors_precomp, opacities = _f32c(sh.to(dev)), _f32c(colors_precomp.to(dev)), _f32c(opacities)
         scales, rotations, cov3Ds_precomp = _f32c(scales.to(dev)), _f32c(rotations.to(dev)), _f32c(cov3Ds_precomp.to(dev))
         M = sh.shape[1] if sh.numel() else 0
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.raw_stream()
         u8 = dict(dtype=torch.uint8, device=dev)
         gbytes, ibytes = lib.fnx_geom_bytes(P, W, H), lib.fnx_image_bytes(W, H)
         geom = torch.empty(V * gbytes, **u8)
@@ -904,7 +904,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
                     vbatch.tan_x, vbatch.tan_y, radii.data_ptr(), geom.data_ptr(), _ptr(binning), ctx.capacity,
                     img.data_ptr(), dL.data_ptr(), None, None, None, None, None, None,
                     g_means3D.data_ptr(), None, None, None, None, ctx.grad_splat_limit, 3)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.raw_stream()
             _lib.check(lib.fnx_rasterize_backward_views_split_opts(*args, *static_args(sb), ctx.status_ptr,
                                                                    C.byref(bopts), stream))
             return (g_means3D,) + (None,) * 13
@@ -924,7 +924,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             g_means2D, g_conic, g_opacity_v, g_colors_v, g_means3D, g_colors, g_opacity, g_cov3D, g_sh, g_scales, g_rot = parts
         if P != 0:
             dL = _f32c(grad_out_color)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.raw_stream()
             args = (Cn, V, P - (sb.P if sb is not None else 0), int(rs.sh_degree), M, vbatch.bg.data_ptr(), W, H,
                     means3D.data_ptr(), _ptr(sh),
                     _ptr(colors_precomp), _ptr(scales), float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp),
@@ -984,7 +984,7 @@ class GaussianRasterizer(nn.Module):
             present = torch.zeros(P, dtype=torch.bool, device=pos.device)
             _lib.check(lib.fnx_mark_visible(P, _ptr(pos), _f32c(rs.view_matrix).data_ptr(),
                                             _f32c(rs.proj_matrix).data_ptr(), _ptr(present),
-                                            torch.cuda.current_stream().cuda_stream))
+                                            _lib.raw_stream()))
         return present
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
