@@ -105,6 +105,12 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
     cfg = dict(Hn.SMOKE)
     if a.no_distance:
         cfg["lambda_current_distance"] = 0.0
+    if getattr(a, "freeze", False):
+        # learning rate 0: every iteration does the same work on the same particles.  For --emulate-world with a placement of
+        # the view-independent terms that leaves a rank without some of them (last-rank, spread): without the all-reduce that
+        # rank would follow another objective, its particles drift (the K-cap watch fires) and the share it times is no
+        # longer the configuration's.
+        cfg["position_lr_init"] = cfg["position_lr_final"] = 0.0
     view_mode = a.views
     if a.unfused_physics or a.image_loss == "torch":
         view_mode = "serial"  # the batched / branch modes build on the fused loss nodes
@@ -120,8 +126,13 @@ def build_workload(cfg_id, n_views, dev, rank, world, a, use_dist):
     # optimise a different objective, its particles drift and the timed workload is no longer the configuration's)
     # auto: last-rank as soon as there is more than one rank (the sum after the all-reduce is the same, gloo-tested in
     # tests/test_distributed_cpu.py, and the work lands on the rank with the fewest views); a single rank has nobody to share with
-    if a.shared_terms == "last-rank" or (a.shared_terms == "auto" and shard_n > 1 and view_mode == "batched"
-                                         and not (a.emulate_world > 1)):
+    if a.shared_terms == "spread":
+        shared_rank = "spread"  # round 6: one term per rank (harness.spread_owners), summed by the same all-reduce
+    elif a.shared_terms == "last-rank" or (a.shared_terms == "auto" and shard_n > 1 and view_mode == "batched"
+                                           and (not (a.emulate_world > 1) or getattr(a, "freeze", False))):
+        # (measured on every rank's emulated share with a frozen scene, profiles/r06_emulated_shares.md: the slowest rank of
+        #  config 4 on 4 ranks runs 1631 it/s per-view, 1664 last-rank, 1659 spread; of config 5 on 8 ranks 1214 / 1244 /
+        #  1211 -- the view-independent terms ride on side streams, where they go moves the bound by 2 %)
         shared_rank = shard_n - 1
     loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=not a.physics_once,
                       shared_terms_rank=shared_rank,
@@ -713,12 +724,17 @@ def main():
     ap.add_argument("--full-geometry", action="store_true",
                     help="write every per-view copy of the reference's GeometryState (default: fnx_set_lean_geometry(1))")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's share to time")
-    ap.add_argument("--shared-terms", default="auto", choices=["auto", "per-view", "last-rank"],
+    ap.add_argument("--freeze", action="store_true",
+                    help="learning rate 0: every iteration repeats the first one's work (for --emulate-world with --shared-terms "
+                         "last-rank / spread, where a rank without the all-reduce would drift off the configuration)")
+    ap.add_argument("--shared-terms", default="auto", choices=["auto", "per-view", "last-rank", "spread"],
                     help="who evaluates the view-independent terms (physics, distance loss) in a multi-rank run: every rank, "
                          "once per local view (per-view, default: the reference's evaluation count, rank by rank), or only the "
                          "last rank -- the one with the fewest views -- `batch` times (last-rank: same sum after the "
-                         "all-reduce, tests/test_distributed_cpu.py; not measured on multi-GPU hardware); auto = last-rank "
-                         "whenever there is more than one rank")
+                         "all-reduce, tests/test_distributed_cpu.py), or one TERM per rank (spread, round 6: the gas term, the "
+                         "next-gas + exyz terms and the distance loss each on the rank with the least work, harness.spread_owners; "
+                         "same sum, same all-reduce); auto = last-rank whenever there is more than one rank (emulated shares: the "
+                         "placement moves the slowest rank by 2 %).  None of them is measured on multi-GPU hardware")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2],
                     help="deep-tile forward kernel (fnx_raster_opts_t.deep_kernel): 0 never (library default), 1 launches of <= 2 views, 2 always")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
@@ -1156,8 +1172,11 @@ def main():
                                    + ("" if graph_ar else " (the captured-collective self-test did not pass or is switched off)"))),
                    "shared_terms": ("physics terms + distance loss on every rank, added once per local view"
                                     if getattr(loop, "shared_terms_rank", None) is None else
-                                    f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "
-                                    "the fewest views), added `batch` times; the all-reduce distributes the sum"),
+                                    (f"spread: gas / next-gas + exyz / distance terms on ranks {_Hn.spread_owners(len(cams), shard_world)} "
+                                     "(each added `batch` times by its owner, the all-reduce sums them)"
+                                     if loop.shared_terms_rank == "spread" else
+                                     f"physics terms + distance loss evaluated on rank {loop.shared_terms_rank} only (the rank with "
+                                     "the fewest views), added `batch` times; the all-reduce distributes the sum")),
                    "host_sync": bool(a.host_sync), "image_loss": a.image_loss,
                    "depth_sort": sort_note or (("coherent: one launch per call repairs the previous call's order, verified on the device "
                                    f"(in-launch full sorts per view over the run: {sort_fallbacks}); first call: " if a.sort == "coherent" else "")

@@ -27,6 +27,22 @@
 
 namespace fnx {
 
+// S floats per entry (the bits of USED say which of them) added into arr[S id + component] with lane l taking component
+// l % S of entry l / S: an instruction touches 64 / S rows instead of 64.  strip: S x 64 floats of wave-private LDS,
+// ids: the wave's 64 entry ids (0xFFFFFFFF: nothing to add) -- LDS is in order per wave, no barrier.
+template <int S, unsigned USED>
+__device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *ids, float *arr, int lane, const float (&v)[S]) {
+#pragma unroll
+    for (int k = 0; k < S; k++) strip[S * lane + k] = v[k];
+#pragma unroll
+    for (int rnd = 0; rnd < S; rnd++) {
+        const int idx = 64 * rnd + lane, c = idx % S;
+        const uint32_t id_ = ids[idx / S];
+        const float val = strip[idx];
+        if (((USED >> c) & 1u) && id_ != 0xFFFFFFFFu) FNX_FLUSH_ADD(&arr[(size_t)S * id_ + c], val);
+    }
+}
+
 #ifdef FNX_EXP_BCLK  // developer timing (tools/bwd_phases.py --lanes): lane 0 of EVERY wave, g_bwd_clock of raster_backward.hip
 // (summed in registers, one set of atomics per wave at the end of the kernel: an atomic per phase and item made the
 //  instrumented kernel 16 x slower and charged its own round trips to whichever phase waited for memory next)
@@ -263,42 +279,39 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     // splats per wave: with lane l adding component l % 3 of entry l / 3 an instruction touches 22 lines instead of 64, a
     // third of the requests for the same sums.  The values change lanes through a wave-private strip of LDS (in-order per
     // wave: no barrier).
-    __shared__ float s_pfv[4][192];
+    // The same for the per-view screen-space arrays of the other modes: the components of one array go out together
+    // (mean2D: 2 of a 3-float row, conic: 3 of a 4-float row, colours: C), lane l adding component l % S of entry l / S.
+    __shared__ float s_pfv[4][256];
     __shared__ uint32_t s_pfi[4][64];
     auto issue_pending = [&]() {
+        if (__ballot(pf_do) == 0ull) return;
+        s_pfi[w][lane] = pf_do ? pf_id : 0xFFFFFFFFu;
         if (kFusedGeom) {
-            if (__ballot(pf_do) == 0ull) return;
-            s_pfi[w][lane] = pf_do ? pf_id : 0xFFFFFFFFu;
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) s_pfv[w][3 * lane + kx] = pf_fl[kx < kFl ? kx : 0];
-#pragma unroll
-            for (int rnd = 0; rnd < 3; rnd++) {
-                const int v = 64 * rnd + lane;
-                const uint32_t id_ = s_pfi[w][v / 3];
-                const float val = s_pfv[w][v];
-                if (id_ != 0xFFFFFFFFu) FNX_FLUSH_ADD(&dL_dmean3D[3 * (size_t)id_ + (v % 3)], val);
-            }
-            pf_do = false;
-            return;
-        }
-        if (!pf_do) return;
-        {
-            float *dL_dmean2D_v = dL_dmean2D + (size_t)pf_vw * P * 3;
-            float *dL_dconic_v = dL_dconic + (size_t)pf_vw * P * 4;
-            float *dL_dopacity_v = kAppearance ? dL_dopacity + (size_t)pf_vw * P : nullptr;
-            float *dL_dcolors_v = kAppearance ? dL_dcolors + (size_t)pf_vw * P * C : nullptr;
+            const float v[3] = {pf_fl[0], pf_fl[1 < kFl ? 1 : 0], pf_fl[2 < kFl ? 2 : 0]};
+            packed_flush_add<3, 7u>(s_pfv[w], s_pfi[w], dL_dmean3D, lane, v);
+        } else {
+            // (a wave's items come from one view: pf_vw is wave-uniform)
+            const int vw_ = __builtin_amdgcn_readfirstlane(pf_vw);
             int o = 0;
             if (kMeans) {
-                FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)pf_id + 0], pf_fl[o++ < kFl ? o - 1 : 0]);
-                FNX_FLUSH_ADD(&dL_dmean2D_v[3 * (size_t)pf_id + 1], pf_fl[o++ < kFl ? o - 1 : 0]);
+                const float v[3] = {pf_fl[0], pf_fl[1 < kFl ? 1 : 0], 0.f};
+                packed_flush_add<3, 3u>(s_pfv[w], s_pfi[w], dL_dmean2D + (size_t)vw_ * P * 3, lane, v);
+                o = 2;
             }
-            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 0], pf_fl[o++ < kFl ? o - 1 : 0]);
-            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 1], pf_fl[o++ < kFl ? o - 1 : 0]);
-            FNX_FLUSH_ADD(&dL_dconic_v[4 * (size_t)pf_id + 3], pf_fl[o++ < kFl ? o - 1 : 0]);
+            {
+                const float v[4] = {pf_fl[o < kFl ? o : 0], pf_fl[o + 1 < kFl ? o + 1 : 0], 0.f, pf_fl[o + 2 < kFl ? o + 2 : 0]};
+                packed_flush_add<4, 11u>(s_pfv[w], s_pfi[w], dL_dconic + (size_t)vw_ * P * 4, lane, v);
+                o += 3;
+            }
             if (kAppearance) {
-                FNX_FLUSH_ADD(&dL_dopacity_v[pf_id], pf_fl[o++ < kFl ? o - 1 : 0]);
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) FNX_FLUSH_ADD(&dL_dcolors_v[(size_t)pf_id * C + ch], pf_fl[o++ < kFl ? o - 1 : 0]);
+                if (pf_do) FNX_FLUSH_ADD(&(dL_dopacity + (size_t)vw_ * P)[pf_id], pf_fl[o < kFl ? o : 0]);
+                o += 1;
+                if (C == 3) {
+                    const float v[3] = {pf_fl[o < kFl ? o : 0], pf_fl[o + 1 < kFl ? o + 1 : 0], pf_fl[o + 2 < kFl ? o + 2 : 0]};
+                    packed_flush_add<3, 7u>(s_pfv[w], s_pfi[w], dL_dcolors + (size_t)vw_ * P * 3, lane, v);
+                } else if (pf_do) {
+                    FNX_FLUSH_ADD(&(dL_dcolors + (size_t)vw_ * P)[pf_id], pf_fl[o < kFl ? o : 0]);
+                }
             }
         }
         pf_do = false;

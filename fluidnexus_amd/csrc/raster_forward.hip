@@ -800,17 +800,24 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x, n_views = gridDim.y;
     const int wg_view = (wg_linear >> 3) % n_views, wg_rank = ((wg_linear >> 3) / n_views) * 8 + (wg_linear & 7);
     if (!SEG && wg_rank >= T) return;  // gridDim.x is T rounded up to a multiple of 8
-    if (iu.pairs && wg_rank < T) {
-        // temporal-coherence depth sort (raster_binning.hip): the rank every splat has in this call's order, for the next
-        // call's preprocess.  The T workgroups of a view share the P ranks.
-        const uint2 *pr = view_at(iu.pairs, vb.geom, wg_view);
-        uint32_t *inv = reinterpret_cast<uint32_t *>(iu.state + iu.stride * (size_t)wg_view + iu.inv);
-        const int per = (iu.P + T - 1) / T, r1 = min(iu.P, (wg_rank + 1) * per);
-        for (int r = wg_rank * per + (int)threadIdx.x; r < r1; r += 256) {
-            const uint32_t id = pr[r].y;
-            if (id < (uint32_t)iu.P) inv[id] = (uint32_t)r;
+    // temporal-coherence depth sort (raster_binning.hip): the rank every splat has in this call's order, for the next
+    // call's preprocess.  The T workgroups of a view share the P ranks.  FNX_INV_LATE writes them at the END of the workgroup
+    // (scattered 4-byte stores in flight sit in front of every later load in the in-order vmcnt queue): measured, no change.
+#ifndef FNX_INV_LATE
+#define FNX_INV_LATE 0  // measured (round 6, A/B in one gpurun call): 277.8 / 276.7 us late against 278.4 / 275.0 early -- nothing
+#endif
+    auto write_inv = [&]() {
+        if (iu.pairs && wg_rank < T) {
+            const uint2 *pr = view_at(iu.pairs, vb.geom, wg_view);
+            uint32_t *inv = reinterpret_cast<uint32_t *>(iu.state + iu.stride * (size_t)wg_view + iu.inv);
+            const int per = (iu.P + T - 1) / T, r1_ = min(iu.P, (wg_rank + 1) * per);
+            for (int r = wg_rank * per + (int)threadIdx.x; r < r1_; r += 256) {
+                const uint32_t id = pr[r].y;
+                if (id < (uint32_t)iu.P) inv[id] = (uint32_t)r;
+            }
         }
-    }
+    };
+    if (!FNX_INV_LATE) write_inv();
     {
         const int vw = wg_view;
         ranges = view_at(ranges, vb.img, vw);
@@ -862,7 +869,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     }
     if (status_out && wg_rank == 0 && threadIdx.x < 8)
         status_out[8 * wg_view + threadIdx.x] = threadIdx.x == HDR_BIN_CAPACITY ? capacity : header[threadIdx.x];
-    if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] == (uint32_t)FNX_ERR_SORT_SPAN) return;
+    if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] == (uint32_t)FNX_ERR_SORT_SPAN) {
+        if (FNX_INV_LATE) write_inv();
+        return;
+    }
     // tile order of the view (tile_scan_kernel): tiles that went deep last time first, then the XCD-aware order.  The
     // waves of a deep tile raise their priority: the launch ends when the longest sequential walk ends, and a walk
     // that shares its SIMDs with four short tiles on equal terms takes several times longer than it has to.
@@ -874,7 +884,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     if (SEG) {
         seg_scratch = sg.base + sg.stride * (size_t)wg_view;
         const uint32_t *sctl = reinterpret_cast<const uint32_t *>(seg_scratch + sg.L.ctl);
-        if ((uint32_t)wg_rank >= sctl[SEG_CTL_WORK]) return;
+        if ((uint32_t)wg_rank >= sctl[SEG_CTL_WORK]) {
+            if (FNX_INV_LATE) write_inv();
+            return;
+        }
         const uint32_t item = reinterpret_cast<const uint32_t *>(seg_scratch + sg.L.items)[wg_rank];
         tile_ = (int)(item & kItemTileMask);
         seg = (item >> kItemTileBits) & 0x3FFu;
@@ -890,7 +903,10 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     }
     const int tile = tile_;
     if (tile_deep[tile]) {
-        if (skip_deep) return;  // blend_forward_deep_kernel takes the tiles that went deep in the previous forward
+        if (skip_deep) {  // blend_forward_deep_kernel takes the tiles that went deep in the previous forward
+            if (FNX_INV_LATE) write_inv();
+            return;
+        }
         __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
     }
     const int tx = tile % gx, ty = tile / gx;
@@ -1380,6 +1396,7 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
                 }
             }
 #endif
+            if (FNX_INV_LATE) write_inv();
             return;
         }
 #ifdef FNX_EXP_CLOCK
@@ -1542,6 +1559,7 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
     }
     if (depth_hint && tid == 0) depth_hint[tile] = qmax;  // how deep the tile went: the next forward's tile order
     if (tid == 0 && staged) atomicAdd(&header[HDR_FWD_ENTRIES], staged);
+    if (FNX_INV_LATE) write_inv();
 #ifdef FNX_EXP_CLOCK
     if (tid == 0) {
         const int wg = wg_view * (T + (SEG ? (int)kSegMax : 0)) + wg_rank;

@@ -50,6 +50,26 @@ SCALAR_REAL = dict(lambda_dssim=0.2, lambda_first_distance=1.0, distance_thresho
                    position_lr_max_steps=30000)
 
 
+# Rough kernel-time weights (us on an MI355X, config 3 / 5) that decide which rank takes which view-independent term
+# when they are spread (HotLoop(shared_terms_rank="spread")): one view of the rasteriser + image loss, the gas term
+# (density over the optimised positions + its backward), the next-gas + exyz terms, the distance loss.
+_SPREAD_COST = dict(view=150.0, gas=150.0, next=90.0, distance=60.0)
+
+
+def spread_owners(n_views: int, world: int):
+    """{"gas", "next" (+ exyz), "distance"} -> rank, for the view-independent terms of an iteration spread over the ranks
+    of a view-sharded run: greedy, the heaviest term first onto the rank with the least kernel time so far (its views
+    first).  The distance term needs a render on its rank.  Deterministic: every rank computes the same table."""
+    load = [len(shard_views(n_views, r, world)) * _SPREAD_COST["view"] for r in range(world)]
+    owners = {}
+    for term in ("gas", "next", "distance"):
+        ranks = [r for r in range(world) if term != "distance" or len(shard_views(n_views, r, world)) > 0]
+        r = min(ranks, key=lambda q: (load[q], -q))
+        owners[term] = r
+        load[r] += _SPREAD_COST[term]
+    return owners
+
+
 def shard_views(n_views: int, rank: int, world: int):
     """view v of the iteration's batch -> rank v mod world (5 views on 4 GPUs = 2/1/1/1)."""
     return [v for v in range(n_views) if v % world == rank]
@@ -271,6 +291,9 @@ class HotLoop:
         # tpp:365-404, rank by rank).  r: only rank r evaluates them and adds them `batch` times; the all-reduce hands the
         # sum to everybody.  bench.py --shared-terms last-rank picks the LAST rank: round-robin sharding gives
         # it the fewest views, so the extra work lands on the rank that would otherwise wait (view-batched loop only).
+        # "spread" (round 6): the three terms go to DIFFERENT ranks (spread_owners: the gas term, the next-gas + exyz terms,
+        # the distance loss -- each to the rank with the least work so far), each added `batch` times by its owner; the same
+        # all-reduce sums them, no new collective.  One rank no longer carries all of the ~300 us of side-stream kernels.
         self.shared_terms_rank = shared_terms_rank
         if shared_terms_rank is not None and not batched_views:
             raise ValueError("shared_terms_rank is implemented by the view-batched loop only (batched_views=True): the serial / "
@@ -627,12 +650,21 @@ class HotLoop:
         # who evaluates the view-independent terms, and how many times their gradient counts (see __init__)
         shared = self.shared_terms_rank if self.shared_terms_rank is not None else (None if self.physics_per_view else 0)
         erank, eworld = self.emulated or (self.rank, self.world)
-        phys_here = shared is None or shared == erank
-        n_phys_weight = len(mine) if shared is None else batch
-        # the distance term needs a render on the rank that evaluates it (its gradient joins the rendered positions')
-        dist_shared = shared is not None and len(shard_views(batch, shared, eworld)) > 0
-        dist_here = (shared == erank) if dist_shared else True
-        n_dist_weight = batch if dist_shared else len(mine)
+        lam_phys = (c["lambda_exyz"], c["lambda_gas_constraints"], c["lambda_next_gas_constraints"])
+        if shared == "spread":
+            own = spread_owners(batch, eworld)
+            lam_phys = (lam_phys[0] if own["next"] == erank else 0.0, lam_phys[1] if own["gas"] == erank else 0.0,
+                        lam_phys[2] if own["next"] == erank else 0.0)
+            phys_here = any(l > 0 for l in lam_phys)
+            n_phys_weight = batch
+            dist_shared, dist_here, n_dist_weight = True, own["distance"] == erank, batch
+        else:
+            phys_here = shared is None or shared == erank
+            n_phys_weight = len(mine) if shared is None else batch
+            # the distance term needs a render on the rank that evaluates it (its gradient joins the rendered positions')
+            dist_shared = shared is not None and len(shard_views(batch, shared, eworld)) > 0
+            dist_here = (shared == erank) if dist_shared else True
+            n_dist_weight = batch if dist_shared else len(mine)
         use_dist = bool(mine) and dist_here and c.get("lambda_current_distance", 0.0) > 0
         if use_dist:
             from .physics import prefer_distance_lists
@@ -662,8 +694,7 @@ class HotLoop:
                     gp = self._gp_zero
                 elif self.fused_physics:  # value and gradient straight from the fused stage (no autograd node)
                     from .physics import physical_stage_value_and_grad
-                    _, gp = physical_stage_value_and_grad(gm, c["lambda_exyz"], c["lambda_gas_constraints"],
-                                                          c["lambda_next_gas_constraints"],
+                    _, gp = physical_stage_value_and_grad(gm, lam_phys[0], lam_phys[1], lam_phys[2],
                                                           gm.state_memo("physics_loss"))
                 else:
                     gp, = torch.autograd.grad(self._physics_loss(), gm._estimate_xyz_nn)

@@ -211,9 +211,14 @@ def _batched_host_loop(rank, world, n_views, shared_rank=None):
         g, = torch.autograd.grad(loss, x)
         return loss.detach(), torch.stack([per.detach(), per.detach()], 1), g
 
+    full = (SMOKE["lambda_exyz"], SMOKE["lambda_gas_constraints"], SMOKE["lambda_next_gas_constraints"])
+
     def physical_stage_value_and_grad(gm_, l1, l2, l3, memo):
+        # the same on every rank, like the real (view-independent) terms; three terms, each switched by its own weight
+        # (a rank of a "spread" run passes zeros for the terms it does not own -- fnx_physical_stage skips those)
         x = gm_._estimate_xyz_nn.detach()
-        return 0.5 * 0.01 * (x ** 2).sum(), 0.01 * x  # the same on every rank, like the real (view-independent) terms
+        k = 0.004 * l1 / full[0] + 0.005 * l2 / full[1] + 0.001 * l3 / full[2]
+        return 0.5 * k * (x ** 2).sum(), k * x
 
     def distance_loss_value_and_grad(xyz, thr):  # a smooth view-independent term of the rendered positions
         return 0.5 * (xyz ** 2).sum(), xyz.clone()
@@ -268,13 +273,14 @@ def _serial_reference_worker(port, n_views, steps, q):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("shared_rank", [None, 1])
+@pytest.mark.parametrize("shared_rank", [None, 1, "spread"])
 def test_batched_local_phase_all_reduce_finish_step_equals_single_rank(shared_rank):
     """5 views over 2 ranks (3 / 2) through `_iteration_body_batched(phase="local")` + all-reduce + `_finish_step`
     against one rank running all 5 views through the un-phased body: same positions after three optimiser steps,
     identical on both ranks.  shared_rank None: the physics and distance terms are added once per LOCAL view on every rank
     (3 + 2 = 5 = the single rank's count); 1: only rank 1 (the one with fewer views) evaluates them and adds them 5 times
-    (what bench.py does in a multi-rank run)."""
+    (bench.py --shared-terms last-rank); "spread": each of the three terms is evaluated by ONE rank (harness.spread_owners)
+    and added 5 times by it -- what bench.py does in a multi-rank run since round 6."""
     n_views, world, steps = 5, 2, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
