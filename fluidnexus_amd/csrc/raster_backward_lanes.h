@@ -619,6 +619,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         // ---- flush: thread t turns the sums of entry t into gradients (as blend_backward_kernel); added at the next top ----
 #pragma unroll
         for (int kx = 0; kx < kFl; kx++) pf_fl[kx] = 0.f;
+        pf_vw = vw;  // (every lane: issue_pending reads it as a wave-uniform value)
         if ((uint32_t)tid < cnt) {
             const uint32_t id = s_id[tid];
             float a[NV];
@@ -631,7 +632,6 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             if (any) {
                 pf_do = !(FNX_LABLATE & 1);
                 pf_id = id;
-                pf_vw = vw;
                 float4 ra = s_ra[tid];
                 float cc = s_rb[tid].x;
                 if (FAST) {
