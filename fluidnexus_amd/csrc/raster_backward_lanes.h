@@ -61,6 +61,9 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
+#ifndef FNX_LANES_CHUNK_PREFETCH
+#define FNX_LANES_CHUNK_PREFETCH 0  // 1: the next chunk's list word and records requested a chunk ahead (10 registers): 236 against 222 us
+#endif
 #ifndef FNX_LANES_EARLY_GATHER
 #define FNX_LANES_EARLY_GATHER 0  // 1: in front of the walk -- nine more live registers there, spills: 249 against 240 us
 #endif
@@ -445,13 +448,16 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             const float pxf0 = (float)(tx * FNX_TILE_X + 8 * (qi & 1) + 4 * (bsub & 1));
             const float pyf = (float)(ty * FNX_TILE_Y + 8 * (qi >> 1) + 4 * (bsub >> 1) + r);
             // the chunk's records are requested one chunk ahead
+#if FNX_LANES_CHUNK_PREFETCH
             uint32_t off_n = mylist[e];
             float4 ra_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off_n);
             float4 rb_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off_n);
             float4 rc_n = (!FAST || C == 3) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off_n)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #pragma unroll 1
             for (uint32_t c = 0; c < nchunks; c++) {
+#if FNX_LANES_CHUNK_PREFETCH
                 const uint32_t off = off_n;
                 const float4 ra = ra_n, rb = rb_n, rc = rc_n;
                 if (c + 1 < nchunks) {
@@ -460,6 +466,13 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                     rb_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off_n);
                     if (!FAST || C == 3) rc_n = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off_n);
                 }
+#else
+                const uint32_t off = mylist[16 * c + e];
+                const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra) + off);
+                const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb) + off);
+                const float4 rc = (!FAST || C == 3) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc) + off)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 const bool wants = (FAST ? (C == 3 ? rc.y : rb.w) : rb.w) != 0.0f;
                 float col[3];
                 if (FAST) {
