@@ -61,6 +61,9 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
+#ifndef FNX_LANES_DYNAMIC_BLOCKS
+#define FNX_LANES_DYNAMIC_BLOCKS 0
+#endif
 #ifndef FNX_LANES_CHUNK_PREFETCH
 #define FNX_LANES_CHUNK_PREFETCH 0  // 1: the next chunk's list word and records requested a chunk ahead (10 registers): 236 against 222 us
 #endif
@@ -105,6 +108,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     __shared__ uint32_t s_first[kMaxViews + 1];
     __shared__ uint32_t s_view_items[kMaxViews];
     __shared__ uint32_t s_tk;
+    __shared__ uint32_t s_next_block;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
@@ -385,6 +389,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
         s_mask[tid] = (uint16_t)((uint32_t)tid < cnt ? cur.qm : 0u);
+        if (FNX_LANES_DYNAMIC_BLOCKS && tid == 0) s_next_block = 4u;  // blocks 0 .. 3 (in draw order) are the waves' first
         FNX_LCLK(1)  // staging
         fnx::lds_barrier();  // B: the batch is staged
         FNX_LCLK(2)  // wait at barrier B
@@ -409,10 +414,24 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         }
 #endif
         // ---- walk: one block of every quadrant per wave ----------------------------------------------------------------
+#if FNX_LANES_DYNAMIC_BLOCKS
+        // the sixteen blocks are handed out by an LDS counter (a wave that drew short lists takes more of them); the first
+        // block of every wave is fixed (no round trip in front of it)
+#pragma unroll 1
+        for (int kb = w; kb < ((FNX_LABLATE & 16) ? 0 : 16);) {
+            const int k = ((kb & 3) << 2) | (kb >> 2);  // consecutive draws go to different quadrants
+            const int qi = k >> 2, bsub = k & 3;
+            {
+                int nk = 0;
+                if (lane == 0) nk = (int)atomicAdd(&s_next_block, 1u);
+                kb = __builtin_amdgcn_readfirstlane(nk);  // the NEXT block of this wave, requested under this one's walk
+            }
+#else
 #pragma unroll 1
         for (int qi = 0; qi < ((FNX_LABLATE & 16) ? 0 : 4); qi++) {
             const int bsub = (w + qi) & 3;
             const int k = 4 * qi + bsub;  // bit of the block in the entries' masks (fnx_device.h block_mask_exact)
+#endif
             const uint32_t bm_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bmax[k]);
             const uint32_t nlim = bm_ > q0 ? min(bm_ - q0, 256u) : 0u;
             if (nlim == 0u) continue;
