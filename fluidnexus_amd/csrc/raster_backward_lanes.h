@@ -108,7 +108,10 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     __shared__ uint32_t s_first[kMaxViews + 1];
     __shared__ uint32_t s_view_items[kMaxViews];
     __shared__ uint32_t s_tk;
+#if FNX_LANES_DYNAMIC_BLOCKS
     __shared__ uint32_t s_next_block;
+#endif
+    __shared__ float s_mz[kFusedGeom ? 256 : 1];  // positions-only flush: the splats' world z (x, y ride in spare record words)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // ch3 backward.cu:444-445
@@ -146,6 +149,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         uint32_t id, qm;
         float4 ra;
         float rbx, rby, rcz, rcw, rdx;
+        float mx, my, mz;  // the splat's world position (record words 13 .. 15, written by the preprocess)
     };
     constexpr uint32_t kNoItem = 0xFFFFFFFFu;
     __syncthreads();  // s_first is written
@@ -192,6 +196,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         if (FNX_LABLATE & 32) {
             f.ra = make_float4(100.f, 100.f, 1.f, 0.f);
             f.rbx = 1.f, f.rby = 0.5f, f.rcz = f.rcw = f.rdx = 0.3f;
+            f.mx = f.my = f.mz = 0.1f;
         } else if (f.item != kNoItem && pos < f.r1) {
             const float4 *rec = (st.base && f.id >= st.id0)
                 ? reinterpret_cast<const float4 *>(st.base + st.stride * f.vw + st.rec) + 4 * (size_t)(f.id - st.id0)
@@ -202,7 +207,15 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             f.rby = rb.y;
             f.rcz = rc.z;
             f.rcw = rc.w;
-            f.rdx = C > 2 ? rec[3].x : 0.f;
+            if (kFusedGeom) {
+                const float4 rd = rec[3];
+                f.rdx = rd.x;
+                f.mx = rd.y;
+                f.my = rd.z;
+                f.mz = rd.w;
+            } else {
+                f.rdx = C > 2 ? rec[3].x : 0.f;
+            }
         }
     };
     // tickets: as blend_backward_kernel (the first two items of a workgroup are fixed, the rest drawn from a device
@@ -261,7 +274,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     // everything the first item was requested is waited for here (see blend_backward_kernel: a register in flight on the
     // way into the loop costs every iteration a vmcnt(0) at its first use)
     asm volatile("" ::"v"(cur.id), "v"(cur.qm), "v"(cur.ra.x), "v"(cur.ra.y), "v"(cur.ra.z), "v"(cur.ra.w), "v"(cur.rbx),
-                 "v"(cur.rby), "v"(cur.rcz), "v"(cur.rcw), "v"(cur.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                 "v"(cur.rby), "v"(cur.rcz), "v"(cur.rcw), "v"(cur.rdx), "v"(cur.mx), "v"(cur.my), "v"(cur.mz), "v"(ahead.T_final), "v"(ahead.last_contributor),
                  "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                  "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                  "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nxt.item));
@@ -378,18 +391,21 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 s_ra[tid] = make_float4(cur.ra.x, cur.ra.y, (-0.5f * kL2e) * cur.ra.z, (-kL2e) * cur.ra.w);
                 s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), cur.rcz,
                                         C == 3 ? cur.rcw : wants_f);
-                if (C == 3) s_rc[tid] = make_float4(cur.rdx, wants_f, 0.f, 0.f);
+                if (C == 3 || kFusedGeom) s_rc[tid] = make_float4(cur.rdx, wants_f, kFusedGeom ? cur.mx : 0.f, kFusedGeom ? cur.my : 0.f);
                 s_rd[FAST ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
             } else {
                 s_ra[tid] = cur.ra;
-                s_rb[tid] = make_float4(cur.rbx, cur.rby, 0.f, wants_f);
-                s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, 0.f);
+                s_rb[tid] = make_float4(cur.rbx, cur.rby, kFusedGeom ? cur.mx : 0.f, wants_f);
+                s_rc[tid] = make_float4(cur.rcz, C > 1 ? cur.rcw : 0.f, C > 2 ? cur.rdx : 0.f, kFusedGeom ? cur.my : 0.f);
             }
         }
+        if (kFusedGeom) s_mz[kFusedGeom ? tid : 0] = cur.mz;
 #pragma unroll
         for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
         s_mask[tid] = (uint16_t)((uint32_t)tid < cnt ? cur.qm : 0u);
-        if (FNX_LANES_DYNAMIC_BLOCKS && tid == 0) s_next_block = 4u;  // blocks 0 .. 3 (in draw order) are the waves' first
+#if FNX_LANES_DYNAMIC_BLOCKS
+        if (tid == 0) s_next_block = 4u;  // blocks 0 .. 3 (in draw order) are the waves' first
+#endif
         FNX_LCLK(1)  // staging
         fnx::lds_barrier();  // B: the batch is staged
         FNX_LCLK(2)  // wait at barrier B
@@ -406,8 +422,6 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 gcov[0] = gcov[3] = gcov[5] = 1e-4f;
             } else if (gid < grad_limit) {
                 const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) gmean[kx] = means3D[3 * (size_t)gid + kx];
 #pragma unroll
                 for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
             }
@@ -630,8 +644,6 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             } else if (gid < grad_limit) {
                 const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) gmean[kx] = means3D[3 * (size_t)gid + kx];
-#pragma unroll
                 for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
             }
         }
@@ -678,7 +690,10 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 if (kFusedGeom && (FNX_LABLATE & 8)) {
                     pf_fl[0] = g0 + gmean[0] + gcov[0], pf_fl[1 < kFl ? 1 : 0] = g1 + gmean[1] + gcov[3], pf_fl[2 < kFl ? 2 : 0] = a[kConic] + gmean[2] + gcov[5];
                 } else if (kFusedGeom) {
-                    const float3 mean = make_float3(gmean[0], gmean[1], gmean[2]);
+                    // the splat's world position came with its record (preprocess: record words 13 .. 15)
+                    const float3 mean = FAST ? make_float3(s_rc[tid].z, s_rc[tid].w, s_mz[kFusedGeom ? tid : 0])
+                                             : make_float3(s_rb[tid].z, s_rc[tid].w, s_mz[kFusedGeom ? tid : 0]);
+                    (void)gmean;
                     float gv[3];
                     geom_backward_view<false>(mean, gcov, viewmatrix + 16 * vw, projmatrix + 16 * vw, vb.focal_x[vw],
                                               vb.focal_y[vw], vb.tan_fovx[vw], vb.tan_fovy[vw], -0.5f * a[kConic],
@@ -712,7 +727,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         // the next item's records and pixels (requested in front of barrier C) are waited for here, with no atomic between
         // their request and this wait
         asm volatile("" ::"v"(nxt.id), "v"(nxt.qm), "v"(nxt.ra.x), "v"(nxt.ra.y), "v"(nxt.ra.z), "v"(nxt.ra.w), "v"(nxt.rbx),
-                     "v"(nxt.rby), "v"(nxt.rcz), "v"(nxt.rcw), "v"(nxt.rdx), "v"(ahead.T_final), "v"(ahead.last_contributor),
+                     "v"(nxt.rby), "v"(nxt.rcz), "v"(nxt.rcw), "v"(nxt.rdx), "v"(nxt.mx), "v"(nxt.my), "v"(nxt.mz), "v"(ahead.T_final), "v"(ahead.last_contributor),
                      "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                      "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                      "v"(ahead.stt.z), "v"(ahead.stt.w));

@@ -307,7 +307,9 @@ preprocess_kernel(int P, int D, int M, const float *__restrict__ means3D, const 
                     rec[0] = make_float4(px, py, conic.x, conic.y);
                     rec[1] = make_float4(conic.z, opac, thr, p_view.z);
                     rec[2] = make_float4(ex, ey, col[0], col[1]);
-                    rec[3] = make_float4(col[2], 0.f, 0.f, 0.f);
+                    // (.yzw: the splat's world position -- the positions-only backward's flush reads it with the record
+                    //  instead of gathering it from means3D, raster_backward_lanes.h)
+                    rec[3] = make_float4(col[2], p_orig.x, p_orig.y, p_orig.z);
                     if (!lean) tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
                     // a NaN depth passes the near cull as in the reference; its key keeps bit 31 out of the way of the flag
                     key = __float_as_uint(p_view.z) & 0x7FFFFFFFu;
