@@ -61,6 +61,9 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
+#ifndef FNX_LANES_NO_FOLD
+#define FNX_LANES_NO_FOLD 0
+#endif
 #ifndef FNX_LANES_DYNAMIC_BLOCKS
 #define FNX_LANES_DYNAMIC_BLOCKS 0
 #endif
@@ -608,6 +611,12 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                         for (int ch = 0; ch < C; ch++) m[kAppearance ? kCol + ch : 0] = SC[ch];
                     }
                     const uint32_t slot = off >> 4;
+#if FNX_LANES_NO_FOLD  // every row adds its own sums: NV LDS atomics with four lanes per address instead of the swaps
+                    if (slot < 256u) {
+#pragma unroll
+                        for (int v = 0; v < NV; v++) atomicAdd(&s_acc[0][0] + v * kAccStride + slot, m[v]);
+                    }
+#else
                     const int vq = ((r & 1) << 1) | (r >> 1);  // which value of a group of four this row ends up with
 #pragma unroll
                     for (int g = 0; g < NV; g += 4) {
@@ -617,6 +626,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                             asm volatile("" ::"v"(t));
                         } else if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
                     }
+#endif
                 }
             }
         }
