@@ -29,6 +29,9 @@
 #endif
 #include "lab/fnx_lab.h"  // experiment switches (all off in the production build)
 #include <cstdlib>
+#ifndef FNX_LANES_DUAL
+#define FNX_LANES_DUAL 1  // the dual mode through the entries-as-lanes kernel too (0: always the row form)
+#endif
 #ifndef FNX_BWD_FORM_DEFAULT
 #define FNX_BWD_FORM_DEFAULT 1  // 1: entries as lanes (raster_backward_lanes.h), 0: pixels as lanes (this file); the dual mode always takes 0
 #endif
@@ -1257,16 +1260,16 @@ static void launch_blend_backward_tf(int n_cu, hipStream_t s, A... args) {
     hipLaunchKernelGGL((blend_backward_kernel<C, MODE, FAST, DUAL>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
 }
 // entries-as-lanes form (raster_backward_lanes.h); takes the row form's arguments without the dual reference
-template <int C, int MODE, bool FAST, typename... A>
+template <int C, int MODE, bool FAST, bool DUAL = false, typename... A>
 static void launch_blend_backward_lanes_tf(int n_cu, hipStream_t s, A... args) {
     static int cache[kMaxDevices];
     static std::mutex mu;
     const int per_cu = per_device_cached(cache, mu, [](int) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_lanes_kernel<C, MODE, FAST>, 256, 0) != hipSuccess || n <= 0) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blend_backward_lanes_kernel<C, MODE, FAST, DUAL>, 256, 0) != hipSuccess || n <= 0) n = 4;
         return n;
     });
-    hipLaunchKernelGGL((blend_backward_lanes_kernel<C, MODE, FAST>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
+    hipLaunchKernelGGL((blend_backward_lanes_kernel<C, MODE, FAST, DUAL>), dim3(n_cu * per_cu), dim3(256), 0, s, args...);
 }
 int g_backward_form = -1;  // fnx_set_backward_form: 0 = one pixel per lane (rows), 1 = one entry per lane; -1: FNX_BWD_FORM or the default
 static int backward_form() {
@@ -1281,8 +1284,8 @@ int get_backward_form() { return backward_form(); }
 template <int C, int MODE, typename... A>
 static void launch_blend_backward_t(int fast, int n_cu, hipStream_t s, const DualRef &du, A... args) {
     if (backward_form() == 1) {
-        if (fast) launch_blend_backward_lanes_tf<C, MODE, true>(n_cu, s, args...);
-        else launch_blend_backward_lanes_tf<C, MODE, false>(n_cu, s, args...);
+        if (fast) launch_blend_backward_lanes_tf<C, MODE, true>(n_cu, s, args..., du);
+        else launch_blend_backward_lanes_tf<C, MODE, false>(n_cu, s, args..., du);
         return;
     }
     if (fast) launch_blend_backward_tf<C, MODE, true>(n_cu, s, args..., du);
@@ -1300,6 +1303,11 @@ void launch_blend_backward(int C, int mode, hipStream_t s, int P, int W, int H, 
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     // persistent workgroups striding over the view's work items (their number is only known on the device)
     const int n_cu = device_cu_count();
+    if (du.img1 && backward_form() == 1 && FNX_LANES_DUAL) {  // dual mode, entries-as-lanes form
+        if (fast) launch_blend_backward_lanes_tf<3, 3, true, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+        else launch_blend_backward_lanes_tf<3, 3, false, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
+        return;
+    }
     if (du.img1) {  // dual mode (the caller has checked: 3 channels, positions only)
         if (fast) launch_blend_backward_tf<3, 3, true, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);
         else launch_blend_backward_tf<3, 3, false, true>(n_cu, s, T, gx, ranges, point_list, W, H, bg, blend_rec, final_Ts, n_contrib, acc_final, dL_dpixels, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors, header, capacity, grad_limit, P, V, st, vb, means3D, cov3Ds, cov3D_stride, viewmatrix, projmatrix, dL_dmean3D, status_out, du);

@@ -77,8 +77,11 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #define FNX_BWDL_WAVES 4  // waves per SIMD the register allocation aims at
 #endif
 
-template <int C, int MODE, bool FAST>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FNX_BWDL_WAVES, FNX_BWDL_WAVES)))
+// DUAL (fnx_raster_dual_t; C = 3, MODE 3): the second, single-channel image of the per-call splats (blend_forward_kernel) adds
+// its share of every dynamic entry's dL/dalpha through its own transmittance / what-lies-behind scans over the same alphas
+// (see blend_backward_kernel); three waves per SIMD (the second image's pixel state and scans need the registers).
+template <int C, int MODE, bool FAST, bool DUAL = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DUAL ? 3 : FNX_BWDL_WAVES, DUAL ? 3 : FNX_BWDL_WAVES)))
 blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W,
                             int H, const float *__restrict__ bg, const float4 *__restrict__ blend_rec,
                             const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
@@ -88,7 +91,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                             uint32_t grad_limit, int P, int n_views, const StaticRef st, const ViewBatch vb,
                             const float *__restrict__ means3D, const float *__restrict__ cov3Ds, size_t cov3D_stride,
                             const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
-                            float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out) {
+                            float *__restrict__ dL_dmean3D, uint32_t *__restrict__ status_out, const DualRef du) {
+    static_assert(!DUAL || (C == 3 && MODE == 3), "dual mode: 3 channels, positions-only backward");
     constexpr bool kMeans = MODE != 2, kAppearance = MODE == 0 || MODE == 2, kFusedGeom = MODE == 3;
     constexpr int kConic = kMeans ? 2 : 0, kOpac = kConic + 3, kCol = kOpac + 1;  // slots of the per-entry sums (as the row form)
     constexpr int NV = kAppearance ? kCol + C : kOpac;
@@ -108,6 +112,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     // the pixels' state in front of the batch, index 16 block + 4 row + column (= the staging thread's index)
     __shared__ __attribute__((aligned(16))) float s_pT[256], s_pR[256], s_pD[C][256];
     __shared__ __attribute__((aligned(16))) uint32_t s_pL[256];
+    // DUAL: the second image's pixel (T in front of the batch, what lies behind, walking limit, dL/dpixel)
+    __shared__ __attribute__((aligned(16))) float s_qT[DUAL ? 256 : 4], s_qR[DUAL ? 256 : 4], s_qD[DUAL ? 256 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qL[DUAL ? 256 : 4];
     __shared__ uint32_t s_first[kMaxViews + 1];
     __shared__ uint32_t s_view_items[kMaxViews];
     __shared__ uint32_t s_tk;
@@ -128,7 +135,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         const uint32_t *h = view_at(header, vb.img, v);
         const uint32_t h_limit = h[HDR_DYN_LIMIT], h_cap = h[HDR_BIN_CAPACITY], h_nr = h[HDR_NUM_RENDERED],
                        h_status = h[HDR_STATUS], h_items = h[HDR_BWD_ITEMS];
-        const bool cut = grad_limit > h_limit;
+        const bool cut = grad_limit > h_limit || (DUAL && grad_limit != h_limit);
         const bool mismatch = h_cap != capacity || cut;
         if (mismatch && blockIdx.x == 0) {
             const_cast<uint32_t *>(h)[HDR_STATUS] = cut ? FNX_ERR_INVALID_ARG : FNX_ERR_CAPACITY;
@@ -244,6 +251,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         uint32_t last_contributor;
         float dL[C], total[C];
         float4 stt;
+        float T_final1, dL1, total1;  // DUAL: the second image's pixel
+        uint32_t last1;
+        float2 stt1;
     } ahead;
     auto load_ahead = [&](const Fetched &f) {
         if (FNX_LABLATE & 4) {
@@ -272,6 +282,17 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) + vb.bin_bstate);
             ahead.stt = nbs[((size_t)(f.r0 >> 8) + nb_ - 1) * 256 + tid];
         }
+        if (DUAL) {
+            const char *i1 = du.img1 + vb.img * (size_t)nv;
+            ahead.T_final1 = nin ? reinterpret_cast<const float *>(i1 + du.final_T)[npix] : 0.f;
+            ahead.last1 = nin ? reinterpret_cast<const uint32_t *>(i1 + du.n_contrib)[npix] : 0u;
+            ahead.dL1 = nin ? du.dL_dpix1[(size_t)nv * H * W + npix] : 0.f;
+            ahead.total1 = nin ? reinterpret_cast<const float *>(i1 + du.acc_final)[npix] : 0.f;
+            ahead.stt1 = make_float2(1.f, 0.f);
+            if (nb_)
+                ahead.stt1 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(view_at(point_list, vb.bin, nv)) +
+                                                              du.bin_bstate1)[((size_t)(f.r0 >> 8) + nb_ - 1) * 256 + tid];
+        }
     };
     if (cur.item != kNoItem) load_ahead(cur);
     // everything the first item was requested is waited for here (see blend_backward_kernel: a register in flight on the
@@ -281,6 +302,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                  "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                  "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                  "v"(ahead.stt.z), "v"(ahead.stt.w), "v"(nxt.item));
+    if (DUAL)
+        asm volatile("" ::"v"(ahead.T_final1), "v"(ahead.last1), "v"(ahead.dL1), "v"(ahead.total1), "v"(ahead.stt1.x), "v"(ahead.stt1.y));
     const int r = lane >> 4, e = lane & 15;
 #ifdef FNX_EXP_BCLK
     unsigned long long lclk[32];
@@ -381,7 +404,13 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             s_pL[tid] = last_contributor > q0 ? min(last_contributor - q0, 256u) << 4 : 0u;
 #pragma unroll
             for (int ch = 0; ch < C; ch++) s_pD[ch][tid] = ahead.dL[ch];
-            uint32_t m = last_contributor;  // a block needs nothing behind its own deepest contributor
+            if (DUAL) {
+                s_qT[DUAL ? tid : 0] = b ? ahead.stt1.x : 1.0f;
+                s_qR[DUAL ? tid : 0] = (ahead.total1 * ahead.dL1 - (b ? ahead.stt1.y : 0.f) * ahead.dL1) + ahead.T_final1 * du.bg1[0] * ahead.dL1;
+                s_qL[DUAL ? tid : 0] = ahead.last1 > q0 ? min(ahead.last1 - q0, 256u) << 4 : 0u;
+                s_qD[DUAL ? tid : 0] = ahead.dL1;
+            }
+            uint32_t m = DUAL ? max(last_contributor, ahead.last1) : last_contributor;  // a block needs nothing behind its own deepest contributor
             for (int off = 8; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
             if (e == 0) s_bmax[tid >> 4] = m;
         }
@@ -481,6 +510,18 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 dLj[ch][2] = d4.z;
                 dLj[ch][3] = d4.w;
             }
+            float Tc1[4] = {1.f, 1.f, 1.f, 1.f}, Rc1[4] = {0.f, 0.f, 0.f, 0.f}, dL1j[4] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t L1j[4] = {0u, 0u, 0u, 0u};
+            if (DUAL) {
+                const float4 t4 = reinterpret_cast<const float4 *>(s_qT)[DUAL ? 4 * k + r : 0];
+                const float4 r4 = reinterpret_cast<const float4 *>(s_qR)[DUAL ? 4 * k + r : 0];
+                const float4 d4 = reinterpret_cast<const float4 *>(s_qD)[DUAL ? 4 * k + r : 0];
+                const uint4 l4 = reinterpret_cast<const uint4 *>(s_qL)[DUAL ? 4 * k + r : 0];
+                Tc1[0] = t4.x, Tc1[1] = t4.y, Tc1[2] = t4.z, Tc1[3] = t4.w;
+                Rc1[0] = r4.x, Rc1[1] = r4.y, Rc1[2] = r4.z, Rc1[3] = r4.w;
+                dL1j[0] = d4.x, dL1j[1] = d4.y, dL1j[2] = d4.z, dL1j[3] = d4.w;
+                L1j[0] = l4.x, L1j[1] = l4.y, L1j[2] = l4.z, L1j[3] = l4.w;
+            }
             const float pxf0 = (float)(tx * FNX_TILE_X + 8 * (qi & 1) + 4 * (bsub & 1));
             const float pyf = (float)(ty * FNX_TILE_Y + 8 * (qi >> 1) + 4 * (bsub >> 1) + r);
             // the chunk's records are requested one chunk ahead
@@ -525,7 +566,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 const float k1 = FAST ? ra.w * dy : 0.f;                    // FAST: (-log2e b) dy
                 const float k0 = (rb.x * dy) * dy;                          // (c dy) dy, FAST: pre-scaled
                 float dx[4], ev[4], a[4], om[4], inv[4], cd[4];
-                bool emits[4];
+                float a1[4], om1[4], inv1[4];  // DUAL: the second image's alpha (dynamic entries in front of ITS last contributor)
+                bool emits[4], act1[4];
                 bool any_emit = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -549,9 +591,19 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                     emits[j] = active && wants;
                     any_emit |= emits[j];
                     a[j] = active ? alpha : 0.0f;
-                    if (!FAST) ev[j] = active ? ev[j] : 0.0f;  // power > 0 can push the range-limited exp out of range
+                    act1[j] = DUAL && hit && wants && (off < L1j[j]);  // a dynamic entry takes gradients (limit = the forward's)
+                    if (!FAST) ev[j] = (active || act1[j]) ? ev[j] : 0.0f;  // power > 0 can push the range-limited exp out of range
                     om[j] = 1 - a[j];
-                    inv[j] = __builtin_amdgcn_rcpf(om[j]);
+                    if (DUAL) {  // (1 - alpha) is the same number in both images wherever both take the entry: one reciprocal
+                        const float ih = __builtin_amdgcn_rcpf(1 - (hit ? alpha : 0.0f));
+                        inv[j] = active ? ih : 1.0f;
+                        inv1[j] = act1[j] ? ih : 1.0f;
+                        a1[j] = act1[j] ? alpha : 0.0f;
+                        om1[j] = 1 - a1[j];
+                        any_emit |= act1[j];
+                    } else {
+                        inv[j] = __builtin_amdgcn_rcpf(om[j]);
+                    }
                     float cdot = col[0] * dLj[0][j];
                     if (C > 1) cdot = __builtin_fmaf(col[1], dLj[C > 1 ? 1 : 0][j], cdot);
                     if (C > 2) cdot = __builtin_fmaf(col[2], dLj[C > 2 ? 2 : 0][j], cdot);
@@ -570,15 +622,36 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 }
                 // what lies behind the entry: the carry minus alpha T (c . dL) of the entries up to and including it
                 row_scan_add4(term);
+                float Tn1[4] = {om1[0], om1[1], om1[2], om1[3]}, Tb1[4], term1[4], cd1[4];
+                if (DUAL) {  // the second image: its value per splat is channel 0 of the colour
+                    row_scan_mul4(Tn1);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        Tn1[j] = Tc1[j] * Tn1[j];
+                        Tb1[j] = row_prev(Tn1[j], Tc1[j]);
+                        cd1[j] = col[0] * dL1j[j];
+                        term1[j] = (a1[j] * Tb1[j]) * cd1[j];
+                    }
+                    row_scan_add4(term1);
+                }
                 float S0 = 0.f, S1 = 0.f, S2 = 0.f, SO = 0.f, SC[C];  // SO: exact arithmetic's opacity sum (G dL/dalpha)
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) SC[ch] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float rest = Rc[j] - term[j];
-                    const float dL_dalpha = __builtin_fmaf(Tb[j], cd[j], -(rest * inv[j]));
+                    float dL_dalpha = __builtin_fmaf(Tb[j], cd[j], -(rest * inv[j]));
+                    bool takes = emits[j];
+                    if (DUAL) {
+                        const float rest1 = Rc1[j] - term1[j];
+                        const float dL_dalpha1 = __builtin_fmaf(Tb1[j], cd1[j], -(rest1 * inv1[j]));
+                        dL_dalpha = (emits[j] ? dL_dalpha : 0.0f) + (act1[j] ? dL_dalpha1 : 0.0f);
+                        takes = emits[j] || act1[j];
+                        Tc1[j] = row_last(Tn1[j]);
+                        Rc1[j] = row_last(rest1);
+                    }
                     // FAST: G dL/dG = (o G) dL/dalpha; exact: G (o dL/dalpha) (ch3 backward.cu:505-512)
-                    const float Ge = emits[j] ? ev[j] : 0.0f;
+                    const float Ge = takes ? ev[j] : 0.0f;
                     const float wgt = FAST ? Ge * dL_dalpha : Ge * (rb.y * dL_dalpha);
                     if (!FAST && kAppearance) SO = __builtin_fmaf(Ge, dL_dalpha, SO);
                     S0 += wgt;
@@ -741,6 +814,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                      "v"(ahead.dL[0]), "v"(ahead.dL[C > 1 ? 1 : 0]), "v"(ahead.dL[C > 2 ? 2 : 0]), "v"(ahead.total[0]),
                      "v"(ahead.total[C > 1 ? 1 : 0]), "v"(ahead.total[C > 2 ? 2 : 0]), "v"(ahead.stt.x), "v"(ahead.stt.y),
                      "v"(ahead.stt.z), "v"(ahead.stt.w));
+        if (DUAL)
+            asm volatile("" ::"v"(ahead.T_final1), "v"(ahead.last1), "v"(ahead.dL1), "v"(ahead.total1), "v"(ahead.stt1.x), "v"(ahead.stt1.y));
         FNX_LSUB(23)  // wait for the next item's records / pixels
         FNX_LCLK(6)   // flush: sums -> gradients (+ the wait for the prefetched registers)
         FNX_LCNT(14, __popcll(__ballot(pf_do)))
