@@ -1015,9 +1015,9 @@ def main():
     split_s = 'true' if (pipes._STATIC_SPLIT and cfg_id != 2 and a.stage != "first") else 'false'
     from fluidnexus_amd import harness as _Hn
     dual_s = 'true' if (cfg_id == 5 and a.stage == "physical" and _Hn._DUAL_FUSED and split_s == 'true') else 'false'
-    lanes = rasterizer.get_backward_form() == "lanes" and dual_s == 'false'
+    lanes = rasterizer.get_backward_form() == "lanes"
     knames = {"blend_forward": f"fnx::blend_forward_kernel<{Cn}, {split_s}, {fast_s}, {dual_s}, false>",
-              "blend_backward": (f"fnx::blend_backward_lanes_kernel<{Cn}, {bwd_mode}, {fast_s}>" if lanes else
+              "blend_backward": (f"fnx::blend_backward_lanes_kernel<{Cn}, {bwd_mode}, {fast_s}, {dual_s}>" if lanes else
                                  f"fnx::blend_backward_kernel<{Cn}, {bwd_mode}, {fast_s}, {dual_s}>")}
     kname = knames[dom]
     suffix = ("" if cfg_id == 3 else f"_config{cfg_id}") + ("" if a.stage == "physical" or cfg_id == 2 else f"_{a.stage}")

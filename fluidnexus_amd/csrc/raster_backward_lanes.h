@@ -57,7 +57,7 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #define FNX_LSUB(i)
 #endif
 // timing experiments (results WRONG): bit 1 no global flush atomics, 2 no mean / covariance gathers, 4 no pixel loads,
-// 8 no geometry in the flush, 16 no walk, 32 no record loads, 64 no LDS atomics in the walk
+// 8 no geometry in the flush, 16 no walk, 32 no record loads, 64 no LDS atomics in the walk, 128 plain LDS stores instead
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
@@ -697,6 +697,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                         const float t = rows_fold4(mv(g), mv(g + 1), mv(g + 2), mv(g + 3));
                         if (FNX_LABLATE & 64) {
                             asm volatile("" ::"v"(t));
+                        } else if (FNX_LABLATE & 128) {  // plain store instead of the atomic: WRONG sums, what ds_add_f32 costs
+                            if (slot < 256u && g + vq < NV) (&s_acc[0][0])[(g + vq) * kAccStride + slot] = t;
                         } else if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
                     }
 #endif

@@ -2,7 +2,7 @@
 # Run on the GPU box: side records of the round (one bench line each) -> gpurun_out/<tag>_extras/<tag>_extra_<name>.json
 # usage: tools/collect_extras.sh <tag>
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/${TAG}_extras
 mkdir -p $O
 run() {  # name, env assignments (comma separated, may be empty), bench arguments
