@@ -108,7 +108,7 @@ SYMBOLS = (
 
 # Version of the C ABI this binding was written against (include/fnx_raster.h FNX_ABI_VERSION): the layouts of the
 # scratch blobs and several argument lists changed since version 1, and a stale library would read garbage silently.
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def raster_path() -> str:

@@ -49,9 +49,11 @@ typedef char *(*fnx_alloc_fn)(size_t bytes, void *user);
  * blob's n_contrib array doubled -- its second half is the backward's per-pixel walking limit, fnx_request_gradient_limit;
  * 4: per-call options fnx_raster_opts_t and the *_opts entry points, the process-wide setters and one-shot requests are
  * deprecated shims; culled splats keep their depth in the sort keys; image header grew to 16 words with the walked-entry
- * counters; 5: fnx_raster_opts_t.dual, fnx_binning_bytes_dual); a caller compares fnx_abi_version() with the
+ * counters; 5: fnx_raster_opts_t.dual, fnx_binning_bytes_dual; 6: fnx_raster_opts_t.segment_scratch; 7: the last three words
+ * of a splat's 64-byte blend record (geometry blob, static blob) carry its world position -- the positions-only backward
+ * reads them -- and fnx_set_backward_form / fnx_get_backward_form); a caller compares fnx_abi_version() with the
  * FNX_ABI_VERSION it was compiled against before anything else. */
-#define FNX_ABI_VERSION 6
+#define FNX_ABI_VERSION 7
 int fnx_abi_version(void);
 const char *fnx_last_error(void);
 

@@ -24,7 +24,7 @@ def test_raster_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     for n in names:
         getattr(lib, n)
-    assert lib.fnx_abi_version() == _lib.ABI_VERSION == 6  # include/fnx_raster.h FNX_ABI_VERSION
+    assert lib.fnx_abi_version() == _lib.ABI_VERSION == 7  # include/fnx_raster.h FNX_ABI_VERSION
 
 
 def test_physics_and_losses_libraries_export_every_declared_symbol():
