@@ -61,6 +61,13 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #ifndef FNX_LABLATE
 #define FNX_LABLATE 0
 #endif
+// 1: every wave adds into an accumulator array of its OWN (plain LDS read-add-write: ds_add_f32 is what the LDS pipe of the
+// shared-accumulator build is busy with, 27 us of 222) and the flush adds the four copies; 16 KB more LDS = three
+// workgroups per compute unit, so this build also takes three waves per SIMD and requests the flush's gathers in front of
+// the walk (the registers are there).  The staged conic / opacity copy (s_rd) goes: the flush rescales the staged values.
+#ifndef FNX_LANES_PRIVATE_ACC
+#define FNX_LANES_PRIVATE_ACC 1  // measured: 222 -> 203.5 us (the same build with the gathers behind the walk: 208)
+#endif
 #ifndef FNX_LANES_NO_FOLD
 #define FNX_LANES_NO_FOLD 0
 #endif
@@ -70,11 +77,14 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #ifndef FNX_LANES_CHUNK_PREFETCH
 #define FNX_LANES_CHUNK_PREFETCH 0  // 1: the next chunk's list word and records requested a chunk ahead (10 registers): 236 against 222 us
 #endif
+#ifndef FNX_LANES_EARLY_RECORDS
+#define FNX_LANES_EARLY_RECORDS 0
+#endif
 #ifndef FNX_LANES_EARLY_GATHER
-#define FNX_LANES_EARLY_GATHER 0  // 1: in front of the walk -- nine more live registers there, spills: 249 against 240 us
+#define FNX_LANES_EARLY_GATHER FNX_LANES_PRIVATE_ACC  // 1: in front of the walk -- nine more live registers there; at four waves per SIMD it spills: 249 against 240 us
 #endif
 #ifndef FNX_BWDL_WAVES
-#define FNX_BWDL_WAVES 4  // waves per SIMD the register allocation aims at
+#define FNX_BWDL_WAVES (FNX_LANES_PRIVATE_ACC ? 3 : 4)  // waves per SIMD the register allocation aims at
 #endif
 
 // DUAL (fnx_raster_dual_t; C = 3, MODE 3): the second, single-channel image of the per-call splats (blend_forward_kernel) adds
@@ -103,9 +113,12 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     __shared__ float4 s_ra[257];  // x, y, conic a, conic b   (FAST: the conic pre-scaled by -log2(e) / 2, -log2(e))
     __shared__ float4 s_rb[257];  // conic c, opacity (FAST: log2 opacity), FAST: colour 0, colour 1 | wants; exact: -, wants
     __shared__ float4 s_rc[257];  // FAST C = 3: colour 2, wants; exact: colour
-    __shared__ float4 s_rd[FAST ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush
+    // (not for the dual mode and the modes with colour sums: their LDS is at three workgroups' worth already)
+    constexpr bool kPrivAcc = FNX_LANES_PRIVATE_ACC != 0 && !DUAL && NV <= 5;
+    __shared__ float4 s_rd[(FAST && !kPrivAcc) ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush
     constexpr int kAccStride = 272;
-    __shared__ float s_acc[NV][kAccStride];
+    constexpr int kAccCopies = kPrivAcc ? 4 : 1;  // kPrivAcc: one accumulator array per wave
+    __shared__ float s_acc[kAccCopies][NV][kAccStride];
     __shared__ __attribute__((aligned(16))) uint16_t s_list[4][kListStride];  // the list of the block a wave is walking
     __shared__ uint16_t s_mask[256];
     __shared__ uint32_t s_bmax[16];
@@ -424,7 +437,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 s_rb[tid] = make_float4((-0.5f * kL2e) * cur.rbx, __builtin_amdgcn_logf(fmaxf(cur.rby, 0.0f)), cur.rcz,
                                         C == 3 ? cur.rcw : wants_f);
                 if (C == 3 || kFusedGeom) s_rc[tid] = make_float4(cur.rdx, wants_f, kFusedGeom ? cur.mx : 0.f, kFusedGeom ? cur.my : 0.f);
-                s_rd[FAST ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
+                if (!kPrivAcc) s_rd[(FAST && !kPrivAcc) ? tid : 0] = make_float4(cur.ra.z, cur.ra.w, cur.rbx, cur.rby);
             } else {
                 s_ra[tid] = cur.ra;
                 s_rb[tid] = make_float4(cur.rbx, cur.rby, kFusedGeom ? cur.mx : 0.f, wants_f);
@@ -433,7 +446,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         }
         if (kFusedGeom) s_mz[kFusedGeom ? tid : 0] = cur.mz;
 #pragma unroll
-        for (int v = 0; v < NV; v++) s_acc[v][tid] = 0.f;
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int cp = 0; cp < kAccCopies; cp++) s_acc[cp][v][tid] = 0.f;  // (own slot in every copy: only this thread reads it)
         s_mask[tid] = (uint16_t)((uint32_t)tid < cnt ? cur.qm : 0u);
 #if FNX_LANES_DYNAMIC_BLOCKS
         if (tid == 0) s_next_block = 4u;  // blocks 0 .. 3 (in draw order) are the waves' first
@@ -443,6 +458,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         FNX_LCLK(2)  // wait at barrier B
         if (w == 0) { FNX_LCNT(8, 1) FNX_LCNT(9, cnt) }
 
+#if FNX_LANES_EARLY_RECORDS
+        fetch_records(nxt);  // lab: the next item's records in flight during the walk (14 registers)
+#endif
 #if FNX_LANES_EARLY_GATHER
         // this item's mean / covariance for the flush: requested HERE, in front of the walk (9 registers that the walk must
         // leave alone) -- requested behind the walk their round trip sat in front of every flush (ablation: 18 of 239 us)
@@ -687,7 +705,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
 #if FNX_LANES_NO_FOLD  // every row adds its own sums: NV LDS atomics with four lanes per address instead of the swaps
                     if (slot < 256u) {
 #pragma unroll
-                        for (int v = 0; v < NV; v++) atomicAdd(&s_acc[0][0] + v * kAccStride + slot, m[v]);
+                        for (int v = 0; v < NV; v++) atomicAdd(&s_acc[0][0][0] + v * kAccStride + slot, m[v]);
                     }
 #else
                     const int vq = ((r & 1) << 1) | (r >> 1);  // which value of a group of four this row ends up with
@@ -698,8 +716,13 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                         if (FNX_LABLATE & 64) {
                             asm volatile("" ::"v"(t));
                         } else if (FNX_LABLATE & 128) {  // plain store instead of the atomic: WRONG sums, what ds_add_f32 costs
-                            if (slot < 256u && g + vq < NV) (&s_acc[0][0])[(g + vq) * kAccStride + slot] = t;
-                        } else if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0] + (g + vq) * kAccStride + slot, t);
+                            if (slot < 256u && g + vq < NV) (&s_acc[0][0][0])[(g + vq) * kAccStride + slot] = t;
+                        } else if (kPrivAcc) {  // this wave's own array: no other wave touches it before barrier C
+                            if (slot < 256u && g + vq < NV) {
+                                float *pacc = &s_acc[kPrivAcc ? w : 0][0][0] + (g + vq) * kAccStride + slot;
+                                *pacc = *pacc + t;
+                            }
+                        } else if (slot < 256u && g + vq < NV) atomicAdd(&s_acc[0][0][0] + (g + vq) * kAccStride + slot, t);
                     }
 #endif
                 }
@@ -733,7 +756,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             }
         }
 #endif
+#if !FNX_LANES_EARLY_RECORDS
         fetch_records(nxt);  // in flight while the accumulators are flushed
+#endif
         FNX_LSUB(18)
         if (nxt.item != kNoItem) load_ahead(nxt);
         FNX_LSUB(19)
@@ -755,7 +780,9 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
             bool any = false;
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                a[v] = s_acc[v][tid];
+                a[v] = s_acc[0][v][tid];
+#pragma unroll
+                for (int cp = 1; cp < kAccCopies; cp++) a[v] += s_acc[cp < kAccCopies ? cp : 0][v][tid];
                 any |= (a[v] != 0.f);
             }
             if (any) {
@@ -763,8 +790,15 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
                 pf_id = id;
                 float4 ra = s_ra[tid];
                 float cc = s_rb[tid].x;
-                if (FAST) {
-                    const float4 rd = s_rd[FAST ? tid : 0];
+                if (FAST && kPrivAcc) {  // the staged coefficients are the conic's, pre-scaled; log2 of the opacity
+                    constexpr float kL2e = 1.44269504088896341f;
+                    const float lo = s_rb[tid].y;
+                    ra.z = ra.z * (-2.0f / kL2e);
+                    ra.w = ra.w * (-1.0f / kL2e);
+                    cc = cc * (-2.0f / kL2e);
+                    if (kAppearance) a[kAppearance ? kOpac : 0] = a[kAppearance ? kOpac : 0] / __builtin_amdgcn_exp2f(lo);
+                } else if (FAST) {
+                    const float4 rd = s_rd[(FAST && !kPrivAcc) ? tid : 0];
                     ra.z = rd.x;
                     ra.w = rd.y;
                     cc = rd.z;
