@@ -1210,6 +1210,10 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
         // stores in order, so a store issued in front of the mask computation (which waits for the batch's records) or of the
         // windows' LDS copies (which wait for the windows) was waited for as well -- a store's round trip on the chain of
         // every batch (round 5).  Nothing waits on vmcnt between here and the next batch's staging.
+#ifndef FNX_EXP_FWD_NOSTORE  // timing experiment (backward unusable): 1 no hand-over records, 2 no ids / masks either
+#define FNX_EXP_FWD_NOSTORE 0
+#endif
+        if (!(FNX_EXP_FWD_NOSTORE & 1))
         if (blending && base != r0 && !(SEG && nseg_t && !nseg && alive == 0.0f)) {  // (second round of a cut tile: the pixels it blends)
             // hand-over record: the pixel's state in front of this batch (the walk below changes it)
             if (SEG && nseg)  // a segment: the workgroup that puts the tile together reads it in this launch
@@ -1218,7 +1222,9 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
             bstate[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
             if (DUAL) bstate1[(size_t)(((base - r0) >> 8) - 1) * 256] = make_float2(d1.Tr, d1.acc);
         }
+        if (!(FNX_EXP_FWD_NOSTORE & 2))
         if (SPLIT && (uint32_t)tid < cnt) point_list[base + tid] = my_id;  // the merged order, as far as it is consumed
+        if (!(FNX_EXP_FWD_NOSTORE & 2))
         if ((uint32_t)tid < cnt && blending)  // the backward pass builds its lists from the same masks
             reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks)[base + tid] = (uint16_t)qm;
         FNX_LOOP_BARRIER_BC();
