@@ -81,7 +81,7 @@ __device__ __forceinline__ void packed_flush_add(float *strip, const uint32_t *i
 #define FNX_LANES_EARLY_RECORDS 0
 #endif
 #ifndef FNX_LANES_EARLY_GATHER
-#define FNX_LANES_EARLY_GATHER FNX_LANES_PRIVATE_ACC  // 1: in front of the walk -- nine more live registers there; at four waves per SIMD it spills: 249 against 240 us
+#define FNX_LANES_EARLY_GATHER 1  // (only in the builds with private accumulators: kEarlyGather)
 #endif
 #ifndef FNX_BWDL_WAVES
 #define FNX_BWDL_WAVES (FNX_LANES_PRIVATE_ACC ? 3 : 4)  // waves per SIMD the register allocation aims at
@@ -114,7 +114,14 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
     __shared__ float4 s_rb[257];  // conic c, opacity (FAST: log2 opacity), FAST: colour 0, colour 1 | wants; exact: -, wants
     __shared__ float4 s_rc[257];  // FAST C = 3: colour 2, wants; exact: colour
     // (not for the dual mode and the modes with colour sums: their LDS is at three workgroups' worth already)
-    constexpr bool kPrivAcc = FNX_LANES_PRIVATE_ACC != 0 && !DUAL && NV <= 5;
+#ifndef FNX_LANES_PRIVATE_MAXNV
+#define FNX_LANES_PRIVATE_MAXNV 9  // sums per entry up to which a wave gets its own accumulators (7, 9: two workgroups per compute unit, still mode 2: 319-326 -> 307 us, mode 0: 0.259 -> 0.241 ms per view forward + backward; the dual mode: 536 -> 655, off)
+#endif
+#ifndef FNX_LANES_PRIVATE_DUAL
+#define FNX_LANES_PRIVATE_DUAL 0
+#endif
+    constexpr bool kPrivAcc = FNX_LANES_PRIVATE_ACC != 0 && (!DUAL || FNX_LANES_PRIVATE_DUAL) && NV <= FNX_LANES_PRIVATE_MAXNV;
+    constexpr bool kEarlyGather = FNX_LANES_EARLY_GATHER != 0 && kPrivAcc;  // (the private-accumulator builds run three waves per SIMD)
     __shared__ float4 s_rd[(FAST && !kPrivAcc) ? 256 : 1];  // FAST: the entry's own conic and opacity for the flush
     constexpr int kAccStride = 272;
     constexpr int kAccCopies = kPrivAcc ? 4 : 1;  // kPrivAcc: one accumulator array per wave
@@ -461,12 +468,11 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
 #if FNX_LANES_EARLY_RECORDS
         fetch_records(nxt);  // lab: the next item's records in flight during the walk (14 registers)
 #endif
-#if FNX_LANES_EARLY_GATHER
-        // this item's mean / covariance for the flush: requested HERE, in front of the walk (9 registers that the walk must
-        // leave alone) -- requested behind the walk their round trip sat in front of every flush (ablation: 18 of 239 us)
+        // this item's covariance (the mean came with the record) for the flush: requested HERE, in front of the walk, by the
+        // builds that have the registers for it (kEarlyGather: three waves per SIMD) -- requested behind the walk the round trip
+        // sits in front of every flush (ablation: 18 of 239 us); at four waves per SIMD it spills (249 against 240 us)
         float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (kFusedGeom && (uint32_t)tid < cnt) {
-            const uint32_t gid = cur.id;
+        auto request_cov = [&](uint32_t gid) {
             if (FNX_LABLATE & 2) {
                 gmean[0] = 0.1f, gmean[1] = 0.2f, gmean[2] = -0.3f;
                 gcov[0] = gcov[3] = gcov[5] = 1e-4f;
@@ -475,8 +481,8 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
 #pragma unroll
                 for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
             }
-        }
-#endif
+        };
+        if (kEarlyGather && kFusedGeom && (uint32_t)tid < cnt) request_cov(cur.id);
         // ---- walk: one block of every quadrant per wave ----------------------------------------------------------------
 #if FNX_LANES_DYNAMIC_BLOCKS
         // the sixteen blocks are handed out by an LDS counter (a wave that drew short lists takes more of them); the first
@@ -740,22 +746,7 @@ blend_backward_lanes_kernel(int T, int gx, const uint32_t *__restrict__ ranges, 
         asm volatile("" ::"v"(nxt.id), "v"(nxt.qm));
         FNX_LSUB(17)  // wait for the next item's ids
 #endif
-#if !FNX_LANES_EARLY_GATHER
-        // this item's mean / covariance for the flush: requested HERE, in front of the walk (9 registers that the walk must
-        // leave alone) -- requested behind the walk their round trip sat in front of every flush (ablation: 18 of 239 us)
-        float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (kFusedGeom && (uint32_t)tid < cnt) {
-            const uint32_t gid = s_id[tid];
-            if (FNX_LABLATE & 2) {
-                gmean[0] = 0.1f, gmean[1] = 0.2f, gmean[2] = -0.3f;
-                gcov[0] = gcov[3] = gcov[5] = 1e-4f;
-            } else if (gid < grad_limit) {
-                const float *cv = view_at(cov3Ds, cov3D_stride, vw) + 6 * (size_t)gid;
-#pragma unroll
-                for (int kx = 0; kx < 6; kx++) gcov[kx] = cv[kx];
-            }
-        }
-#endif
+        if (!kEarlyGather && kFusedGeom && (uint32_t)tid < cnt) request_cov(s_id[tid]);
 #if !FNX_LANES_EARLY_RECORDS
         fetch_records(nxt);  // in flight while the accumulators are flushed
 #endif
