@@ -263,7 +263,7 @@ struct ProfClass {
 uint32_t g_deep_min = 1024;  // list depth from which a tile is scheduled first in the next blend forward
 int g_sort_narrow = 0;       // the fourth depth-sort pass is not launched (fnx_set_sort_narrow)
 int g_lean_geometry = 0;     // view batches: skip the unread GeometryState copies, one world covariance for all views
-int g_deep_kernel = 0;       // fast mode: deep tiles go to the super-batch kernel (fnx_set_deep_kernel); off by default
+int g_deep_kernel = 5;       // which blend forward kernel takes which tiles (fnx_set_deep_kernel); 5: by the launch's view count
 int g_blend_math = 0;        // 0: bit-reproducible arithmetic (fixed exp sequence, no contraction), 1: fast (fnx_set_blend_math)
 // Deprecated one-shot requests: per host thread, and TAKEN (cleared) at the top of the entry point they are meant for,
 // whatever that call then returns -- an early return can no longer leave a stale pointer or limit armed for an
@@ -312,7 +312,7 @@ int resolve_opts(const fnx_raster_opts_t *o, float *pending_zero3, uint32_t pend
     if (out->sort_mode < FNX_SORT_FULL || out->sort_mode > FNX_SORT_COHERENT) return fail(FNX_ERR_INVALID_ARG, "bad sort_mode");
     if (out->sort_mode == FNX_SORT_COHERENT && !out->sort_state)
         return fail(FNX_ERR_INVALID_ARG, "sort_mode FNX_SORT_COHERENT needs fnx_raster_opts_t.sort_state");
-    if (out->deep_kernel < 0 || out->deep_kernel > 2) return fail(FNX_ERR_INVALID_ARG, "deep_kernel must be 0, 1 or 2");
+    if (out->deep_kernel < 0 || out->deep_kernel > 5) return fail(FNX_ERR_INVALID_ARG, "deep_kernel must be 0 .. 5");
     return FNX_OK;
 }
 bool g_prof_on = false;
@@ -904,7 +904,9 @@ int fnx_set_lean_geometry(int on) {
     return FNX_OK;
 }
 int fnx_set_deep_kernel(int mode) {
-    if (mode < 0 || mode > 2) return fail(FNX_ERR_INVALID_ARG, "deep kernel mode must be 0 (off), 1 (auto) or 2 (always)");
+    if (mode < 0 || mode > 5)
+        return fail(FNX_ERR_INVALID_ARG, "deep kernel mode must be 0 (per-tile kernel only), 1 / 2 (lab super-batch kernel: auto / always), "
+                                         "3 / 4 (staging waves: deep tiles / all tiles) or 5 (staging waves by the launch's view count, the default)");
     g_deep_kernel = mode;
     return FNX_OK;
 }

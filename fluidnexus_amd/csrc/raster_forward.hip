@@ -905,7 +905,9 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
     }
     const int tile = tile_;
     if (tile_deep[tile]) {
-        if (skip_deep) {  // blend_forward_deep_kernel takes the tiles that went deep in the previous forward
+        // blend_forward_deep_kernel / blend_forward_ws_kernel takes the tiles that went deep in the previous forward (the
+        // first skip_deep of the view's order at most: they lead it)
+        if (wg_rank < skip_deep) {
             if (FNX_INV_LATE) write_inv();
             return;
         }
@@ -1582,6 +1584,7 @@ again:  // (SEG: the workgroup that put a tile's segments together comes back he
 }
 
 #include "lab/blend_forward_deep.h"  // K5b: opt-in super-batch forward for deep tiles (lab)
+#include "raster_forward_ws.h"       // staging waves (deep_kernel = 3 / 4)
 
 // rasterizer_impl.cu:52-63
 __global__ void __launch_bounds__(256)
@@ -1680,6 +1683,22 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     // launch is bound by its longest walks -- few views per launch (a rank's share of a sharded batch) -- and costs
     // throughput when thousands of other tiles wait for those compute units: deep = 1 (auto) uses it up to two views.
     const int use_deep = (fast && depth_hint && !du.img1 && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
+    // deep = 3: the deep tiles go to the staging-wave kernel (raster_forward_ws.h; both arithmetics, bit-identical to the
+    // per-tile kernel) on the helper stream; deep = 4: every tile does, instead of the per-tile kernel
+    const bool ws_ok = !du.img1 && !(sg.base && fast && !materialize_all && depth_hint);
+    // deep = 5 (the default): by the number of views in the launch -- one or two views are bound by their deepest tiles'
+    // chains (a one-view forward of config 3: 233 us, of which the five-view launch adds only 70) and take the staging waves
+    // for every tile (233 -> 166 us), three views for the deep tiles only, more views are bound by the compute units'
+    // instruction throughput and keep the per-tile kernel (measured)
+    if (deep == 5) deep = !ws_ok ? 0 : V <= 2 ? 4 : (V == 3 && depth_hint) ? 3 : 0;
+    const int use_ws = (ws_ok && deep == 3 && depth_hint) ? 1 : (ws_ok && deep == 4) ? 2 : 0;
+    // deep tiles per view the staging-wave launch takes (the deepest ones: they lead the order; the rest stay with the
+    // per-tile kernel).  FNX_WS_MAX (developer switch, multiple of 8) overrides it.
+    static const int kWsDeepMax = [] {
+        const char *e = getenv("FNX_WS_MAX");
+        const int v = e ? atoi(e) : 512;
+        return v < 8 ? 8 : (v + 7) & ~7;
+    }();
     // the two kernels touch disjoint tiles: the deep one runs on a helper stream beside the per-tile kernel
     // (one helper per caller stream and device: two renders on two streams -- the 3-channel and the 1-channel one of a
     // dual-channel iteration -- may be in flight, or being captured into two branches of a graph, at the same time)
@@ -1695,7 +1714,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     hipStream_t helper = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t sd = s;
-    if (use_deep) {
+    if (use_deep || use_ws == 1) {
         const int n_cu = device_cu_count();
         {
             int dev = 0;
@@ -1726,12 +1745,32 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     hipLaunchKernelGGL((blend_forward_deep_kernel<CC, SS>), dim3(n_cu), dim3(256 * FNX_DEEP_GROUPS), 0, sd, T, gx,     \
                        ranges, point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header,      \
                        capacity, tile_count, dyn_start, acc_final, tile_order, depth_hint, st, materialize_all, vb, V)
+#define FNX_LAUNCH_WS(CC, SS, FF, GX, DEEP_ONLY, ST)                                                                    \
+    hipLaunchKernelGGL((blend_forward_ws_kernel<CC, SS, FF>), dim3(GX, V), dim3(512), 0, ST, T, gx, ranges, point_list, \
+                       W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,    \
+                       tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
+                       DEEP_ONLY, dyn_limit, iu)
+#define FNX_LAUNCH_WS_ALL(GX, DEEP_ONLY, ST)                                                                            \
+    do {                                                                                                               \
+        if (C == 3 && st.base) { if (fast) FNX_LAUNCH_WS(3, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(3, true, false, GX, DEEP_ONLY, ST); } \
+        else if (C == 3) { if (fast) FNX_LAUNCH_WS(3, false, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(3, false, false, GX, DEEP_ONLY, ST); }     \
+        else if (st.base) { if (fast) FNX_LAUNCH_WS(1, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, true, false, GX, DEEP_ONLY, ST); }      \
+        else { if (fast) FNX_LAUNCH_WS(1, false, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, false, false, GX, DEEP_ONLY, ST); }                 \
+    } while (0)
+        if (use_ws == 1) {
+            FNX_LAUNCH_WS_ALL(std::min((T + 7) & ~7, kWsDeepMax), 1, sd);
+        } else
         if (C == 3 && st.base) FNX_LAUNCH_BD(3, true);
         else if (C == 3) FNX_LAUNCH_BD(3, false);
         else if (st.base) FNX_LAUNCH_BD(1, true);
         else FNX_LAUNCH_BD(1, false);
 #undef FNX_LAUNCH_BD
     }
+    if (use_ws == 2) {
+        FNX_LAUNCH_WS_ALL((T + 7) & ~7, 0, s);
+        return;
+    }
+    const int skip_deep = use_ws == 1 ? kWsDeepMax : use_deep ? 0x7FFFFFFF : 0;
 #define FNX_LAUNCH_BF(CC, SS)                                                                                          \
     if (fast)                                                                                                          \
         FNX_LAUNCH_BF_(CC, SS, true);                                                                                  \
@@ -1743,14 +1782,14 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       use_deep, dyn_limit, iu, du, sg)
+                       skip_deep, dyn_limit, iu, du, sg)
     // segmented deep tiles (the work list tile_scan_kernel left in the segment scratch): fast arithmetic, one image
-    const bool use_seg = sg.base && fast && !du.img1 && !materialize_all && !use_deep && depth_hint;
+    const bool use_seg = sg.base && fast && !du.img1 && !materialize_all && !use_deep && !use_ws && depth_hint;
 #define FNX_LAUNCH_SEG(CC, SS)                                                                                         \
     hipLaunchKernelGGL((blend_forward_kernel<CC, SS, true, false, true>), dim3((T + (int)kSegMax + 7) & ~7, V), dim3(256), \
                        0, s, T, gx, ranges, point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth,  \
                        header, capacity, status_out, tile_count, dyn_start, acc_final, tile_order, tile_deep,           \
-                       depth_hint, st, materialize_all, vb, use_deep, dyn_limit, iu, du, sg)
+                       depth_hint, st, materialize_all, vb, skip_deep, dyn_limit, iu, du, sg)
     if (use_seg) {
         if (C == 3 && st.base) { FNX_LAUNCH_SEG(3, true); }
         else if (C == 3) { FNX_LAUNCH_SEG(3, false); }
@@ -1769,7 +1808,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
 #undef FNX_LAUNCH_BF_
 #undef FNX_LAUNCH_BF__
 #undef FNX_LAUNCH_SEG
-    if (use_deep && sd != s) {  // join
+    if ((use_deep || use_ws == 1) && sd != s) {  // join
         (void)hipEventRecord(ev_join, sd);
         (void)hipStreamWaitEvent(s, ev_join, 0);
     }

@@ -332,6 +332,13 @@ class HotLoop:
         if self.fused_step:
             assert self.batched_views and capturable, "fused_step needs batched_views and capturable=True"
         self.view_streams = []
+        # View groups (round 6, FNX_VIEW_GROUPS="3,2" or the attribute): the local views' render -> image loss -> backward
+        # chains run as that many INDEPENDENT view batches on streams of their own (parallel branches of the captured graph)
+        # instead of one launch sequence over all views: the tail of one group's blend kernels -- a few deep tiles on
+        # otherwise idle compute units -- lies under the other group's kernels.  None: one batch (the default).
+        vg = os.environ.get("FNX_VIEW_GROUPS", "")
+        self.view_groups = [int(x) for x in vg.replace("+", ",").split(",") if x.strip()] if vg else None
+        self.group_streams = []
         gm.training_setup_current(self.optim_args, capturable=capturable)
         self.itr = 0
         self.last = {}
@@ -343,6 +350,20 @@ class HotLoop:
         # accumulation is bound to the stream a leaf was first used on, and a leaf first used on the
         # default stream would drag that stream into the capture.
         self.stream = torch.cuda.Stream(device=dev) if capturable else None
+
+    def _group_lists(self, mine):
+        """The local views cut into `view_groups` consecutive groups (sizes; a remainder joins the last group)."""
+        if not self.view_groups or len(mine) < 2:
+            return [mine]
+        out, at = [], 0
+        for n in self.view_groups:
+            if at >= len(mine):
+                break
+            out.append(mine[at:at + n])
+            at += n
+        if at < len(mine):
+            out[-1] = out[-1] + mine[at:]
+        return out
 
     def _mine(self, batch):
         """Views of the batch this rank renders: its round-robin share, or an explicit `view_subset` (single-process
@@ -596,7 +617,7 @@ class HotLoop:
         if self._gt_cache is None:
             self._gt_cache = {}
         imgs = [getattr(self.cams[v], attr) for v in mine]
-        key = (attr, bool(grey_mean))
+        key = (attr, bool(grey_mean), tuple(mine))
         hit = self._gt_cache.get(key)
         if hit is None or len(hit[0]) != len(imgs) or any(a is not b for a, b in zip(hit[0], imgs)):
             stack = torch.stack(imgs).contiguous()
@@ -720,7 +741,13 @@ class HotLoop:
                 from .renderer import pipes as _pipes
                 dual_fused = (self.dual_channel and _DUAL_FUSED and not _SCREEN_GRAD and _pipes._STATIC_SPLIT
                               and gm.get_gs_xyz.shape[0] > 0)
-                pkg = render_dynamics_views([self.cams[v] for v in mine], gm, None, self.background,
+                # view groups: the first group takes the place of the one batch; the others follow on their own streams below
+                groups = self._group_lists(mine) if not self.dual_channel else [mine]
+                first = groups[0]
+                if len(groups) > 1:
+                    fork_g = torch.cuda.Event()
+                    fork_g.record(main)
+                pkg = render_dynamics_views([self.cams[v] for v in first], gm, None, self.background,
                                             GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
                                             scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD,
                                             dual_bg=self.background[:1] if dual_fused else None)
@@ -731,7 +758,7 @@ class HotLoop:
         if mine:
             dimg_ready = None
             if use_dist and _DIST_AT == "loss":  # the image term first: the distance branch forks behind it
-                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine, grey_mean=_GT_GREY), c["lambda_dssim"],
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(first, grey_mean=_GT_GREY), c["lambda_dssim"],
                                                                  c["lambda_image"])
                 dimg_ready = (loss, per_view, dimg)
                 fork_d.record(main)
@@ -766,7 +793,7 @@ class HotLoop:
             if dimg_ready is not None:
                 loss, per_view, dimg = dimg_ready
             else:
-                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(mine, grey_mean=_GT_GREY), c["lambda_dssim"],
+                loss, per_view, dimg = image_loss_value_and_grad(pkg["render"].detach(), self._gt_stack(first, grey_mean=_GT_GREY), c["lambda_dssim"],
                                                                  c["lambda_image"])
             if self.log_scalars:
                 self.last = dict(l1=per_view[-1, 0].item(), ssim=1.0 - per_view[-1, 1].item(), total=loss.item())
@@ -805,6 +832,24 @@ class HotLoop:
                 outs.append(pkg1["render"])
                 seeds.append(dimg1)
             g_means, = torch.autograd.grad(outs, [means3D], grad_outputs=seeds)
+            if len(groups) > 1:
+                # the other groups' chains (render -> image term -> backward), each a view batch of its own (camera tensors,
+                # static bins, sort states and depth hints are kept per camera set) on a stream of its own: parallel branches
+                # of the captured graph from the point where the rendered positions exist to the sum of the gradients
+                while len(self.group_streams) < len(groups) - 1:
+                    self.group_streams.append(torch.cuda.Stream(device=gm._xyz.device))
+                for gi, grp in enumerate(groups[1:]):
+                    gs = self.group_streams[gi]
+                    gs.wait_event(fork_g)
+                    with torch.cuda.stream(gs):
+                        pkg2 = render_dynamics_views([self.cams[v] for v in grp], gm, None, self.background,
+                                                     GRsetting=self.GRsetting, GRzer=self.GRzer, pos_type="guess_visual_nn",
+                                                     scale=True, means3D=means3D, screen_grad=_SCREEN_GRAD)
+                        _, _, dimg2 = image_loss_value_and_grad(pkg2["render"].detach(), self._gt_stack(grp, grey_mean=_GT_GREY),
+                                                                c["lambda_dssim"], c["lambda_image"])
+                        g2, = torch.autograd.grad([pkg2["render"]], [means3D], grad_outputs=[dimg2])
+                    main.wait_stream(gs)
+                    g_means = g_means.add_(g2)
             extra = None
             if gd is not None:  # added inside the hidden<-visual backward instead of by a pass over g_means
                 main.wait_stream(self.dist_stream)

@@ -57,7 +57,7 @@ def set_deep_variant(enabled: bool, min_depth: int | None = None):
 # forward to the library's deprecated process-wide setters, which only the single-view entry points still read.
 SORT_NARROW_MAX_BITS = 25   # widest depth-key span (bits) for which callers switch to the three-pass sort: two below the
                             # 27 bits three 9-bit passes order
-_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=0, coherent_sort=0, sort_key=None,
+_OPTS = dict(blend_math=0, lean_geometry=0, sort_narrow=0, deep_kernel=5, coherent_sort=0, sort_key=None,
              segments=1 if os.environ.get("FNX_SEG_FORWARD", "0") == "1" else 0)
 
 

@@ -362,10 +362,17 @@ int fnx_get_blend_math(void);
  * (csrc/raster_forward.hip, blend_forward_deep_kernel), on a helper stream beside the per-tile kernel.  A deep
  * workgroup holds a whole compute unit to cut the tile's latency: it pays when a launch is bound by its longest walks
  * (one or two views per launch: a rank's share of a sharded batch) and costs throughput otherwise.
- * mode 0 (default): never; 1: launches of at most two views; 2: always.
+ * mode 0: never; 1: launches of at most two views; 2: always.
  * Measured: a one-view forward alone 259 -> 171 us, but inside the replayed iteration the 1024-thread
  * workgroups wait for an empty compute unit behind the per-tile kernel's workgroups and the iteration gets slower
- * (config 3, 2 of 5 views: 1251 -> 1216 it/s), so it is opt-in. */
+ * (config 3, 2 of 5 views: 1251 -> 1216 it/s), so it is opt-in.
+ * Modes 3 .. 5 (round 6), both arithmetics, one image: the blend forward with STAGING WAVES (csrc/raster_forward_ws.h,
+ * blend_forward_ws_kernel) -- 512 threads per tile, four waves walk a batch while four others stage the next one into the
+ * other half of double-buffered LDS arrays; per pixel the per-tile kernel's arithmetic in its order, outputs bit-equal to
+ * its (tests/test_staging_waves_gpu.py).  3: the tiles that went deep in the previous forward, on a helper stream beside
+ * the per-tile kernel; 4: every tile, instead of the per-tile kernel; 5 (DEFAULT): by the number of views in the launch --
+ * 4 for one or two views, 3 for three, the per-tile kernel for more (a launch of few views is bound by its deepest tiles'
+ * chains, a launch of many by the compute units' instruction throughput: DESIGN.md 4.11). */
 int fnx_set_deep_kernel(int mode);
 /* Which form of the blend BACKWARD the next calls run (process-wide; both are parity-tested against the oracle, same work
  * items, same staging, same gradients within the backward's stated fp32 bound -- the sums are associated differently):

@@ -1,0 +1,103 @@
+"""-m gpu: the blend forward with staging waves (csrc/raster_forward_ws.h, deep_kernel = 3: the tiles that went deep in the
+previous forward, beside the per-tile kernel; = 4: every tile) against the per-tile kernel.
+
+Per pixel the staging-wave kernel runs the per-tile kernel's arithmetic in the per-tile kernel's order -- it only moves
+the staging of a batch to other waves -- so colours, depths, final T, last contributors and the tiles' depth hints are
+BIT-EQUAL in both arithmetics (and through the per-tile kernel's own tests therefore equal to the oracle's in the exact
+one); gradients agree within the backward's mixed bound (the backward reads the hand-over records, masks and merged ids
+this kernel wrote; its work items arrive in another order, so its sums associate differently)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from fluidnexus_amd import synthetic as S  # noqa: E402
+from tests.test_fast_math_gpu import mixed_bound_report  # noqa: E402
+
+
+def _render(g, cams, W, H, bg_np, channels, deep_mode, math_mode, min_depth=256, static_split=False, seed=4, rounds=3):
+    import torch
+    from fluidnexus_amd import rasterizer
+    from fluidnexus_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizerViews, StaticBin
+    rasterizer.set_blend_math(math_mode)
+    rasterizer.set_deep_kernel(deep_mode)
+    rasterizer.set_deep_variant(True, min_depth)
+    rasterizer.keep_last_blobs(True)
+    try:
+        t = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+        bg = torch.from_numpy(bg_np).cuda()
+        tan = math.tan(0.4)
+        rs = [GaussianRasterizationSettings(H, W, tan, tan, bg, 1.0, c.world_view_transform.cuda(), c.full_proj_transform.cuda(),
+                                            0, c.camera_center.cuda(), False) for c in cams]
+        rz = GaussianRasterizerViews(rs, channels=channels)
+        P, V = t["means3D"].shape[0], len(cams)
+        if static_split:
+            n_dyn = static_split
+            rz.static_bin = StaticBin(rz.view_batch, t["means3D"][n_dyn:], t["opacities"][n_dyn:], colors_precomp=t["colors"][n_dyn:],
+                                      scales=t["scales"][n_dyn:], rotations=t["rotations"][n_dyn:], channels=channels,
+                                      id_offset=n_dyn)
+            rz.grad_splat_limit = n_dyn
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        out = None
+        for _ in range(rounds):  # the later forwards see the depth hints of the earlier ones: deep tiles exist
+            m2d = torch.zeros(V, P, 3, device="cuda", requires_grad=True)
+            out = rz(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                     scales=leaves["scales"], rotations=leaves["rotations"])
+        hint = rz.view_batch.depth_hint(channels)
+        dL = torch.from_numpy(np.random.RandomState(seed).normal(size=tuple(out[0].shape)).astype(np.float32)).cuda()
+        gl = torch.autograd.grad([out[0]], [leaves["means3D"], leaves["opacities"], leaves["colors"], leaves["scales"],
+                                            leaves["rotations"]], grad_outputs=[dL])
+        grads = [x.detach().cpu().numpy() for x in gl]
+        torch.cuda.synchronize()
+        rasterizer.check_status()
+        return dict(color=out[0].detach().cpu().numpy(), depth=out[2].detach().cpu().numpy(), hint=hint.cpu().numpy(),
+                    walked=rasterizer.walked_entries(), grads=grads)
+    finally:
+        rasterizer.set_deep_kernel(0)
+        rasterizer.set_deep_variant(True, 1024)
+        rasterizer.set_blend_math("exact")
+        rasterizer.keep_last_blobs(False)
+
+
+@pytest.mark.parametrize("math_mode", ["exact", "fast"])
+@pytest.mark.parametrize("channels,split", [(3, False), (1, False), (3, True)])
+@pytest.mark.parametrize("deep_mode", [3, 4])
+def test_staging_wave_forward_is_bit_equal_to_the_per_tile_kernel(channels, split, deep_mode, math_mode):
+    W = H = 160
+    n_dyn = 14_000
+    g = S.smoke_scene(n_dyn, 6_000, seed=9, channels=3, ring=True) if channels == 3 else S.plume_gaussians(n_dyn, seed=9, channels=1)
+    cams = S.ring_cameras(8, W, H, device="cpu")[3:6]
+    bg = np.array([0.05, 0.1, 0.2], np.float32)
+    sp = n_dyn if split else False
+    a = _render(g, cams, W, H, bg, channels, deep_mode, math_mode, static_split=sp)
+    r = _render(g, cams, W, H, bg, channels, 0, math_mode, static_split=sp)
+    assert int((r["hint"] >= 256).sum()) > 10, "the scene must have deep tiles"
+    for k in ("color", "depth", "hint"):
+        x, y = a[k], r[k]
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert (x == y).all(), f"{k}: {int((x != y).sum())} of {x.size} words differ from the per-tile kernel's"
+    assert a["walked"] == r["walked"] or a["walked"] is None, f"entry counters differ: {a['walked']} vs {r['walked']}"
+    names = ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")
+    bad = []
+    for n, x, y in zip(names, a["grads"], r["grads"]):
+        lim = n_dyn if split else x.shape[0]
+        ok, msg = mixed_bound_report(y[:lim], x[:lim])
+        if not ok:
+            bad.append(n + ": " + msg)
+    assert not bad, "\n".join(bad)
+
+
+def test_staging_wave_forward_on_empty_and_single_batch_tiles():
+    """A sparse scene: most tiles are empty or hold a single short batch; every tile goes through the staging-wave kernel."""
+    W, H = 200, 120  # ragged: the last tile column / row is cut by the image border
+    g = S.random_gaussians(600, seed=3, log_scale=(-4.5, -2.5), channels=3)
+    cams = [S.front_camera(W, H, device="cpu")]
+    bg = np.array([0.3, 0.2, 0.1], np.float32)
+    for math_mode in ("exact", "fast"):
+        a = _render(g, cams, W, H, bg, 3, 4, math_mode, rounds=2)
+        r = _render(g, cams, W, H, bg, 3, 0, math_mode, rounds=2)
+        for k in ("color", "depth"):
+            assert (a[k].view(np.uint32) == r[k].view(np.uint32)).all(), k

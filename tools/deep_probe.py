@@ -19,6 +19,8 @@ else:
 bg = torch.zeros(3, device="cuda")
 rasterizer.set_host_sync(False)
 rasterizer.set_blend_math(os.environ.get("FNX_MATH", "exact"))
+if os.environ.get("FNX_DEEP_KERNEL"):
+    rasterizer.set_deep_kernel(int(os.environ["FNX_DEEP_KERNEL"]))
 with torch.no_grad():
     for _ in range(3):
         f()
@@ -39,6 +41,16 @@ if hasattr(lib, "fnx_debug_fwd_clock"):
     for w in range(4):
         v = [int(x) for x in buf[16 * w:16 * w + 16]]
         print("wave", w, dict(loop_top=v[0], all_done_barrier=v[1], masks_and_stores=v[4], barrier_b=v[5], list_build=v[6], merge_search=v[7], barrier_c=v[10], fetch_next=v[2], blend_loop=v[3], sum_n_w=v[8], batches=v[9], list_length=v[15]))
+if hasattr(lib, "fnx_debug_ws_clock") and os.environ.get("FNX_DEEP_KERNEL", "0") in ("3", "4"):
+    buf = (C.c_ulonglong * 128)()
+    lib.fnx_debug_ws_clock(buf)
+    for w in range(8):
+        v = [int(x) for x in buf[16 * w:16 * w + 16]]
+        if w < 4:
+            print("walker", w, dict(loop_top=v[0], wait_for_batch=v[1], walk=v[2], batches=v[9], list_length=v[15]))
+        else:
+            print("stager", w - 4, dict(loop_top=v[0], wait_for_buffer=v[1], records_masks_stores=v[2], sbar1=v[3], lists=v[4],
+                                        merge=v[5], sbar2=v[6], advance_requests=v[7]))
 if hasattr(lib, "fnx_debug_fwd_stats"):
     buf = (C.c_ulonglong * 8)()
     lib.fnx_debug_fwd_stats(buf, 1)
