@@ -1685,7 +1685,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     const int use_deep = (fast && depth_hint && !du.img1 && (deep == 2 || (deep == 1 && V <= 2))) ? 1 : 0;
     // deep = 3: the deep tiles go to the staging-wave kernel (raster_forward_ws.h; both arithmetics, bit-identical to the
     // per-tile kernel) on the helper stream; deep = 4: every tile does, instead of the per-tile kernel
-    const bool ws_ok = !du.img1 && !(sg.base && fast && !materialize_all && depth_hint);
+    const bool ws_ok = !(sg.base && fast && !du.img1 && !materialize_all && depth_hint);
     // deep = 5 (the default): by the number of views in the launch -- one or two views are bound by their deepest tiles'
     // chains (a one-view forward of config 3: 233 us, of which the five-view launch adds only 70) and take the staging waves
     // for every tile (233 -> 166 us), three views for the deep tiles only, more views are bound by the compute units'
@@ -1745,14 +1745,16 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     hipLaunchKernelGGL((blend_forward_deep_kernel<CC, SS>), dim3(n_cu), dim3(256 * FNX_DEEP_GROUPS), 0, sd, T, gx,     \
                        ranges, point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header,      \
                        capacity, tile_count, dyn_start, acc_final, tile_order, depth_hint, st, materialize_all, vb, V)
-#define FNX_LAUNCH_WS(CC, SS, FF, GX, DEEP_ONLY, ST)                                                                    \
-    hipLaunchKernelGGL((blend_forward_ws_kernel<CC, SS, FF>), dim3(GX, V), dim3(512), 0, ST, T, gx, ranges, point_list, \
-                       W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,    \
-                       tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
-                       DEEP_ONLY, dyn_limit, iu)
+#define FNX_LAUNCH_WS(CC, SS, FF, GX, DEEP_ONLY, ST) FNX_LAUNCH_WS_(CC, SS, FF, false, GX, DEEP_ONLY, ST)
+#define FNX_LAUNCH_WS_(CC, SS, FF, DD, GX, DEEP_ONLY, ST)                                                              \
+    hipLaunchKernelGGL((blend_forward_ws_kernel<CC, SS, FF, DD>), dim3(GX, V), dim3(512), 0, ST, T, gx, ranges,        \
+                       point_list, W, H, blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity,    \
+                       status_out, tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st,            \
+                       materialize_all, vb, DEEP_ONLY, dyn_limit, iu, du)
 #define FNX_LAUNCH_WS_ALL(GX, DEEP_ONLY, ST)                                                                            \
     do {                                                                                                               \
-        if (C == 3 && st.base) { if (fast) FNX_LAUNCH_WS(3, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(3, true, false, GX, DEEP_ONLY, ST); } \
+        if (du.img1) { if (fast) FNX_LAUNCH_WS_(3, true, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS_(3, true, false, true, GX, DEEP_ONLY, ST); } \
+        else if (C == 3 && st.base) { if (fast) FNX_LAUNCH_WS(3, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(3, true, false, GX, DEEP_ONLY, ST); } \
         else if (C == 3) { if (fast) FNX_LAUNCH_WS(3, false, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(3, false, false, GX, DEEP_ONLY, ST); }     \
         else if (st.base) { if (fast) FNX_LAUNCH_WS(1, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, true, false, GX, DEEP_ONLY, ST); }      \
         else { if (fast) FNX_LAUNCH_WS(1, false, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, false, false, GX, DEEP_ONLY, ST); }                 \

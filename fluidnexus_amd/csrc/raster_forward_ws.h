@@ -33,7 +33,7 @@ extern "C" int fnx_debug_ws_clock(unsigned long long *host) {
 #else
 #define FNX_WCLK(i)
 #endif
-template <int C, bool SPLIT, bool FAST>
+template <int C, bool SPLIT, bool FAST, bool DUAL = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FNX_FWD_WAVES, FNX_FWD_WAVES)))
 blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_t *__restrict__ point_list, int W,
                         int H, const float4 *__restrict__ blend_rec, const float *__restrict__ bg,
@@ -43,7 +43,8 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                         const uint32_t *__restrict__ dyn_start, float *__restrict__ acc_final,
                         const uint32_t *__restrict__ tile_order, const uint8_t *__restrict__ tile_deep,
                         uint32_t *__restrict__ depth_hint, const StaticRef st, int materialize_all, const ViewBatch vb,
-                        int deep_only, uint32_t dyn_limit, const InvUpdate iu) {
+                        int deep_only, uint32_t dyn_limit, const InvUpdate iu, const DualRef du) {
+    static_assert(!DUAL || (C == 3 && SPLIT), "dual mode: three channels, static-split lists");
     const char *static_blob = nullptr;
     // workgroup -> (view, rank in the view's tile order): blend_forward_kernel's mapping
     const int wg_linear = blockIdx.y * gridDim.x + blockIdx.x, n_views = gridDim.y;
@@ -78,6 +79,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             static_blob = st.base + st.stride * vw;
         }
     }
+    char *img1 = DUAL ? du.img1 + vb.img * (size_t)wg_view : nullptr;  // DUAL: the second image's per-pixel arrays
     constexpr int kGroup = FNX_FWD_GROUP;
     constexpr int kListStride = (256 + kGroup + 7) & ~7;
     __shared__ float4 s_ra[2][257];
@@ -323,11 +325,13 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t mk = (uint32_t)s_mask[64 * k + lane] >> (4 * w);
+                    // DUAL: a static splat's entry is marked in its list word (staging wave k left the batch's dynamic flags)
+                    const uint32_t flag = (DUAL && !((s_dynmask[p][k] >> lane) & 1ull)) ? kListStatic : 0u;
 #pragma unroll
                     for (int bb = 0; bb < 4; bb++) {
                         const bool bit = ((mk >> bb) & 1u) && ((live >> bb) & 1u);
                         const unsigned long long m = __ballot(bit);
-                        if (bit) s_list[p][4 * w + bb][len[bb] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)((64 * k + lane) * 16);
+                        if (bit) s_list[p][4 * w + bb][len[bb] + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(((64 * k + lane) * 16) | flag);
                         len[bb] += (uint32_t)__popcll(m);
                     }
                 }
@@ -390,12 +394,21 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
 #pragma unroll
         for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
         float Dm = 15.0f;
+        DualPixel d1;  // DUAL: the second image's pixel
+        d1.acc = 0.f;
+        d1.Tr = 1.0f;
+        d1.alive = inside ? 1.0f : 0.0f;
+        d1.Dm = 15.0f;
+        d1.hit_off = 0xFFFFFFFFu;
+        uint32_t last_contributor1 = 0;
         float4 *bstate = reinterpret_cast<float4 *>(reinterpret_cast<char *>(point_list) + vb.bin_bstate) +
                          (size_t)(r0 >> 8) * 256 + sid;
+        float2 *bstate1 = DUAL ? reinterpret_cast<float2 *>(reinterpret_cast<char *>(point_list) + du.bin_bstate1) +
+                                     (size_t)(r0 >> 8) * 256 + sid : nullptr;
         uint32_t b = 0;
         for (uint32_t base = b_lo; base < b_hi; base += 256, b++) {
             const int p = (int)(b & 1u);
-            const bool wave_done = __all(alive == 0.0f);
+            const bool wave_done = __all(alive == 0.0f && (!DUAL || d1.alive == 0.0f));
             FNX_WCLK(0)
             bool ended = false;
             for (;;) {  // the batch, or the word that there will be none
@@ -411,6 +424,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             FNX_WCLK(1)
             if (base != r0)  // hand-over record of the backward pass: the pixel's state in front of this batch
                 bstate[(size_t)(b - 1u) * 256] = make_float4(Tr, acc[0], acc[C > 1 ? 1 : 0], acc[C > 2 ? 2 : 0]);
+            if (DUAL && base != r0) bstate1[(size_t)(b - 1u) * 256] = make_float2(d1.Tr, d1.acc);
             if (!wave_done) {
                 n_blended = b + 1u;
                 const uint4 ln = *reinterpret_cast<const uint4 *>(&s_len[p][4 * w]);
@@ -418,11 +432,12 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                 const uint16_t *mylist = s_list[p][4 * w + row];
                 const uint32_t pos0 = base - r0 + 1;
                 uint32_t hit_off = 0xFFFFFFFFu;
+                d1.hit_off = 0xFFFFFFFFu;
                 if (FAST) {
-                    fast_walk<C, false>(mylist, n_w, s_ra[p], s_rb[p], s_rc[p], pxf, pyf, acc, Tr, alive, Dm, hit_off, nullptr);
+                    fast_walk<C, DUAL>(mylist, n_w, s_ra[p], s_rb[p], s_rc[p], pxf, pyf, acc, Tr, alive, Dm, hit_off, &d1);
                 } else
                 for (uint32_t i0 = 0; i0 < n_w; i0 += kGroup) {
-                    if (__all(alive == 0.0f)) break;
+                    if (__all(alive == 0.0f && (!DUAL || d1.alive == 0.0f))) break;
                     uint32_t jw[kGroup / 2];
 #pragma unroll
                     for (int k = 0; k < kGroup / 2; k++) jw[k] = reinterpret_cast<const uint32_t *>(mylist + i0)[k];
@@ -430,7 +445,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                     float4 rc[kGroup];
 #pragma unroll
                     for (int k = 0; k < kGroup; k++) {
-                        const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                        const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                         const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_ra[p]) + off);
                         const float4 rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rb[p]) + off);
                         rc[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rc[p]) + off);
@@ -439,9 +454,24 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                         const float alpha = fminf(0.99f, rb.y * exp_fixed_in_range(fmaxf(power, -87.0f)));
                         a_h[k] = (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) ? alpha : 0.0f;
                     }
+                    if (DUAL) {  // the second image: the same entries, static ones with alpha 0, its own T and stop rule
+#pragma unroll
+                        for (int k = 0; k < kGroup; k++) {
+                            const uint32_t raw = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, off = raw & kListOffMask;
+                            const float ae = ((raw & kListStatic) ? 0.0f : a_h[k]) * d1.alive;
+                            const float test_T = d1.Tr * (1 - ae);
+                            const bool stop = test_T < 0.0001f;
+                            const float a_eff = stop ? 0.0f : ae;
+                            d1.acc = d1.acc + rc[k].x * a_eff * d1.Tr;
+                            d1.Dm = (d1.Tr > 0.5f && test_T < 0.5f) ? rc[k].w : d1.Dm;
+                            d1.Tr = stop ? d1.Tr : test_T;
+                            d1.hit_off = (a_eff > 0.0f) ? off : d1.hit_off;
+                            d1.alive = stop ? 0.0f : d1.alive;
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < kGroup; k++) {
-                        const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                        const uint32_t off = (jw[k >> 1] >> (16 * (k & 1))) & (DUAL ? kListOffMask : 0xFFFFu);
                         const float ae = a_h[k] * alive;
                         const float test_T = Tr * (1 - ae);
                         const bool stop = test_T < 0.0001f;
@@ -469,6 +499,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                     }
                     const uint32_t d_all = dyn_at_or_below(255u);
                     if (d_all != 0xFFFFFFFFu) dyn_before = pos0 + d_all;
+                    if (DUAL && d1.hit_off != 0xFFFFFFFFu) last_contributor1 = pos0 + (d1.hit_off >> 4);
                 }
             }
             FNX_WCLK(2)
@@ -476,7 +507,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             if (wg_rank == 0 && wg_view == 0 && lane == 0) g_ws_clock[16 * w8 + 9] += 1;
 #endif
             // this wave has left buffer p; which of its blocks go on
-            const unsigned long long lv = __ballot(alive != 0.0f);
+            const unsigned long long lv = __ballot(alive != 0.0f || (DUAL && d1.alive != 0.0f));
             const uint32_t live4 = ((lv & 0xFFFFull) ? 1u : 0u) | ((lv & 0xFFFF0000ull) ? 2u : 0u) |
                                    ((lv & 0xFFFF00000000ull) ? 4u : 0u) | ((lv & 0xFFFF000000000000ull) ? 8u : 0u);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -500,8 +531,18 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                 acc_final[(size_t)ch * H * W + pix_id] = acc[ch];
             }
             out_depth[pix_id] = Dm;
+            if (DUAL) {  // the second image: every contributor of its is a dynamic entry, so both halves of n_contrib agree
+                reinterpret_cast<float *>(img1 + du.final_T)[pix_id] = d1.Tr;
+                uint32_t *nc1 = reinterpret_cast<uint32_t *>(img1 + du.n_contrib);
+                nc1[pix_id] = last_contributor1;
+                nc1[(size_t)W * H + pix_id] = last_contributor1;
+                reinterpret_cast<float *>(img1 + du.acc_final)[pix_id] = d1.acc;
+                du.out_color1[(size_t)wg_view * H * W + pix_id] = d1.acc + d1.Tr * du.bg1[0];
+                du.out_depth1[(size_t)wg_view * H * W + pix_id] = d1.Dm;
+            }
         }
-        uint32_t m = last_contributor, md = last_dyn;
+        uint32_t m = DUAL ? max(last_contributor, last_contributor1) : last_contributor;
+        uint32_t md = DUAL ? max(last_dyn, last_contributor1) : last_dyn;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             m = max(m, (uint32_t)__shfl_xor((int)m, off));

@@ -213,7 +213,7 @@ def _views_render(g, cams, W, H, bg_np, channels, deep_kernel, min_depth=256, ba
         rasterizer.check_status()
         return out[0].detach().cpu().numpy(), out[2].detach().cpu().numpy(), hint.cpu().numpy(), grads
     finally:
-        rasterizer.set_deep_kernel(0)
+        rasterizer.set_deep_kernel(5)  # the library's default
         rasterizer.set_deep_variant(True, 1024)
 
 

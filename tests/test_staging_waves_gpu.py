@@ -55,7 +55,7 @@ def _render(g, cams, W, H, bg_np, channels, deep_mode, math_mode, min_depth=256,
         return dict(color=out[0].detach().cpu().numpy(), depth=out[2].detach().cpu().numpy(), hint=hint.cpu().numpy(),
                     walked=rasterizer.walked_entries(), grads=grads)
     finally:
-        rasterizer.set_deep_kernel(0)
+        rasterizer.set_deep_kernel(5)  # the library's default
         rasterizer.set_deep_variant(True, 1024)
         rasterizer.set_blend_math("exact")
         rasterizer.keep_last_blobs(False)
@@ -101,3 +101,42 @@ def test_staging_wave_forward_on_empty_and_single_batch_tiles():
         r = _render(g, cams, W, H, bg, 3, 0, math_mode, rounds=2)
         for k in ("color", "depth"):
             assert (a[k].view(np.uint32) == r[k].view(np.uint32)).all(), k
+
+
+@pytest.mark.parametrize("math_mode", ["exact", "fast"])
+@pytest.mark.parametrize("deep_mode,V", [(4, 2), (3, 3), (5, 1)])
+def test_staging_wave_forward_dual_mode(deep_mode, V, math_mode):
+    """DUAL mode (the 3-channel image and the 1-channel image of the per-call splats out of one pass, config 5): both images,
+    both depths bit-equal to the per-tile kernel's; the positions' gradient within the backward's bound."""
+    import torch
+    from fluidnexus_amd import rasterizer
+    from tests.test_dual_mode_gpu import _renders, _scene
+    gm, cams = _scene(V=V, size=160)
+    rasterizer.set_blend_math(math_mode)
+    rasterizer.set_deep_variant(True, 256)
+    try:
+        base = gm.render_means_from_nn().detach().clone()
+        rng = torch.Generator("cuda").manual_seed(3)
+        H, W = int(cams[0].image_height), int(cams[0].image_width)
+        dL3 = torch.randn(V, 3, H, W, device="cuda", generator=rng)
+        dL1 = torch.randn(V, 1, H, W, device="cuda", generator=rng)
+        out = {}
+        for mode in (0, deep_mode):
+            rasterizer.set_deep_kernel(mode)
+            for _ in range(3):  # the later forwards see the depth hints of the earlier ones
+                m = base.clone().requires_grad_(True)
+                c3, d3, c1, d1 = _renders(gm, cams, m, True)
+            g, = torch.autograd.grad([c3, c1], [m], grad_outputs=[dL3, dL1])
+            torch.cuda.synchronize()
+            rasterizer.check_status()
+            out[mode] = (c3.detach(), d3.detach(), c1.detach(), d1.detach(), g)
+        a, b = out[0], out[deep_mode]
+        for k, name in enumerate(("render", "depth", "render1", "depth1")):
+            assert torch.equal(a[k], b[k]), f"{name}: {int((a[k] != b[k]).sum())} values differ from the per-tile kernel's"
+        assert float(b[2].abs().max()) > 0.01
+        ok, msg = mixed_bound_report(a[4].cpu().numpy(), b[4].cpu().numpy())
+        assert ok, msg
+    finally:
+        rasterizer.set_deep_kernel(5)
+        rasterizer.set_deep_variant(True, 1024)
+        rasterizer.set_blend_math("exact")
