@@ -1696,7 +1696,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     // per-tile kernel).  FNX_WS_MAX (developer switch, multiple of 8) overrides it.
     static const int kWsDeepMax = [] {
         const char *e = getenv("FNX_WS_MAX");
-        const int v = e ? atoi(e) : 512;
+        const int v = e ? atoi(e) : 64;  // (3 views: 1 611 it/s at 512, 1 641 at 64; profiles/r06_lab_staging_waves.md)
         return v < 8 ? 8 : (v + 7) & ~7;
     }();
     // the two kernels touch disjoint tiles: the deep one runs on a helper stream beside the per-tile kernel
@@ -1713,7 +1713,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
     static std::mutex helpers_mu;
     hipStream_t helper = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t sd = s;
+    hipStream_t sd = s, s_main = s;
     if (use_deep || use_ws == 1) {
         const int n_cu = device_cu_count();
         {
@@ -1759,8 +1759,15 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
         else if (st.base) { if (fast) FNX_LAUNCH_WS(1, true, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, true, false, GX, DEEP_ONLY, ST); }      \
         else { if (fast) FNX_LAUNCH_WS(1, false, true, GX, DEEP_ONLY, ST); else FNX_LAUNCH_WS(1, false, false, GX, DEEP_ONLY, ST); }                 \
     } while (0)
+        // The staging-wave kernel goes on the CALLER's stream and the per-tile kernel on the helper: a captured graph keeps
+        // the first-enqueued successor of a node on the node's hardware queue, and the deep tiles' chains must START first --
+        // 512-thread workgroups enqueued beside a per-tile launch that already fills the chip wait for two of its
+        // workgroups to retire on the same compute unit (measured: the deep tiles then start ~100 us late).
+        // FNX_WS_SWAP=0 (developer switch): the other way round.
+        static const bool ws_swap = [] { const char *e = getenv("FNX_WS_SWAP"); return !e || atoi(e) != 0; }();
         if (use_ws == 1) {
-            FNX_LAUNCH_WS_ALL(std::min((T + 7) & ~7, kWsDeepMax), 1, sd);
+            FNX_LAUNCH_WS_ALL(std::min((T + 7) & ~7, kWsDeepMax), 1, (ws_swap ? s : sd));
+            if (ws_swap) s_main = sd;
         } else
         if (C == 3 && st.base) FNX_LAUNCH_BD(3, true);
         else if (C == 3) FNX_LAUNCH_BD(3, false);
@@ -1780,7 +1787,7 @@ void launch_blend_forward(int C, hipStream_t s, int W, int H, const uint32_t *ra
         FNX_LAUNCH_BF_(CC, SS, false)
 #define FNX_LAUNCH_BF_(CC, SS, FF) FNX_LAUNCH_BF__(CC, SS, FF, false)
 #define FNX_LAUNCH_BF__(CC, SS, FF, DD)                                                                                \
-    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF, DD>), dim3((T + 7) & ~7, V), dim3(256), 0, s, T, gx, ranges,  \
+    hipLaunchKernelGGL((blend_forward_kernel<CC, SS, FF, DD>), dim3((T + 7) & ~7, V), dim3(256), 0, s_main, T, gx, ranges,  \
                        point_list, W, H,                                                                               \
                        blend_rec, bg, final_T, n_contrib, out_color, out_depth, header, capacity, status_out,          \
                        tile_count, dyn_start, acc_final, tile_order, tile_deep, depth_hint, st, materialize_all, vb,   \
