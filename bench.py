@@ -736,7 +736,9 @@ def main():
                          "same sum, same all-reduce); auto = last-rank whenever there is more than one rank (emulated shares: the "
                          "placement moves the slowest rank by 2 %).  None of them is measured on multi-GPU hardware")
     ap.add_argument("--deep-kernel", type=int, default=None, choices=[0, 1, 2, 3, 4, 5],
-                    help="deep-tile forward kernel (fnx_raster_opts_t.deep_kernel): 0 never (library default), 1 launches of <= 2 views, 2 always")
+                    help="which blend forward kernel takes which tiles (fnx_raster_opts_t.deep_kernel): 0 per-tile kernel only, 1 / 2 lab "
+                         "super-batch kernel (launches of <= 2 views / always), 3 / 4 staging waves (deep tiles / every tile), "
+                         "5 staging waves by the launch's view count (library default)")
     ap.add_argument("--sh-degree", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="also time the SH pipe's rasteriser (colours as spherical-harmonics coefficients of this degree) "
                          "on the configuration's Gaussians: record key `sh` (not part of the timed training step)")

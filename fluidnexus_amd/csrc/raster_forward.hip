@@ -391,11 +391,10 @@ struct DualPixel {
     uint32_t hit_off;
 };
 // REC (segmented tiles): vstop keeps the test value of the entry that stopped the pixel (T (1 - alpha) < 1e-4; 0: none yet).
-template <int C, bool DUAL = false, bool REC = false>
-__device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
+template <int C, bool DUAL, bool REC, bool HALF>
+__device__ __forceinline__ void fast_walk_impl(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
                                           const float4 *s_rc, float pxf, float pyf, float (&acc)[C], float &Tr,
-                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du = nullptr,
-                                          float *vstop = nullptr) {
+                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du, float *vstop) {
     constexpr int kGroup = 4;
     // entries of this walk after which the pixel's T is still >= 1/2: T never rises, so they are a prefix of the
     // walk, and if T crosses 1/2 here the entry that took it across is mylist[n_half] (forward.cu:351-354)
@@ -443,7 +442,7 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
                 du->acc = __builtin_fmaf(col[k][0], wgt, du->acc);
                 du->Tr = stop ? du->Tr : t;
                 du->alive = stop ? 0.0f : t;
-                n_half1 += (du->Tr >= 0.5f) ? 1u : 0u;
+                if (HALF) n_half1 += (du->Tr >= 0.5f) ? 1u : 0u;
                 du->hit_off = (wgt > 0.0f) ? off : du->hit_off;
             }
         }
@@ -460,20 +459,33 @@ __device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, 
             if (C > 2) acc[C > 2 ? 2 : 0] = __builtin_fmaf(col[k][2], wgt, acc[C > 2 ? 2 : 0]);
             Tr = stop ? Tr : t;
             alive = stop ? 0.0f : t;
-            n_half += (Tr >= 0.5f) ? 1u : 0u;
+            if (HALF) n_half += (Tr >= 0.5f) ? 1u : 0u;
             hit_off = (wgt > 0.0f) ? off : hit_off;
         }
     }
-    if (T_in >= 0.5f && Tr < 0.5f) {
+    if (HALF && T_in >= 0.5f && Tr < 0.5f) {
         const uint32_t off = mylist[n_half] & (DUAL ? kListOffMask : 0xFFFFu);
         Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
                     : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
     }
-    if (DUAL && T1_in >= 0.5f && du->Tr < 0.5f) {
+    if (HALF && DUAL && T1_in >= 0.5f && du->Tr < 0.5f) {
         const uint32_t off = mylist[n_half1] & kListOffMask;
         du->Dm = C == 3 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rc) + off)[1]
                         : reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_rb) + off)[3];
     }
+}
+
+// The median-depth bookkeeping (n_half: two instructions per entry and image) only where some pixel of the wave can still
+// cross T = 1/2 in this walk: T never rises, and behind the first few batches of a deep tile no pixel's does (round 6).
+template <int C, bool DUAL = false, bool REC = false>
+__device__ __forceinline__ void fast_walk(const uint16_t *mylist, uint32_t n_w, const float4 *s_ra, const float4 *s_rb,
+                                          const float4 *s_rc, float pxf, float pyf, float (&acc)[C], float &Tr,
+                                          float &alive, float &Dm, uint32_t &hit_off, DualPixel *du = nullptr,
+                                          float *vstop = nullptr) {
+    if (__any((Tr >= 0.5f && alive != 0.0f) || (DUAL && du->Tr >= 0.5f && du->alive != 0.0f)))
+        fast_walk_impl<C, DUAL, REC, true>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off, du, vstop);
+    else
+        fast_walk_impl<C, DUAL, REC, false>(mylist, n_w, s_ra, s_rb, s_rc, pxf, pyf, acc, Tr, alive, Dm, hit_off, du, vstop);
 }
 
 // Transmittance only: the product of (1 - alpha) over the lane's list, without the stop rule (the caller applies it
