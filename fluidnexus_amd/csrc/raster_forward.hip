@@ -551,7 +551,7 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
                  uint32_t *__restrict__ dyn_start, uint32_t *__restrict__ header, size_t img_stride, int NB, int gy,
                  const uint32_t *__restrict__ blk_total, uint32_t *__restrict__ emit_ctl,
                  uint32_t *__restrict__ emit_items, size_t geom_stride, uint32_t *__restrict__ depth_hint,
-                 uint32_t deep_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
+                 uint32_t deep_min, uint32_t prio_min, uint32_t *__restrict__ tile_order, uint8_t *__restrict__ tile_deep,
                  const StaticRef st, const uint32_t *__restrict__ sort_ctl, const SegRef sg) {
     constexpr int kDeepSorted = 1024;
     __shared__ uint32_t s_wave[16];
@@ -593,7 +593,8 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         // priority: their sequential walks are the critical path of the launch and must not start last.
         const uint32_t hint = depth_hint ? depth_hint[i] : 0u;
         const bool deep = depth_hint && c && hint >= deep_min;
-        tile_deep[i] = deep ? 1 : 0;
+        // 2: also at raised wave priority (prio_min >= deep_min: the ORDER may reach further down than the priority)
+        tile_deep[i] = deep ? (hint >= prio_min ? 2 : 1) : 0;
         if (deep) {
             const uint32_t at = atomicAdd(&s_deep_n, 1u);
             tile_order[at] = (uint32_t)i;
@@ -606,15 +607,53 @@ tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t *__res
         // deepest first (the deep-tile kernel hands them out in this order: longest jobs first); ties by tile index.
         // Beyond kDeepSorted deep tiles the rest keep their arrival order.
         const uint32_t nd = min(s_deep_n, (uint32_t)kDeepSorted);
-        for (uint32_t e = tid; e < nd; e += 1024) {
-            const uint2 me = s_deep[e];
-            uint32_t rank = 0;
-            for (uint32_t o = 0; o < nd; o++) {
-                const uint2 ot = s_deep[o];
-                rank += (ot.x > me.x || (ot.x == me.x && ot.y < me.y)) ? 1u : 0u;
+        if (nd <= 128u) {  // few: every element counts the ones in front of it
+            for (uint32_t e = tid; e < nd; e += 1024) {
+                const uint2 me = s_deep[e];
+                uint32_t rank = 0;
+                for (uint32_t o = 0; o < nd; o++) {
+                    const uint2 ot = s_deep[o];
+                    rank += (ot.x > me.x || (ot.x == me.x && ot.y < me.y)) ? 1u : 0u;
+                }
+                tile_order[rank] = me.y;
+                s_sorted[rank] = me;
             }
-            tile_order[rank] = me.y;
-            s_sorted[rank] = me;
+        } else {
+            // many (the order reaches down to shallow tiles, FNX_DEEP_ORDER_MIN): bitonic sort of kDeepSorted = 1024 keys
+            // (hint, ~tile), one per thread, DESCENDING; exchanges at distances below 64 stay inside a wave (shuffles),
+            // the ten at distances 64 .. 512 go through LDS.  Empty slots hold key 0 and sink to the end.
+            static_assert(kDeepSorted == 1024, "one key per thread");
+            unsigned long long key = 0ull;
+            if ((uint32_t)tid < nd) {
+                const uint2 me = s_deep[tid];
+                key = ((unsigned long long)me.x << 32) | (unsigned long long)(0xFFFFFFFFu - me.y);
+            }
+            unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_sorted);  // (written for good below)
+            for (uint32_t k = 2; k <= 1024u; k <<= 1) {
+                for (uint32_t j = k >> 1; j >= 1u; j >>= 1) {
+                    unsigned long long other;
+                    if (j >= 64u) {
+                        __syncthreads();
+                        s_key[tid] = key;
+                        __syncthreads();
+                        other = s_key[(uint32_t)tid ^ j];
+                    } else {
+                        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j);
+                        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j);
+                        other = ((unsigned long long)hi << 32) | lo;
+                    }
+                    // descending overall: in a block whose bit k is clear the larger key goes to the lower index
+                    const bool lower = ((uint32_t)tid & j) == 0u, desc = ((uint32_t)tid & k) == 0u || k == 1024u;
+                    const bool take_max = lower == desc;
+                    key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+                }
+            }
+            __syncthreads();
+            if ((uint32_t)tid < nd) {
+                const uint2 me = make_uint2((uint32_t)(key >> 32), 0xFFFFFFFFu - (uint32_t)key);
+                tile_order[tid] = me.y;
+                s_sorted[tid] = me;
+            }
         }
     }
     __syncthreads();
@@ -923,7 +962,7 @@ blend_forward_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint32_
             if (FNX_INV_LATE) write_inv();
             return;
         }
-        __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
+        if (tile_deep[tile] >= 2) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
     }
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1674,9 +1713,14 @@ void launch_tile_scan(hipStream_t s, int T, const uint32_t *tile_count, uint32_t
                       uint32_t deep_min, uint32_t *tile_order, uint8_t *tile_deep, int V, const ViewBatch &vb,
                       const StaticRef &st, const SegRef &sg) {
     const SortScratch L = sort_scratch(P);
+    // FNX_DEEP_ORDER_MIN (developer switch): tiles at least this deep are ORDERED deepest first; the raised wave priority stays
+    // with those at least deep_min deep
+    static const uint32_t order_min = [] { const char *e = getenv("FNX_DEEP_ORDER_MIN"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t prio_min = deep_min;
+    if (order_min && order_min < deep_min) deep_min = order_min;
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, V), dim3(1024), 0, s, T, tile_count, ranges, dyn_start, header, vb.img,
                        splat_blocks(P), tiles_y(H), sort_scratch_words + L.blk_total, sort_scratch_words + L.emit_ctl,
-                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, tile_order, tile_deep, st,
+                       sort_scratch_words + L.emit_items, vb.geom, depth_hint, deep_min, prio_min, tile_order, tile_deep, st,
                        sort_scratch_words + L.ctl, sg);
 }
 

@@ -110,8 +110,8 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
     if (header[HDR_NUM_RENDERED] > capacity || header[HDR_STATUS] == (uint32_t)FNX_ERR_SORT_SPAN) return;
     if (deep_only && (uint32_t)wg_rank >= (header[HDR_DEEP_COUNT] & 0xFFFFFFu)) return;
     const int tile = (int)tile_order[wg_rank];
-    if (tile_deep[tile]) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
-    else if (deep_only) return;
+    if (tile_deep[tile] >= 2) __builtin_amdgcn_s_setprio(FNX_DEEP_PRIO);
+    else if (deep_only && !tile_deep[tile]) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);

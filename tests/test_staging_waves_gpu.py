@@ -140,3 +140,25 @@ def test_staging_wave_forward_dual_mode(deep_mode, V, math_mode):
         rasterizer.set_deep_kernel(5)
         rasterizer.set_deep_variant(True, 1024)
         rasterizer.set_blend_math("exact")
+
+
+def test_tile_order_reaching_down_to_shallow_tiles_changes_nothing():
+    """tile_scan_kernel orders the tiles that went at least `deep_threshold` deep in the previous forward deepest first;
+    above 128 of them per view it sorts them with its bitonic network (1 024 keys, one per thread).  A threshold of 32 on a
+    512 x 512 plume puts several hundred tiles per view through that path: the images do not notice the order."""
+    import torch
+    from fluidnexus_amd import rasterizer
+    W = H = 512
+    n_dyn = 60_000
+    g = S.smoke_scene(n_dyn, 20_000, seed=5, channels=3)
+    cams = S.arc_cameras(5, W, H, device="cpu")[:4]
+    bg = np.array([0.0, 0.0, 0.0], np.float32)
+    ref = _render(g, cams, W, H, bg, 3, 0, "fast", min_depth=1 << 20, static_split=n_dyn)  # nothing flagged: the plain tile order
+    got = _render(g, cams, W, H, bg, 3, 0, "fast", min_depth=32, static_split=n_dyn)
+    n_flagged = int((got["hint"] >= 32).sum())
+    assert n_flagged > 4 * 128, f"only {n_flagged} tiles reach the threshold: the bitonic path did not run"
+    for k in ("color", "depth", "hint"):
+        x, y = got[k], ref[k]
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert (x == y).all(), k
