@@ -82,12 +82,16 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
     char *img1 = DUAL ? du.img1 + vb.img * (size_t)wg_view : nullptr;  // DUAL: the second image's per-pixel arrays
     constexpr int kGroup = FNX_FWD_GROUP;
     constexpr int kListStride = (256 + kGroup + 7) & ~7;
-    __shared__ float4 s_ra[2][257];
-    __shared__ float4 s_rb[2][257];
-    __shared__ float4 s_rc[2][257];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[2][16][kListStride];
-    __shared__ __attribute__((aligned(16))) uint32_t s_len[2][16];  // lengths of the lists of a staged batch
-    __shared__ unsigned long long s_dynmask[2][4];
+#ifndef FNX_WS_BUFFERS
+#define FNX_WS_BUFFERS 2
+#endif
+    constexpr int kBuf = FNX_WS_BUFFERS;  // staged batches in LDS at a time
+    __shared__ float4 s_ra[kBuf][257];
+    __shared__ float4 s_rb[kBuf][257];
+    __shared__ float4 s_rc[kBuf][257];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[kBuf][16][kListStride];
+    __shared__ __attribute__((aligned(16))) uint32_t s_len[kBuf][16];  // lengths of the lists of a staged batch
+    __shared__ unsigned long long s_dynmask[kBuf][4];
     __shared__ uint16_t s_mask[256];
     __shared__ uint32_t s_wk[SPLIT ? 2 : 1][SPLIT ? 256 : 1];
     __shared__ uint32_t s_wi[SPLIT ? 2 : 1][SPLIT ? 256 : 1];
@@ -118,7 +122,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
     const bool stager = w8 >= 4;
     const int w = w8 & 3;       // the walker's quadrant / the stager's quarter of the slots (and the quadrant it builds lists for)
     const int sid = tid & 255;  // pixel of a walker thread, slot of a stager thread
-    if (tid < 2) {
+    if (tid < kBuf) {
         s_ra[tid][256] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_rb[tid][256] = FAST ? make_float4(0.f, -200.0f, 0.f, 0.f) : make_float4(0.f, 0.f, -87.0f, 0.f);
         s_rc[tid][256] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -160,12 +164,10 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             while (lds_load(&s_sbar) < sbar_n) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         };
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
-        float pd = 0.f;
         uint32_t id_ahead = 0;
         const uint2 *sp = nullptr, *fp = nullptr;
         const float4 *rec_s = nullptr;
-        uint32_t ns = 0, nf = 0, si = 0, fj = 0, my_id = 0;
+        uint32_t ns = 0, nf = 0, si = 0, fj = 0;
         uint2 ws = make_uint2(0u, 0u), wf = ws;
         auto record_of = [&](uint32_t id) -> const float4 * {
             return (SPLIT && id >= st.id0) ? rec_s + 4 * (size_t)(id - st.id0) : blend_rec + 4 * (size_t)id;
@@ -208,6 +210,26 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             }
             return id;
         };
+        // Two record sets in flight: set A holds the even batches, set B the odd ones; the records of batch b + 2 are requested
+        // into the set batch b has just been staged from, and the merge runs TWO batches ahead -- a set's loads have a whole
+        // iteration to arrive (with one set the stagers' chain held a global round trip per batch: requested at the end of a
+        // batch's staging, consumed at the top of the next; the per-tile kernel hides that under its walk, the stagers have
+        // nothing else to do).
+        struct RecSet {
+            float4 pa, pb, pc;
+            float pd;
+            uint32_t id;
+        };
+        RecSet A, B;
+        A.pa = A.pb = A.pc = B.pa = B.pb = B.pc = make_float4(0.f, 0.f, 0.f, 0.f);
+        A.pd = B.pd = 0.f;
+        A.id = B.id = 0u;
+        auto request = [&](RecSet &R, const float4 *rec) {
+            R.pa = rec[0];
+            R.pb = rec[1];
+            R.pc = rec[2];
+            if (C > 2) R.pd = rec[3].x;
+        };
         if (SPLIT) {
             const uint32_t *starts = reinterpret_cast<const uint32_t *>(static_blob + st.starts);
             const uint32_t s0 = starts[tile];
@@ -220,36 +242,43 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
             store_windows();
             sbar();
             const uint32_t cnt0 = min(256u, b_hi - b_lo);
-            my_id = merge_batch(cnt0);
+            A.id = merge_batch(cnt0);
             sbar();
             if (cnt0) {
                 const uint32_t a = s_adv;
                 si += a;
                 fj += cnt0 - a;
             }
-            if ((uint32_t)sid < cnt0) {
-                const float4 *rec = record_of(my_id);
-                pa = rec[0];
-                pb = rec[1];
-                pc = rec[2];
-                if (C > 2) pd = rec[3].x;
+            if ((uint32_t)sid < cnt0) request(A, record_of(A.id));
+            load_windows();
+            const uint32_t cnt1 = b_lo + 256u < b_hi ? min(256u, b_hi - b_lo - 256u) : 0u;
+            store_windows();
+            sbar();
+            B.id = merge_batch(cnt1);
+            sbar();
+            if (cnt1) {
+                const uint32_t a = s_adv;
+                si += a;
+                fj += cnt1 - a;
             }
             load_windows();
+            request(B, record_of(B.id));  // unconditional (see blend_forward_kernel); a slot beyond the batch reads splat 0's
         } else {
             if (b_lo + (uint32_t)sid < b_hi) {
-                my_id = point_list[b_lo + sid];
-                const float4 *rec = blend_rec + 4 * (size_t)my_id;
-                pa = rec[0];
-                pb = rec[1];
-                pc = rec[2];
-                if (C > 2) pd = rec[3].x;
+                A.id = point_list[b_lo + sid];
+                request(A, blend_rec + 4 * (size_t)A.id);
             }
-            if (b_lo + 256u + (uint32_t)sid < b_hi) id_ahead = point_list[b_lo + 256u + sid];
+            if (b_lo + 256u + (uint32_t)sid < b_hi) {
+                B.id = point_list[b_lo + 256u + sid];
+                request(B, blend_rec + 4 * (size_t)B.id);
+            }
+            if (b_lo + 512u + (uint32_t)sid < b_hi) id_ahead = point_list[b_lo + 512u + sid];
         }
         bool blending = true;
-        uint32_t b = 0, published = 0;
-        for (uint32_t base = b_lo; base < b_hi; base += 256, b++) {
-            const int p = (int)(b & 1u);
+        uint32_t published = 0;
+        // one batch: staged from R (its records arrived an iteration ago), then R is refilled with batch b + 2's
+        auto stage = [&](RecSet &R, const uint32_t b, const uint32_t base) -> bool {
+            const int p = (int)(b % (uint32_t)kBuf);
             FNX_WCLK(0)
             if (blending) {
                 // the stagers' common decision of the previous batch: every pixel has stopped -> nothing more to stage
@@ -258,26 +287,29 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         lds_store(&s_nbatches, published);
                     }
-                    if (!SPLIT || !materialize_all) break;
+                    if (!SPLIT || !materialize_all) return false;
                     blending = false;
                 }
             }
-            if (blending && b >= 2u) {  // buffer p is free once every walker has finished batch b - 2
+            if (blending && b >= (uint32_t)kBuf) {  // buffer p is free once every walker has finished batch b - kBuf
                 for (;;) {
                     const uint32_t m = min(min(lds_load(&s_walked[0]), lds_load(&s_walked[1])),
                                            min(lds_load(&s_walked[2]), lds_load(&s_walked[3])));
-                    if (m >= b - 1u) break;
+                    if (m >= b + 1u - (uint32_t)kBuf) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");
             }
             FNX_WCLK(1)
             const uint32_t cnt = min(256u, b_hi - base);
+            const uint32_t my_id = R.id;
             uint32_t qm = 0;
             if (blending) {
                 const unsigned long long dm = __ballot((uint32_t)sid < cnt && my_id < dyn_limit);
                 if (lane == 0) s_dynmask[p][w] = dm;
                 if ((uint32_t)sid < cnt) {
+                    const float4 pa = R.pa, pb = R.pb, pc = R.pc;
+                    const float pd = R.pd;
                     qm = block_mask_exact(pa.x, pa.y, pa.z, pa.w, pb.x, pb.z, pc.x, pc.y, tile_x0, tile_y0);
                     if (FAST) {
                         constexpr float kL2e = 1.44269504088896341f;
@@ -296,26 +328,13 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                     }
                 }
             }
-            if (SPLIT) {
-                store_windows();
-            } else {
-                if (base + 256u + (uint32_t)sid < b_hi) {
-                    my_id = id_ahead;
-                    const float4 *rec = blend_rec + 4 * (size_t)id_ahead;
-                    pa = rec[0];
-                    pb = rec[1];
-                    pc = rec[2];
-                    if (C > 2) pd = rec[3].x;
-                }
-                if (base + 512u + (uint32_t)sid < b_hi) id_ahead = point_list[base + 512u + sid];
-            }
-            const uint32_t my_id_now = my_id;  // (SPLIT: the id of this batch's slot; the non-split path has moved on)
             s_mask[sid] = (uint16_t)qm;
             if (blending) {
                 const uint4 nul = make_uint4(0x10001000u, 0x10001000u, 0x10001000u, 0x10001000u);
                 uint4 *mine = reinterpret_cast<uint4 *>(&s_list[p][4 * w][0]);
                 for (int i = lane; i < 4 * kListStride / 8; i += 64) mine[i] = nul;
             }
+            if (SPLIT) store_windows();  // (requested at the end of the previous batch: behind the masks, not in front of them)
             FNX_WCLK(2)
             sbar();
             FNX_WCLK(3)
@@ -343,13 +362,13 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                 }
             }
             FNX_WCLK(4)
-            uint32_t next_cnt = 0, next_id = 0;
+            uint32_t n2_cnt = 0, n2_id = 0;  // the batch after next: merged here, its records requested below
             if (SPLIT) {
-                next_cnt = base + 256u < b_hi ? min(256u, b_hi - base - 256u) : 0u;
-                next_id = merge_batch(next_cnt);
+                n2_cnt = base + 512u < b_hi ? min(256u, b_hi - base - 512u) : 0u;
+                n2_id = merge_batch(n2_cnt);
             }
             FNX_WCLK(5)
-            if (SPLIT && (uint32_t)sid < cnt) point_list[base + sid] = my_id_now;
+            if (SPLIT && (uint32_t)sid < cnt) point_list[base + sid] = my_id;
             if ((uint32_t)sid < cnt && blending)
                 reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(point_list) + vb.bin_masks)[base + sid] = (uint16_t)qm;
             sbar();
@@ -359,22 +378,36 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                 if (w == 0 && lane == 0) lds_store(&s_staged, published);  // (every stager's LDS writes were complete at the barrier)
             }
             if (SPLIT) {
-                if (next_cnt) {
+                if (n2_cnt) {
                     const uint32_t a = s_adv;
                     si += a;
-                    fj += next_cnt - a;
+                    fj += n2_cnt - a;
                 }
-                my_id = next_id;
-                {
-                    const float4 *rec = record_of(my_id);  // unconditional (see blend_forward_kernel)
-                    pa = rec[0];
-                    pb = rec[1];
-                    pc = rec[2];
-                    if (C > 2) pd = rec[3].x;
-                }
+                // the windows FIRST: vmcnt retires in order, and the next batch's staging waits for the windows, not for these
+                // records (they are consumed two batches on)
                 load_windows();
+                R.id = n2_id;
+                request(R, record_of(n2_id));  // unconditional (see blend_forward_kernel)
+            } else {
+                if (base + 512u + (uint32_t)sid < b_hi) {
+                    R.id = id_ahead;
+                    request(R, blend_rec + 4 * (size_t)id_ahead);
+                }
+                if (base + 768u + (uint32_t)sid < b_hi) id_ahead = point_list[base + 768u + sid];
             }
             FNX_WCLK(7)
+            return true;
+        };
+        {
+            uint32_t b = 0, base = b_lo;
+            for (;;) {
+                if (base >= b_hi || !stage(A, b, base)) break;
+                b++;
+                base += 256u;
+                if (base >= b_hi || !stage(B, b, base)) break;
+                b++;
+                base += 256u;
+            }
         }
         if (blending && w == 0 && lane == 0) {  // the list ended (or every pixel stopped at its last batch)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -407,7 +440,7 @@ blend_forward_ws_kernel(int T, int gx, const uint32_t *__restrict__ ranges, uint
                                      (size_t)(r0 >> 8) * 256 + sid : nullptr;
         uint32_t b = 0;
         for (uint32_t base = b_lo; base < b_hi; base += 256, b++) {
-            const int p = (int)(b & 1u);
+            const int p = (int)(b % (uint32_t)kBuf);
             const bool wave_done = __all(alive == 0.0f && (!DUAL || d1.alive == 0.0f));
             FNX_WCLK(0)
             bool ended = false;
