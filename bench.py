@@ -39,6 +39,15 @@ sys.path.insert(0, ROOT)
 # the host driver only supports dmabuf IPC: RCCL between processes needs this before the HIP runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+# Caching-allocator settings of this process, unless the caller has set some (read at the first device allocation): the
+# sequence leg re-captures its loop frame after frame while every per-splat array grows by 0.3 % per frame.  Rounding
+# requests up to eighths of a power of two and never splitting blocks above 32 MB lets a frame reuse the previous frame's
+# blocks instead of taking new segments from the driver (a hipMalloc costs 0.1 ms on one box and several ms on another:
+# profiles/r06_sequence_setup.md); it costs a few per cent of reserved memory.
+_ALLOC_VARS = ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_ALLOC_CONF")
+if not any(os.environ.get(_k) for _k in _ALLOC_VARS):
+    for _k in _ALLOC_VARS[:2]:
+        os.environ[_k] = "roundup_power2_divisions:8,max_split_size_mb:32"
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -582,7 +591,14 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     graph = loop.capturable
     gi = max(1, min(int(a.seq_graph_iters), n))
     seg = dict(simulate=0.0, setup=0.0, optimise=0.0, accept=0.0)
-    counts, sort_switched, frame_s, knn_checked, setup_s = [], [], [], [], []
+    counts, sort_switched, frame_s, knn_checked, setup_s, full_sorts_setup, full_sorts_frame = [], [], [], [], [], [], []
+    setup_split = []  # [prepare, loop object, eager iterations, status, capture, first replay + counters] ms per frame
+    # one memory pool for the captures of all frames (HotLoop.capture: private pools of destroyed graphs pile up otherwise)
+    # (a torch.cuda.MemPool keeps the pool alive between one frame's graph going and the next one's capture: a bare handle's
+    #  pool is dropped with its last graph and capture_begin then asserts)
+    seq_pool_obj = torch.cuda.MemPool() if (graph and os.environ.get("FNX_SEQ_SHARED_POOL", "1") != "0") else None
+    seq_pool = seq_pool_obj.id if seq_pool_obj is not None else None
+    seg_split = []
 
     def tick():
         torch.cuda.synchronize()
@@ -602,25 +618,43 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         # training_setup_current + the loop object of the frame (its warm-up iterations are optimisation iterations)
         gm.prepare_visual_particles_for_rendering()
         rasterizer.release_captured_status()
+        from fluidnexus_amd import physics as _physics
+        _physics.release_captured_distance_state()  # (the distance loss's pair-list state the previous frame's graph pinned)
+        if os.environ.get("FNX_SEQ_RELEASE_GRAPH", "1") != "0":
+            loop.release_graph()  # the previous frame's graph and its memory go now, not when the collector finds the loop
+        if os.environ.get("FNX_SEQ_GC") == "1":  # developer switch
+            import gc
+            gc.collect()
+        ts = [tick()]  # set-up split: five more synchronisations per frame (~0.1 ms of a 10 ms set-up)
+        ms0 = torch.cuda.memory_stats(dev)
         loop = Hn.HotLoop(gm, cams, rank=rank, world=world, force_all_reduce=use_dist, physics_per_view=loop.physics_per_view,
                           shared_terms_rank=loop.shared_terms_rank, image_loss=loop.image_loss, fused_physics=loop.fused_physics,
                           defer_visual_backward=True, capturable=graph, cfg=loop.cfg, batched_views=loop.batched_views,
-                          fused_step=loop.fused_step, dual_channel=loop.dual_channel)
+                          fused_step=loop.fused_step, dual_channel=loop.dual_channel,
+                          reuse_streams_of=loop if os.environ.get("FNX_SEQ_REUSE_STREAMS", "1") != "0" else None)
         done = 0
         rasterizer.set_coherent_sort(a.coh)
         P_frame = int(gm._visual_xyz.shape[0])  # the per-call splats of this frame: only their sort states count below
         c0 = rasterizer.coherent_sort_counters(P_frame)
         # eager: sizes the binning buffers for the new particle count, seeds the sort state, and shows whether this
         # frame's particles stay inside the coherent sort's repair window (else: radix passes for this frame)
+        if ts is not None:
+            ts.append(tick())
         for _ in range(max(1, int(a.seq_eager))):
             loop.iteration()
             done += 1
+        if ts is not None:
+            ts.append(tick())
         rasterizer.check_status()
+        if ts is not None:
+            ts.append(tick())
         captured = False
         if graph and n - done - 1 >= gi:
-            loop.capture(warmup=int(a.seq_capture_warmup), iterations=gi)
+            loop.capture(warmup=int(a.seq_capture_warmup), iterations=gi, pool=seq_pool)
             done += int(a.seq_capture_warmup)
             captured = True
+        if ts is not None:
+            ts.append(tick())
         if a.sort == "coherent":
             # does the frame stay inside the coherent sort's reach?  Judged on the first replay (round 5: two eager iterations
             # fewer per frame than judging before the capture); a frame that does not is re-captured on the radix passes
@@ -632,20 +666,31 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
                     loop.iteration()
                     done += loop.iterations_per_call
             c1 = rasterizer.coherent_sort_counters(P_frame)
+            full_sorts_setup.append(c1[1] - c0[1])
             if c1[1] - c0[1] > rasterizer.coherent_sort_states(P_frame):
                 rasterizer.set_coherent_sort(False)
                 sort_switched.append(len(counts))
                 if captured and n - done - 1 >= gi:
                     loop.use_graph(False)
-                    loop.capture(warmup=1, iterations=gi)
+                    loop.capture(warmup=1, iterations=gi, pool=seq_pool)
                     done += 1
         t2 = tick()
+        if ts is not None:
+            setup_split.append([round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t1] + ts, ts + [t2])])
+            ms1 = torch.cuda.memory_stats(dev)
+            # device-memory segments the caching allocator took from / gave back to the driver during the set-up, reserved GiB
+            seg_split.append([int(ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0)),
+                              int(ms1.get("segment.all.freed", 0) - ms0.get("segment.all.freed", 0)),
+                              round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 2),
+                              round(ms1.get("allocated_bytes.all.current", 0) / 2**30, 2)])
         while done < n:
             if loop.iterations_per_call > n - done:
                 loop.use_graph(False)
             done += loop.iterations_per_call
             loop.iteration()
         rasterizer.check_status()
+        if a.sort == "coherent":
+            full_sorts_frame.append(rasterizer.coherent_sort_counters(P_frame)[1] - c0[1])
         if getattr(gm, "_knn_flags", None) is not None:
             gm.check_knn_k()  # raises when a fused neighbour search of this frame met a list longer than KNN_K (device flag)
             knn_checked.append(1)
@@ -665,10 +710,38 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         return t4 - t0
 
     one_frame(False)  # untimed: first-use allocations of every stage
+    if os.environ.get("FNX_SEQ_SNAPSHOT") == "2":
+        torch.cuda.memory._record_memory_history(enabled="all", context="alloc", stacks="python")
     sort_switched.clear()
     knn_checked.clear()
+    full_sorts_setup.clear()
+    full_sorts_frame.clear()
+    setup_split.clear()
+    seg_split.clear()
     total = sum(one_frame(True) for _ in range(K))
     rasterizer.set_coherent_sort(a.coh)
+    if os.environ.get("FNX_SEQ_SNAPSHOT") == "2":  # developer switch: who allocated the blocks that are still alive
+        import collections
+        live = collections.Counter()
+        for sg in torch.cuda.memory_snapshot():
+            for b in sg["blocks"]:
+                if b["state"] == "active_allocated":
+                    fr = [f for f in b.get("frames", []) if "/repo/" in f.get("filename", "")][:3]
+                    live[" < ".join(f"{os.path.basename(f['filename'])}:{f['line']}" for f in fr)] += b["size"]
+        for k, v in live.most_common(14):
+            print(f"[live] {v / 2**20:9.1f} MiB  {k}", file=sys.stderr, flush=True)
+    if os.environ.get("FNX_SEQ_SNAPSHOT") == "1":  # developer switch: where the reserved device memory sits after the sequence
+        import collections
+        by_pool = collections.defaultdict(lambda: [0, 0, 0, 0])
+        for sg in torch.cuda.memory_snapshot():
+            e = by_pool[tuple(sg.get("segment_pool_id", (0, 0)))]
+            e[0] += 1
+            e[1] += sg["total_size"]
+            e[2] += sg["allocated_size"]
+            e[3] += sum(1 for b in sg["blocks"] if b["state"] == "active_allocated")
+        for k, e in sorted(by_pool.items(), key=lambda kv: -kv[1][1])[:12]:
+            print(f"[snapshot] pool {k}: {e[0]} segments, {e[1] / 2**30:.2f} GiB reserved, {e[2] / 2**30:.2f} GiB allocated, {e[3]} live blocks",
+                  file=sys.stderr, flush=True)
     per_frame = total / K
     return {"frames": K, "iters_per_frame": n, "seq_iters_per_s": K * n / total, "ms_per_frame": per_frame * 1e3,
             "frame_boundary_ms": (per_frame - n * steady_ms * 1e-3) * 1e3,
@@ -682,6 +755,10 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             "particles_first_frame": {"hidden": counts[0][0], "visual": counts[0][1]},
             "setup_ms_by_frame": [round(x * 1e3, 1) for x in setup_s],
             "frames_switched_to_radix": list(sort_switched),
+            # in-launch full sorts of the coherent depth sort (all views): during a frame's set-up (eager iterations + first
+            # replay), and over the whole frame (a frame switched to the radix passes stops counting)
+            "full_sorts_in_setup_by_frame": list(full_sorts_setup), "full_sorts_by_frame": list(full_sorts_frame),
+            **({"setup_split_ms_by_frame": setup_split, "allocator_segments_by_frame": seg_split} if setup_split else {}),
             "knn_watch": (f"checked at every frame boundary ({len(knn_checked)} frames): no fused neighbour search met a list longer "
                           f"than KNN_K = {int(gm.KNN_K)}") if knn_checked else None,
             "note": "per frame: remove -> emit -> predict -> solver counts x3 -> project x3 | new Adam + loop, two eager "

@@ -274,7 +274,7 @@ class HotLoop:
     def __init__(self, gm, cams, rd_pipe="render_dynamics", rank=0, world=1, log_scalars=False, cfg=SMOKE,
                  physics_per_view=True, shared_terms_rank=None, image_loss="torch", fused_physics=False, defer_visual_backward=False,
                  force_all_reduce=False, capturable=False, parallel_views=False, batched_views=False,
-                 fused_step=False, dual_channel=False):
+                 fused_step=False, dual_channel=False, reuse_streams_of=None):
         self.gm, self.cams, self.rank, self.world, self.cfg = gm, cams, rank, world, dict(cfg)
         self.view_subset = None
         self.render_func, self.GRsetting, self.GRzer = get_render_pipe(rd_pipe)
@@ -350,6 +350,20 @@ class HotLoop:
         # accumulation is bound to the stream a leaf was first used on, and a leaf first used on the
         # default stream would drag that stream into the capture.
         self.stream = torch.cuda.Stream(device=dev) if capturable else None
+        # `reuse_streams_of`: a loop this one replaces (frame after frame of a sequence).  The caching allocator hands a freed
+        # block only to requests on the stream it was allocated on: a new loop on NEW streams finds none of its predecessor's
+        # blocks usable and takes ~1.2 GiB from the driver per frame of config 3 (28 hipMallocs, 70 GiB reserved after 60
+        # frames; a hipMalloc costs 0.1 ms on a good day and 1.3 ms on a bad one: set-up 10 -> 45 ms).
+        if reuse_streams_of is not None and capturable and getattr(reuse_streams_of, "stream", None) is not None:
+            o = reuse_streams_of
+            self.stream, self.side_stream, self.ch1_stream = o.stream, o.side_stream, o.ch1_stream
+            self.dist_stream = getattr(o, "dist_stream", None)
+            self.view_streams, self.group_streams = list(o.view_streams), list(o.group_streams)
+            # ... and its background tensor: the camera batch (renderer.pipes._view_batch) is cached per (cameras, background
+            # tensor), and with it the static bins, the depth hints and the sort states -- a new tensor per frame made every
+            # frame start without depth hints and left 64 frames' worth of static bins (72 MB each) in the caches
+            if getattr(o, "background", None) is not None and o.background.device == dev:
+                self.background = o.background
 
     def _group_lists(self, mine):
         """The local views cut into `view_groups` consecutive groups (sizes; a remainder joins the last group)."""
@@ -434,12 +448,18 @@ class HotLoop:
         if getattr(self, "view_streams", None):
             self.view_streams = [torch.cuda.Stream(device=dev) for _ in self.view_streams]
 
-    def capture(self, warmup=3, iterations=1):
+    def capture(self, warmup=3, iterations=1, pool=None):
         """Record one whole iteration (all views forward + losses + backward + gradient mean + Adam) as a
         hipGraph; later iteration() calls replay it.  Needs the sync-free rasteriser mode with a seeded
         binning capacity (run a few eager iterations first) and capturable=True.  The launch sequence is
         frozen: the binning capacity and every cache decision are those of the recorded iteration;
         rasterizer.check_status() after replays still reports a capacity overflow.
+        `pool`: a `torch.cuda.graph_pool_handle()` the capture allocates from instead of a private pool of its own.  A
+        caller that re-captures frame after frame (bench.py --frames) passes ONE handle for all its captures: a destroyed
+        graph's private pool is only handed back by `torch.cuda.empty_cache()` -- which this capture does not call, see
+        _graph_capture -- so private pools pile up at ~1.1 GiB per frame of config 3 (28 segments from the driver per
+        capture, 70 GiB reserved after 60 frames, and late frames' captures slow down to 20 ms); in a shared pool the
+        previous frame's blocks are free again when its graph has gone.
         `iterations` > 1 records that many consecutive iterations in one graph (one launch gap per replay instead
         of one per iteration; the learning rate is constant in this stage, gm.update_learning_rate_current): every
         iteration() call then advances the optimisation by `iterations` steps (self.iterations_per_call)."""
@@ -476,7 +496,7 @@ class HotLoop:
                     _drain_collective_watchdog()
                     # thread_local: calls of other threads (the process group's watchdog, the allocator) do not
                     # invalidate this capture
-                    with _graph_capture(g, self.stream, capture_error_mode="thread_local"):
+                    with _graph_capture(g, self.stream, pool=pool, capture_error_mode="thread_local"):
                         for k in range(int(iterations)):
                             self._iteration_body_batched(phase="local")
                             dist.all_reduce(self._reduce_buf, op=dist.ReduceOp.SUM)
@@ -505,7 +525,7 @@ class HotLoop:
                     self.gm.invalidate_caches()
                     rasterizer._pending_status.clear()
             try:
-                with _graph_capture(g, self.stream):
+                with _graph_capture(g, self.stream, pool=pool):
                     self._iteration_body_batched(phase="local")
             except Exception:
                 _leak(g)
@@ -523,7 +543,7 @@ class HotLoop:
             iterations = 1
         else:
             itr0, tot0 = self.itr, self.gm.total_iterations
-            with _graph_capture(g, self.stream):
+            with _graph_capture(g, self.stream, pool=pool):
                 for _ in range(int(iterations)):
                     self._iteration_body()
             self.itr, self.gm.total_iterations = itr0, tot0  # recording is not running
@@ -531,6 +551,14 @@ class HotLoop:
         self.graph_iterations = int(iterations)
         self._replay = True
         return g
+
+    def release_graph(self):
+        """Drop the captured graph(s) NOW (and with them the memory their captures allocated), without waiting for this
+        object to be collected: a loop that is replaced frame after frame may sit in a reference cycle until the cyclic
+        collector runs, and its graph's pool (~1.1 GiB for config 3) with it."""
+        self.graph = None
+        self.graph_finish = None
+        self._replay = False
 
     @property
     def iterations_per_call(self):

@@ -287,6 +287,10 @@ def release_captured_status():
     global _captured_next
     _captured_status.clear()
     _captured_next = 0
+    # ... and un-pin the temporal-coherence sort states those graphs referred to by raw pointer: a sequence that re-captures
+    # frame after frame with a growing splat count otherwise keeps every frame's state (~60 MB per frame of config 3)
+    for vb in list(_VIEW_BATCHES or ()):
+        vb.release_captured_sort_states()
 
 
 def check_status():
