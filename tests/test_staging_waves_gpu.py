@@ -162,3 +162,22 @@ def test_tile_order_reaching_down_to_shallow_tiles_changes_nothing():
         if x.dtype == np.float32:
             x, y = x.view(np.uint32), y.view(np.uint32)
         assert (x == y).all(), k
+
+
+def test_more_tiles_than_the_sorted_prefix_holds():
+    """An image of 3 072 tiles with a threshold low enough to flag more than 1 024 of them: tile_scan_kernel sorts the first
+    1 024 flagged tiles (its bitonic network's width) and keeps the arrival order of the rest; the staging-wave kernel takes
+    every tile (one view).  Bit-equal to the per-tile kernel without any flagged tile."""
+    W, H = 1024, 768
+    n_dyn = 60_000
+    g = S.smoke_scene(n_dyn, 20_000, seed=6, channels=3)
+    cams = S.arc_cameras(5, W, H, device="cpu")[2:3]
+    bg = np.array([0.1, 0.0, 0.2], np.float32)
+    ref = _render(g, cams, W, H, bg, 3, 0, "exact", min_depth=1 << 20)
+    got = _render(g, cams, W, H, bg, 3, 4, "exact", min_depth=8)
+    assert int((got["hint"] >= 8).sum()) > 1024, f"only {int((got['hint'] >= 8).sum())} tiles reach the threshold"
+    for k in ("color", "depth", "hint"):
+        x, y = got[k], ref[k]
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert (x == y).all(), k
