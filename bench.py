@@ -593,6 +593,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     seg = dict(simulate=0.0, setup=0.0, optimise=0.0, accept=0.0)
     counts, sort_switched, frame_s, knn_checked, setup_s, full_sorts_setup, full_sorts_frame = [], [], [], [], [], [], []
     setup_split = []  # [prepare, loop object, eager iterations, status, capture, first replay + counters] ms per frame
+    full_sort_why = []
     # one memory pool for the captures of all frames (HotLoop.capture: private pools of destroyed graphs pile up otherwise)
     # (a torch.cuda.MemPool keeps the pool alive between one frame's graph going and the next one's capture: a bare handle's
     #  pool is dropped with its last graph and capture_begin then asserts)
@@ -691,6 +692,13 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
         rasterizer.check_status()
         if a.sort == "coherent":
             full_sorts_frame.append(rasterizer.coherent_sort_counters(P_frame)[1] - c0[1])
+            why = 0  # sticky reasons of this frame's states (csrc/fnx_state.h COH_WHY: 1 record not of this call, 2 bucket
+            for vb_ in list(rasterizer._VIEW_BATCHES or ()):  # overflow, 4 chunk not increasing, 8 chunk boundary, 16 unseeded)
+                for key_ in list(vb_._sort_state):
+                    if key_[1] == P_frame:
+                        for row_ in vb_.sort_counters(key_[0], key_[1], why=True, sort_key=key_[2] if len(key_) > 2 else None):
+                            why |= row_[2]
+            full_sort_why.append(why)
         if getattr(gm, "_knn_flags", None) is not None:
             gm.check_knn_k()  # raises when a fused neighbour search of this frame met a list longer than KNN_K (device flag)
             knn_checked.append(1)
@@ -718,6 +726,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
     full_sorts_frame.clear()
     setup_split.clear()
     seg_split.clear()
+    full_sort_why.clear()
     total = sum(one_frame(True) for _ in range(K))
     rasterizer.set_coherent_sort(a.coh)
     if os.environ.get("FNX_SEQ_SNAPSHOT") == "2":  # developer switch: who allocated the blocks that are still alive
@@ -758,6 +767,7 @@ def sequence_timing(a, dev, cfg_id, rank, world, use_dist, steady_ms):
             # in-launch full sorts of the coherent depth sort (all views): during a frame's set-up (eager iterations + first
             # replay), and over the whole frame (a frame switched to the radix passes stops counting)
             "full_sorts_in_setup_by_frame": list(full_sorts_setup), "full_sorts_by_frame": list(full_sorts_frame),
+            "full_sort_reasons_by_frame": list(full_sort_why),
             **({"setup_split_ms_by_frame": setup_split, "allocator_segments_by_frame": seg_split} if setup_split else {}),
             "knn_watch": (f"checked at every frame boundary ({len(knn_checked)} frames): no fused neighbour search met a list longer "
                           f"than KNN_K = {int(gm.KNN_K)}") if knn_checked else None,
