@@ -181,3 +181,37 @@ def test_more_tiles_than_the_sorted_prefix_holds():
         if x.dtype == np.float32:
             x, y = x.view(np.uint32), y.view(np.uint32)
         assert (x == y).all(), k
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FNX_RANDOM_CASES", "8"))))
+def test_staging_wave_forward_random_scenes(seed):
+    """Seeded random scenes: image sizes with partial tiles, one to three views, thin (deep lists, nothing saturates) or
+    opaque splats, 1 or 3 channels, with and without the static split, either arithmetic, deep tiles only or every tile --
+    bit-equal to the per-tile kernel every time."""
+    rng = np.random.RandomState(4200 + seed)
+    channels = int(rng.choice([1, 3]))
+    W, H = int(rng.randint(40, 260)), int(rng.randint(40, 220))
+    V = int(rng.randint(1, 4))
+    n_dyn = int(rng.choice([300, 4000, 15000]))
+    n_stat = int(rng.choice([0, 200, 5000])) if channels == 3 else 0
+    math_mode = str(rng.choice(["exact", "fast"]))
+    deep_mode = int(rng.choice([3, 4]))
+    g = S.smoke_scene(n_dyn, max(n_stat, 1), seed=700 + seed, channels=3) if channels == 3 else S.plume_gaussians(n_dyn, seed=700 + seed, channels=1)
+    if rng.rand() < 0.5:  # thin: lists of thousands of entries
+        g["opacities"] = rng.uniform(0.004, 0.05, size=g["opacities"].shape).astype(np.float32)
+    cams = S.arc_cameras(5, W, H, device="cpu")[:V]
+    bg = rng.uniform(0, 0.3, size=3).astype(np.float32)
+    sp = n_dyn if (channels == 3 and n_stat > 0) else False
+    thr = int(rng.choice([16, 256, 1024]))
+    a = _render(g, cams, W, H, bg, channels, deep_mode, math_mode, min_depth=thr, static_split=sp, rounds=3)
+    r = _render(g, cams, W, H, bg, channels, 0, math_mode, min_depth=thr, static_split=sp, rounds=3)
+    for k in ("color", "depth", "hint"):
+        x, y = a[k], r[k]
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert (x == y).all(), f"seed {seed} ({W}x{H}, V={V}, ch{channels}, split={bool(sp)}, {math_mode}, mode {deep_mode}): {k}"
+    names = ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")
+    for n, x, y in zip(names, a["grads"], r["grads"]):
+        lim = n_dyn if sp else x.shape[0]
+        ok, msg = mixed_bound_report(y[:lim], x[:lim])
+        assert ok, f"seed {seed} {n}: {msg}"
